@@ -1,0 +1,148 @@
+/*
+ * phmm.h -- C ABI of the MI355X-native PairHMM read x haplotype likelihood engine.
+ *
+ * This is the drop-in boundary for Lorikeet's PairHMM path.  The reference has no FFI of its
+ * own on this path; the seam it does have is the function pointer returned by
+ * `gkl::pairhmm::forward()` and the batch loop around it:
+ *
+ *   reference/src/pair_hmm/pair_hmm.rs:345-375   PairHMM::compute_likelihoods
+ *       for read { for hap { forward(hap, read, read_quals, ins_gop, del_gop, gcp) -> f64 } }
+ *       => m_log_likelihood_array, Nr*Nh f64, READ-MAJOR, haplotypes in initialize() order
+ *   reference/src/pair_hmm/pair_hmm.rs:217-341   PairHMM::compute_log10_likelihoods (caller)
+ *   reference/tests/vector_pair_hmm_unit_tests.rs:51-59   the same call shape in the tests
+ *
+ * Every entry point below takes plain pointers and sizes (no C++/torch types).  Inputs are the
+ * arrays the Rust call site already holds (`ReadDataHolder`, pair_hmm.rs:720-745, and
+ * `m_haplotype_data_array`, :71-79) flattened into struct-of-arrays with prefix-sum offsets, so
+ * that any number of assembly regions travel in one call.  INTEGRATION.md shows the Rust
+ * `extern "C"` block and the `AVXMode::Hip` arm that binds them.
+ *
+ * Semantics (identical to the reference):
+ *   - log10 Pr(read | haplotype) of the M/I/D forward recurrence of pair_hmm.rs:503-615,
+ *     tristate correction ON unless PHMM_FLAG_NO_TRISTATE (pair_hmm.rs:189-191, :643-651);
+ *   - base comparison is raw byte equality, uppercase 'N' on either side is a wildcard (:643);
+ *   - qualities are full u8 (0..=255); reads longer than the haplotype are legal; an empty read
+ *     gives -inf; an empty read list is a no-op (:224);
+ *   - every result satisfies <= 0.0; a violation (the reference asserts, :478-481) is reported
+ *     as PHMM_ERR_POSITIVE_RESULT.
+ * Results agree with the reference's scalar f64 path to ~1e-12 relative (FMA contraction and the
+ * order of the final row sum are the only differences); the reference's own gate is 1e-5 abs.
+ *
+ * Threading: a handle may be used by one thread at a time; create one per host thread (the
+ * reference clones its engine per rayon task, assembly_region_walker.rs:227) or serialise.
+ * There is NO CPU fallback: without a HIP device phmm_create() fails.
+ */
+#ifndef PHMM_H
+#define PHMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHMM_VERSION 1
+
+/* flags for phmm_create */
+#define PHMM_FLAG_NO_TRISTATE 1u /* PairHMM::do_not_use_tristate_correction (pair_hmm.rs:189) */
+
+/* status codes (0 == success) */
+#define PHMM_OK 0
+#define PHMM_ERR_INVALID_ARG 1      /* null pointer, non-monotonic offsets, size mismatch      */
+#define PHMM_ERR_NO_DEVICE 2        /* no HIP device / bad device id                           */
+#define PHMM_ERR_HIP 3              /* a HIP runtime call failed; see phmm_last_error          */
+#define PHMM_ERR_POSITIVE_RESULT 4  /* some log10 likelihood > 0 (reference asserts, :478-481) */
+#define PHMM_ERR_NOT_BOUND 5        /* phmm_batch_launch before device buffers were bound      */
+
+typedef struct phmm_handle phmm_handle;
+typedef struct phmm_batch phmm_batch;
+
+/* Number of HIP devices visible to the process (0 if none / no driver). */
+int phmm_device_count(void);
+
+/* Create an engine on HIP device `device_id`.  Builds the quality->probability tables
+ * (quality_utils.rs:82-104, pair_hmm_model.rs:47-78) once and keeps them resident in HBM;
+ * owns a stream, pinned staging and device arenas that grow on demand.
+ * Replaces PairHMM::initialize's per-region table/matrix construction (pair_hmm.rs:63-165).
+ * Returns NULL on failure (phmm_last_error(NULL) has the message). */
+phmm_handle *phmm_create(int device_id, unsigned flags);
+void phmm_destroy(phmm_handle *h);
+
+/* Last error message of this handle (or of the failed phmm_create when h == NULL).
+ * Never NULL; valid until the next call on the same handle. */
+const char *phmm_last_error(phmm_handle *h);
+
+/*
+ * Synchronous whole-batch call on HOST buffers (pageable is fine): plan, H2D, kernels, D2H.
+ * Replaces PairHMM::compute_likelihoods (pair_hmm.rs:345-375) for `n_regions` regions at once.
+ *
+ *   region_read_off[n_regions+1]  prefix sums: region g owns reads  [region_read_off[g], region_read_off[g+1])
+ *   region_hap_off [n_regions+1]  prefix sums: region g owns haps   [region_hap_off[g],  region_hap_off[g+1])
+ *   read_off[n_reads+1]           byte offsets of each read into the five per-base read arrays
+ *   read_bases, base_q, ins_q, del_q, gcp   read_off[n_reads] bytes each (ReadDataHolder fields)
+ *   hap_off[n_haps+1], hap_bases  byte offsets / bases of each haplotype
+ *   out_off[n_regions+1]          element offsets into out; region g needs Nr_g*Nh_g doubles
+ *   out                           per region row-major [read][hap] == m_log_likelihood_array order
+ *
+ * All pointers are caller-owned and not retained.  Returns a PHMM_* status.
+ */
+int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                 const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases,
+                 const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp,
+                 const uint32_t *hap_off, const uint8_t *hap_bases, const uint64_t *out_off, double *out);
+
+/*
+ * Split-phase interface for device-resident data and for overlapping transfers with compute.
+ * A batch owns the launch plan (regions binned into kernel shape classes) and the device copy
+ * of the offset arrays; the byte payload and the output live in device memory that is either
+ * caller-owned (phmm_batch_bind_device) or uploaded from host buffers (phmm_batch_upload).
+ *
+ *   b = phmm_batch_create(h, <offset arrays on the host>);
+ *   phmm_batch_bind_device(b, d_read_bases, ..., d_out);   // or phmm_batch_upload(b, host ptrs)
+ *   phmm_batch_launch(b, stream);                           // async: kernels only
+ *   ... hipStreamSynchronize / phmm_batch_download(b, out) ...
+ *   phmm_batch_destroy(b);
+ */
+phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                              const uint32_t *region_hap_off, const uint32_t *read_off,
+                              const uint32_t *hap_off, const uint64_t *out_off);
+void phmm_batch_destroy(phmm_batch *b);
+
+/* Device pointers (on the handle's device), caller-owned, must stay valid until the launch completes. */
+int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q,
+                           const uint8_t *d_ins_q, const uint8_t *d_del_q, const uint8_t *d_gcp,
+                           const uint8_t *d_hap_bases, double *d_out);
+
+/* Copy host payload into batch-owned device buffers (async on the handle's stream) and bind them. */
+int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                      const uint8_t *del_q, const uint8_t *gcp, const uint8_t *hap_bases);
+
+/* Enqueue the forward kernels on `stream` (a hipStream_t; NULL = the handle's own stream).
+ * Asynchronous; no host<->device copies, no allocation. */
+int phmm_batch_launch(phmm_batch *b, void *stream);
+
+/* Wait for the handle's stream, copy batch-owned output to `out` (host) and check the device
+ * status word.  Only valid after phmm_batch_upload + phmm_batch_launch(b, NULL). */
+int phmm_batch_download(phmm_batch *b, double *out);
+
+/* Read and clear the device status word after the caller synchronised its own stream
+ * (for the bind_device flow).  Returns PHMM_OK or PHMM_ERR_POSITIVE_RESULT. */
+int phmm_batch_status(phmm_batch *b);
+
+/* Introspection for tests / bench: totals of the plan. */
+uint64_t phmm_batch_cells(const phmm_batch *b);           /* sum over regions of (sum R)*(sum H)      */
+uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b); /* sum 5R + sum H + 8*Nr*Nh    */
+uint32_t phmm_batch_num_launches(const phmm_batch *b);    /* kernel launches one phmm_batch_launch does */
+/* Name of the kernel shape class doing most cells of this batch, e.g. "phmm_forward<16,19>". */
+const char *phmm_batch_dominant_kernel(const phmm_batch *b);
+
+/* Host copies of the device tables, for parity tests against the oracle:
+ * eps[q] = 10^(-q/10) for q in 0..=255, mm = triangular match->match table incl. row 255. */
+size_t phmm_table_eps(const double **eps);
+size_t phmm_table_match_to_match(const double **mm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHMM_H */

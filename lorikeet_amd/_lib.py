@@ -1,0 +1,66 @@
+"""ctypes binding of libphmm.so (the C ABI declared in include/phmm.h).
+
+The library is built in-tree by `__graft_entry__.build()` (or `make -C lorikeet_amd/csrc`).
+There is deliberately NO fallback: if the shared library is missing, or no HIP device is
+present when an engine is created, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphmm.so")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+
+PHMM_FLAG_NO_TRISTATE = 1
+PHMM_OK = 0
+PHMM_ERR_INVALID_ARG = 1
+PHMM_ERR_NO_DEVICE = 2
+PHMM_ERR_HIP = 3
+PHMM_ERR_POSITIVE_RESULT = 4
+PHMM_ERR_NOT_BOUND = 5
+
+# every symbol include/phmm.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("phmm_device_count", C.c_int, []),
+    ("phmm_create", C.c_void_p, [C.c_int, C.c_uint]),
+    ("phmm_destroy", None, [C.c_void_p]),
+    ("phmm_last_error", C.c_char_p, [C.c_void_p]),
+    ("phmm_compute", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p, u32p, u8p, u64p, f64p]),
+    ("phmm_batch_create", C.c_void_p, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u32p, u64p]),
+    ("phmm_batch_destroy", None, [C.c_void_p]),
+    ("phmm_batch_bind_device", C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    ("phmm_batch_upload", C.c_int, [C.c_void_p, u8p, u8p, u8p, u8p, u8p, u8p]),
+    ("phmm_batch_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("phmm_batch_download", C.c_int, [C.c_void_p, f64p]),
+    ("phmm_batch_status", C.c_int, [C.c_void_p]),
+    ("phmm_batch_cells", C.c_uint64, [C.c_void_p]),
+    ("phmm_batch_algorithmic_bytes", C.c_uint64, [C.c_void_p]),
+    ("phmm_batch_num_launches", C.c_uint32, [C.c_void_p]),
+    ("phmm_batch_dominant_kernel", C.c_char_p, [C.c_void_p]),
+    ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),
+    ("phmm_table_match_to_match", C.c_size_t, [C.POINTER(f64p)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libphmm.so and bind every symbol of include/phmm.h.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "lorikeet_amd: %s not found -- the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,574 @@
+// C ABI (include/phmm.h) + launch planner of the MI355X PairHMM engine.
+//
+// Host side of the drop-in boundary: takes the flattened (reads, haplotypes, quals) of any number
+// of assembly regions, bins the regions into kernel shape classes <L lanes per pair, K haplotype
+// columns per lane>, and launches one gfx950 kernel per class.  Replaces, for the whole batch,
+//   PairHMM::initialize            (reference src/pair_hmm/pair_hmm.rs:63-125)   -> phmm_create / plan
+//   PairHMM::compute_likelihoods   (:345-375)                                     -> phmm_compute
+// There is no CPU fallback anywhere in this file.
+#include "../../include/phmm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "phmm_internal.hpp"
+#include "phmm_tables.hpp"
+
+using namespace phmm;
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_err = "";
+
+constexpr size_t kLdsBytesPerCU = 160 * 1024;
+constexpr size_t kLdsRowBytes = 56;  // 6 f64 + 1 byte, rows rounded to a multiple of 8
+constexpr uint32_t kNumSimd = 256 * 4;
+constexpr uint64_t kGenericScratchBytes = 1ull << 30;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ShapeClass {
+    int L = 0, K = 0;  // L == 0 -> generic kernel
+    std::vector<uint32_t> reads;  // global read indices (host copy; uploaded unless identity)
+    bool identity = false;        // reads == 0..n-1
+    uint32_t max_r = 0, max_h = 0, max_quads = 0;
+    uint64_t cells = 0;
+    // launch configuration
+    uint32_t lds_rows = 8;
+    int waves_per_block = MAX_WAVES_PER_BLOCK;
+    size_t lds_bytes = 0;
+    dim3 grid;
+    // device
+    uint32_t *d_reads = nullptr;
+    // generic only
+    std::vector<uint64_t> pair_first;
+    uint64_t *d_pair_first = nullptr;
+    double *d_scratch = nullptr;
+    uint32_t generic_blocks = 0;
+    char name[48] = {0};
+};
+
+}  // namespace
+
+struct phmm_handle {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr;
+    std::string err;
+    int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
+    int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
+};
+
+struct phmm_batch {
+    phmm_handle *h = nullptr;
+    uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
+    uint64_t n_out = 0, read_bytes = 0, hap_bytes = 0;
+    uint64_t cells = 0, alg_bytes = 0;
+    std::vector<ShapeClass> classes;
+    // device metadata (one allocation)
+    void *d_meta = nullptr;
+    uint32_t *d_read_region = nullptr, *d_region_read_off = nullptr, *d_region_hap_off = nullptr, *d_read_off = nullptr,
+             *d_hap_off = nullptr, *d_status = nullptr;
+    uint64_t *d_out_off = nullptr;
+    // payload
+    const uint8_t *d_read_bases = nullptr, *d_base_q = nullptr, *d_ins_q = nullptr, *d_del_q = nullptr, *d_gcp = nullptr,
+                  *d_hap_bases = nullptr;
+    double *d_out = nullptr;
+    void *d_owned = nullptr;  // batch-owned payload + out (phmm_batch_upload)
+    bool bound = false;
+    std::string dominant;
+};
+
+namespace {
+
+bool hip_ok(phmm_handle *h, hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (h) h->err = buf;
+    else {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_err = buf;
+    }
+    return false;
+}
+#define HIP_TRY(h, call, ret)                  \
+    do {                                       \
+        if (!hip_ok((h), (call), #call)) return ret; \
+    } while (0)
+
+int round_up_k(int k) {
+    for (int i = 0; i < kNumInstantiatedK; ++i)
+        if (kInstantiatedK[i] >= k) return kInstantiatedK[i];
+    return 0;
+}
+
+// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates).
+int waves_per_simd(int K) { return K <= 4 ? 4 : K <= 8 ? 3 : K <= 16 ? 2 : 1; }
+
+// Fraction of issued lane-steps that are useful cells for a region under <L,K>.
+double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h) {
+    const int G = WAVE / L;
+    const double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
+    const double ramp = (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
+    const double col_fill = (double)max_h / (double)(L * K);
+    return hap_fill * ramp * col_fill;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phmm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *phmm_last_error(phmm_handle *h) {
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_create_err.c_str();
+}
+
+phmm_handle *phmm_create(int device_id, unsigned flags) {
+    int n = phmm_device_count();
+    if (device_id < 0 || device_id >= n) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_err = "phmm_create: no HIP device with that id (this engine has no CPU fallback)";
+        return nullptr;
+    }
+    if (!hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice")) return nullptr;
+    phmm_handle *h = new phmm_handle();
+    h->device = device_id;
+    h->flags = flags;
+    if (const char *e = getenv("PHMM_FORCE_L")) h->force_L = atoi(e);
+    if (const char *e = getenv("PHMM_FORCE_QUAD_SPLIT")) h->force_split = atoi(e);
+    const auto &eps = table_eps();
+    const auto &eps3 = table_eps_third();
+    const auto &mm = table_match_to_match();
+    bool ok = hip_ok(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+              hip_ok(nullptr, hipMalloc(&h->d_eps, 256 * sizeof(double)), "hipMalloc eps") &&
+              hip_ok(nullptr, hipMalloc(&h->d_eps_mis, 256 * sizeof(double)), "hipMalloc eps_mis") &&
+              hip_ok(nullptr, hipMalloc(&h->d_mm, mm.size() * sizeof(double)), "hipMalloc mm") &&
+              hip_ok(nullptr, hipMemcpy(h->d_eps, eps.data(), 256 * sizeof(double), hipMemcpyHostToDevice), "copy eps") &&
+              hip_ok(nullptr,
+                     hipMemcpy(h->d_eps_mis, (flags & PHMM_FLAG_NO_TRISTATE) ? eps.data() : eps3.data(),
+                               256 * sizeof(double), hipMemcpyHostToDevice),
+                     "copy eps_mis") &&
+              hip_ok(nullptr, hipMemcpy(h->d_mm, mm.data(), mm.size() * sizeof(double), hipMemcpyHostToDevice), "copy mm");
+    if (!ok) {
+        phmm_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void phmm_destroy(phmm_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->d_eps) (void)hipFree(h->d_eps);
+    if (h->d_eps_mis) (void)hipFree(h->d_eps_mis);
+    if (h->d_mm) (void)hipFree(h->d_mm);
+    delete h;
+}
+
+size_t phmm_table_eps(const double **eps) {
+    *eps = table_eps().data();
+    return table_eps().size();
+}
+size_t phmm_table_match_to_match(const double **mm) {
+    *mm = table_match_to_match().data();
+    return table_match_to_match().size();
+}
+
+void phmm_batch_destroy(phmm_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->h->device);
+    for (auto &c : b->classes) {
+        if (c.d_reads) (void)hipFree(c.d_reads);
+        if (c.d_pair_first) (void)hipFree(c.d_pair_first);
+        if (c.d_scratch) (void)hipFree(c.d_scratch);
+    }
+    if (b->d_meta) (void)hipFree(b->d_meta);
+    if (b->d_owned) (void)hipFree(b->d_owned);
+    delete b;
+}
+
+phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                              const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off,
+                              const uint64_t *out_off) {
+    if (!h) return nullptr;
+    h->err.clear();
+    if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
+        h->err = "phmm_batch_create: null offset array";
+        return nullptr;
+    }
+    if (region_read_off[0] != 0 || region_hap_off[0] != 0 || read_off[0] != 0 || hap_off[0] != 0 || out_off[0] != 0) {
+        h->err = "phmm_batch_create: offset arrays must start at 0";
+        return nullptr;
+    }
+    const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if (region_read_off[g + 1] < region_read_off[g] || region_hap_off[g + 1] < region_hap_off[g]) {
+            h->err = "phmm_batch_create: region offsets not monotonic";
+            return nullptr;
+        }
+        const uint64_t need = (uint64_t)(region_read_off[g + 1] - region_read_off[g]) *
+                              (uint64_t)(region_hap_off[g + 1] - region_hap_off[g]);
+        if (out_off[g + 1] < out_off[g] || out_off[g + 1] - out_off[g] < need) {
+            h->err = "phmm_batch_create: out_off leaves too little room for a region (needs Nr*Nh doubles)";
+            return nullptr;
+        }
+    }
+    for (uint32_t r = 0; r < n_reads; ++r)
+        if (read_off[r + 1] < read_off[r]) {
+            h->err = "phmm_batch_create: read_off not monotonic";
+            return nullptr;
+        }
+    for (uint32_t a = 0; a < n_haps; ++a)
+        if (hap_off[a + 1] < hap_off[a]) {
+            h->err = "phmm_batch_create: hap_off not monotonic";
+            return nullptr;
+        }
+    if (hipSetDevice(h->device) != hipSuccess) {
+        h->err = "hipSetDevice failed";
+        return nullptr;
+    }
+
+    phmm_batch *b = new phmm_batch();
+    b->h = h;
+    b->n_regions = n_regions;
+    b->n_reads = n_reads;
+    b->n_haps = n_haps;
+    b->n_out = out_off[n_regions];
+    b->read_bytes = read_off[n_reads];
+    b->hap_bytes = hap_off[n_haps];
+
+    // ---- per-region shape, totals -----------------------------------------------------------
+    struct RegionShape {
+        uint32_t nr, nh, max_r, max_h, mean_r;
+        uint64_t cells;
+    };
+    std::vector<RegionShape> shape(n_regions);
+    std::vector<uint32_t> read_region(n_reads);
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        RegionShape s{};
+        s.nr = region_read_off[g + 1] - region_read_off[g];
+        s.nh = region_hap_off[g + 1] - region_hap_off[g];
+        uint64_t sum_r = 0, sum_h = 0;
+        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) {
+            const uint32_t len = read_off[r + 1] - read_off[r];
+            s.max_r = std::max(s.max_r, len);
+            sum_r += len;
+            read_region[r] = g;
+        }
+        for (uint32_t a = region_hap_off[g]; a < region_hap_off[g + 1]; ++a) {
+            const uint32_t len = hap_off[a + 1] - hap_off[a];
+            s.max_h = std::max(s.max_h, len);
+            sum_h += len;
+        }
+        s.mean_r = s.nr ? (uint32_t)(sum_r / s.nr) : 0;
+        s.cells = sum_r * sum_h;
+        b->cells += s.cells;
+        b->alg_bytes += 5 * sum_r + sum_h + 8ull * s.nr * s.nh;
+        shape[g] = s;
+    }
+
+    // ---- choose <L,K> per region ------------------------------------------------------------
+    // Candidates L in {16,32,64}; K = ceil(max_h / L) rounded up to an instantiated value.
+    // Pick the most efficient one, then trade lanes-per-pair for more waves while the batch is
+    // too small to fill the chip.
+    auto pick = [&](const RegionShape &s, int min_L, int &L_out, int &K_out) {
+        double best = -1.0;
+        L_out = 0;
+        K_out = 0;
+        for (int L : {16, 32, 64}) {
+            if (L < min_L) continue;
+            if (h->force_L && L != h->force_L) continue;
+            const int k = round_up_k((int)((std::max<uint32_t>(s.max_h, 1) + L - 1) / L));
+            if (!k) continue;
+            // resident waves hide the serial D chain: weigh by min(1, waves/2)
+            const double occ = std::min(1.0, waves_per_simd(k) / 2.0);
+            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h) * (0.75 + 0.25 * occ);
+            if (e > best) {
+                best = e;
+                L_out = L;
+                K_out = k;
+            }
+        }
+    };
+    std::vector<int> reg_L(n_regions), reg_K(n_regions);
+    int min_L = 16;
+    for (;;) {
+        uint64_t waves = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) {
+            const RegionShape &s = shape[g];
+            if (!s.nr || !s.nh) {
+                reg_L[g] = reg_K[g] = -1;  // nothing to do
+                continue;
+            }
+            pick(s, min_L, reg_L[g], reg_K[g]);
+            if (reg_L[g]) waves += (uint64_t)s.nr * ((s.nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
+        }
+        if (waves >= 2ull * kNumSimd || min_L == 64 || h->force_L) break;
+        min_L *= 2;
+    }
+
+    std::map<std::pair<int, int>, ShapeClass> by_shape;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if (reg_L[g] < 0) continue;
+        const RegionShape &s = shape[g];
+        int L = reg_L[g], K = reg_K[g];
+        // LDS staging must hold the longest read of the region, one wave per block at least
+        const size_t rows = align_up((size_t)s.max_r + 1, 8);
+        if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
+        ShapeClass &c = by_shape[{L, K}];
+        c.L = L;
+        c.K = K;
+        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.reads.push_back(r);
+        c.max_r = std::max(c.max_r, s.max_r);
+        c.max_h = std::max(c.max_h, s.max_h);
+        if (L) c.max_quads = std::max(c.max_quads, (s.nh + WAVE / L - 1) / (WAVE / L));
+        c.cells += s.cells;
+        if (!L)
+            for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.pair_first.push_back(s.nh);
+    }
+
+    // ---- device metadata --------------------------------------------------------------------
+    const size_t sz_rr = align_up((size_t)n_reads * 4, 256), sz_rro = align_up((size_t)(n_regions + 1) * 4, 256),
+                 sz_ro = align_up((size_t)(n_reads + 1) * 4, 256), sz_ho = align_up((size_t)(n_haps + 1) * 4, 256),
+                 sz_oo = align_up((size_t)(n_regions + 1) * 8, 256);
+    const size_t meta_bytes = sz_rr + 2 * sz_rro + sz_ro + sz_ho + sz_oo + 256;
+    if (!hip_ok(h, hipMalloc(&b->d_meta, meta_bytes), "hipMalloc(meta)")) {
+        phmm_batch_destroy(b);
+        return nullptr;
+    }
+    char *p = (char *)b->d_meta;
+    b->d_read_region = (uint32_t *)p; p += sz_rr;
+    b->d_region_read_off = (uint32_t *)p; p += sz_rro;
+    b->d_region_hap_off = (uint32_t *)p; p += sz_rro;
+    b->d_read_off = (uint32_t *)p; p += sz_ro;
+    b->d_hap_off = (uint32_t *)p; p += sz_ho;
+    b->d_out_off = (uint64_t *)p; p += sz_oo;
+    b->d_status = (uint32_t *)p;
+    bool ok = true;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        if (ok && bytes) ok = hip_ok(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream), "H2D meta");
+    };
+    up(b->d_read_region, read_region.data(), (size_t)n_reads * 4);
+    up(b->d_region_read_off, region_read_off, (size_t)(n_regions + 1) * 4);
+    up(b->d_region_hap_off, region_hap_off, (size_t)(n_regions + 1) * 4);
+    up(b->d_read_off, read_off, (size_t)(n_reads + 1) * 4);
+    up(b->d_hap_off, hap_off, (size_t)(n_haps + 1) * 4);
+    up(b->d_out_off, out_off, (size_t)(n_regions + 1) * 8);
+    if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->stream), "memset status");
+
+    // ---- finalise classes -------------------------------------------------------------------
+    uint64_t best_cells = 0;
+    for (auto &kv : by_shape) {
+        ShapeClass c = std::move(kv.second);
+        const uint32_t n_items = (uint32_t)c.reads.size();
+        c.identity = (n_items == n_reads);
+        for (uint32_t i = 0; c.identity && i < n_items; ++i) c.identity = (c.reads[i] == i);
+        if (!c.identity && ok) {
+            ok = hip_ok(h, hipMalloc(&c.d_reads, (size_t)n_items * 4), "hipMalloc(class reads)");
+            up(c.d_reads, c.reads.data(), (size_t)n_items * 4);
+        }
+        if (c.L) {
+            c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
+            const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
+            c.waves_per_block = (int)std::min<size_t>(MAX_WAVES_PER_BLOCK, kLdsBytesPerCU / per_wave);
+            c.lds_bytes = per_wave * c.waves_per_block;
+            // Enough reads to fill the chip -> one wave walks all haplotype groups of its read (row
+            // constants staged once); otherwise spread the groups over gridDim.y.
+            bool split = (uint64_t)n_items < 4ull * kNumSimd;
+            if (h->force_split >= 0) split = h->force_split != 0;
+            c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
+            snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
+        } else {
+            // generic: exclusive prefix of pairs per read, scratch for a bounded grid
+            uint64_t acc = 0;
+            for (auto &v : c.pair_first) {
+                const uint64_t nh = v;
+                v = acc;
+                acc += nh;
+            }
+            c.pair_first.push_back(acc);
+            const uint64_t per_thread = 6ull * (c.max_h + 1) * sizeof(double);
+            uint64_t threads = std::min<uint64_t>(align_up(acc, 256), 1024ull * 256);
+            threads = std::min<uint64_t>(threads, std::max<uint64_t>(256, kGenericScratchBytes / per_thread / 256 * 256));
+            c.generic_blocks = (uint32_t)(threads / 256);
+            if (ok) ok = hip_ok(h, hipMalloc(&c.d_scratch, threads * per_thread), "hipMalloc(generic scratch)");
+            if (ok) ok = hip_ok(h, hipMalloc(&c.d_pair_first, c.pair_first.size() * 8), "hipMalloc(pair_first)");
+            up(c.d_pair_first, c.pair_first.data(), c.pair_first.size() * 8);
+            snprintf(c.name, sizeof c.name, "phmm_forward_generic");
+        }
+        if (c.cells >= best_cells) {
+            best_cells = c.cells;
+            b->dominant = c.name;
+        }
+        b->classes.push_back(std::move(c));
+    }
+    // host staging vectors die at return: finish the async copies first
+    if (ok) ok = hip_ok(h, hipStreamSynchronize(h->stream), "sync(meta)");
+    if (!ok) {
+        phmm_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q, const uint8_t *d_ins_q,
+                           const uint8_t *d_del_q, const uint8_t *d_gcp, const uint8_t *d_hap_bases, double *d_out) {
+    if (!b) return PHMM_ERR_INVALID_ARG;
+    if ((b->read_bytes && (!d_read_bases || !d_base_q || !d_ins_q || !d_del_q || !d_gcp)) ||
+        (b->hap_bytes && !d_hap_bases) || (b->n_out && !d_out)) {
+        b->h->err = "phmm_batch_bind_device: null device pointer";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    b->d_read_bases = d_read_bases;
+    b->d_base_q = d_base_q;
+    b->d_ins_q = d_ins_q;
+    b->d_del_q = d_del_q;
+    b->d_gcp = d_gcp;
+    b->d_hap_bases = d_hap_bases;
+    b->d_out = d_out;
+    b->bound = true;
+    return PHMM_OK;
+}
+
+int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                      const uint8_t *del_q, const uint8_t *gcp, const uint8_t *hap_bases) {
+    if (!b) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h = b->h;
+    if ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases)) {
+        h->err = "phmm_batch_upload: null host pointer";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    HIP_TRY(h, hipSetDevice(h->device), PHMM_ERR_HIP);
+    const size_t rb = align_up(b->read_bytes, 256), hb = align_up(b->hap_bytes, 256), ob = align_up(b->n_out * 8, 256);
+    if (!b->d_owned) HIP_TRY(h, hipMalloc(&b->d_owned, 5 * rb + hb + ob + 256), PHMM_ERR_HIP);
+    uint8_t *p = (uint8_t *)b->d_owned;
+    uint8_t *d[6];
+    for (int i = 0; i < 5; ++i) { d[i] = p; p += rb; }
+    d[5] = p; p += hb;
+    double *d_out = (double *)p;
+    const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
+    for (int i = 0; i < 6; ++i) {
+        const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
+        if (bytes) HIP_TRY(h, hipMemcpyAsync(d[i], src[i], bytes, hipMemcpyHostToDevice, h->stream), PHMM_ERR_HIP);
+    }
+    return phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
+}
+
+int phmm_batch_launch(phmm_batch *b, void *stream_v) {
+    if (!b) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h = b->h;
+    if (!b->bound) {
+        h->err = "phmm_batch_launch: no device buffers bound";
+        return PHMM_ERR_NOT_BOUND;
+    }
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : h->stream;
+    for (auto &c : b->classes) {
+        ForwardParams p{};
+        p.class_reads = c.identity ? nullptr : c.d_reads;
+        p.n_items = (uint32_t)c.reads.size();
+        p.read_region = b->d_read_region;
+        p.region_read_off = b->d_region_read_off;
+        p.region_hap_off = b->d_region_hap_off;
+        p.read_off = b->d_read_off;
+        p.hap_off = b->d_hap_off;
+        p.out_off = b->d_out_off;
+        p.read_bases = b->d_read_bases;
+        p.base_q = b->d_base_q;
+        p.ins_q = b->d_ins_q;
+        p.del_q = b->d_del_q;
+        p.gcp = b->d_gcp;
+        p.hap_bases = b->d_hap_bases;
+        p.out = b->d_out;
+        p.eps = h->d_eps;
+        p.eps_mis = h->d_eps_mis;
+        p.mm = h->d_mm;
+        p.initial_condition = initial_condition();
+        p.initial_condition_log10 = initial_condition_log10();
+        p.lds_rows = c.lds_rows;
+        p.status = b->d_status;
+        if (!p.n_items) continue;
+        hipError_t e;
+        if (c.L) {
+            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
+        } else {
+            GenericParams gp{};
+            gp.f = p;
+            gp.scratch = c.d_scratch;
+            gp.max_h = c.max_h;
+            gp.pair_first = c.d_pair_first;
+            gp.n_pairs = c.pair_first.back();
+            gp.n_blocks = c.generic_blocks;
+            e = gp.n_pairs ? launch_generic(gp, stream) : hipSuccess;
+        }
+        if (!hip_ok(h, e, c.name)) return PHMM_ERR_HIP;
+    }
+    return PHMM_OK;
+}
+
+int phmm_batch_status(phmm_batch *b) {
+    if (!b) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h = b->h;
+    uint32_t st = 0;
+    HIP_TRY(h, hipMemcpy(&st, b->d_status, 4, hipMemcpyDeviceToHost), PHMM_ERR_HIP);
+    if (st) {
+        HIP_TRY(h, hipMemset(b->d_status, 0, 4), PHMM_ERR_HIP);
+        h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+        return PHMM_ERR_POSITIVE_RESULT;
+    }
+    return PHMM_OK;
+}
+
+int phmm_batch_download(phmm_batch *b, double *out) {
+    if (!b || (b->n_out && !out)) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h = b->h;
+    if (!b->bound) return PHMM_ERR_NOT_BOUND;
+    if (b->n_out)
+        HIP_TRY(h, hipMemcpyAsync(out, b->d_out, b->n_out * 8, hipMemcpyDeviceToHost, h->stream), PHMM_ERR_HIP);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), PHMM_ERR_HIP);
+    return phmm_batch_status(b);
+}
+
+int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                 const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                 const uint64_t *out_off, double *out) {
+    if (!h) return PHMM_ERR_INVALID_ARG;
+    phmm_batch *b = phmm_batch_create(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off);
+    if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
+    int st = phmm_batch_upload(b, read_bases, base_q, ins_q, del_q, gcp, hap_bases);
+    // slots the kernels never write (gaps the caller left in out_off) come back as NaN
+    if (st == PHMM_OK && b->n_out && !hip_ok(h, hipMemsetAsync(b->d_out, 0xff, b->n_out * 8, h->stream), "memset out"))
+        st = PHMM_ERR_HIP;
+    if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
+    if (st == PHMM_OK) st = phmm_batch_download(b, out);
+    std::string keep = h->err;
+    phmm_batch_destroy(b);
+    h->err = keep;
+    return st;
+}
+
+uint64_t phmm_batch_cells(const phmm_batch *b) { return b ? b->cells : 0; }
+uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b) { return b ? b->alg_bytes : 0; }
+uint32_t phmm_batch_num_launches(const phmm_batch *b) { return b ? (uint32_t)b->classes.size() : 0; }
+const char *phmm_batch_dominant_kernel(const phmm_batch *b) { return b ? b->dominant.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Internal declarations shared by the C ABI (phmm_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phmm {
+
+constexpr int WAVE = 64;              // CDNA4 wavefront
+constexpr int MAX_WAVES_PER_BLOCK = 4;  // independent waves; a block is only a launch granule
+constexpr int KMAX = 32;              // max haplotype columns per lane
+constexpr int LDS_ROW_BYTES = 6 * 8 + 1;  // per read row staged in LDS: mm mi md ii eq px (f64) + base
+
+// Everything a forward launch needs.  All pointers are device pointers.
+struct ForwardParams {
+    // work list: items of this shape class.  item i -> global read index class_reads[i] (or i when null)
+    const uint32_t *class_reads;
+    uint32_t n_items;
+    // batch metadata (device copies of the ABI offset arrays)
+    const uint32_t *read_region;      // [n_reads] region id of each read
+    const uint32_t *region_read_off;  // [n_regions+1]
+    const uint32_t *region_hap_off;   // [n_regions+1]
+    const uint32_t *read_off;         // [n_reads+1]
+    const uint32_t *hap_off;          // [n_haps+1]
+    const uint64_t *out_off;          // [n_regions+1]
+    // payload
+    const uint8_t *read_bases, *base_q, *ins_q, *del_q, *gcp, *hap_bases;
+    double *out;
+    // tables
+    const double *eps;    // [256]  10^(-q/10)
+    const double *eps_mis;  // [256]  mismatch prior: eps/3 (tristate) or eps
+    const double *mm;     // triangular [256*257/2] match->match
+    // scalars
+    double initial_condition;        // 2^1020
+    double initial_condition_log10;  // log10(2^1020), host libm
+    uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
+    uint32_t *status;                // device status word (bit0: positive result)
+};
+
+// Launch the <L,K> instantiation.  Returns hipErrorInvalidValue if (L,K) is not instantiated.
+hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int waves_per_block, size_t lds_bytes,
+                          hipStream_t stream);
+// Generic any-shape fallback (one thread per pair, rolling rows in global scratch).
+struct GenericParams {
+    ForwardParams f;
+    double *scratch;        // [n_threads_total * 6 * (max_h+1)]
+    uint32_t max_h;         // longest haplotype of the class
+    const uint64_t *pair_first;  // [n_items+1] prefix of pairs per item-read (Nh of its region)
+    uint64_t n_pairs;
+    uint32_t n_blocks;      // grid the scratch was sized for (256 threads per block)
+};
+hipError_t launch_generic(const GenericParams &p, hipStream_t stream);
+
+// The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
+extern const int kInstantiatedK[];
+extern const int kNumInstantiatedK;
+
+}  // namespace phmm

@@ -1,0 +1,131 @@
+"""Thin object wrapper over the C ABI: one `HipPairHMMEngine` == one `phmm_handle`.
+
+All compute happens in libphmm.so's gfx950 kernels; this file only moves pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .batch import RegionBatch
+
+
+class PhmmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("phmm error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DevicePlan:
+    """A `phmm_batch`: launch plan + device copies of the offset arrays."""
+
+    def __init__(self, engine, batch):
+        self.engine = engine
+        self.batch = batch
+        L = engine.lib
+        self._b = L.phmm_batch_create(engine._h, batch.n_regions, _p(batch.region_read_off, _lib.u32p),
+                                      _p(batch.region_hap_off, _lib.u32p), _p(batch.read_off, _lib.u32p),
+                                      _p(batch.hap_off, _lib.u32p), _p(batch.out_off, _lib.u64p))
+        if not self._b:
+            raise PhmmError(_lib.PHMM_ERR_INVALID_ARG, engine.last_error())
+        self._keep = None
+
+    def bind_torch(self, tensors, out):
+        """tensors: dict of uint8 CUDA tensors (read_bases, base_q, ins_q, del_q, gcp, hap_bases);
+        out: float64 CUDA tensor with batch.n_out elements."""
+        self._keep = (tensors, out)
+        ptrs = [tensors[k].data_ptr() for k in ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")]
+        self.engine._check(self.engine.lib.phmm_batch_bind_device(self._b, *ptrs, out.data_ptr()))
+
+    def upload(self):
+        b = self.batch
+        self.engine._check(self.engine.lib.phmm_batch_upload(
+            self._b, _p(b.read_bases, _lib.u8p), _p(b.base_q, _lib.u8p), _p(b.ins_q, _lib.u8p),
+            _p(b.del_q, _lib.u8p), _p(b.gcp, _lib.u8p), _p(b.hap_bases, _lib.u8p)))
+
+    def launch(self, stream=None):
+        """Enqueue the forward kernels.  stream: raw hipStream_t as int (e.g.
+        torch.cuda.current_stream().cuda_stream) or None for the engine's own stream."""
+        self.engine._check(self.engine.lib.phmm_batch_launch(self._b, C.c_void_p(stream) if stream else None))
+
+    def download(self):
+        out = np.empty(self.batch.n_out, dtype=np.float64)
+        self.engine._check(self.engine.lib.phmm_batch_download(self._b, _p(out, _lib.f64p)))
+        return out
+
+    def status(self):
+        self.engine._check(self.engine.lib.phmm_batch_status(self._b))
+
+    @property
+    def cells(self):
+        return int(self.engine.lib.phmm_batch_cells(self._b))
+
+    @property
+    def algorithmic_bytes(self):
+        return int(self.engine.lib.phmm_batch_algorithmic_bytes(self._b))
+
+    @property
+    def num_launches(self):
+        return int(self.engine.lib.phmm_batch_num_launches(self._b))
+
+    @property
+    def dominant_kernel(self):
+        return self.engine.lib.phmm_batch_dominant_kernel(self._b).decode()
+
+    def close(self):
+        if self._b:
+            self.engine.lib.phmm_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipPairHMMEngine:
+    """phmm_create / phmm_destroy.  Raises if there is no HIP device (no CPU fallback)."""
+
+    def __init__(self, device_id=0, do_not_use_tristate_correction=False):
+        self.lib = _lib.load()
+        flags = _lib.PHMM_FLAG_NO_TRISTATE if do_not_use_tristate_correction else 0
+        self._h = self.lib.phmm_create(int(device_id), flags)
+        if not self._h:
+            raise PhmmError(_lib.PHMM_ERR_NO_DEVICE, self.lib.phmm_last_error(None).decode())
+
+    def last_error(self):
+        return self.lib.phmm_last_error(self._h).decode()
+
+    def _check(self, code):
+        if code != _lib.PHMM_OK:
+            raise PhmmError(code, self.last_error())
+
+    def compute(self, batch: RegionBatch):
+        """Synchronous phmm_compute on host arrays.  Returns out (float64, batch.n_out)."""
+        out = np.empty(batch.n_out, dtype=np.float64)
+        self._check(self.lib.phmm_compute(
+            self._h, batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
+            _p(batch.read_off, _lib.u32p), _p(batch.read_bases, _lib.u8p), _p(batch.base_q, _lib.u8p),
+            _p(batch.ins_q, _lib.u8p), _p(batch.del_q, _lib.u8p), _p(batch.gcp, _lib.u8p),
+            _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(batch.out_off, _lib.u64p),
+            _p(out, _lib.f64p)))
+        return out
+
+    def plan(self, batch: RegionBatch):
+        return DevicePlan(self, batch)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.phmm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (oracle/pairhmm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from lorikeet_amd/ (the product path has no CPU fallback).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+
+
+def build(native=False):
+    """(Re)build liboracle.so with gcc.  native=True adds -march=native (bench cpu_baseline on the
+    box it runs on); the default build is portable so the .so made here runs on the GPU box."""
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+    return os.path.join(_HERE, target)
+
+
+def _load(path):
+    lib = C.CDLL(path)
+    lib.oracle_qual_to_error_prob.restype = C.c_double
+    lib.oracle_qual_to_error_prob.argtypes = [C.c_uint8]
+    lib.oracle_qual_to_prob.restype = C.c_double
+    lib.oracle_qual_to_prob.argtypes = [C.c_uint8]
+    lib.oracle_approximate_log10_sum_log10.restype = C.c_double
+    lib.oracle_approximate_log10_sum_log10.argtypes = [C.c_double, C.c_double]
+    lib.oracle_match_to_match_prob.restype = C.c_double
+    lib.oracle_match_to_match_prob.argtypes = [C.c_uint, C.c_uint]
+    lib.oracle_qual_to_trans_probs.restype = None
+    lib.oracle_qual_to_trans_probs.argtypes = [_f64p, C.c_uint8, C.c_uint8, C.c_uint8]
+    lib.oracle_pairhmm_new.restype = C.c_void_p
+    lib.oracle_pairhmm_new.argtypes = [C.c_size_t, C.c_size_t]
+    lib.oracle_pairhmm_free.restype = None
+    lib.oracle_pairhmm_free.argtypes = [C.c_void_p]
+    lib.oracle_pairhmm_do_not_use_tristate_correction.restype = None
+    lib.oracle_pairhmm_do_not_use_tristate_correction.argtypes = [C.c_void_p]
+    lib.oracle_find_first_position_where_haplotypes_differ.restype = C.c_size_t
+    lib.oracle_find_first_position_where_haplotypes_differ.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t]
+    lib.oracle_compute_read_likelihood_given_haplotype_log10.restype = C.c_double
+    lib.oracle_compute_read_likelihood_given_haplotype_log10.argtypes = [
+        C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, _u8p, _u8p, _u8p, C.c_int, _u8p, C.c_size_t,
+        C.POINTER(C.c_int)]
+    lib.oracle_compute.restype = C.c_int
+    lib.oracle_compute.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u32p, _u8p,
+                                   _u64p, _f64p, C.c_int, C.c_int]
+    lib.oracle_mm_table_len.restype = C.c_size_t
+    lib.oracle_mm_prob_table.restype = _f64p
+    return lib
+
+
+_lib = None
+
+
+def lib(native=False):
+    global _lib
+    if native:
+        return _load(build(native=True))
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = _load(path)
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a,
+                             dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+class OraclePairHMM:
+    """Mirror of the reference's scalar PairHMM object (pair_hmm.rs:128-165, 405-501)."""
+
+    def __init__(self, max_read_length, max_haplotype_length):
+        self._lib = lib()
+        self._h = self._lib.oracle_pairhmm_new(max_read_length, max_haplotype_length)
+
+    def do_not_use_tristate_correction(self):
+        self._lib.oracle_pairhmm_do_not_use_tristate_correction(self._h)
+
+    def compute_read_likelihood_given_haplotype_log10(self, hap, read, quals, ins, dele, gcp, recache=True,
+                                                      next_hap=None):
+        hap_a, hap_p = _u8(hap)
+        read_a, read_p = _u8(read)
+        q_a, q_p = _u8(quals)
+        i_a, i_p = _u8(ins)
+        d_a, d_p = _u8(dele)
+        g_a, g_p = _u8(gcp)
+        assert len(q_a) == len(read_a) == len(i_a) == len(d_a) == len(g_a)
+        if next_hap is None:
+            n_a, n_p, n_len = None, None, 0
+        else:
+            n_a, n_p = _u8(next_hap)
+            n_len = len(n_a)
+        st = C.c_int(0)
+        v = self._lib.oracle_compute_read_likelihood_given_haplotype_log10(
+            self._h, hap_p, len(hap_a), read_p, len(read_a), q_p, i_p, d_p, g_p, int(bool(recache)), n_p, n_len,
+            C.byref(st))
+        if st.value not in (0,):
+            raise AssertionError({1: "Must call initialize first", 2: "Haplotype bases is too long",
+                                  4: "PairHmm Log Probability cannot be greater than 0.0"}.get(st.value, "error"))
+        return v
+
+    def __del__(self):
+        try:
+            self._lib.oracle_pairhmm_free(self._h)
+        except Exception:
+            pass
+
+
+def compute_batch(batch, disable_tristate=False, n_threads=1, native=False):
+    """batch: dict with the SoA arrays of include/phmm.h (numpy).  Returns out (float64)."""
+    L = lib(native=native)
+    rro = np.ascontiguousarray(batch["region_read_off"], dtype=np.uint32)
+    rho = np.ascontiguousarray(batch["region_hap_off"], dtype=np.uint32)
+    ro = np.ascontiguousarray(batch["read_off"], dtype=np.uint32)
+    ho = np.ascontiguousarray(batch["hap_off"], dtype=np.uint32)
+    oo = np.ascontiguousarray(batch["out_off"], dtype=np.uint64)
+    arrs = [np.ascontiguousarray(batch[k], dtype=np.uint8) for k in
+            ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")]
+    out = np.zeros(int(oo[-1]), dtype=np.float64)
+    p8 = [a.ctypes.data_as(_u8p) for a in arrs]
+    st = L.oracle_compute(len(rro) - 1, rro.ctypes.data_as(_u32p), rho.ctypes.data_as(_u32p),
+                          ro.ctypes.data_as(_u32p), p8[0], p8[1], p8[2], p8[3], p8[4], ho.ctypes.data_as(_u32p),
+                          p8[5], oo.ctypes.data_as(_u64p), out.ctypes.data_as(_f64p), int(disable_tristate),
+                          int(n_threads))
+    if st:
+        raise AssertionError("oracle status %d" % st)
+    return out
+
+
+def load_kat(path):
+    """Parse the reference fixture pairhmm-testdata.txt the way
+    tests/vector_pair_hmm_unit_tests.rs:22-50 does (ASCII-33; base quals floored at 6)."""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            t = line.split()
+            hap, read = t[0].encode(), t[1].encode()
+
+            def q(s, lo):
+                return np.maximum(np.frombuffer(s.encode(), dtype=np.uint8).astype(np.int32) - 33, lo).astype(np.uint8)
+            rows.append(dict(hap=hap, read=read, qual=q(t[2], 6), ins=q(t[3], 0), dele=q(t[4], 0), gcp=q(t[5], 0),
+                             expected=float(t[6])))
+    return rows
