@@ -57,6 +57,13 @@ def load():
         raise RuntimeError(
             "lorikeet_amd: %s not found -- the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)." % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64; if libphmm.so pulled in the system
+    # copy first, torch's later initialisation would see "No HIP GPUs".  Import torch first (when it is
+    # installed) so both resolve to the same runtime.  Plain C / Rust callers link the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
