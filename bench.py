@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- PairHMM cell-updates/s (GCUPS) on MI355X, the metric BASELINE.json names.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (phmm_batch_launch: the forward kernels, nothing else) over
+one batch of synthetic assembly regions already resident in HBM.  Workload at every N: per GPU
+`--regions` (default 1024) regions of the BASELINE.json configs[1] shape -- 128 reads x 8
+haplotypes, 150 bp reads, 300 bp haplotypes -- i.e. SURVEY.md 8(d)'s batched form of config 2;
+rank r draws its own regions (seed base+r): regions shard across GPUs with no collective ("weak"
+scaling).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     algorithmic HBM bytes (5*sum R + sum H + 8*Nr*Nh per region) per launch
+               / the dominant kernel's mean launch duration (HIP events on the launch stream), vs
+               8 TB/s.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes, read from
+               profiles/ (null if no summary for this workload is committed).  The path is NOT
+               HBM-bound: `valu_f64` carries the binding roofline next to it.
+  cpu_baseline the CPU oracle (C port of the reference's scalar path, oracle/) on the host cores of
+               this box, rank 0 at N=1 only, on a bounded sample of the same regions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_F64_PEAK_TFLOPS = 78.6  # vector FP64 peak (256 CU * 2.4 GHz * 128 flop/clk)
+FLOP_PER_CELL = 12           # M 4 mul + 2 add, I 2+1, D 2+1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--regions", type=int, default=1024, help="regions per GPU per step")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_workload(name, n_regions, seed):
+    from lorikeet_amd import synthetic
+    if name == "config2":
+        return synthetic.config2(n_regions, seed=seed), "128 reads x 8 haps, R=150, H=300"
+    if name == "config3":
+        return synthetic.config3(n_regions, seed=seed), "128 reads x 8 haps, H=300, R in {100,150,250}"
+    return synthetic.config5(n_regions, seed=seed), "512 reads x 64 haps, R=150, H=400"
+
+
+def cpu_baseline(batch, budget_s=20.0):
+    """Oracle ("port" of the reference's scalar path) on all host cores, bounded sample."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    # calibrate on one region per core, then size the sample to ~budget_s
+    n0 = min(batch.n_regions, cores)
+    sub = batch.region_slice(0, n0)
+    t = time.perf_counter()
+    oracle.compute_batch(sub.as_dict(), n_threads=cores, native=native)
+    dt0 = time.perf_counter() - t
+    rounds = max(1, min(int(budget_s / max(dt0, 1e-3)), batch.n_regions // n0))
+    n1 = n0 * rounds
+    sub = batch.region_slice(0, n1)
+    t = time.perf_counter()
+    oracle.compute_batch(sub.as_dict(), n_threads=cores, native=native)
+    dt = time.perf_counter() - t
+    return {"value": round(sub.cells() / dt / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "first %d regions of rank 0's batch (%.3g cells, %.1f s); oracle/pairhmm_oracle.c, f64 scalar, "
+                      "one region per pthread task%s" % (n1, sub.cells(), dt, ", -march=native" if native else "")}
+
+
+def pmc_traffic(workload, regions):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        for e in json.load(open(path)):
+            if e["workload"] == workload and e["regions"] == regions:
+                return e["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # barrier + max-over-ranks only; no data-path collective
+
+    from lorikeet_amd import HipPairHMMEngine
+    batch, shape = make_workload(a.workload, a.regions, a.seed + rank)
+    eng = HipPairHMMEngine(local_rank)
+    plan = eng.plan(batch)
+    tens = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in
+            ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
+    out = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
+    plan.bind_torch(tens, out)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for _ in range(a.warmup):
+            plan.launch(sh)
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        for i in range(a.steps):
+            plan.launch(sh)
+            ev[i + 1].record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    plan.status()  # raises if any likelihood came out > 0
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    cells_total = plan.cells * world  # identical shapes on every rank
+    regions_total = batch.n_regions * world
+
+    if rank == 0:
+        res = out.cpu().numpy()
+        assert (res <= 0).all(), "non-finite or positive likelihoods"
+        mean_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3 / max(plan.num_launches, 1)
+        alg_bytes = plan.algorithmic_bytes
+        achieved_gbs = alg_bytes / mean_kernel_s / 1e9
+        line = {
+            "metric": "PairHMM cell-updates/s (GCUPS)",
+            "value": round(cells_total * a.steps / elapsed / 1e9, 2),
+            "unit": "GCUPS",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s x %d regions per GPU: %s (BASELINE.json configs[1] shape, batched per "
+                                   "SURVEY 8d)" % (a.workload, a.regions, shape)
+                       if a.workload == "config2" else "%s x %d regions per GPU: %s" % (a.workload, a.regions, shape),
+                       "regions_per_gpu": a.regions, "pairs_per_gpu": int(batch.n_out),
+                       "cells_per_gpu_per_step": int(plan.cells), "seed": a.seed,
+                       "sharding": "regions, one process per GPU, no collective"},
+            "regions_per_s": round(regions_total * a.steps / elapsed, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(a.workload, a.regions),
+                         "kernel": plan.dominant_kernel, "kernel_ms": round(mean_kernel_s * 1e3, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "compulsory traffic is 2.3e-3 B/cell: the path is FP64-VALU bound, see valu_f64"},
+            "valu_f64": {"achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
+                         "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
+                         "flop_per_cell": FLOP_PER_CELL},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
