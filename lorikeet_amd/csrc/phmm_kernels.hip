@@ -18,6 +18,8 @@
 // count and there is no divergence except the start-up / drain predicate.
 #include "phmm_internal.hpp"
 
+#include <type_traits>
+
 namespace phmm {
 
 // ---- DPP lane shifts (zero fill where there is no source lane) ---------------------------------
@@ -45,31 +47,95 @@ __device__ __forceinline__ double from_left(double v, bool group_head) {
     return __hiloint2double(hi, lo);
 }
 
-struct RowConst {  // per read row, staged in LDS
-    double mm, mi, md, ii, eq, px;
-    uint32_t x;
+// Per read row, staged in wave-private LDS as one 56-byte record: all seven fields of a row are
+// reached from ONE address register with immediate offsets.  A 56-byte stride maps 32 consecutive
+// rows onto 32 distinct bank pairs, so the staggered per-lane reads (lane l reads row t-l) are
+// conflict-free, and lanes of different haplotype groups reading the same row broadcast.
+struct alignas(8) RowConst {
+    double mm, mi, md, ii, eq, px;  // match->match, match->ins, match->del, gap ext., eps(q), mismatch prior
+    uint32_t x, pad;                // read base
 };
+static_assert(sizeof(RowConst) == 56, "LDS row record");
 
 struct LdsView {
-    const double *mm, *mi, *md, *ii, *eq, *px;
-    const uint8_t *x;
-    __device__ __forceinline__ RowConst load(int row) const {
-        RowConst c;
-        c.mm = mm[row];
-        c.mi = mi[row];
-        c.md = md[row];
-        c.ii = ii[row];
-        c.eq = eq[row];
-        c.px = px[row];
-        c.x = x[row];
-        return c;
+    const RowConst *rows;  // index 0 = neutral row, read row r at index r+1
+    __device__ __forceinline__ RowConst load(int idx) const { return rows[idx]; }
+};
+
+// compile-time k = K-1 .. 0
+template <int K, class F>
+__device__ __forceinline__ void static_for_down(F &&f) {
+    if constexpr (K > 0) {
+        f(std::integral_constant<int, K - 1>{});
+        static_for_down<K - 1>(f);
+    }
+}
+
+// Haplotype columns of a lane, two 16-bit fields per dword (column k of the lane = l*K+k): the
+// compare then is a single v_cmp_eq_u16 with a half-word select, no extraction ops.
+template <int K>
+struct HapCols {
+    static constexpr int W = (K + 1) / 2;
+    uint32_t y[W];  // base (0 where the haplotype has 'N' and HAPN is set)
+    uint32_t m[W];  // HAPN only: 0xff = compare, 0x00 = wildcard column
+    __device__ __forceinline__ uint16_t base(int k) const { return (uint16_t)(y[k >> 1] >> (16 * (k & 1))); }
+    __device__ __forceinline__ uint16_t mask(int k) const { return (uint16_t)(m[k >> 1] >> (16 * (k & 1))); }
+    __device__ __forceinline__ void set(int k, uint32_t yv, uint32_t mv) {
+        y[k >> 1] |= yv << (16 * (k & 1));
+        m[k >> 1] |= mv << (16 * (k & 1));
     }
 };
 
+// One read row for the K columns of this lane, every register updated in place.
+//   in : Mp/Ip/Dp = row i-1;  (plM,plI,plD) = left neighbour's last column, row i-1;
+//        (lM,lD) = left neighbour's last column, row i
+//   out: Mp/Ip/Dp = row i
+template <int K, bool HAPN>
+__device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], double (&Dp)[K], const double plM,
+                                           const double plI, const double plD, const double lM, const double lD,
+                                           const RowConst &c, const HapCols<K> &hc) {
+    const double im = 1.0 - c.ii;  // qual_to_prob(gcp)
+    const double pm = 1.0 - c.eq;  // qual_to_prob(q)
+    // Pass 1, columns right-to-left: I(i,k) reads the old M/I of column k, then M(i,k) overwrites
+    // M[k] using the still-old column k-1.
+    static_for_down<K>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double prior;
+        const uint16_t x16 = (uint16_t)c.x;
+        if constexpr (HAPN)
+            prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? pm : c.px;
+        else
+            prior = (x16 == hc.base(k)) ? pm : c.px;
+        // I(i,k) = M(i-1,k)*mi + I(i-1,k)*ii, written so the two-address FMA accumulates into I's own
+        // register (v_mul I,I,ii ; v_fmac I,M,mi) -- no copy of the old value is needed
+        Ip[k] = fma(Mp[k], c.mi, Ip[k] * c.ii);
+        const double dM = k ? Mp[k - 1] : plM;   // (i-1, k-1)
+        const double dI = k ? Ip[k - 1] : plI;
+        const double dD = k ? Dp[k - 1] : plD;
+        double a = dM * c.mm;
+        a = fma(dI, im, a);
+        a = fma(dD, im, a);
+        Mp[k] = prior * a;
+    });
+    // Pass 2, left-to-right: the serial chain D(i,k) = M(i,k-1)*md + D(i,k-1)*dd.
+    double leftM = lM, leftD = lD;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        Dp[k] = fma(leftD, c.ii, leftM * c.md);
+        leftM = Mp[k];
+        leftD = Dp[k];
+    }
+}
+
 // One (read x up-to-64/L haplotypes) sweep.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
+//
+// Step t: lane l works on read row t-l.  LDS row index 0 holds a NEUTRAL row (mi=md=0, ii=1,
+// eq=1, px=0) under which the row-0 state (M=0, I=0, D=c) is a fixed point, so lanes that have not
+// started yet simply run it: the first R steps need no predicate at all.  Only the L-1 drain steps
+// (lanes past their last row must freeze) are predicated.
 template <int L, int K, bool HAPN>
 __device__ __forceinline__ double sweep(const LdsView &lds, const int R, const int l, const bool group_head,
-                                        const uint32_t (&yc)[K], const int H, const double c) {
+                                        const HapCols<K> &hc, const int H, const double c) {
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -77,55 +143,53 @@ __device__ __forceinline__ double sweep(const LdsView &lds, const int R, const i
         Ip[k] = 0.0;
         Dp[k] = c;  // D[0][j] = 2^1020 / H for every column (pair_hmm.rs:515-529)
     }
-    // (row i-1) values of the left neighbour's last column; row 0 there is (0, 0, c)
-    double plM = 0.0, plI = 0.0, plD = c;
-
-    const int nsteps = R + L - 1;
-    int row = -l;  // 0-based read row this lane works on at step t (= t - l)
-    const int rmax = R - 1;
-    RowConst cur = lds.load(max(min(row, rmax), 0));
-    for (int t = 0; t < nsteps; ++t) {
-        const int nrow = row + 1;
-        const RowConst nxt = lds.load(max(min(nrow, rmax), 0));  // one step ahead
-        // left neighbour's last column after ITS previous step == row `row` there
+    // (row i-1) values of the left neighbour's last column; row 0 there is (0, 0, c).
+    // Two steps per trip with the roles of the (constants, left-column) register sets swapped, so
+    // nothing is copied between steps: step A reads cA / previous-left B and fills cB / left A, step B
+    // the other way round.
+    double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c;
+    int row = -l;  // 0-based read row of this lane at step t (= t - l); LDS index = row + 1
+    RowConst cA = lds.load(max(row + 1, 0)), cB;
+    // ---- fill + steady state: no lane has finished yet, no predicate ----
+    int t = 0;
+    for (; t + 1 < R; t += 2) {
+        cB = lds.load(max(row + 2, 0));  // one step ahead (index R at most)
+        aM = from_left<L>(Mp[K - 1], group_head);
+        aI = from_left<L>(Ip[K - 1], group_head);
+        aD = from_left<L>(Dp[K - 1], group_head);
+        row_update<K, HAPN>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc);
+        cA = lds.load(max(row + 3, 0));
+        bM = from_left<L>(Mp[K - 1], group_head);
+        bI = from_left<L>(Ip[K - 1], group_head);
+        bD = from_left<L>(Dp[K - 1], group_head);
+        row_update<K, HAPN>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc);
+        row += 2;
+    }
+    RowConst cur = cA;
+    double plM = bM, plI = bI, plD = bD;
+    if (t < R) {  // odd read length: one more unpredicated step
+        const RowConst nxt = lds.load(max(row + 2, 0));
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        if (row >= 0 && row < R) {
-            const double im = 1.0 - cur.ii;  // qual_to_prob(gcp)
-            const double pm = 1.0 - cur.eq;  // qual_to_prob(q)
-            // Pass 1, columns right-to-left so every register is updated in place: I(i,k) reads the old
-            // M/I of column k, then M(i,k) overwrites M[k] using the still-old column k-1.
-#pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                bool match;
-                if constexpr (HAPN)
-                    match = (cur.x & (yc[k] >> 8)) == (yc[k] & 0xffu);
-                else
-                    match = cur.x == yc[k];
-                const double prior = match ? pm : cur.px;
-                Ip[k] = fma(Ip[k], cur.ii, Mp[k] * cur.mi);  // I(i,k) = M(i-1,k)*mi + I(i-1,k)*ii
-                const double dM = k ? Mp[k - 1] : plM;       // (i-1, k-1)
-                const double dI = k ? Ip[k - 1] : plI;
-                const double dD = k ? Dp[k - 1] : plD;
-                double a = dM * cur.mm;
-                a = fma(dI, im, a);
-                a = fma(dD, im, a);
-                Mp[k] = prior * a;
-            }
-            // Pass 2, left-to-right: the serial D chain D(i,k) = M(i,k-1)*md + D(i,k-1)*dd.
-            double leftM = lM, leftD = lD;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                Dp[k] = fma(leftD, cur.ii, leftM * cur.md);
-                leftM = Mp[k];
-                leftD = Dp[k];
-            }
-        }
+        row_update<K, HAPN>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc);
         plM = lM;
         plI = lI;
         plD = lD;
-        row = nrow;
+        ++row;
+        cur = nxt;
+    }
+    // ---- drain: lane l still has rows while row < R ----
+    for (int d = 0; d < L - 1; ++d) {
+        const RowConst nxt = lds.load(max(min(row + 2, R), 0));
+        const double lM = from_left<L>(Mp[K - 1], group_head);
+        const double lI = from_left<L>(Ip[K - 1], group_head);
+        const double lD = from_left<L>(Dp[K - 1], group_head);
+        if (row < R) row_update<K, HAPN>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc);
+        plM = lM;
+        plI = lI;
+        plD = lD;
+        ++row;
         cur = nxt;
     }
     double s = 0.0;
@@ -136,7 +200,7 @@ __device__ __forceinline__ double sweep(const LdsView &lds, const int R, const i
 }
 
 template <int L, int K>
-__global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) void phmm_forward(const ForwardParams p) {
+__global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void phmm_forward(const ForwardParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -152,12 +216,13 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) void phmm_forward(const 
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
     double *out_row = p.out + p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh;
 
-    // ---- stage this read's per-row constants in wave-private LDS (SoA, conflict-free) ----------
-    const uint32_t rows = p.lds_rows;  // multiple of 8
-    unsigned char *base = smem + (size_t)wave * rows * 56u;
-    double *s_mm = reinterpret_cast<double *>(base);
-    double *s_mi = s_mm + rows, *s_md = s_mi + rows, *s_ii = s_md + rows, *s_eq = s_ii + rows, *s_px = s_eq + rows;
-    uint8_t *s_x = reinterpret_cast<uint8_t *>(s_px + rows);
+    // ---- stage this read's per-row constants in wave-private LDS (56-byte records, conflict-free) ----------
+    RowConst *srow = reinterpret_cast<RowConst *>(smem) + (size_t)wave * p.lds_rows;
+    if (lane == 0) {  // neutral row: keeps (M, I, D) = (0, 0, c) fixed for lanes that have not started
+        RowConst n;
+        n.mm = 0.0; n.mi = 0.0; n.md = 0.0; n.ii = 1.0; n.eq = 1.0; n.px = 0.0; n.x = 0; n.pad = 0;
+        srow[0] = n;
+    }
     for (int row = lane; row < R; row += WAVE) {
         const uint32_t x = p.read_bases[ro + row];
         const uint32_t q = p.base_q[ro + row];
@@ -165,20 +230,22 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) void phmm_forward(const 
         const uint32_t dq = p.del_q[ro + row];
         const uint32_t g = p.gcp[ro + row];
         const uint32_t mx = max(iq, dq), mn = min(iq, dq);
-        const double eq = p.eps[q];
-        s_mm[row] = p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
-        s_mi[row] = p.eps[iq];
-        s_md[row] = p.eps[dq];
-        s_ii[row] = p.eps[g];
-        s_eq[row] = eq;
-        s_px[row] = (x == 'N') ? (1.0 - eq) : p.eps_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
-        s_x[row] = (uint8_t)x;
+        RowConst n;
+        n.eq = p.eps[q];
+        n.mm = p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
+        n.mi = p.eps[iq];
+        n.md = p.eps[dq];
+        n.ii = p.eps[g];
+        n.px = (x == 'N') ? (1.0 - n.eq) : p.eps_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
+        n.x = x;
+        n.pad = 0;
+        srow[row + 1] = n;
     }
     // LDS ops of one wave execute in order; only the compiler must not reorder across this point.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const LdsView lds{s_mm, s_mi, s_md, s_ii, s_eq, s_px, s_x};
+    const LdsView lds{srow};
     const bool group_head = (L == 32) && (lane == 32);
 
     const int nquads = (Nh + G - 1) / G;
@@ -191,23 +258,27 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) void phmm_forward(const 
             ho = p.hap_off[h0 + a];
             H = (int)(p.hap_off[h0 + a + 1] - ho);
         }
-        uint32_t yc[K];
+        HapCols<K> hc;
         bool lane_n = false;
+#pragma unroll
+        for (int w = 0; w < HapCols<K>::W; ++w) {
+            hc.y[w] = 0u;
+            hc.m[w] = 0u;
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int col = l * K + k;
             const uint32_t y = (col < H) ? (uint32_t)p.hap_bases[ho + col] : 0u;
-            yc[k] = y;
-            lane_n |= (y == 'N');
+            const bool is_n = (y == 'N');
+            lane_n |= is_n;
+            hc.set(k, is_n ? 0u : y, is_n ? 0u : 0xffu);
         }
         const double c = p.initial_condition / (double)H;
         double s;
-        if (__ballot(lane_n) != 0ull) {  // rare: haplotype 'N' is a wildcard too
-#pragma unroll
-            for (int k = 0; k < K; ++k) yc[k] = (yc[k] == 'N') ? 0u : (yc[k] | 0xff00u);
-            s = sweep<L, K, true>(lds, R, l, group_head, yc, H, c);
+        if (__ballot(lane_n) != 0ull) {  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643)
+            s = sweep<L, K, true>(lds, R, l, group_head, hc, H, c);
         } else {
-            s = sweep<L, K, false>(lds, R, l, group_head, yc, H, c);
+            s = sweep<L, K, false>(lds, R, l, group_head, hc, H, c);
         }
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
