@@ -30,7 +30,7 @@ std::mutex g_err_mu;
 std::string g_create_err = "";
 
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
-constexpr size_t kLdsRowBytes = 56;  // 6 f64 + 1 byte, rows rounded to a multiple of 8
+constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
 constexpr uint32_t kNumSimd = 256 * 4;
 constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 

@@ -8,7 +8,7 @@ namespace phmm {
 constexpr int WAVE = 64;              // CDNA4 wavefront
 constexpr int MAX_WAVES_PER_BLOCK = 4;  // independent waves; a block is only a launch granule
 constexpr int KMAX = 32;              // max haplotype columns per lane
-constexpr int LDS_ROW_BYTES = 6 * 8 + 1;  // per read row staged in LDS: mm mi md ii eq px (f64) + base
+constexpr int LDS_ROW_BYTES = 72;         // sizeof(RowConst): per read row staged in LDS
 
 // Everything a forward launch needs.  All pointers are device pointers.
 struct ForwardParams {

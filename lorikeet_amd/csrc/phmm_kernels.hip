@@ -47,15 +47,25 @@ __device__ __forceinline__ double from_left(double v, bool group_head) {
     return __hiloint2double(hi, lo);
 }
 
-// Per read row, staged in wave-private LDS as one 56-byte record: all seven fields of a row are
-// reached from ONE address register with immediate offsets.  A 56-byte stride maps 32 consecutive
+// Per read row, staged in wave-private LDS as one 72-byte record: all fields of a row are reached
+// from ONE address register with immediate offsets.  A 72-byte stride (18 dwords) maps 32 consecutive
 // rows onto 32 distinct bank pairs, so the staggered per-lane reads (lane l reads row t-l) are
 // conflict-free, and lanes of different haplotype groups reading the same row broadcast.
+//
+// The record holds the coefficients of the row update in the form the kernel evaluates it:
+//   M(i,k) = prior * ( M(i-1,k-1)*mm + (I^(i-1,k-1) + D^(i-1,k-1)) * imx )
+//   I^(i,k) = M(i-1,k)*bI + I^(i-1,k)*gI
+//   D^(i,k) = M(i,k-1)*dD + D^(i,k-1)*dd
+// Plain rows (any read):       I^ = I, D^ = D, bI = mi, gI = ii, dD = md, dd = ii, imx = im = 1 - dd.
+// Pre-scaled rows (no gcp==0): I^(i) = I(i)*im(i+1), D^(i) = D(i)*im(i+1) with im(R+1) = 1, so the
+//   indel->match factor is already folded in (imx == 1, one f64 op less per cell):
+//   bI = mi*im(i+1), gI = ii*im(i+1)/im(i), dD = md*im(i+1), dd = ii.
 struct alignas(8) RowConst {
-    double mm, mi, md, ii, eq, px;  // match->match, match->ins, match->del, gap ext., eps(q), mismatch prior
-    uint32_t x, pad;                // read base
+    double mm, bI, gI, dD, dd, pm, px;  // pm = 1 - eps(q) (match prior), px = mismatch prior
+    uint32_t x, pad0;                   // read base
+    double pad1;
 };
-static_assert(sizeof(RowConst) == 56, "LDS row record");
+static_assert(sizeof(RowConst) == 72, "LDS row record");
 
 struct LdsView {
     const RowConst *rows;  // index 0 = neutral row, read row r at index r+1
@@ -90,79 +100,75 @@ struct HapCols {
 //   in : Mp/Ip/Dp = row i-1;  (plM,plI,plD) = left neighbour's last column, row i-1;
 //        (lM,lD) = left neighbour's last column, row i
 //   out: Mp/Ip/Dp = row i
-template <int K, bool HAPN>
+// FAST: pre-scaled rows and a haplotype without 'N' (the common case).  Otherwise the general form:
+// `imx` multiplies the indel->match term (1.0 for pre-scaled rows) and the compare honours the
+// haplotype wildcard mask.
+template <int K, bool FAST>
 __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], double (&Dp)[K], const double plM,
                                            const double plI, const double plD, const double lM, const double lD,
-                                           const RowConst &c, const HapCols<K> &hc) {
-    const double im = 1.0 - c.ii;  // qual_to_prob(gcp)
-    const double pm = 1.0 - c.eq;  // qual_to_prob(q)
+                                           const RowConst &c, const HapCols<K> &hc, const double imx) {
+    const uint16_t x16 = (uint16_t)c.x;
     // Pass 1, columns right-to-left: I(i,k) reads the old M/I of column k, then M(i,k) overwrites
     // M[k] using the still-old column k-1.
     static_for_down<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         double prior;
-        const uint16_t x16 = (uint16_t)c.x;
-        if constexpr (HAPN)
-            prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? pm : c.px;
+        if constexpr (FAST)
+            prior = (x16 == hc.base(k)) ? c.pm : c.px;
         else
-            prior = (x16 == hc.base(k)) ? pm : c.px;
-        // I(i,k) = M(i-1,k)*mi + I(i-1,k)*ii, written so the two-address FMA accumulates into I's own
-        // register (v_mul I,I,ii ; v_fmac I,M,mi) -- no copy of the old value is needed
-        Ip[k] = fma(Mp[k], c.mi, Ip[k] * c.ii);
-        const double dM = k ? Mp[k - 1] : plM;   // (i-1, k-1)
+            prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? c.pm : c.px;
+        // written so the two-address FMA accumulates into I's own register (v_mul I,I,gI ; v_fmac I,M,bI)
+        Ip[k] = fma(Mp[k], c.bI, Ip[k] * c.gI);
+        const double dM = k ? Mp[k - 1] : plM;  // (i-1, k-1)
         const double dI = k ? Ip[k - 1] : plI;
         const double dD = k ? Dp[k - 1] : plD;
-        double a = dM * c.mm;
-        a = fma(dI, im, a);
-        a = fma(dD, im, a);
-        Mp[k] = prior * a;
+        double t = dI + dD;
+        if constexpr (!FAST) t *= imx;
+        Mp[k] = prior * fma(dM, c.mm, t);
     });
-    // Pass 2, left-to-right: the serial chain D(i,k) = M(i,k-1)*md + D(i,k-1)*dd.
+    // Pass 2, left-to-right: the serial chain D(i,k) = M(i,k-1)*dD + D(i,k-1)*dd.
     double leftM = lM, leftD = lD;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        Dp[k] = fma(leftD, c.ii, leftM * c.md);
+        Dp[k] = fma(leftD, c.dd, leftM * c.dD);
         leftM = Mp[k];
         leftD = Dp[k];
     }
 }
 
-// One (read x up-to-64/L haplotypes) sweep.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
-//
-// Step t: lane l works on read row t-l.  LDS row index 0 holds a NEUTRAL row (mi=md=0, ii=1,
-// eq=1, px=0) under which the row-0 state (M=0, I=0, D=c) is a fixed point, so lanes that have not
-// started yet simply run it: the first R steps need no predicate at all.  Only the L-1 drain steps
-// (lanes past their last row must freeze) are predicated.
-template <int L, int K, bool HAPN>
-__device__ __forceinline__ double sweep(const LdsView &lds, const int R, const int l, const bool group_head,
-                                        const HapCols<K> &hc, const int H, const double c) {
+// Sweeps.  Step t: lane l works on read row t-l.  LDS row index 0 holds a NEUTRAL row (bI=dD=0,
+// gI=dd=1, pm=px=0) under which the row-0 state (M=0, I=0, D=c0) is an exact fixed point, so lanes
+// that have not started yet simply run it: the first R steps need no predicate at all.  Only the L-1
+// drain steps (lanes past their last row must freeze) are predicated.
+// c0 = D(0,j) = 2^1020/H (pair_hmm.rs:515-529), times im(1) for pre-scaled rows.
+
+// Fast sweep: two steps per trip with the roles of the (constants, left-column) register sets swapped,
+// so nothing is copied between steps.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
+template <int L, int K>
+__device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, const int l, const bool group_head,
+                                             const HapCols<K> &hc, const int H, const double c0) {
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         Mp[k] = 0.0;
         Ip[k] = 0.0;
-        Dp[k] = c;  // D[0][j] = 2^1020 / H for every column (pair_hmm.rs:515-529)
+        Dp[k] = c0;
     }
-    // (row i-1) values of the left neighbour's last column; row 0 there is (0, 0, c).
-    // Two steps per trip with the roles of the (constants, left-column) register sets swapped, so
-    // nothing is copied between steps: step A reads cA / previous-left B and fills cB / left A, step B
-    // the other way round.
-    double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c;
+    double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c0;  // left neighbour's last column: row i / row i-1
     int row = -l;  // 0-based read row of this lane at step t (= t - l); LDS index = row + 1
     RowConst cA = lds.load(max(row + 1, 0)), cB;
-    // ---- fill + steady state: no lane has finished yet, no predicate ----
     int t = 0;
-    for (; t + 1 < R; t += 2) {
+    for (; t + 1 < R; t += 2) {  // fill + steady state: no lane has finished yet, no predicate
         cB = lds.load(max(row + 2, 0));  // one step ahead (index R at most)
         aM = from_left<L>(Mp[K - 1], group_head);
         aI = from_left<L>(Ip[K - 1], group_head);
         aD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, HAPN>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc);
+        row_update<K, true>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
         cA = lds.load(max(row + 3, 0));
         bM = from_left<L>(Mp[K - 1], group_head);
         bI = from_left<L>(Ip[K - 1], group_head);
         bD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, HAPN>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc);
+        row_update<K, true>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
         row += 2;
     }
     RowConst cur = cA;
@@ -172,25 +178,57 @@ __device__ __forceinline__ double sweep(const LdsView &lds, const int R, const i
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, HAPN>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc);
+        row_update<K, true>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
         ++row;
         cur = nxt;
     }
-    // ---- drain: lane l still has rows while row < R ----
-    for (int d = 0; d < L - 1; ++d) {
+    for (int d = 0; d < L - 1; ++d) {  // drain: lane l still has rows while row < R
         const RowConst nxt = lds.load(max(min(row + 2, R), 0));
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        if (row < R) row_update<K, HAPN>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc);
+        if (row < R) row_update<K, true>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
         ++row;
         cur = nxt;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (l * K + k < H) s += Mp[k] + Ip[k];
+    return s;
+}
+
+// General sweep (haplotype with 'N', or a read with gcp == 0 whose rows cannot be pre-scaled):
+// one compact predicated loop, kept small on purpose -- it is rare.
+template <int L, int K>
+__device__ __noinline__ double sweep_general(const LdsView &lds, const int R, const int l, const bool group_head,
+                                             const HapCols<K> &hc, const int H, const double c0, const bool scaled) {
+    double Mp[K], Ip[K], Dp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        Mp[k] = 0.0;
+        Ip[k] = 0.0;
+        Dp[k] = c0;
+    }
+    double plM = 0.0, plI = 0.0, plD = c0;
+    int row = -l;
+    for (int t = 0; t < R + L - 1; ++t) {
+        const RowConst cur = lds.load(max(min(row + 1, R), 0));
+        const double lM = from_left<L>(Mp[K - 1], group_head);
+        const double lI = from_left<L>(Ip[K - 1], group_head);
+        const double lD = from_left<L>(Dp[K - 1], group_head);
+        const double imx = scaled ? 1.0 : 1.0 - cur.dd;  // plain rows: dd == ii, im = 1 - ii
+        if (row < R) row_update<K, false>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, imx);
+        plM = lM;
+        plI = lI;
+        plD = lD;
+        ++row;
     }
     double s = 0.0;
 #pragma unroll
@@ -216,11 +254,16 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void 
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
     double *out_row = p.out + p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh;
 
-    // ---- stage this read's per-row constants in wave-private LDS (56-byte records, conflict-free) ----------
+    // ---- stage this read's per-row constants in wave-private LDS (72-byte records, conflict-free) ----------
     RowConst *srow = reinterpret_cast<RowConst *>(smem) + (size_t)wave * p.lds_rows;
-    if (lane == 0) {  // neutral row: keeps (M, I, D) = (0, 0, c) fixed for lanes that have not started
+    // gcp == 0 means im = 1 - eps(0) = 0: such a read keeps plain rows (rare; production gcp is 10)
+    bool lane_zero_gcp = false;
+    for (int row = lane; row < R; row += WAVE) lane_zero_gcp |= (p.gcp[ro + row] == 0);
+    const bool scaled = __ballot(lane_zero_gcp) == 0ull;
+    if (lane == 0) {  // neutral row: keeps (M, I, D) = (0, 0, c0) fixed for lanes that have not started
         RowConst n;
-        n.mm = 0.0; n.mi = 0.0; n.md = 0.0; n.ii = 1.0; n.eq = 1.0; n.px = 0.0; n.x = 0; n.pad = 0;
+        n.mm = 0.0; n.bI = 0.0; n.gI = 1.0; n.dD = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+        n.x = 0; n.pad0 = 0; n.pad1 = 0.0;
         srow[0] = n;
     }
     for (int row = lane; row < R; row += WAVE) {
@@ -230,17 +273,30 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void 
         const uint32_t dq = p.del_q[ro + row];
         const uint32_t g = p.gcp[ro + row];
         const uint32_t mx = max(iq, dq), mn = min(iq, dq);
+        const double eq = p.eps[q], mi = p.eps[iq], md = p.eps[dq], ii = p.eps[g];
         RowConst n;
-        n.eq = p.eps[q];
         n.mm = p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
-        n.mi = p.eps[iq];
-        n.md = p.eps[dq];
-        n.ii = p.eps[g];
-        n.px = (x == 'N') ? (1.0 - n.eq) : p.eps_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
+        n.pm = 1.0 - eq;                           // qual_to_prob(q)
+        n.px = (x == 'N') ? n.pm : p.eps_mis[q];   // read 'N' matches everything (pair_hmm.rs:643)
+        n.dd = ii;
+        if (scaled) {
+            const double im = 1.0 - ii;
+            const double im_next = (row + 1 < R) ? 1.0 - p.eps[p.gcp[ro + row + 1]] : 1.0;
+            n.bI = mi * im_next;
+            n.gI = ii * (im_next / im);
+            n.dD = md * im_next;
+        } else {
+            n.bI = mi;
+            n.gI = ii;
+            n.dD = md;
+        }
         n.x = x;
-        n.pad = 0;
+        n.pad0 = 0;
+        n.pad1 = 0.0;
         srow[row + 1] = n;
     }
+    // D(0,j) scale: pre-scaled rows carry im of the first read row
+    const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
     // LDS ops of one wave execute in order; only the compiler must not reorder across this point.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -273,13 +329,12 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void 
             lane_n |= is_n;
             hc.set(k, is_n ? 0u : y, is_n ? 0u : 0xffu);
         }
-        const double c = p.initial_condition / (double)H;
+        const double c0 = p.initial_condition / (double)H * scale0;
         double s;
-        if (__ballot(lane_n) != 0ull) {  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643)
-            s = sweep<L, K, true>(lds, R, l, group_head, hc, H, c);
-        } else {
-            s = sweep<L, K, false>(lds, R, l, group_head, hc, H, c);
-        }
+        if (scaled && __ballot(lane_n) == 0ull)
+            s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0);
+        else  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0
+            s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled);
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
