@@ -47,6 +47,7 @@ struct ShapeClass {
     int waves_per_block = MAX_WAVES_PER_BLOCK;
     size_t lds_bytes = 0;
     dim3 grid;
+    uint32_t exec_select = 0;
     // device
     uint32_t *d_reads = nullptr;
     // generic only
@@ -396,6 +397,11 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
             bool split = (uint64_t)n_items < 4ull * kNumSimd;
             if (h->force_split >= 0) split = h->force_split != 0;
             c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
+            // the EXEC-masked prior select trades a VALU op for an SALU op: a win only when a second wave on
+            // the SIMD can use the freed VALU slot (measured: +3 % at 2 waves/SIMD, -8 % at 1)
+            const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
+            c.exec_select = (waves >= 2ull * kNumSimd && c.K <= 19) ? 1u : 0u;
+            if (const char *e = getenv("PHMM_FORCE_EXEC_SELECT")) c.exec_select = atoi(e) ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {
             // generic: exclusive prefix of pairs per read, scratch for a bounded grid
@@ -504,6 +510,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.initial_condition = initial_condition();
         p.initial_condition_log10 = initial_condition_log10();
         p.lds_rows = c.lds_rows;
+        p.exec_select = c.exec_select;
         p.status = b->d_status;
         if (!p.n_items) continue;
         hipError_t e;

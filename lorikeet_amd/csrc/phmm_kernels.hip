@@ -103,7 +103,9 @@ struct HapCols {
 // FAST: pre-scaled rows and a haplotype without 'N' (the common case).  Otherwise the general form:
 // `imx` multiplies the indel->match term (1.0 for pre-scaled rows) and the compare honours the
 // haplotype wildcard mask.
-template <int K, bool FAST>
+enum : int { ROW_GENERAL = 0, ROW_FAST = 1, ROW_FAST_EXEC = 2 };
+
+template <int K, int MODE>
 __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], double (&Dp)[K], const double plM,
                                            const double plI, const double plD, const double lM, const double lD,
                                            const RowConst &c, const HapCols<K> &hc, const double imx) {
@@ -112,19 +114,34 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
     // M[k] using the still-old column k-1.
     static_for_down<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        double prior;
-        if constexpr (FAST)
-            prior = (x16 == hc.base(k)) ? c.pm : c.px;
-        else
-            prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? c.pm : c.px;
         // written so the two-address FMA accumulates into I's own register (v_mul I,I,gI ; v_fmac I,M,bI)
         Ip[k] = fma(Mp[k], c.bI, Ip[k] * c.gI);
         const double dM = k ? Mp[k - 1] : plM;  // (i-1, k-1)
         const double dI = k ? Ip[k - 1] : plI;
         const double dD = k ? Dp[k - 1] : plD;
         double t = dI + dD;
-        if constexpr (!FAST) t *= imx;
-        Mp[k] = prior * fma(dM, c.mm, t);
+        if constexpr (MODE == ROW_GENERAL) t *= imx;
+        const double a = fma(dM, c.mm, t);
+        if constexpr (MODE == ROW_FAST_EXEC) {
+            // prior select without v_cndmask: multiply by the mismatch prior everywhere, then redo the
+            // multiply with the match prior under EXEC = (x == y).  Two VALU + one SALU instead of four
+            // VALU (compare, two v_cndmask, multiply).  Only valid where all 64 lanes are active.
+            double m = c.px * a;
+            asm volatile("v_cmpx_eq_u32_e32 vcc, %1, %2\n\t"
+                         "v_mul_f64 %0, %3, %4\n\t"
+                         "s_mov_b64 exec, -1"
+                         : "+v"(m)
+                         : "v"(c.x), "v"((uint32_t)hc.base(k)), "v"(c.pm), "v"(a)
+                         : "vcc");
+            Mp[k] = m;
+        } else {
+            double prior;
+            if constexpr (MODE == ROW_FAST)
+                prior = (x16 == hc.base(k)) ? c.pm : c.px;
+            else
+                prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? c.pm : c.px;
+            Mp[k] = prior * a;
+        }
     });
     // Pass 2, left-to-right: the serial chain D(i,k) = M(i,k-1)*dD + D(i,k-1)*dd.
     double leftM = lM, leftD = lD;
@@ -144,7 +161,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
 
 // Fast sweep: two steps per trip with the roles of the (constants, left-column) register sets swapped,
 // so nothing is copied between steps.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
-template <int L, int K>
+template <int L, int K, int STEADY>
 __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, const int l, const bool group_head,
                                              const HapCols<K> &hc, const int H, const double c0) {
     double Mp[K], Ip[K], Dp[K];
@@ -163,12 +180,12 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         aM = from_left<L>(Mp[K - 1], group_head);
         aI = from_left<L>(Ip[K - 1], group_head);
         aD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, true>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
         cA = lds.load(max(row + 3, 0));
         bM = from_left<L>(Mp[K - 1], group_head);
         bI = from_left<L>(Ip[K - 1], group_head);
         bD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, true>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
         row += 2;
     }
     RowConst cur = cA;
@@ -178,7 +195,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, true>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
@@ -190,7 +207,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        if (row < R) row_update<K, true>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
+        if (row < R) row_update<K, ROW_FAST>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
@@ -207,7 +224,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
 // General sweep (haplotype with 'N', or a read with gcp == 0 whose rows cannot be pre-scaled):
 // one compact predicated loop, kept small on purpose -- it is rare.
 template <int L, int K>
-__device__ __noinline__ double sweep_general(const LdsView &lds, const int R, const int l, const bool group_head,
+__device__ __forceinline__ double sweep_general(const LdsView &lds, const int R, const int l, const bool group_head,
                                              const HapCols<K> &hc, const int H, const double c0, const bool scaled) {
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
@@ -224,7 +241,7 @@ __device__ __noinline__ double sweep_general(const LdsView &lds, const int R, co
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
         const double imx = scaled ? 1.0 : 1.0 - cur.dd;  // plain rows: dd == ii, im = 1 - ii
-        if (row < R) row_update<K, false>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, imx);
+        if (row < R) row_update<K, ROW_GENERAL>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, imx);
         plM = lM;
         plI = lI;
         plD = lD;
@@ -332,7 +349,8 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void 
         const double c0 = p.initial_condition / (double)H * scale0;
         double s;
         if (scaled && __ballot(lane_n) == 0ull)
-            s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0);
+            s = p.exec_select ? sweep_fast<L, K, ROW_FAST_EXEC>(lds, R, l, group_head, hc, H, c0)
+                              : sweep_fast<L, K, ROW_FAST>(lds, R, l, group_head, hc, H, c0);
         else  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0
             s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled);
 #pragma unroll
