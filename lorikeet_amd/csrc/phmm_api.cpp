@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,7 @@ constexpr size_t kLdsBytesPerCU = 160 * 1024;
 constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
 constexpr uint32_t kNumSimd = 256 * 4;
 constexpr uint64_t kGenericScratchBytes = 1ull << 30;
+constexpr size_t kDirectCopyBytes = 4u << 20;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -60,7 +62,16 @@ struct ShapeClass {
 
 }  // namespace
 
+// Grow-only device arena with a pinned host mirror at identical offsets.  phmm_compute() places the
+// whole batch (offset arrays, work lists, payload, status word, results) in it, so a call costs one
+// H2D copy, the kernel launches and one D2H copy -- no hipMalloc/hipFree once the arena is warm.
+struct Arena {
+    char *dev = nullptr, *host = nullptr;
+    size_t cap = 0, used = 0;
+};
+
 struct phmm_handle {
+    Arena arena;
     int device = 0;
     unsigned flags = 0;
     hipStream_t stream = nullptr;
@@ -86,6 +97,10 @@ struct phmm_batch {
                   *d_hap_bases = nullptr;
     double *d_out = nullptr;
     void *d_owned = nullptr;  // batch-owned payload + out (phmm_batch_upload)
+    Arena *arena = nullptr;   // non-null: every device allocation of this batch lives in the handle's arena
+    std::vector<void *> mallocs;  // hipMalloc'ed pieces owned by this batch (persistent batches, generic scratch)
+    size_t out_arena_off = 0;     // arena mode: offset of [status word | out]
+    bool tight_out = true;        // out_off has no gaps (every slot is written by a kernel)
     bool bound = false;
     std::string dominant;
 };
@@ -182,6 +197,8 @@ void phmm_destroy(phmm_handle *h) {
     if (h->d_eps) (void)hipFree(h->d_eps);
     if (h->d_eps_mis) (void)hipFree(h->d_eps_mis);
     if (h->d_mm) (void)hipFree(h->d_mm);
+    if (h->arena.dev) (void)hipFree(h->arena.dev);
+    if (h->arena.host) (void)hipHostFree(h->arena.host);
     delete h;
 }
 
@@ -197,19 +214,13 @@ size_t phmm_table_match_to_match(const double **mm) {
 void phmm_batch_destroy(phmm_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->h->device);
-    for (auto &c : b->classes) {
-        if (c.d_reads) (void)hipFree(c.d_reads);
-        if (c.d_pair_first) (void)hipFree(c.d_pair_first);
-        if (c.d_scratch) (void)hipFree(c.d_scratch);
-    }
-    if (b->d_meta) (void)hipFree(b->d_meta);
-    if (b->d_owned) (void)hipFree(b->d_owned);
+    for (void *m : b->mallocs) (void)hipFree(m);
     delete b;
 }
 
-phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
-                              const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off,
-                              const uint64_t *out_off) {
+static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                                     const uint32_t *region_hap_off, const uint32_t *read_off,
+                                     const uint32_t *hap_off, const uint64_t *out_off, bool use_arena) {
     if (!h) return nullptr;
     h->err.clear();
     if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
@@ -221,6 +232,7 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
         return nullptr;
     }
     const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
+    bool tight = true;
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (region_read_off[g + 1] < region_read_off[g] || region_hap_off[g + 1] < region_hap_off[g]) {
             h->err = "phmm_batch_create: region offsets not monotonic";
@@ -232,6 +244,7 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
             h->err = "phmm_batch_create: out_off leaves too little room for a region (needs Nr*Nh doubles)";
             return nullptr;
         }
+        if (out_off[g + 1] - out_off[g] != need) tight = false;
     }
     for (uint32_t r = 0; r < n_reads; ++r)
         if (read_off[r + 1] < read_off[r]) {
@@ -256,6 +269,60 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
     b->n_out = out_off[n_regions];
     b->read_bytes = read_off[n_reads];
     b->hap_bytes = hap_off[n_haps];
+    b->tight_out = tight;
+
+    // ---- device memory provider ---------------------------------------------------------------
+    // arena mode: bump-allocate from the handle's arena, "uploads" go to the pinned mirror and travel in
+    // one copy later; otherwise hipMalloc per piece and async copies on the handle's stream.
+    bool ok = true;
+    if (use_arena) {
+        const size_t need = align_up((size_t)n_reads * 4, 256) * 2 + align_up((size_t)(n_regions + 1) * 4, 256) * 2 +
+                            align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
+                            align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
+                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024;
+        Arena &A = h->arena;
+        if (A.cap < need) {
+            (void)hipStreamSynchronize(h->stream);
+            if (A.dev) (void)hipFree(A.dev);
+            if (A.host) (void)hipHostFree(A.host);
+            A.dev = A.host = nullptr;
+            A.cap = 0;
+            const size_t cap = std::max<size_t>(need + need / 2, 1 << 20);
+            ok = hip_ok(h, hipMalloc((void **)&A.dev, cap), "hipMalloc(arena)") &&
+                 hip_ok(h, hipHostMalloc((void **)&A.host, cap, hipHostMallocDefault), "hipHostMalloc(arena)");
+            if (!ok) {
+                delete b;
+                return nullptr;
+            }
+            A.cap = cap;
+        }
+        A.used = 0;
+        b->arena = &A;
+    }
+    auto dalloc = [&](size_t bytes, void **mirror) -> void * {
+        if (mirror) *mirror = nullptr;
+        if (!ok) return nullptr;
+        if (b->arena && align_up(b->arena->used, 256) + bytes <= b->arena->cap) {
+            const size_t off = align_up(b->arena->used, 256);
+            b->arena->used = off + bytes;
+            if (mirror) *mirror = b->arena->host + off;
+            return b->arena->dev + off;
+        }
+        void *p = nullptr;
+        ok = hip_ok(h, hipMalloc(&p, std::max<size_t>(bytes, 256)), "hipMalloc(batch)");
+        if (ok) b->mallocs.push_back(p);
+        return p;
+    };
+    bool async_pending = false;
+    auto up = [&](void *dst, void *mirror, const void *src, size_t bytes) {
+        if (!ok || !bytes) return;
+        if (mirror) {
+            memcpy(mirror, src, bytes);
+        } else {
+            ok = hip_ok(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream), "H2D meta");
+            async_pending = true;
+        }
+    };
 
     // ---- per-region shape, totals -----------------------------------------------------------
     struct RegionShape {
@@ -348,33 +415,23 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
     }
 
     // ---- device metadata --------------------------------------------------------------------
-    const size_t sz_rr = align_up((size_t)n_reads * 4, 256), sz_rro = align_up((size_t)(n_regions + 1) * 4, 256),
-                 sz_ro = align_up((size_t)(n_reads + 1) * 4, 256), sz_ho = align_up((size_t)(n_haps + 1) * 4, 256),
-                 sz_oo = align_up((size_t)(n_regions + 1) * 8, 256);
-    const size_t meta_bytes = sz_rr + 2 * sz_rro + sz_ro + sz_ho + sz_oo + 256;
-    if (!hip_ok(h, hipMalloc(&b->d_meta, meta_bytes), "hipMalloc(meta)")) {
-        phmm_batch_destroy(b);
-        return nullptr;
+    void *m_rr, *m_rro, *m_rho, *m_ro, *m_ho, *m_oo;
+    b->d_read_region = (uint32_t *)dalloc((size_t)n_reads * 4, &m_rr);
+    b->d_region_read_off = (uint32_t *)dalloc((size_t)(n_regions + 1) * 4, &m_rro);
+    b->d_region_hap_off = (uint32_t *)dalloc((size_t)(n_regions + 1) * 4, &m_rho);
+    b->d_read_off = (uint32_t *)dalloc((size_t)(n_reads + 1) * 4, &m_ro);
+    b->d_hap_off = (uint32_t *)dalloc((size_t)(n_haps + 1) * 4, &m_ho);
+    b->d_out_off = (uint64_t *)dalloc((size_t)(n_regions + 1) * 8, &m_oo);
+    up(b->d_read_region, m_rr, read_region.data(), (size_t)n_reads * 4);
+    up(b->d_region_read_off, m_rro, region_read_off, (size_t)(n_regions + 1) * 4);
+    up(b->d_region_hap_off, m_rho, region_hap_off, (size_t)(n_regions + 1) * 4);
+    up(b->d_read_off, m_ro, read_off, (size_t)(n_reads + 1) * 4);
+    up(b->d_hap_off, m_ho, hap_off, (size_t)(n_haps + 1) * 4);
+    up(b->d_out_off, m_oo, out_off, (size_t)(n_regions + 1) * 8);
+    if (!b->arena) {  // persistent batch: own status word (arena mode keeps it next to the results)
+        b->d_status = (uint32_t *)dalloc(256, nullptr);
+        if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->stream), "memset status");
     }
-    char *p = (char *)b->d_meta;
-    b->d_read_region = (uint32_t *)p; p += sz_rr;
-    b->d_region_read_off = (uint32_t *)p; p += sz_rro;
-    b->d_region_hap_off = (uint32_t *)p; p += sz_rro;
-    b->d_read_off = (uint32_t *)p; p += sz_ro;
-    b->d_hap_off = (uint32_t *)p; p += sz_ho;
-    b->d_out_off = (uint64_t *)p; p += sz_oo;
-    b->d_status = (uint32_t *)p;
-    bool ok = true;
-    auto up = [&](void *dst, const void *src, size_t bytes) {
-        if (ok && bytes) ok = hip_ok(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream), "H2D meta");
-    };
-    up(b->d_read_region, read_region.data(), (size_t)n_reads * 4);
-    up(b->d_region_read_off, region_read_off, (size_t)(n_regions + 1) * 4);
-    up(b->d_region_hap_off, region_hap_off, (size_t)(n_regions + 1) * 4);
-    up(b->d_read_off, read_off, (size_t)(n_reads + 1) * 4);
-    up(b->d_hap_off, hap_off, (size_t)(n_haps + 1) * 4);
-    up(b->d_out_off, out_off, (size_t)(n_regions + 1) * 8);
-    if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->stream), "memset status");
 
     // ---- finalise classes -------------------------------------------------------------------
     uint64_t best_cells = 0;
@@ -383,9 +440,10 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
         const uint32_t n_items = (uint32_t)c.reads.size();
         c.identity = (n_items == n_reads);
         for (uint32_t i = 0; c.identity && i < n_items; ++i) c.identity = (c.reads[i] == i);
-        if (!c.identity && ok) {
-            ok = hip_ok(h, hipMalloc(&c.d_reads, (size_t)n_items * 4), "hipMalloc(class reads)");
-            up(c.d_reads, c.reads.data(), (size_t)n_items * 4);
+        if (!c.identity) {
+            void *mirror;
+            c.d_reads = (uint32_t *)dalloc((size_t)n_items * 4, &mirror);
+            up(c.d_reads, mirror, c.reads.data(), (size_t)n_items * 4);
         }
         if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
@@ -416,9 +474,12 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
             uint64_t threads = std::min<uint64_t>(align_up(acc, 256), 1024ull * 256);
             threads = std::min<uint64_t>(threads, std::max<uint64_t>(256, kGenericScratchBytes / per_thread / 256 * 256));
             c.generic_blocks = (uint32_t)(threads / 256);
-            if (ok) ok = hip_ok(h, hipMalloc(&c.d_scratch, threads * per_thread), "hipMalloc(generic scratch)");
-            if (ok) ok = hip_ok(h, hipMalloc(&c.d_pair_first, c.pair_first.size() * 8), "hipMalloc(pair_first)");
-            up(c.d_pair_first, c.pair_first.data(), c.pair_first.size() * 8);
+            // scratch can be large: always its own allocation, never the arena
+            if (ok) ok = hip_ok(h, hipMalloc((void **)&c.d_scratch, threads * per_thread), "hipMalloc(generic scratch)");
+            if (ok) b->mallocs.push_back(c.d_scratch);
+            void *mirror;
+            c.d_pair_first = (uint64_t *)dalloc(c.pair_first.size() * 8, &mirror);
+            up(c.d_pair_first, mirror, c.pair_first.data(), c.pair_first.size() * 8);
             snprintf(c.name, sizeof c.name, "phmm_forward_generic");
         }
         if (c.cells >= best_cells) {
@@ -427,13 +488,19 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
         }
         b->classes.push_back(std::move(c));
     }
-    // host staging vectors die at return: finish the async copies first
-    if (ok) ok = hip_ok(h, hipStreamSynchronize(h->stream), "sync(meta)");
+    // host staging vectors die at return: finish the async copies first (arena mode copied into the mirror)
+    if (ok && async_pending) ok = hip_ok(h, hipStreamSynchronize(h->stream), "sync(meta)");
     if (!ok) {
         phmm_batch_destroy(b);
         return nullptr;
     }
     return b;
+}
+
+phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                              const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off,
+                              const uint64_t *out_off) {
+    return batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, false);
 }
 
 int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q, const uint8_t *d_ins_q,
@@ -465,7 +532,10 @@ int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *b
     }
     HIP_TRY(h, hipSetDevice(h->device), PHMM_ERR_HIP);
     const size_t rb = align_up(b->read_bytes, 256), hb = align_up(b->hap_bytes, 256), ob = align_up(b->n_out * 8, 256);
-    if (!b->d_owned) HIP_TRY(h, hipMalloc(&b->d_owned, 5 * rb + hb + ob + 256), PHMM_ERR_HIP);
+    if (!b->d_owned) {
+        HIP_TRY(h, hipMalloc(&b->d_owned, 5 * rb + hb + ob + 256), PHMM_ERR_HIP);
+        b->mallocs.push_back(b->d_owned);
+    }
     uint8_t *p = (uint8_t *)b->d_owned;
     uint8_t *d[6];
     for (int i = 0; i < 5; ++i) { d[i] = p; p += rb; }
@@ -559,17 +629,76 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
                  const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
                  const uint64_t *out_off, double *out) {
     if (!h) return PHMM_ERR_INVALID_ARG;
-    phmm_batch *b = phmm_batch_create(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off);
+    static const bool trace = getenv("PHMM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
+    const double t1 = now();
     if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
-    int st = phmm_batch_upload(b, read_bases, base_q, ins_q, del_q, gcp, hap_bases);
-    // slots the kernels never write (gaps the caller left in out_off) come back as NaN
-    if (st == PHMM_OK && b->n_out && !hip_ok(h, hipMemsetAsync(b->d_out, 0xff, b->n_out * 8, h->stream), "memset out"))
-        st = PHMM_ERR_HIP;
+    int st = PHMM_OK;
+    if ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases) ||
+        (b->n_out && !out)) {
+        h->err = "phmm_compute: null pointer";
+        st = PHMM_ERR_INVALID_ARG;
+    }
+    Arena &A = h->arena;
+    if (st == PHMM_OK) {
+        // payload into the arena mirror, then [status | out] last so that one copy each way suffices
+        const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
+        const uint8_t *d[6];
+        for (int i = 0; i < 6; ++i) {
+            const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
+            const size_t off = align_up(A.used, 256);
+            A.used = off + bytes;
+            // small arrays ride in the single mirror copy; large ones go straight from the caller's memory
+            // (a second pass over 100 MB on one host core costs more than the extra copy call)
+            if (bytes > kDirectCopyBytes) {
+                if (st == PHMM_OK && !hip_ok(h, hipMemcpyAsync(A.dev + off, src[i], bytes, hipMemcpyHostToDevice, h->stream),
+                                             "H2D payload"))
+                    st = PHMM_ERR_HIP;
+            } else if (bytes) {
+                memcpy(A.host + off, src[i], bytes);
+            }
+            d[i] = (const uint8_t *)(A.dev + off);
+        }
+        const size_t in_bytes = align_up(A.used, 256);
+        b->out_arena_off = in_bytes;
+        A.used = in_bytes + 256 + b->n_out * 8;
+        memset(A.host + in_bytes, 0, 256);  // status word
+        b->d_status = (uint32_t *)(A.dev + in_bytes);
+        double *d_out = (double *)(A.dev + in_bytes + 256);
+        if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->stream), "H2D batch"))
+            st = PHMM_ERR_HIP;
+        // slots the kernels never write (gaps the caller left in out_off) come back as NaN
+        if (st == PHMM_OK && !b->tight_out && b->n_out &&
+            !hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->stream), "memset out"))
+            st = PHMM_ERR_HIP;
+        if (st == PHMM_OK) st = phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
+    }
+    const double t2 = now();
     if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
-    if (st == PHMM_OK) st = phmm_batch_download(b, out);
+    const double t3 = now();
+    if (st == PHMM_OK) {
+        char *hs = A.host + b->out_arena_off;
+        if (!hip_ok(h, hipMemcpyAsync(hs, A.dev + b->out_arena_off, 256 + b->n_out * 8, hipMemcpyDeviceToHost, h->stream),
+                    "D2H results") ||
+            !hip_ok(h, hipStreamSynchronize(h->stream), "sync"))
+            st = PHMM_ERR_HIP;
+        else {
+            if (b->n_out) memcpy(out, hs + 256, b->n_out * 8);
+            if (*(const uint32_t *)hs) {
+                h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+                st = PHMM_ERR_POSITIVE_RESULT;
+            }
+        }
+    }
+    const double t4 = now();
     std::string keep = h->err;
     phmm_batch_destroy(b);
     h->err = keep;
+    if (trace)
+        fprintf(stderr, "phmm_compute: plan %.1f us, stage+H2D %.1f us, launch %.1f us, wait+D2H %.1f us, destroy %.1f us\n",
+                t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
     return st;
 }
 

@@ -108,12 +108,14 @@ class HipPairHMMEngine:
     def compute(self, batch: RegionBatch):
         """Synchronous phmm_compute on host arrays.  Returns out (float64, batch.n_out)."""
         out = np.empty(batch.n_out, dtype=np.float64)
-        self._check(self.lib.phmm_compute(
-            self._h, batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
-            _p(batch.read_off, _lib.u32p), _p(batch.read_bases, _lib.u8p), _p(batch.base_q, _lib.u8p),
-            _p(batch.ins_q, _lib.u8p), _p(batch.del_q, _lib.u8p), _p(batch.gcp, _lib.u8p),
-            _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(batch.out_off, _lib.u64p),
-            _p(out, _lib.f64p)))
+        args = getattr(batch, "_abi_args", None)
+        if args is None:  # pointer conversion is the slow part of a ctypes call: do it once per batch
+            args = (batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
+                    _p(batch.read_off, _lib.u32p), _p(batch.read_bases, _lib.u8p), _p(batch.base_q, _lib.u8p),
+                    _p(batch.ins_q, _lib.u8p), _p(batch.del_q, _lib.u8p), _p(batch.gcp, _lib.u8p),
+                    _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(batch.out_off, _lib.u64p))
+            batch._abi_args = args
+        self._check(self.lib.phmm_compute(self._h, *args, _p(out, _lib.f64p)))
         return out
 
     def plan(self, batch: RegionBatch):
