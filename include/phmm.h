@@ -137,6 +137,52 @@ uint32_t phmm_batch_num_launches(const phmm_batch *b);    /* kernel launches one
 /* Name of the kernel shape class doing most cells of this batch, e.g. "phmm_forward<16,19>". */
 const char *phmm_batch_dominant_kernel(const phmm_batch *b);
 
+/*
+ * Engine-level call: everything PairHMMLikelihoodCalculationEngine::compute_read_likelihoods does with
+ * the numbers (reference src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs:195-242), for
+ * n_regions regions at once, on the device:
+ *   1. modify_read_qualities (:352-388, default branch): PCR indel error model (:502-611) and the
+ *      quality caps (:428-466) on copies of the read qualities; gcp = constant (:649-651);
+ *   2. the PairHMM forward kernels on the modified qualities (pair_hmm.rs:345-375);
+ *   3. normalize_likelihoods (src/model/allele_likelihoods.rs:378-508) with
+ *      log10_global_read_mismapping_rate as the cap;
+ *   4. the keep / remove decision of filter_poorly_modeled_evidence (:925-1041) with the static or
+ *      dynamic threshold of :229-239 (computed from the ORIGINAL base qualities, as the reference does).
+ * The caller keeps ownership of the evidence lists: `keep[r] == 0` marks reads the reference would move
+ * to filtered_evidence_by_sample_index; compaction of the [allele, read] matrix happens when the caller
+ * scatters `out` (read-major) into its AlleleLikelihoods.  Per-sample structure does not matter here:
+ * every step is per read.
+ */
+typedef struct phmm_engine_config {
+    uint8_t constant_gcp;                                   /* engine.rs:130  (CLI default 10)            */
+    uint8_t pcr_error_model;                                /* :61-70  0 None 1 Hostile 2 Aggressive 3 Conservative */
+    uint8_t base_quality_score_threshold;                   /* :133    (CLI default 18)                   */
+    uint8_t dynamic_read_disqualification;                  /* :134                                       */
+    uint8_t symmetrically_normalize_alleles_to_reference;   /* :137                                       */
+    uint8_t disable_cap_read_qualities_to_mapq;             /* :138                                       */
+    uint8_t reserved[2];
+    double log10_global_read_mismapping_rate;               /* :131    cap of normalize_likelihoods       */
+    double read_disqualification_scale;                     /* :135                                       */
+    double expected_error_rate_per_base;                    /* :136                                       */
+} phmm_engine_config;
+
+/*
+ *   base_q            ORIGINAL base qualities (read.qual())
+ *   ins_q, del_q      BI / BD tags, or NULL for the reference's flat Q45 default (read_utils.rs:23,372-416)
+ *   mapq[n_reads]     mapping quality per read (cap_minimum_read_qualities, :438)
+ *   region_ref_hap    [n_regions] index INSIDE the region of the reference haplotype, -1 if none; may be
+ *                     NULL (only consulted when symmetric normalisation is off)
+ *   out               per region row-major [read][hap], NORMALISED log10 likelihoods
+ *   keep[n_reads]     1 = evidence kept, 0 = removed as poorly modelled
+ * Haplotypes of a region must be distinct (the reference de-duplicates them, haplotype.rs:263-275).
+ */
+int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions,
+                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                        const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
+                        const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
+                        double *out, uint8_t *keep);
+
 /* Host copies of the device tables, for parity tests against the oracle:
  * eps[q] = 10^(-q/10) for q in 0..=255, mm = triangular match->match table incl. row 255. */
 size_t phmm_table_eps(const double **eps);

@@ -23,6 +23,16 @@ PHMM_ERR_HIP = 3
 PHMM_ERR_POSITIVE_RESULT = 4
 PHMM_ERR_NOT_BOUND = 5
 
+class EngineConfig(C.Structure):
+    """phmm_engine_config (include/phmm.h)."""
+    _fields_ = [("constant_gcp", C.c_uint8), ("pcr_error_model", C.c_uint8),
+                ("base_quality_score_threshold", C.c_uint8), ("dynamic_read_disqualification", C.c_uint8),
+                ("symmetrically_normalize_alleles_to_reference", C.c_uint8),
+                ("disable_cap_read_qualities_to_mapq", C.c_uint8), ("reserved", C.c_uint8 * 2),
+                ("log10_global_read_mismapping_rate", C.c_double), ("read_disqualification_scale", C.c_double),
+                ("expected_error_rate_per_base", C.c_double)]
+
+
 # every symbol include/phmm.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("phmm_device_count", C.c_int, []),
@@ -41,6 +51,8 @@ SYMBOLS = [
     ("phmm_batch_algorithmic_bytes", C.c_uint64, [C.c_void_p]),
     ("phmm_batch_num_launches", C.c_uint32, [C.c_void_p]),
     ("phmm_batch_dominant_kernel", C.c_char_p, [C.c_void_p]),
+    ("phmm_engine_compute", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
+                                      u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),
     ("phmm_table_match_to_match", C.c_size_t, [C.POINTER(f64p)]),
 ]

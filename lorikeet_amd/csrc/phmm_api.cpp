@@ -76,6 +76,7 @@ struct phmm_handle {
     unsigned flags = 0;
     hipStream_t stream = nullptr;
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr;
+    uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
     int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
     int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
@@ -183,6 +184,15 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
                                256 * sizeof(double), hipMemcpyHostToDevice),
                      "copy eps_mis") &&
               hip_ok(nullptr, hipMemcpy(h->d_mm, mm.data(), mm.size() * sizeof(double), hipMemcpyHostToDevice), "copy mm");
+    if (ok) {
+        std::vector<unsigned char> all(4 * 128, 0);
+        for (int m = 1; m <= 3; ++m) {
+            const auto c = pcr_error_model_cache(m);
+            std::copy(c.begin(), c.end(), all.begin() + m * 128);
+        }
+        ok = hip_ok(nullptr, hipMalloc((void **)&h->d_pcr_cache, all.size()), "hipMalloc pcr") &&
+             hip_ok(nullptr, hipMemcpy(h->d_pcr_cache, all.data(), all.size(), hipMemcpyHostToDevice), "copy pcr");
+    }
     if (!ok) {
         phmm_destroy(h);
         return nullptr;
@@ -197,6 +207,7 @@ void phmm_destroy(phmm_handle *h) {
     if (h->d_eps) (void)hipFree(h->d_eps);
     if (h->d_eps_mis) (void)hipFree(h->d_eps_mis);
     if (h->d_mm) (void)hipFree(h->d_mm);
+    if (h->d_pcr_cache) (void)hipFree(h->d_pcr_cache);
     if (h->arena.dev) (void)hipFree(h->arena.dev);
     if (h->arena.host) (void)hipHostFree(h->arena.host);
     delete h;
@@ -220,7 +231,8 @@ void phmm_batch_destroy(phmm_batch *b) {
 
 static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
                                      const uint32_t *region_hap_off, const uint32_t *read_off,
-                                     const uint32_t *hap_off, const uint64_t *out_off, bool use_arena) {
+                                     const uint32_t *hap_off, const uint64_t *out_off, bool use_arena,
+                                     size_t extra_arena_bytes = 0) {
     if (!h) return nullptr;
     h->err.clear();
     if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
@@ -279,7 +291,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         const size_t need = align_up((size_t)n_reads * 4, 256) * 2 + align_up((size_t)(n_regions + 1) * 4, 256) * 2 +
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
                             align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
-                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024;
+                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes;
         Arena &A = h->arena;
         if (A.cap < need) {
             (void)hipStreamSynchronize(h->stream);
@@ -699,6 +711,130 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     if (trace)
         fprintf(stderr, "phmm_compute: plan %.1f us, stage+H2D %.1f us, launch %.1f us, wait+D2H %.1f us, destroy %.1f us\n",
                 t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+    return st;
+}
+
+int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions,
+                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                        const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases,
+                        const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep) {
+    if (!h || !cfg) return PHMM_ERR_INVALID_ARG;
+    if (cfg->pcr_error_model > 3) {
+        h->err = "phmm_engine_compute: Unknown PCR Error Model";  // engine.rs:89
+        return PHMM_ERR_INVALID_ARG;
+    }
+    if (!region_read_off || !read_off) {
+        h->err = "phmm_engine_compute: null offset array";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    const uint32_t n_reads = region_read_off[n_regions];
+    const size_t rbytes = align_up((size_t)read_off[n_reads], 256);
+    // originals (4 x read bytes + mapq + ref index) and device-only copies (4 x read bytes, thresholds, keep)
+    const size_t extra = 4 * rbytes + 4 * rbytes + align_up((size_t)n_reads, 256) * 2 + align_up((size_t)n_reads * 8, 256) +
+                         align_up((size_t)n_regions * 4, 256) + 16 * 256;
+    phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true, extra);
+    if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
+    int st = PHMM_OK;
+    if ((b->read_bytes && (!read_bases || !base_q)) || (n_reads && (!mapq || !keep)) || (b->hap_bytes && !hap_bases) ||
+        (b->n_out && !out)) {
+        h->err = "phmm_engine_compute: null pointer";
+        st = PHMM_ERR_INVALID_ARG;
+    }
+    Arena &A = h->arena;
+    if (st == PHMM_OK) {
+        auto place = [&](const void *src, size_t bytes) -> char * {  // into the mirror (travels in the one H2D copy)
+            const size_t off = align_up(A.used, 256);
+            A.used = off + bytes;
+            if (src && bytes) memcpy(A.host + off, src, bytes);
+            return A.dev + off;
+        };
+        const uint8_t *d_bases = (const uint8_t *)place(read_bases, b->read_bytes);
+        const uint8_t *d_q0 = (const uint8_t *)place(base_q, b->read_bytes);
+        const uint8_t *d_i0 = ins_q ? (const uint8_t *)place(ins_q, b->read_bytes) : nullptr;
+        const uint8_t *d_d0 = del_q ? (const uint8_t *)place(del_q, b->read_bytes) : nullptr;
+        const uint8_t *d_mapq = (const uint8_t *)place(mapq, n_reads);
+        const uint8_t *d_haps = (const uint8_t *)place(hap_bases, b->hap_bytes);
+        const int32_t *d_ref = region_ref_hap ? (const int32_t *)place(region_ref_hap, (size_t)n_regions * 4) : nullptr;
+        const size_t in_bytes = align_up(A.used, 256);
+        // device-only
+        uint8_t *d_q = (uint8_t *)place(nullptr, b->read_bytes), *d_i = (uint8_t *)place(nullptr, b->read_bytes),
+                *d_d = (uint8_t *)place(nullptr, b->read_bytes), *d_g = (uint8_t *)place(nullptr, b->read_bytes);
+        double *d_thr = (double *)place(nullptr, (size_t)n_reads * 8);
+        // results: [status (256 B) | keep | out] contiguous, one D2H
+        const size_t res_off = align_up(A.used, 256);
+        const size_t keep_bytes = align_up((size_t)n_reads, 256);
+        A.used = res_off + 256 + keep_bytes + b->n_out * 8;
+        b->d_status = (uint32_t *)(A.dev + res_off);
+        uint8_t *d_keep = (uint8_t *)(A.dev + res_off + 256);
+        double *d_out = (double *)(A.dev + res_off + 256 + keep_bytes);
+        bool ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->stream), "H2D batch") &&
+                  hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->stream), "memset status");
+        if (ok && !b->tight_out && b->n_out) ok = hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->stream), "memset out");
+        uint32_t max_r = 0;
+        for (uint32_t r = 0; r < n_reads; ++r) max_r = std::max(max_r, read_off[r + 1] - read_off[r]);
+        PrepParams pp{};
+        pp.n_reads = n_reads;
+        pp.read_off = b->d_read_off;
+        pp.read_bases = d_bases;
+        pp.base_q = d_q0;
+        pp.ins_q = d_i0;
+        pp.del_q = d_d0;
+        pp.mapq = d_mapq;
+        pp.pcr_cache = cfg->pcr_error_model ? h->d_pcr_cache + 128 * cfg->pcr_error_model : nullptr;
+        pp.out_q = d_q;
+        pp.out_ins = d_i;
+        pp.out_del = d_d;
+        pp.out_gcp = d_g;
+        pp.threshold = d_thr;
+        pp.lds_bytes_per_wave = (uint32_t)align_up((size_t)max_r + 1, 16);
+        pp.default_indel_qual = 45;  // ReadUtils::DEFAULT_INSERTION_DELETION_QUAL (read_utils.rs:23)
+        pp.constant_gcp = cfg->constant_gcp;
+        pp.base_quality_score_threshold = cfg->base_quality_score_threshold;
+        pp.disable_cap_to_mapq = cfg->disable_cap_read_qualities_to_mapq;
+        pp.dynamic_disqualification = cfg->dynamic_read_disqualification;
+        pp.read_disqualification_scale = cfg->read_disqualification_scale;
+        pp.expected_error_rate_per_base = cfg->expected_error_rate_per_base;
+        if (ok && (size_t)pp.lds_bytes_per_wave * 4 > kLdsBytesPerCU) {
+            h->err = "phmm_engine_compute: read too long for the pre-step kernel";
+            ok = false;
+            st = PHMM_ERR_INVALID_ARG;
+        }
+        if (ok) ok = hip_ok(h, launch_prep(pp, h->stream), "phmm_prep_reads");
+        if (ok) ok = phmm_batch_bind_device(b, d_bases, d_q, d_i, d_d, d_g, d_haps, d_out) == PHMM_OK;
+        if (ok) ok = phmm_batch_launch(b, nullptr) == PHMM_OK;
+        PostParams po{};
+        po.n_reads = n_reads;
+        po.read_region = b->d_read_region;
+        po.region_read_off = b->d_region_read_off;
+        po.region_hap_off = b->d_region_hap_off;
+        po.out_off = b->d_out_off;
+        po.region_ref_hap = d_ref;
+        po.out = d_out;
+        po.threshold = d_thr;
+        po.keep = d_keep;
+        po.max_likelihood_difference_cap = cfg->log10_global_read_mismapping_rate;
+        po.symmetric = cfg->symmetrically_normalize_alleles_to_reference;
+        if (ok) ok = hip_ok(h, launch_post(po, h->stream), "phmm_post_reads");
+        const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
+        if (ok) ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->stream),
+                            "D2H results") &&
+                     hip_ok(h, hipStreamSynchronize(h->stream), "sync");
+        if (ok) {
+            const char *hs = A.host + res_off;
+            if (n_reads) memcpy(keep, hs + 256, n_reads);
+            if (b->n_out) memcpy(out, hs + 256 + keep_bytes, b->n_out * 8);
+            if (*(const uint32_t *)hs) {
+                h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+                st = PHMM_ERR_POSITIVE_RESULT;
+            }
+        } else if (st == PHMM_OK) {
+            st = PHMM_ERR_HIP;
+        }
+    }
+    std::string keep_err = h->err;
+    phmm_batch_destroy(b);
+    h->err = keep_err;
     return st;
 }
 

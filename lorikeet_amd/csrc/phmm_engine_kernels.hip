@@ -1,0 +1,204 @@
+// gfx950 kernels of the engine-level steps around the PairHMM forward kernel:
+//
+//   phmm_prep_reads   PairHMMLikelihoodCalculationEngine::modify_read_qualities
+//                     (reference src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs:352-388, default
+//                     branch): PCR indel error model (:502-611) + quality caps (:428-466), and the
+//                     per-read disqualification threshold (:229-239, :244-319) from the ORIGINAL quals.
+//   phmm_post_reads   AlleleLikelihoods::normalize_likelihoods (src/model/allele_likelihoods.rs:378-508)
+//                     and the keep / remove decision of filter_poorly_modeled_evidence (:925-1041).
+//
+// Both are byte / small-integer work over O(sum R) and O(Nr*Nh) data: one wave per read for the pre-step
+// (read staged in LDS, one lane per base position), one thread per read for the post-step.
+#include "phmm_internal.hpp"
+
+namespace phmm {
+
+namespace {
+
+constexpr int MAX_STR_UNIT_LENGTH = 20;  // engine.rs:98
+constexpr int MAX_REPEAT_LENGTH = 100;   // engine.rs:99
+constexpr uint32_t MIN_USABLE_Q = 6;     // quality_utils.rs:23
+
+// engine.rs:23-39, (mean, variance) per base quality 1..40
+__constant__ double kDynQualTable[40][2] = {
+    {5.996842844, 0.196616587}, {5.870018422, 1.388545569}, {5.401558531, 5.641990128}, {4.818940919, 10.33176216},
+    {4.218758304, 14.25799688}, {3.646319832, 17.02880749}, {3.122346753, 18.64537883}, {2.654731979, 19.27521677},
+    {2.244479156, 19.13584613}, {1.88893867, 18.43922003},  {1.583645342, 17.36842261}, {1.3233807, 16.07088712},
+    {1.102785365, 14.65952563}, {0.916703025, 13.21718577}, {0.760361881, 11.80207947}, {0.629457387, 10.45304833},
+    {0.520175654, 9.194183767}, {0.42918208, 8.038657241},  {0.353590663, 6.991779595}, {0.290923699, 6.053379213},
+    {0.23906788, 5.219610436},  {0.196230431, 4.484302033}, {0.160897421, 3.839943445}, {0.131795374, 3.27839108},
+    {0.1078567, 2.791361596},   {0.088189063, 2.370765375}, {0.072048567, 2.008921719}, {0.058816518, 1.698687797},
+    {0.047979438, 1.433525748}, {0.039111985, 1.207526336}, {0.031862437, 1.015402928}, {0.025940415, 0.852465956},
+    {0.021106532, 0.714585285}, {0.017163711, 0.598145851}, {0.013949904, 0.500000349}, {0.011332027, 0.41742159},
+    {0.009200898, 0.348056286}, {0.007467036, 0.289881373}, {0.006057179, 0.241163527}, {0.004911394, 0.200422214}};
+
+__device__ __forceinline__ bool same(const uint8_t *s, int a, int b, int len) {
+    for (int i = 0; i < len; ++i)
+        if (s[a + i] != s[b + i]) return false;
+    return true;
+}
+
+// Number of consecutive copies of unit s[u, u+len) in s[lo, lo+tl), counted from the front (leading)
+// or from the back -- VariantContextUtils::find_number_of_repetitions_main
+// (src/model/variant_context_utils.rs:276-335) on sub-ranges of one string.
+__device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, bool leading) {
+    if (tl == 0) return 0;
+    const int diff = tl - len;
+    int n = 0;
+    if (leading) {
+        for (int start = 0; start <= diff; start += len) {
+            if (!same(s, lo + start, u, len)) return n;
+            ++n;
+        }
+    } else {
+        for (int start = diff; start >= 0; start -= len) {
+            if (!same(s, lo + start, u, len)) return n;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// find_tandem_repeat_units (engine.rs:528-611) -> length of the tandem repeat around `offset`.
+__device__ int tandem_repeat_length(const uint8_t *s, int n, int offset) {
+    int max_bw = 0, bw_u = offset, bw_len = 1;
+    for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
+        if (offset + 1 < str) break;
+        max_bw = repetitions(s, offset + 1 - str, str, 0, offset + 1, false);
+        if (max_bw > 1) {
+            bw_u = offset + 1 - str;
+            bw_len = str;
+            break;
+        }
+    }
+    int max_rl = max_bw;
+    if (offset < n - 1) {
+        int max_fw = 0, fw_len = 1;
+        const int fw_u = offset + 1;
+        for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
+            if (offset + str + 1 > n) break;
+            max_fw = repetitions(s, offset + 1, str, offset + 1, n - offset - 1, true);
+            if (max_fw > 1) {
+                fw_len = str;
+                break;
+            }
+        }
+        if (fw_len == bw_len && same(s, fw_u, bw_u, bw_len)) {
+            max_rl = max_bw + max_fw;
+        } else {  // the forward unit may still tile the sequence behind the offset (:589-603)
+            max_bw = repetitions(s, fw_u, fw_len, 0, offset + 1, false);
+            max_rl = max_fw + max_bw;
+        }
+    }
+    return max_rl > MAX_REPEAT_LENGTH ? MAX_REPEAT_LENGTH : max_rl;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= p.n_reads) return;
+    const uint32_t ro = p.read_off[r];
+    const int n = (int)(p.read_off[r + 1] - ro);
+    uint8_t *s = smem + (size_t)wave * p.lds_bytes_per_wave;
+    for (int i = lane; i < n; i += 64) s[i] = p.read_bases[ro + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t mapq = p.mapq[r];
+    for (int i = lane; i < n; i += 64) {
+        uint32_t q = p.base_q[ro + i];
+        uint32_t iq = p.ins_q ? p.ins_q[ro + i] : p.default_indel_qual;  // ReadUtils default Q45 (read_utils.rs:23)
+        uint32_t dq = p.del_q ? p.del_q[ro + i] : p.default_indel_qual;
+        if (p.pcr_cache && i < n - 1) {  // apply_pcr_error_model touches every base but the last (:513-523)
+            const uint32_t c = p.pcr_cache[tandem_repeat_length(s, n, i)];
+            iq = min(iq, c);
+            dq = min(dq, c);
+        }
+        // cap_minimum_read_qualities (:436-457)
+        if (!p.disable_cap_to_mapq) q = min(q, mapq);
+        if (q < p.base_quality_score_threshold) q = MIN_USABLE_Q;
+        if (iq < MIN_USABLE_Q) iq = MIN_USABLE_Q;
+        if (dq < MIN_USABLE_Q) dq = MIN_USABLE_Q;
+        p.out_q[ro + i] = (uint8_t)q;
+        p.out_ins[ro + i] = (uint8_t)iq;
+        p.out_del[ro + i] = (uint8_t)dq;
+        p.out_gcp[ro + i] = p.constant_gcp;  // PairHMMInputScoreImputator::gap_continuation_penalties (:649-651)
+    }
+    // Threshold handed to filter_poorly_modeled_evidence (:229-239).  Sequential sums in one lane keep
+    // the reference's summation order (150 adds per read are noise next to the forward kernel).
+    if (lane == 0) {
+        const double e = ceil((double)n * p.expected_error_rate_per_base);  // log10_min_true_likelihood (:293-319)
+        double thr;
+        if (!p.dynamic_disqualification) {
+            thr = fmin(2.0, e) * -4.0;
+        } else {
+            double sum_mean = 0.0, sum_var = 0.0;  // calculate_log10_dynamic_read_qual_threshold (:261-291)
+            for (int i = 0; i < n; ++i) {
+                const uint32_t bq = p.base_q[ro + i];  // ORIGINAL quals (the "HMMQuals" lookup never hits, :268)
+                const uint32_t idx = bq <= 1 ? 0u : min(40u, bq) - 1u;
+                sum_mean += kDynQualTable[idx][0];
+                sum_var += kDynQualTable[idx][1];
+            }
+            const double dyn = (sum_mean + p.read_disqualification_scale * sqrt(sum_var)) * -0.1;
+            const double cap = e * -4.0;
+            thr = dyn < cap ? dyn : cap;  // dynamic_log10_min_likelihood_model (:244-259)
+        }
+        p.threshold[r] = thr;
+    }
+}
+
+__global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    const uint32_t g = p.read_region[r];
+    const uint32_t nh = p.region_hap_off[g + 1] - p.region_hap_off[g];
+    double *row = p.out + p.out_off[g] + (uint64_t)(r - p.region_read_off[g]) * nh;
+    const int ref = p.region_ref_hap ? p.region_ref_hap[g] : -1;
+    double best_all = -INFINITY;  // maximum_likelihood_over_all_alleles (:1026-1041)
+    for (uint32_t a = 0; a < nh; ++a) best_all = row[a] > best_all ? row[a] : best_all;
+    // normalize_likelihoods (:378-444): nothing to do for 0/1 alleles or an infinite cap
+    if (nh > 1 && p.max_likelihood_difference_cap != -INFINITY) {
+        // search_best_allele(can_be_reference = symmetric, priorities = None) (:457-508)
+        const bool can_be_ref = p.symmetric != 0;
+        uint32_t first = (can_be_ref || ref != 0) ? 0u : 1u;
+        double best = row[first];
+        for (uint32_t a = first + 1; a < nh; ++a) {
+            if (!can_be_ref && ref == (int)a) continue;
+            best = row[a] > best ? row[a] : best;
+        }
+        const double worst = best + p.max_likelihood_difference_cap;
+        for (uint32_t a = 0; a < nh; ++a)
+            if (row[a] < worst) row[a] = worst;
+        // the cap can only raise values up to `worst` <= best: the all-allele maximum is unchanged unless
+        // every allele sat below `worst` (asymmetric mode with only the reference above the alts)
+        best_all = best_all > worst ? best_all : worst;
+    }
+    // filter_poorly_modeled_evidence removes evidence whose best likelihood is below its threshold (:941-958)
+    p.keep[r] = (best_all < p.threshold[r]) ? 0 : 1;
+}
+
+hipError_t launch_prep(const PrepParams &p, hipStream_t stream) {
+    if (!p.n_reads) return hipSuccess;
+    const int wpb = 4;
+    const size_t lds = (size_t)p.lds_bytes_per_wave * wpb;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(phmm_prep_reads),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(phmm_prep_reads, dim3((p.n_reads + wpb - 1) / wpb), dim3(64 * wpb), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_post(const PostParams &p, hipStream_t stream) {
+    if (!p.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(phmm_post_reads, dim3((p.n_reads + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace phmm

@@ -52,6 +52,34 @@ struct GenericParams {
 };
 hipError_t launch_generic(const GenericParams &p, hipStream_t stream);
 
+// ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------
+struct PrepParams {
+    uint32_t n_reads;
+    const uint32_t *read_off;
+    const uint8_t *read_bases, *base_q, *ins_q, *del_q;  // originals; ins_q / del_q may be null (flat default)
+    const uint8_t *mapq;                                 // [n_reads]
+    const uint8_t *pcr_cache;                            // [101] or null when the PCR model is None
+    uint8_t *out_q, *out_ins, *out_del, *out_gcp;        // modified copies the forward kernel reads
+    double *threshold;                                   // [n_reads] read-disqualification threshold
+    uint32_t lds_bytes_per_wave;                         // >= longest read
+    uint32_t default_indel_qual, constant_gcp, base_quality_score_threshold, disable_cap_to_mapq,
+        dynamic_disqualification;
+    double read_disqualification_scale, expected_error_rate_per_base;
+};
+struct PostParams {
+    uint32_t n_reads;
+    const uint32_t *read_region, *region_read_off, *region_hap_off;
+    const uint64_t *out_off;
+    const int32_t *region_ref_hap;  // [n_regions] reference haplotype index inside the region, -1 = none; may be null
+    double *out;                    // [region][read][hap], normalised in place
+    const double *threshold;        // [n_reads]
+    uint8_t *keep;                  // [n_reads] 1 = evidence survives filter_poorly_modeled_evidence
+    double max_likelihood_difference_cap;
+    uint32_t symmetric;
+};
+hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
+hipError_t launch_post(const PostParams &p, hipStream_t stream);
+
 // The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
 extern const int kInstantiatedK[];
 extern const int kNumInstantiatedK;

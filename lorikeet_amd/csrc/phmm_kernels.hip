@@ -116,9 +116,10 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         constexpr int k = decltype(kc)::value;
         // written so the two-address FMA accumulates into I's own register (v_mul I,I,gI ; v_fmac I,M,bI)
         Ip[k] = fma(Mp[k], c.bI, Ip[k] * c.gI);
-        const double dM = k ? Mp[k - 1] : plM;  // (i-1, k-1)
-        const double dI = k ? Ip[k - 1] : plI;
-        const double dD = k ? Dp[k - 1] : plD;
+        constexpr int km1 = k > 0 ? k - 1 : 0;
+        const double dM = k > 0 ? Mp[km1] : plM;  // (i-1, k-1)
+        const double dI = k > 0 ? Ip[km1] : plI;
+        const double dD = k > 0 ? Dp[km1] : plD;
         double t = dI + dD;
         if constexpr (MODE == ROW_GENERAL) t *= imx;
         const double a = fma(dM, c.mm, t);

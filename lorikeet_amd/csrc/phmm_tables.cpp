@@ -7,6 +7,7 @@
 // the reference's scalar path computes, then uploaded once per handle.
 #include "phmm_tables.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 
@@ -76,5 +77,21 @@ const std::vector<double> &table_eps_third() { return tables().eps_third; }
 const std::vector<double> &table_match_to_match() { return tables().mm; }
 double initial_condition() { return std::pow(2.0, 1020.0); }                       // pair_hmm.rs:16
 double initial_condition_log10() { return std::log10(std::pow(2.0, 1020.0)); }    // pair_hmm.rs:17
+
+
+// PairHMMLikelihoodCalculationEngine::initialize_pcr_error_model / get_error_model_adjusted_qual
+// (pair_hmm_likelihood_calculation_engine.rs:169-193): max(6, (40 - exp(len / (rate * pi)) + 1) as usize) as u8,
+// where the rate factor is the enum discriminant of the PCR model.
+std::vector<unsigned char> pcr_error_model_cache(int model) {
+    std::vector<unsigned char> cache(101, 0);
+    if (model <= 0) return cache;
+    const double pi = 3.14159265358979323846264338327950288;  // std::f64::consts::PI
+    for (int i = 0; i <= 100; ++i) {
+        const double v = 40.0 - std::exp((double)i / ((double)model * pi)) + 1.0;
+        const long u = v > 0.0 ? (long)v : 0;  // Rust float -> usize casts saturate at 0
+        cache[i] = (unsigned char)std::max<long>(6, u);
+    }
+    return cache;
+}
 
 }  // namespace phmm

@@ -53,6 +53,23 @@ def _load(path):
                                    _u64p, _f64p, C.c_int, C.c_int]
     lib.oracle_mm_table_len.restype = C.c_size_t
     lib.oracle_mm_prob_table.restype = _f64p
+    # engine_oracle.c
+    lib.oracle_pcr_error_model_cache.restype = None
+    lib.oracle_pcr_error_model_cache.argtypes = [C.c_int, _u8p]
+    lib.oracle_find_tandem_repeat_length.restype = C.c_size_t
+    lib.oracle_find_tandem_repeat_length.argtypes = [_u8p, C.c_size_t, C.c_size_t]
+    lib.oracle_modify_read_qualities.restype = None
+    lib.oracle_modify_read_qualities.argtypes = [C.c_int, _u8p, C.c_size_t, C.c_uint8, _u8p, _u8p, _u8p, C.c_uint8, C.c_int]
+    lib.oracle_read_disqualification_threshold.restype = C.c_double
+    lib.oracle_read_disqualification_threshold.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_double, C.c_double]
+    lib.oracle_log10_min_true_likelihood.restype = C.c_double
+    lib.oracle_log10_min_true_likelihood.argtypes = [C.c_size_t, C.c_double, C.c_int]
+    lib.oracle_log10_dynamic_read_qual_threshold.restype = C.c_double
+    lib.oracle_log10_dynamic_read_qual_threshold.argtypes = [_u8p, C.c_size_t, C.c_double]
+    lib.oracle_normalize_likelihoods.restype = None
+    lib.oracle_normalize_likelihoods.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_long]
+    lib.oracle_filter_poorly_modeled_evidence.restype = C.c_size_t
+    lib.oracle_filter_poorly_modeled_evidence.argtypes = [_f64p, C.c_size_t, C.c_size_t, _f64p, _u8p]
     return lib
 
 
@@ -154,3 +171,47 @@ def load_kat(path):
             rows.append(dict(hap=hap, read=read, qual=q(t[2], 6), ins=q(t[3], 0), dele=q(t[4], 0), gcp=q(t[5], 0),
                              expected=float(t[6])))
     return rows
+
+
+# ---- engine-level steps (engine_oracle.c) -----------------------------------------------------------
+PCR_MODELS = {"none": 0, "hostile": 1, "aggressive": 2, "conservative": 3}
+
+
+def pcr_error_model_cache(model):
+    c = np.zeros(101, np.uint8)
+    lib().oracle_pcr_error_model_cache(PCR_MODELS[model], c.ctypes.data_as(_u8p))
+    return c
+
+
+def modify_read_qualities(model, bases, mapq, quals, ins, dele, base_quality_score_threshold,
+                          disable_cap_read_qualities_to_mapq=False):
+    """Returns modified copies (quals, ins, dele) -- engine.rs:352-388."""
+    b, bp = _u8(bases)
+    q = np.array(quals, np.uint8); i = np.array(ins, np.uint8); d = np.array(dele, np.uint8)
+    lib().oracle_modify_read_qualities(PCR_MODELS[model], bp, len(b), int(mapq), q.ctypes.data_as(_u8p),
+                                       i.ctypes.data_as(_u8p), d.ctypes.data_as(_u8p),
+                                       int(base_quality_score_threshold), int(disable_cap_read_qualities_to_mapq))
+    return q, i, d
+
+
+def read_disqualification_threshold(orig_quals, dynamic, scale, expected_error_rate_per_base):
+    q, qp = _u8(np.asarray(orig_quals, np.uint8))
+    return lib().oracle_read_disqualification_threshold(qp, len(q), int(dynamic), float(scale),
+                                                       float(expected_error_rate_per_base))
+
+
+def normalize_likelihoods(values, cap, symmetric, reference_allele_index):
+    """values: [allele, read] float64 (modified in place and returned)."""
+    v = np.ascontiguousarray(values, np.float64)
+    lib().oracle_normalize_likelihoods(v.ctypes.data_as(_f64p), v.shape[0], v.shape[1], float(cap), int(symmetric),
+                                       -1 if reference_allele_index is None else int(reference_allele_index))
+    return v
+
+
+def filter_poorly_modeled_evidence(values, thresholds):
+    v = np.ascontiguousarray(values, np.float64)
+    t = np.ascontiguousarray(thresholds, np.float64)
+    keep = np.zeros(v.shape[1], np.uint8)
+    n = lib().oracle_filter_poorly_modeled_evidence(v.ctypes.data_as(_f64p), v.shape[0], v.shape[1],
+                                                    t.ctypes.data_as(_f64p), keep.ctypes.data_as(_u8p))
+    return v, keep.astype(bool), int(n)

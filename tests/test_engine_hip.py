@@ -1,0 +1,138 @@
+"""Engine-level parity on the GPU: phmm_engine_compute (pre-step, PairHMM, normalise, disqualification
+decision) against the oracle pipeline, and the reference's own engine test
+(tests/pair_hmm_likelihood_calculation_engine_unit_tests.rs:21-88) through the mirrored interface."""
+import math
+
+import numpy as np
+import pytest
+
+from lorikeet_amd.batch import Read, RegionBatch
+from lorikeet_amd.likelihood_engine import (AssemblyResultSet, AVXMode, PairHMMLikelihoodCalculationEngine,
+                                            PCRErrorModel, log_to_log10, qual_to_error_prob_log10)
+from lorikeet_amd.pair_hmm import Haplotype, HmmRead
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+MODELS = {PCRErrorModel.NONE: "none", PCRErrorModel.HOSTILE: "hostile", PCRErrorModel.AGGRESSIVE: "aggressive",
+          PCRErrorModel.CONSERVATIVE: "conservative"}
+
+
+def test_compute_likelihoods_reference_engine_test():
+    """The reference's test, argument for argument."""
+    lce = PairHMMLikelihoodCalculationEngine(
+        93, log_to_log10(qual_to_error_prob_log10(45)), PCRErrorModel.CONSERVATIVE, 16, False, 1.0, 0.02, True, False,
+        True, AVXMode.Hip)
+    n = 10
+    read1 = HmmRead(b"A" * n, [30] * n, mapq=60)   # create_artificial_read_default("test", 0, 0, 10): 10 x 'A', Q30
+    per_sample_read_list = {0: [read1]}
+    ref_bases = b"A" * (n + 1)
+    hap1 = Haplotype(ref_bases, True)
+    assembly_result_set = AssemblyResultSet(hap1)
+    assembly_result_set.add_haplotype(hap1)
+    hap2 = Haplotype(ref_bases[:5] + b"C" + ref_bases[6:], False)
+    assembly_result_set.add_haplotype(hap2)
+    likes = lce.compute_read_likelihoods(assembly_result_set, [0], per_sample_read_list)
+    assert len(likes.alleles) == 2
+    assert likes.evidence_count() == 1
+    v1, v2 = likes.sample_matrix(0)[0, 0], likes.sample_matrix(0)[1, 0]
+    assert v1 > v2, "Matching hap should have a higher likelihood"
+    # SURVEY.md section 4 known answers for this fixture
+    assert abs(v1 - -0.7446794209931795) < 1e-9 and abs(v2 - -2.6990045895578127) < 1e-9
+
+
+def _oracle_pipeline(cfg, regions):
+    """engine.rs:195-242 with the oracle's pieces; returns per region (normalised [read][hap], keep)."""
+    res = []
+    for reads, haps in regions:
+        mod, thr = [], []
+        for r in reads:
+            q, i, d = oracle.modify_read_qualities(MODELS[cfg["pcr"]], r.bases, r.mapq, r.quals,
+                                                   r.base_insertion_qualities(), r.base_deletion_qualities(),
+                                                   cfg["bq_threshold"], cfg["disable_cap"])
+            mod.append(Read(r.bases, q, i, d, np.full(len(r), cfg["gcp"], np.uint8)))
+            thr.append(oracle.read_disqualification_threshold(r.quals, cfg["dynamic"], cfg["scale"], cfg["err"]))
+        b = RegionBatch.from_regions([(mod, [h.get_bases() for h in haps])])
+        raw = oracle.compute_batch(b.as_dict(), n_threads=4).reshape(len(reads), len(haps))
+        ref = next((j for j, h in enumerate(haps) if h.is_ref), None)
+        norm = oracle.normalize_likelihoods(raw.T.copy(), cfg["cap"], cfg["symmetric"], ref)
+        _, keep, _ = oracle.filter_poorly_modeled_evidence(norm.copy(), thr)
+        res.append((norm.T, keep))
+    return res
+
+
+def _random_regions(rng, n_regions, with_tags):
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    regions = []
+    for _ in range(n_regions):
+        nh = int(rng.integers(1, 7))
+        root = alpha[rng.integers(0, 4, int(rng.integers(60, 260)))]
+        # low-complexity stretches so the PCR model has tandem repeats to find
+        for _ in range(3):
+            s = int(rng.integers(0, len(root) - 30))
+            unit = alpha[rng.integers(0, 4, int(rng.integers(1, 5)))]
+            rep = np.tile(unit, 12)[:int(rng.integers(6, 25))]
+            root[s:s + len(rep)] = rep[:len(root) - s]
+        haps = []
+        for j in range(nh):
+            h = root.copy()
+            for _ in range(int(rng.integers(0, 3)) if j else 0):
+                h[int(rng.integers(0, len(h)))] = alpha[int(rng.integers(0, 4))]
+            hh = Haplotype(bytes(h), is_ref=(j == int(rng.integers(0, nh))))
+            if hh not in haps:
+                haps.append(hh)
+        reads = []
+        for _ in range(int(rng.integers(0, 12))):
+            n = int(rng.integers(1, min(120, len(root))))
+            s = int(rng.integers(0, len(root) - n + 1))
+            bases = root[s:s + n].copy()
+            flips = rng.random(n) < 0.03
+            bases[flips] = alpha[rng.integers(0, 4, int(flips.sum()))]
+            quals = rng.choice([2, 6, 12, 17, 18, 22, 27, 32, 37, 41], n)
+            ins = rng.integers(0, 60, n) if with_tags else None
+            dele = rng.integers(0, 60, n) if with_tags else None
+            reads.append(HmmRead(bytes(bases), quals, ins, dele, mapq=int(rng.choice([0, 10, 29, 60]))))
+        regions.append((reads, haps))
+    return regions
+
+
+@pytest.mark.parametrize("pcr", list(MODELS))
+@pytest.mark.parametrize("dynamic,symmetric,with_tags", [(False, True, False), (True, False, True), (True, True, True)])
+def test_engine_matches_oracle_pipeline(pcr, dynamic, symmetric, with_tags):
+    cfg = dict(gcp=10, cap=-4.5 * math.log10(math.e), pcr=pcr, bq_threshold=18, dynamic=dynamic, scale=1.0, err=0.02,
+               symmetric=symmetric, disable_cap=(pcr == PCRErrorModel.HOSTILE))
+    eng = PairHMMLikelihoodCalculationEngine(cfg["gcp"], cfg["cap"], pcr, cfg["bq_threshold"], dynamic, cfg["scale"],
+                                             cfg["err"], symmetric, cfg["disable_cap"])
+    regions = _random_regions(np.random.default_rng(100 + int(pcr) + 10 * dynamic), 12, with_tags)
+    got = eng.compute_regions(regions)
+    want = _oracle_pipeline(cfg, regions)
+    n_removed = 0
+    for (gm, gk), (wm, wk) in zip(got, want):
+        assert gm.shape == wm.shape
+        if gm.size:
+            assert np.max(np.abs(gm - wm)) <= 1e-9
+        assert np.array_equal(gk, wk)
+        n_removed += int((~wk).sum())
+    if dynamic:
+        assert n_removed > 0  # the test data does exercise the removal branch
+
+
+def test_engine_surface_filters_and_compacts():
+    """compute_read_likelihoods moves poorly modelled reads to filtered evidence, compacts the [allele, read]
+    matrix and pads with NaN (allele_likelihoods.rs:968-1018)."""
+    eng = PairHMMLikelihoodCalculationEngine(10, -4.5 * math.log10(math.e), PCRErrorModel.CONSERVATIVE, 18, True, 1.0,
+                                             0.02, True, False)
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    ref = alpha[rng.integers(0, 4, 120)]
+    alt = ref.copy(); alt[60] = alpha[(np.where(alpha == alt[60])[0][0] + 1) % 4]
+    ars = AssemblyResultSet(Haplotype(bytes(ref), True))
+    ars.add_haplotype(Haplotype(bytes(alt), False))
+    good = [HmmRead(bytes(ref[s:s + 50]), [30] * 50, mapq=60) for s in (5, 30, 60)]
+    junk = [HmmRead(bytes(alpha[rng.integers(0, 4, 50)]), [30] * 50, mapq=60) for _ in range(2)]
+    likes = eng.compute_read_likelihoods(ars, [0, 1], {0: [good[0], junk[0], good[1]], 1: [junk[1], good[2]]})
+    assert [len(likes.evidence_by_sample_index[s]) for s in (0, 1)] == [2, 1]
+    assert likes.filtered_evidence_by_sample_index[0] == [junk[0]] and likes.filtered_evidence_by_sample_index[1] == [junk[1]]
+    m0, m1 = likes.sample_matrix(0), likes.sample_matrix(1)
+    assert m0.shape == (2, 3) and m1.shape == (2, 2)
+    assert not np.isnan(m0[:, :2]).any() and np.isnan(m0[:, 2]).all() and np.isnan(m1[:, 1]).all()
+    assert (m0[0, :2] >= m0[1, :2]).all()  # reads copied from the reference prefer it
