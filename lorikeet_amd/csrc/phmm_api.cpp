@@ -787,7 +787,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         pp.out_del = d_d;
         pp.out_gcp = d_g;
         pp.threshold = d_thr;
-        pp.lds_bytes_per_wave = (uint32_t)align_up((size_t)max_r + 1, 16);
+        pp.lds_rows = (uint32_t)align_up((size_t)max_r + 1, 8);
         pp.default_indel_qual = 45;  // ReadUtils::DEFAULT_INSERTION_DELETION_QUAL (read_utils.rs:23)
         pp.constant_gcp = cfg->constant_gcp;
         pp.base_quality_score_threshold = cfg->base_quality_score_threshold;
@@ -795,7 +795,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         pp.dynamic_disqualification = cfg->dynamic_read_disqualification;
         pp.read_disqualification_scale = cfg->read_disqualification_scale;
         pp.expected_error_rate_per_base = cfg->expected_error_rate_per_base;
-        if (ok && (size_t)pp.lds_bytes_per_wave * 4 > kLdsBytesPerCU) {
+        if (ok && (size_t)pp.lds_rows * 17 * 4 > kLdsBytesPerCU) {
             h->err = "phmm_engine_compute: read too long for the pre-step kernel";
             ok = false;
             st = PHMM_ERR_INVALID_ARG;

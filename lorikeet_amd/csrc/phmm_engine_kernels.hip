@@ -40,18 +40,30 @@ __device__ __forceinline__ bool same(const uint8_t *s, int a, int b, int len) {
 
 // Number of consecutive copies of unit s[u, u+len) in s[lo, lo+tl), counted from the front (leading)
 // or from the back -- VariantContextUtils::find_number_of_repetitions_main
-// (src/model/variant_context_utils.rs:276-335) on sub-ranges of one string.
-__device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, bool leading) {
+// (src/model/variant_context_utils.rs:276-335) on sub-ranges of one string.  `first_is_unit`: the copy
+// at the counted end IS the unit itself (the caller cut the unit out of that end), so its compare is
+// skipped -- same count, one LDS pass less.
+__device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, bool leading, bool first_is_unit) {
     if (tl == 0) return 0;
     const int diff = tl - len;
     int n = 0;
     if (leading) {
-        for (int start = 0; start <= diff; start += len) {
+        int start = 0;
+        if (first_is_unit && diff >= 0) {
+            n = 1;
+            start = len;
+        }
+        for (; start <= diff; start += len) {
             if (!same(s, lo + start, u, len)) return n;
             ++n;
         }
     } else {
-        for (int start = diff; start >= 0; start -= len) {
+        int start = diff;
+        if (first_is_unit && diff >= 0) {
+            n = 1;
+            start = diff - len;
+        }
+        for (; start >= 0; start -= len) {
             if (!same(s, lo + start, u, len)) return n;
             ++n;
         }
@@ -60,33 +72,66 @@ __device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, boo
 }
 
 // find_tandem_repeat_units (engine.rs:528-611) -> length of the tandem repeat around `offset`.
+//
+// A unit of length `str` <= 20 repeats (count > 1) iff the adjacent block of the same length equals it,
+// and both blocks lie within 40 bases of the offset.  So the 40 bases on either side are fetched up front
+// with independent LDS reads and all 2 x 20 candidate unit lengths are decided in registers, branch-free
+// (no divergence between the 64 positions a wave works on); the exact, data-dependent count runs only at
+// positions that really sit in a tandem repeat.  Same results as the plain loops.
 __device__ int tandem_repeat_length(const uint8_t *s, int n, int offset) {
+    constexpr int W = 2 * MAX_STR_UNIT_LENGTH;
+    uint32_t wb[W], wf[W];  // wb[d] = s[offset - d], wf[d] = s[offset + 1 + d]; distinct sentinels outside the read
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+        wb[d] = (offset - d >= 0) ? (uint32_t)s[offset - d] : 0x100u + d;
+        wf[d] = (offset + 1 + d < n) ? (uint32_t)s[offset + 1 + d] : 0x200u + d;
+    }
     int max_bw = 0, bw_u = offset, bw_len = 1;
+    bool bw_done = false;
+#pragma unroll
     for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
-        if (offset + 1 < str) break;
-        max_bw = repetitions(s, offset + 1 - str, str, 0, offset + 1, false);
-        if (max_bw > 1) {
-            bw_u = offset + 1 - str;
-            bw_len = str;
-            break;
+        if (!bw_done && offset + 1 >= str) {
+            // unit = s[offset+1-str, offset+1); the copy before it starts at offset+1-2str
+            max_bw = 1;
+            bool twice = true;
+#pragma unroll
+            for (int d = 0; d < str; ++d) twice &= (wb[d] == wb[d + str]);
+            if (twice) max_bw = repetitions(s, offset + 1 - str, str, 0, offset + 1, false, true);
+            if (max_bw > 1) {
+                bw_u = offset + 1 - str;
+                bw_len = str;
+                bw_done = true;
+            }
+        } else {
+            bw_done = true;  // (offset + 1).checked_sub(str) failed: stop (:535-537)
         }
     }
     int max_rl = max_bw;
     if (offset < n - 1) {
         int max_fw = 0, fw_len = 1;
         const int fw_u = offset + 1;
+        bool fw_done = false;
+#pragma unroll
         for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
-            if (offset + str + 1 > n) break;
-            max_fw = repetitions(s, offset + 1, str, offset + 1, n - offset - 1, true);
-            if (max_fw > 1) {
-                fw_len = str;
-                break;
+            if (!fw_done && offset + str + 1 <= n) {
+                // unit = s[offset+1, offset+1+str); the copy after it starts at offset+1+str
+                max_fw = 1;
+                bool twice = true;
+#pragma unroll
+                for (int d = 0; d < str; ++d) twice &= (wf[d] == wf[d + str]);
+                if (twice) max_fw = repetitions(s, offset + 1, str, offset + 1, n - offset - 1, true, true);
+                if (max_fw > 1) {
+                    fw_len = str;
+                    fw_done = true;
+                }
+            } else {
+                fw_done = true;
             }
         }
         if (fw_len == bw_len && same(s, fw_u, bw_u, bw_len)) {
             max_rl = max_bw + max_fw;
         } else {  // the forward unit may still tile the sequence behind the offset (:589-603)
-            max_bw = repetitions(s, fw_u, fw_len, 0, offset + 1, false);
+            max_bw = repetitions(s, fw_u, fw_len, 0, offset + 1, false, false);
             max_rl = max_fw + max_bw;
         }
     }
@@ -103,7 +148,11 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     if (r >= p.n_reads) return;
     const uint32_t ro = p.read_off[r];
     const int n = (int)(p.read_off[r + 1] - ro);
-    uint8_t *s = smem + (size_t)wave * p.lds_bytes_per_wave;
+    // wave-private LDS: [mean f64 x rows | variance f64 x rows | bases u8 x rows]
+    const uint32_t rows = p.lds_rows;
+    double *s_mean = reinterpret_cast<double *>(smem + (size_t)wave * rows * 17);
+    double *s_var = s_mean + rows;
+    uint8_t *s = reinterpret_cast<uint8_t *>(s_var + rows);
     for (int i = lane; i < n; i += 64) s[i] = p.read_bases[ro + i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -112,6 +161,11 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     const uint32_t mapq = p.mapq[r];
     for (int i = lane; i < n; i += 64) {
         uint32_t q = p.base_q[ro + i];
+        if (p.dynamic_disqualification) {  // table rows for the ORIGINAL qual (the "HMMQuals" lookup never hits, :268)
+            const uint32_t idx = q <= 1 ? 0u : min(40u, q) - 1u;
+            s_mean[i] = kDynQualTable[idx][0];
+            s_var[i] = kDynQualTable[idx][1];
+        }
         uint32_t iq = p.ins_q ? p.ins_q[ro + i] : p.default_indel_qual;  // ReadUtils default Q45 (read_utils.rs:23)
         uint32_t dq = p.del_q ? p.del_q[ro + i] : p.default_indel_qual;
         if (p.pcr_cache && i < n - 1) {  // apply_pcr_error_model touches every base but the last (:513-523)
@@ -129,8 +183,12 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
         p.out_del[ro + i] = (uint8_t)dq;
         p.out_gcp[ro + i] = p.constant_gcp;  // PairHMMInputScoreImputator::gap_continuation_penalties (:649-651)
     }
-    // Threshold handed to filter_poorly_modeled_evidence (:229-239).  Sequential sums in one lane keep
-    // the reference's summation order (150 adds per read are noise next to the forward kernel).
+    // Threshold handed to filter_poorly_modeled_evidence (:229-239).  The per-base table values were
+    // gathered in parallel above; one lane adds them from LDS in read order, which keeps the reference's
+    // summation order (bit-identical threshold) at ~1 us per read.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane == 0) {
         const double e = ceil((double)n * p.expected_error_rate_per_base);  // log10_min_true_likelihood (:293-319)
         double thr;
@@ -139,10 +197,8 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
         } else {
             double sum_mean = 0.0, sum_var = 0.0;  // calculate_log10_dynamic_read_qual_threshold (:261-291)
             for (int i = 0; i < n; ++i) {
-                const uint32_t bq = p.base_q[ro + i];  // ORIGINAL quals (the "HMMQuals" lookup never hits, :268)
-                const uint32_t idx = bq <= 1 ? 0u : min(40u, bq) - 1u;
-                sum_mean += kDynQualTable[idx][0];
-                sum_var += kDynQualTable[idx][1];
+                sum_mean += s_mean[i];
+                sum_var += s_var[i];
             }
             const double dyn = (sum_mean + p.read_disqualification_scale * sqrt(sum_var)) * -0.1;
             const double cap = e * -4.0;
@@ -185,7 +241,7 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream) {
     if (!p.n_reads) return hipSuccess;
     const int wpb = 4;
-    const size_t lds = (size_t)p.lds_bytes_per_wave * wpb;
+    const size_t lds = (size_t)p.lds_rows * 17 * wpb;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(phmm_prep_reads),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -61,7 +61,7 @@ struct PrepParams {
     const uint8_t *pcr_cache;                            // [101] or null when the PCR model is None
     uint8_t *out_q, *out_ins, *out_del, *out_gcp;        // modified copies the forward kernel reads
     double *threshold;                                   // [n_reads] read-disqualification threshold
-    uint32_t lds_bytes_per_wave;                         // >= longest read
+    uint32_t lds_rows;                                   // >= longest read, multiple of 8 (17 B of LDS per row)
     uint32_t default_indel_qual, constant_gcp, base_quality_score_threshold, disable_cap_to_mapq,
         dynamic_disqualification;
     double read_disqualification_scale, expected_error_rate_per_base;
