@@ -130,16 +130,21 @@ int round_up_k(int k) {
     return 0;
 }
 
-// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates).
-int waves_per_simd(int K) { return K <= 4 ? 4 : K <= 8 ? 3 : K <= 16 ? 2 : 1; }
+// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates; K <= 19 is
+// compiled for 2 waves).
+int waves_per_simd(int K) { return K <= 6 ? 3 : K <= 19 ? 2 : 1; }
 
-// Fraction of issued lane-steps that are useful cells for a region under <L,K>.
+// Throughput model of a region under <L,K>, calibrated on MI355X (tools/shapes.py): useful fraction of
+// issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~12 of 9.5*K+12 VALU ops per
+// step) x a small bonus for a second resident wave (measured ~1-3 %).
 double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h) {
     const int G = WAVE / L;
     const double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
     const double ramp = (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
     const double col_fill = (double)max_h / (double)(L * K);
-    return hap_fill * ramp * col_fill;
+    const double step = 9.5 * K / (9.5 * K + 12.0);
+    const double occ = waves_per_simd(K) >= 2 ? 1.0 : 0.97;
+    return hap_fill * ramp * col_fill * step * occ;
 }
 
 }  // namespace
@@ -379,9 +384,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             if (h->force_L && L != h->force_L) continue;
             const int k = round_up_k((int)((std::max<uint32_t>(s.max_h, 1) + L - 1) / L));
             if (!k) continue;
-            // resident waves hide the serial D chain: weigh by min(1, waves/2)
-            const double occ = std::min(1.0, waves_per_simd(k) / 2.0);
-            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h) * (0.75 + 0.25 * occ);
+            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h);
             if (e > best) {
                 best = e;
                 L_out = L;
@@ -460,7 +463,12 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
             const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
-            c.waves_per_block = (int)std::min<size_t>(MAX_WAVES_PER_BLOCK, kLdsBytesPerCU / per_wave);
+            // One wave per workgroup: waves are independent (no barrier, private LDS), and a multi-wave block
+            // would hold its LDS until its longest read finishes -- with mixed read lengths that idles SIMDs.
+            c.waves_per_block = 1;
+            if (const char *e = getenv("PHMM_WAVES_PER_BLOCK"))
+                c.waves_per_block = (int)std::min<size_t>(std::max(1, atoi(e)),
+                                                          std::min<size_t>(MAX_WAVES_PER_BLOCK, kLdsBytesPerCU / per_wave));
             c.lds_bytes = per_wave * c.waves_per_block;
             // Enough reads to fill the chip -> one wave walks all haplotype groups of its read (row
             // constants staged once); otherwise spread the groups over gridDim.y.

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void 
     }
 }
 
+#ifdef PHMM_WITH_GENERIC
 // ---- generic any-shape fallback -----------------------------------------------------------------
 // One thread per (read, haplotype) pair, two rolling rows of M/I/D in global scratch, interleaved by
 // thread so that neighbouring threads touch neighbouring addresses.  Only used for shapes outside
@@ -441,15 +442,24 @@ __global__ __launch_bounds__(256) void phmm_forward_generic(const GenericParams 
     }
 }
 
-// ---- launch tables -------------------------------------------------------------------------------
-#define PHMM_K_LIST(X, L) X(L, 2) X(L, 4) X(L, 6) X(L, 8) X(L, 10) X(L, 13) X(L, 16) X(L, 19) X(L, 22) X(L, 25) X(L, 28) X(L, 32)
-const int kInstantiatedK[] = {2, 4, 6, 8, 10, 13, 16, 19, 22, 25, 28, 32};
-const int kNumInstantiatedK = sizeof(kInstantiatedK) / sizeof(int);
+#endif  // PHMM_WITH_GENERIC
 
-hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int waves_per_block, size_t lds_bytes,
-                          hipStream_t stream) {
+// ---- launch tables -------------------------------------------------------------------------------
+#define PHMM_K_LIST(X, L)                                                                              \
+    X(L, 2) X(L, 3) X(L, 4) X(L, 5) X(L, 6) X(L, 7) X(L, 8) X(L, 9) X(L, 10) X(L, 11) X(L, 12) X(L, 13) X(L, 14)  \
+    X(L, 15) X(L, 16) X(L, 17) X(L, 18) X(L, 19) X(L, 20) X(L, 21) X(L, 22) X(L, 23) X(L, 24) X(L, 25) X(L, 26) \
+    X(L, 27) X(L, 28) X(L, 29) X(L, 30) X(L, 31) X(L, 32)
+// This file is compiled once per lanes-per-pair value (-DPHMM_L=16|32|64) so the three sets of 31
+// instantiations build in parallel; the L=16 object also carries the generic kernel and the dispatcher.
+#ifndef PHMM_L
+#error "compile with -DPHMM_L=16|32|64"
+#endif
+#define PHMM_CAT2(a, b) a##b
+#define PHMM_CAT(a, b) PHMM_CAT2(a, b)
+hipError_t PHMM_CAT(launch_forward_L, PHMM_L)(int K, const ForwardParams &p, dim3 grid, int waves_per_block,
+                                              size_t lds_bytes, hipStream_t stream) {
 #define PHMM_CASE(LL, KK)                                                                          \
-    if (L == LL && K == KK) {                                                                      \
+    if (K == KK) {                                                                                 \
         auto kern = phmm_forward<LL, KK>;                                                          \
         if (lds_bytes > 64 * 1024) {                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),               \
@@ -459,10 +469,21 @@ hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int w
         hipLaunchKernelGGL(kern, grid, dim3(WAVE * waves_per_block), lds_bytes, stream, p);        \
         return hipGetLastError();                                                                  \
     }
-    PHMM_K_LIST(PHMM_CASE, 16)
-    PHMM_K_LIST(PHMM_CASE, 32)
-    PHMM_K_LIST(PHMM_CASE, 64)
+    PHMM_K_LIST(PHMM_CASE, PHMM_L)
 #undef PHMM_CASE
+    return hipErrorInvalidValue;
+}
+
+#ifdef PHMM_WITH_GENERIC
+hipError_t launch_forward_L16(int, const ForwardParams &, dim3, int, size_t, hipStream_t);
+hipError_t launch_forward_L32(int, const ForwardParams &, dim3, int, size_t, hipStream_t);
+hipError_t launch_forward_L64(int, const ForwardParams &, dim3, int, size_t, hipStream_t);
+
+hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int waves_per_block, size_t lds_bytes,
+                          hipStream_t stream) {
+    if (L == 16) return launch_forward_L16(K, p, grid, waves_per_block, lds_bytes, stream);
+    if (L == 32) return launch_forward_L32(K, p, grid, waves_per_block, lds_bytes, stream);
+    if (L == 64) return launch_forward_L64(K, p, grid, waves_per_block, lds_bytes, stream);
     return hipErrorInvalidValue;
 }
 
@@ -471,5 +492,10 @@ hipError_t launch_generic(const GenericParams &gp, hipStream_t stream) {
     hipLaunchKernelGGL(phmm_forward_generic, dim3(gp.n_blocks), dim3(256), 0, stream, gp);
     return hipGetLastError();
 }
+
+const int kInstantiatedK[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                              18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
+const int kNumInstantiatedK = sizeof(kInstantiatedK) / sizeof(int);
+#endif  // PHMM_WITH_GENERIC
 
 }  // namespace phmm
