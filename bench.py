@@ -82,15 +82,15 @@ def cpu_baseline(batch, budget_s=20.0):
 
 
 def pmc_traffic(workload, regions):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+    """(HBM bytes per launch, L2 hit rate) measured with rocprofv3 PMC passes (profiles/pmc_traffic.json)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         for e in json.load(open(path)):
             if e["workload"] == workload and e["regions"] == regions:
-                return e["hbm_bytes_per_launch"]
+                return e["hbm_bytes_per_launch"], e.get("l2_hit_rate")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -146,6 +146,28 @@ def main():
     cells_total = plan.cells * world  # identical shapes on every rank
     regions_total = batch.n_regions * world
 
+    single = None
+    if rank == 0:  # configs[1] literally: ONE region per launch (latency mode: the planner spreads it over all SIMDs)
+        one, _ = make_workload(a.workload, 1, a.seed + 7919)
+        p1 = eng.plan(one)
+        t1 = {k: torch.from_numpy(getattr(one, k)).to(dev) for k in
+              ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
+        o1 = torch.empty(one.n_out, dtype=torch.float64, device=dev)
+        p1.bind_torch(t1, o1)
+        with torch.cuda.stream(stream):
+            for _ in range(10):
+                p1.launch(sh)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(100):
+                p1.launch(sh)
+            e1.record(stream)
+            stream.synchronize()
+        us = e0.elapsed_time(e1) * 10.0
+        single = {"regions": 1, "us_per_region": round(us, 2), "gcups": round(p1.cells / us / 1e3, 1),
+                  "kernel": p1.dominant_kernel, "note": "one region per launch, back-to-back launches on one stream"}
+        p1.close()
+
     if rank == 0:
         res = out.cpu().numpy()
         assert (res <= 0).all(), "non-finite or positive likelihoods"
@@ -168,7 +190,8 @@ def main():
                        "sharding": "regions, one process per GPU, no collective"},
             "regions_per_s": round(regions_total * a.steps / elapsed, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(a.workload, a.regions),
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(a.workload, a.regions)[0],
+                         "l2_hit_rate": pmc_traffic(a.workload, a.regions)[1],
                          "kernel": plan.dominant_kernel, "kernel_ms": round(mean_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "compulsory traffic is 2.3e-3 B/cell: the path is FP64-VALU bound, see valu_f64"},
@@ -177,6 +200,7 @@ def main():
                          "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
                          "flop_per_cell": FLOP_PER_CELL},
         }
+        line["single_region"] = single
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(line), flush=True)
