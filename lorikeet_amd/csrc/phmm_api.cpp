@@ -130,9 +130,9 @@ int round_up_k(int k) {
     return 0;
 }
 
-// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates; K <= 19 is
+// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates; K <= 21 is
 // compiled for 2 waves).
-int waves_per_simd(int K) { return K <= 6 ? 3 : K <= 19 ? 2 : 1; }
+int waves_per_simd(int K) { return K <= 6 ? 3 : K <= 21 ? 2 : 1; }
 
 // Throughput model of a region under <L,K>, calibrated on MI355X (tools/shapes.py): useful fraction of
 // issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~12 of 9.5*K+12 VALU ops per
@@ -478,7 +478,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             // the EXEC-masked prior select trades a VALU op for an SALU op: a win only when a second wave on
             // the SIMD can use the freed VALU slot (measured: +3 % at 2 waves/SIMD, -8 % at 1)
             const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
-            c.exec_select = (waves >= 2ull * kNumSimd && c.K <= 19) ? 1u : 0u;
+            c.exec_select = (waves >= 2ull * kNumSimd && c.K <= 21) ? 1u : 0u;
             if (const char *e = getenv("PHMM_FORCE_EXEC_SELECT")) c.exec_select = atoi(e) ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {

@@ -20,6 +20,11 @@
 
 #include <type_traits>
 
+// K up to this value is compiled for two resident waves per SIMD (<= 256 VGPRs, no spills)
+#ifndef PHMM_TWO_WAVE_MAX_K
+#define PHMM_TWO_WAVE_MAX_K 21
+#endif
+
 namespace phmm {
 
 // ---- DPP lane shifts (zero fill where there is no source lane) ---------------------------------
@@ -256,7 +261,7 @@ __device__ __forceinline__ double sweep_general(const LdsView &lds, const int R,
 }
 
 template <int L, int K>
-__global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= 19 ? 2 : 1)) void phmm_forward(const ForwardParams p) {
+__global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_K ? 2 : 1)) void phmm_forward(const ForwardParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & (WAVE - 1);

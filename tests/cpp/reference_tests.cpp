@@ -1,0 +1,367 @@
+// The reference's own PairHMM tests, restated against the C++ host layer
+// (lorikeet_amd/csrc/host/lorikeet_pair_hmm.hpp) above the C ABI -- every likelihood below is computed by
+// the gfx950 kernels.  Each test names the Rust test it mirrors; tolerances are the reference's.
+//
+//   reference tests/vector_pair_hmm_unit_tests.rs                         test_likelihoods_avx
+//   reference tests/pair_hmm_unit_tests.rs                                make_basic_likelihood_tests, ...
+//   reference tests/pair_hmm_likelihood_calculation_engine_unit_tests.rs  test_compute_likelihoods
+//
+// usage: reference_tests <path to pairhmm-testdata.txt>     (run by tests/test_cpp_host_layer.py, -m gpu)
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <sstream>
+
+#include "../../lorikeet_amd/csrc/host/lorikeet_pair_hmm.hpp"
+
+using namespace lorikeet;
+
+static int g_checks = 0;
+#define ASSERT(cond, ...)                                                  \
+    do {                                                                   \
+        ++g_checks;                                                        \
+        if (!(cond)) {                                                     \
+            std::fprintf(stderr, "ASSERT FAILED %s:%d: %s -- ", __FILE__, __LINE__, #cond); \
+            std::fprintf(stderr, __VA_ARGS__);                             \
+            std::fprintf(stderr, "\n");                                    \
+            throw std::runtime_error("assertion failed");                  \
+        }                                                                  \
+    } while (0)
+
+static bool relative_eq(double a, double b, double epsilon) {  // approx::relative_eq! with only epsilon given
+    if (a == b) return true;
+    const double d = std::fabs(a - b);
+    if (d <= epsilon) return true;
+    return d <= std::max(std::fabs(a), std::fabs(b)) * 2.220446049250313e-16;
+}
+static bool is_valid_log10_probability(double v) { return v <= 0.0; }  // MathUtils::is_valid_log10_probability
+
+// ---------------------------------------------------------------------------------------------------------
+// tests/vector_pair_hmm_unit_tests.rs:22-92
+// ---------------------------------------------------------------------------------------------------------
+static void test_likelihoods_avx(const std::string &path) {
+    std::ifstream file(path);
+    ASSERT(file.good(), "cannot open %s", path.c_str());
+    std::string line;
+    int n = 0;
+    while (std::getline(file, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream tokens(line);
+        std::string hap_s, bases_s, q_s, i_s, d_s, g_s;
+        double expected_result;
+        tokens >> hap_s >> bases_s >> q_s >> i_s >> d_s >> g_s >> expected_result;
+        auto parse_qual = [](const std::string &s, uint8_t min) {
+            Bytes q;
+            for (char c : s) q.push_back(std::max<uint8_t>(min, (uint8_t)(c - 33)));
+            return q;
+        };
+        const Bytes hap_bases = bytes(hap_s), read_bases = bytes(bases_s);
+        const Bytes base_quals = parse_qual(q_s, 6), insertion_quals = parse_qual(i_s, 0), deletion_quals = parse_qual(d_s, 0),
+                    gcp = parse_qual(g_s, 0);
+        const double result = forward(hap_bases, read_bases, base_quals, insertion_quals, deletion_quals, gcp);
+        ASSERT(std::fabs(result - expected_result) < 1e-5, "direct result %g expected %g", result, expected_result);
+
+        Haplotype hap(hap_bases, true);
+        HmmRead read(read_bases, base_quals);
+        read.ins_quals = insertion_quals;
+        read.del_quals = deletion_quals;
+        std::map<size_t, std::vector<HmmRead>> read_map{{0, {read}}};
+        std::vector<Haplotype> hap_vec{hap};
+        PairHMM hmm = PairHMM::initialize(hap_vec, read_map, AVXMode::Hip);
+        AlleleLikelihoods likelihoods(hap_vec, {0}, read_map);
+        PairHMMInputScoreImputator score_imputator(gcp[0]);
+        hmm.compute_log10_likelihoods(0, likelihoods, {read}, score_imputator);
+        const auto &la = hmm.get_log_likelihood_array();
+        ASSERT(std::fabs(la[0] - expected_result) < 1e-5,
+               "Likelihood not in expected range for PairHMM implementation: got %g expected %g", la[0], expected_result);
+        ASSERT(likelihoods.sample_matrix(0)(0, 0) == la[0], "scatter");
+        ++n;
+    }
+    ASSERT(n == 104, "expected 104 vectors, read %d", n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tests/pair_hmm_unit_tests.rs
+// ---------------------------------------------------------------------------------------------------------
+static const std::string CONTEXT = "ACGTAATGACGATTGCA";
+static const std::string LEFT_FLANK = "GATTTATCATCGAGTCTGC";
+static const std::string RIGHT_FLANK = "CATGGATCGTTATCAGCTATCTCGAGGGATTCACTTAACAGTTTTA";
+static const uint8_t MASSIVE_QUAL = 100;
+static const std::string BASES = "ACGT";
+
+static std::string as_bytes(const std::string &b, bool left, bool right) {  // :156-165
+    return (left ? LEFT_FLANK : "") + CONTEXT + b + CONTEXT + (right ? RIGHT_FLANK : "");
+}
+
+struct BasicLikelihoodTestProvider {  // :33-154
+    std::string reference, read, ref_bases_with_context, read_bases_with_context;
+    uint8_t base_qual, ins_qual, del_qual, gcp;
+    size_t expected_qual;
+    BasicLikelihoodTestProvider(const std::string &reference_, const std::string &read_, uint8_t bq, uint8_t iq, uint8_t dq,
+                                size_t expected, uint8_t gcp_, bool left, bool right)
+        : reference(reference_), read(read_), ref_bases_with_context(as_bytes(reference_, left, right)),
+          read_bases_with_context(as_bytes(read_, false, false)), base_qual(bq), ins_qual(iq), del_qual(dq), gcp(gcp_),
+          expected_qual(expected) {}
+    double expected_log_likelihood() const {
+        return (double)expected_qual / -10.0 + 0.03 + std::log10(1.0 / (double)ref_bases_with_context.size());
+    }
+    Bytes qual_as_bytes(uint8_t phred_qual, bool do_gop, bool anchor_indel) const {
+        Bytes q(read_bases_with_context.size(), anchor_indel ? MASSIVE_QUAL : phred_qual);
+        if (anchor_indel) {
+            if (do_gop) q[CONTEXT.size()] = phred_qual;
+            else for (size_t i = 0; i < read.size(); ++i) q[i + CONTEXT.size()] = phred_qual;
+        }
+        return q;
+    }
+    double calc_log10_likelihood(PairHMM &pair_hmm, bool anchor_indel) const {
+        return pair_hmm.compute_read_likelihood_given_haplotype_log10(
+            bytes(ref_bases_with_context), bytes(read_bases_with_context), qual_as_bytes(base_qual, false, anchor_indel),
+            qual_as_bytes(ins_qual, true, anchor_indel), qual_as_bytes(del_qual, true, anchor_indel),
+            qual_as_bytes(gcp, false, anchor_indel), true, std::nullopt);
+    }
+};
+
+static void test_basic_likelihoods(PairHMM &hmm, const BasicLikelihoodTestProvider &cfg) {  // :300-326
+    const double actual = cfg.calc_log10_likelihood(hmm, true), expected = cfg.expected_log_likelihood();
+    ASSERT(relative_eq(actual, expected, 0.2), "Failed with hmm calc %g -> %g", actual, expected);
+    ASSERT(is_valid_log10_probability(actual), "Bad log likelihood %g", actual);
+}
+
+static void make_basic_likelihood_tests() {  // :169-298
+    PairHMM hmm = PairHMM::quick_initialize(0, 0);
+    hmm.do_not_use_tristate_correction();
+    int n = 0;
+    for (uint8_t base_qual : {10, 20, 30, 40, 50})
+        for (uint8_t indel_qual : {20, 30, 40, 50})
+            for (uint8_t gcp : {8, 10, 20}) {
+                for (char ref_base : BASES)
+                    for (char read_base : BASES) {
+                        test_basic_likelihoods(hmm, BasicLikelihoodTestProvider(std::string(1, ref_base), std::string(1, read_base),
+                                                                                base_qual, indel_qual, indel_qual,
+                                                                                ref_base == read_base ? 0 : base_qual, gcp, false, false));
+                        ++n;
+                    }
+                for (int size : {2, 3, 4, 5, 7, 8, 9, 10, 20, 30, 35})
+                    for (char base : BASES) {
+                        const size_t expected = (size_t)(indel_qual + (size - 2) * gcp);
+                        for (bool insertion_p : {true, false}) {
+                            const std::string small(1, base), big((size_t)size, base);
+                            const std::string reference = insertion_p ? small : big, read = insertion_p ? big : small;
+                            for (auto lr : {std::pair<bool, bool>{false, false}, {true, false}, {false, true}, {true, true}}) {
+                                test_basic_likelihoods(hmm, BasicLikelihoodTestProvider(reference, read, base_qual, indel_qual, indel_qual,
+                                                                                        expected, gcp, lr.first, lr.second));
+                                ++n;
+                            }
+                        }
+                    }
+            }
+    ASSERT(n == 5 * 4 * 3 * (16 + 11 * 4 * 2 * 4), "case count %d", n);
+}
+
+static void mismatch_every_position(const std::string &hap_s, bool centred) {  // :328-405
+    const Bytes haplotype_1 = bytes(hap_s);
+    const uint8_t match_qual = 90, mismatch_qual = 20, indel_qual = 80;
+    const size_t offset = 2, n = haplotype_1.size() - (centred ? 2 * offset : offset);
+    const Bytes gop(n, indel_qual), gcp(n, indel_qual);
+    PairHMM logless_hmm = PairHMM::quick_initialize(n, haplotype_1.size());
+    logless_hmm.do_not_use_tristate_correction();
+    for (size_t k = 0; k < n; ++k) {
+        Bytes quals(n, match_qual);
+        quals[k] = mismatch_qual;  // one base mismatches the haplotype
+        Bytes m_read(haplotype_1.begin() + offset, centred ? haplotype_1.end() - offset : haplotype_1.end());
+        m_read[k] = m_read[k] == 'C' ? 'T' : 'C';
+        const double res_1 = logless_hmm.compute_read_likelihood_given_haplotype_log10(haplotype_1, m_read, quals, gop, gop, gcp,
+                                                                                       true, std::nullopt);
+        const double expected = std::log10((1.0 / (double)haplotype_1.size()) *
+                                           std::pow(QualityUtils::qual_to_prob(match_qual), (double)(m_read.size() - 1)) *
+                                           QualityUtils::qual_to_error_prob(mismatch_qual));
+        ASSERT(relative_eq(res_1, expected, 1e-2), "Result %g, Expected %g", res_1, expected);
+    }
+}
+
+static double get_expected_matching_log_likelihood(size_t read_len, size_t ref_len, uint8_t base_qual, uint8_t ins_qual) {  // :471-492
+    const double ic = std::fabs((double)ref_len - (double)read_len + 1.0) / (double)ref_len;
+    if (read_len < ref_len) return std::log10(ic * std::pow(QualityUtils::qual_to_prob(base_qual), (double)read_len));
+    if (read_len > ref_len)
+        return std::log10(ic * std::pow(QualityUtils::qual_to_prob(base_qual), (double)ref_len) *
+                          std::pow(QualityUtils::qual_to_error_prob(ins_qual), (double)read_len - (double)ref_len));
+    return 0.0;
+}
+
+static double run_flat(const Bytes &ref, const Bytes &read, uint8_t bq, uint8_t iq, uint8_t dq, uint8_t gcp) {
+    PairHMM hmm = PairHMM::quick_initialize(read.size(), ref.size());
+    hmm.do_not_use_tristate_correction();
+    const size_t n = read.size();
+    return hmm.compute_read_likelihood_given_haplotype_log10(ref, read, Bytes(n, bq), Bytes(n, iq), Bytes(n, dq), Bytes(n, gcp), true,
+                                                             std::nullopt);
+}
+
+static void hmm_providers() {  // hmm_provider_simple :522-527, make_hmm_provider :529-539
+    for (size_t read_size : {1, 2, 5, 10}) {
+        const Bytes read_bases(read_size, 'A');
+        ASSERT(run_flat(read_bases, read_bases, 20, 37, 37, 10) <= 0.0, "test_read_same_as_haplotype");
+        for (size_t ref_size : {1, 2, 5, 10})
+            if (ref_size > read_size) {
+                ASSERT(run_flat(bytes("CC" + std::string(ref_size, 'A') + "GGA"), read_bases, 20, 37, 37, 10) <= 0.0,
+                       "test_multiple_read_matches_in_haplotype");
+                const double d = run_flat(Bytes(ref_size, 'A'), read_bases, 20, 100, 100, 100);
+                const double expected = get_expected_matching_log_likelihood(read_size, ref_size, 20, 100);
+                ASSERT(relative_eq(d, expected, 1e-3),
+                       "Likelihoods should sum to just the error prob of the read but got Result %g, Expected %g", d, expected);
+            }
+    }
+}
+
+static void make_big_read_hmm_provider() {  // :541-597
+    const std::string read_1 = "ACCAAGTAGTCACCGT", ref_1 = "ACCAAGTAGTCACCGTAACG";
+    for (int n_read_copies : {1, 2, 10, 20, 50})
+        for (int n_ref_copies : {1, 2, 10, 20, 100})
+            if (n_ref_copies > n_read_copies) {
+                std::string read, reference;
+                for (int i = 0; i < n_read_copies; ++i) read += read_1;
+                for (int i = 0; i < n_ref_copies; ++i) reference += ref_1;
+                const double d = run_flat(bytes(reference), bytes(read), 30, 40, 40, 10);  // up to 800 x 2000
+                ASSERT(d <= 0.0 && !std::isnan(d), "test_really_big_reads %g", d);
+            }
+}
+
+static void test_likelihoods_from_haplotypes() {  // :637-683
+    const size_t read_size = 10, ref_size = 20;
+    const Bytes read_bases(read_size, 'A'), ref_bases(ref_size, 'A');
+    const uint8_t base_qual = 20, ins_qual = MASSIVE_QUAL;
+    Haplotype ref_h(ref_bases, true);
+    HmmRead read(read_bases, Bytes(read_size, base_qual));  // no BI/BD tags: flat Q45, as in the reference's test
+    std::vector<HmmRead> reads{read};
+    std::map<size_t, std::vector<HmmRead>> sample_evidence_map{{0, reads}};
+    PairHMMInputScoreImputator input_score_imputator(MASSIVE_QUAL);
+    PairHMM hmm = PairHMM::quick_initialize(read_size, ref_size);
+    hmm.do_not_use_tristate_correction();
+    AlleleLikelihoods haplotype_mat({ref_h}, {0}, sample_evidence_map);
+    hmm.compute_log10_likelihoods(0, haplotype_mat, {}, input_score_imputator);
+    ASSERT(hmm.get_log_likelihood_array().size() == 0, "empty read list is a no-op");
+    hmm.compute_log10_likelihoods(0, haplotype_mat, reads, input_score_imputator);
+    const double expected = get_expected_matching_log_likelihood(read_size, ref_size, base_qual, ins_qual);
+    const auto &la = hmm.get_log_likelihood_array();
+    ASSERT(la.size() == 1, "one likelihood");
+    ASSERT(relative_eq(la[0], expected, 1e-3), "got Result %g, Expected %g", la[0], expected);
+}
+
+static void make_haplotype_indexing_provider() {  // :725-814: cached == full recompute, 1e-9
+    const std::string prefix = "AACCGGTTTTTGGGCCCAAACGTACGTACAGTTGGTCAACATCGATCAGGTTCCGGAGTAC";
+    const std::string root_1 = "ACGTGTCAAACCGGGTT", root_2 = "ACGTGTCACACTGGGTT", root_3 = "ACGTGTCACTCCGCGTT";
+    for (const std::string &read_full : {std::string("ACGTGTCACACTGGATT"), root_1, root_2, std::string("ACGTGTCACACTGGATTCGAT"),
+                                         std::string("CCAGTAACGTGTCACACTGGATTCGAT")})
+        for (size_t read_length = 10; read_length < read_full.size(); read_length += 3) {
+            const Bytes read = bytes(read_full.substr(0, read_length));
+            const size_t n = read.size();
+            PairHMM hmm = PairHMM::quick_initialize(n, prefix.size() + root_1.size());
+            hmm.do_not_use_tristate_correction();
+            auto calc = [&](const std::string &hap, const std::optional<std::string> &next, bool recache) {
+                return hmm.compute_read_likelihood_given_haplotype_log10(
+                    bytes(hap), read, Bytes(n, 30), Bytes(n, 45), Bytes(n, 40), Bytes(n, 10), recache,
+                    next ? std::optional<Bytes>(bytes(*next)) : std::nullopt);
+            };
+            for (int prefix_start = (int)prefix.size(); prefix_start >= 0; prefix_start -= 9) {
+                const std::string my_prefix = prefix.substr((size_t)prefix_start);
+                const std::string hap_1 = my_prefix + root_1, hap_2 = my_prefix + root_2, hap_3 = my_prefix + root_3;
+                calc(hap_1, hap_2, true);
+                const double actual_2 = calc(hap_2, hap_3, false);
+                const double expected_2 = calc(hap_2, std::nullopt, true);
+                ASSERT(relative_eq(actual_2, expected_2, 1e-9), "HMM caching calculation failed: expected %g got %g", expected_2, actual_2);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tests/pair_hmm_likelihood_calculation_engine_unit_tests.rs:21-88
+// ---------------------------------------------------------------------------------------------------------
+static void test_compute_likelihoods() {
+    PairHMMLikelihoodCalculationEngine lce(93, MathUtils::log_to_log10(QualityUtils::qual_to_error_prob_log10(45)),
+                                           PCRErrorModel::Conservative, 16, false, 1.0, 0.02, true, false, true, AVXMode::Hip);
+    std::map<size_t, std::vector<HmmRead>> per_sample_read_list;
+    const size_t n = 10;
+    HmmRead read1(Bytes(n, 'A'), Bytes(n, 30));  // create_artificial_read_default("test", 0, 0, 10, false)
+    read1.name = "test";
+    read1.mapq = 60;
+    per_sample_read_list[0] = {read1};
+    const std::vector<size_t> sample{0};
+    Bytes ref_bases(n + 1, 'A');
+    Haplotype hap1(ref_bases, true);
+    AssemblyResultSet assembly_result_set(hap1);
+    assembly_result_set.add_haplotype(hap1);
+    Bytes bases_modified = ref_bases;
+    bases_modified[5] = 'C';
+    Haplotype hap2(bases_modified, false);
+    assembly_result_set.add_haplotype(hap2);
+    AlleleLikelihoods likes = lce.compute_read_likelihoods(assembly_result_set, sample, per_sample_read_list);
+    ASSERT(likes.alleles().size() == 2, "alleles");
+    ASSERT(likes.evidence_count() == 1, "evidence");
+    const double v1 = likes.sample_matrix(0)(0, 0), v2 = likes.sample_matrix(0)(1, 0);
+    ASSERT(v1 > v2, "Matching hap should have a higher likelihood %g -> %g", v1, v2);
+    // SURVEY.md section 4 known answers for this fixture (derived from the reference formulas)
+    ASSERT(std::fabs(v1 - -0.7446794209931795) < 1e-9 && std::fabs(v2 - -2.6990045895578127) < 1e-9, "known answers %.16g %.16g", v1, v2);
+}
+
+static void test_error_behaviour() {
+    // pair_hmm.rs:425-440 asserts
+    bool threw = false;
+    try {
+        forward(bytes("ACGT"), bytes("ACG"), Bytes(3, 30), Bytes(2, 40), Bytes(3, 40), Bytes(3, 10));
+    } catch (const Panic &e) {
+        threw = std::string(e.what()) == "Read bases and insertion gcp aren't the same size";
+    }
+    ASSERT(threw, "length mismatch must panic with the reference's message");
+    // pair_hmm.rs:478-481: an improper model (Q0 gap-open) makes a matching read score > 0
+    threw = false;
+    try {
+        forward(Bytes(20, 'A'), Bytes(12, 'A'), Bytes(12, 60), Bytes(12, 0), Bytes(12, 0), Bytes(12, 60));
+    } catch (const Panic &e) {
+        threw = std::string(e.what()) == "PairHmm Log Probability cannot be greater than 0.0";
+    }
+    ASSERT(threw, "positive result must panic with the reference's message");
+    threw = false;
+    try {
+        pcr_error_model_from_arg("bogus");
+    } catch (const Panic &e) {
+        threw = std::string(e.what()) == "Unknown PCR Error Model";
+    }
+    ASSERT(threw, "Unknown PCR Error Model");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
+        return 2;
+    }
+    if (detect_mode() != AVXMode::Hip) {
+        std::fprintf(stderr, "no HIP device: the host layer has no CPU fallback\n");
+        return 3;
+    }
+    const std::string fixture = argv[1];
+    const std::vector<std::pair<const char *, std::function<void()>>> tests = {
+        {"test_likelihoods_avx", [&] { test_likelihoods_avx(fixture); }},
+        {"make_basic_likelihood_tests", make_basic_likelihood_tests},
+        {"test_mismatch_in_every_position_in_the_read_with_centred_haplotype",
+         [] { mismatch_every_position("TTCTCTTCTGTTGTGGCTGGTTTTCTCTTCTGTTGTGGCTGGTTTTCTCTTCTGTTGTGGCTGGTT", true); }},
+        {"test_mismatch_in_every_position_in_the_read", [] { mismatch_every_position("TTCTCTTCTGTTGTGGCTGGTT", false); }},
+        {"hmm_provider_simple+make_hmm_provider", hmm_providers},
+        {"make_big_read_hmm_provider", make_big_read_hmm_provider},
+        {"test_likelihoods_from_haplotypes", test_likelihoods_from_haplotypes},
+        {"make_haplotype_indexing_provider", make_haplotype_indexing_provider},
+        {"test_compute_likelihoods", test_compute_likelihoods},
+        {"error_behaviour", test_error_behaviour},
+    };
+    int failed = 0;
+    for (const auto &t : tests) {
+        const int before = g_checks;
+        try {
+            t.second();
+            std::printf("PASS %s (%d checks)\n", t.first, g_checks - before);
+        } catch (const std::exception &e) {
+            std::printf("FAIL %s: %s\n", t.first, e.what());
+            ++failed;
+        }
+    }
+    std::printf("%d tests, %d failed, %d checks\n", (int)tests.size(), failed, g_checks);
+    return failed ? 1 : 0;
+}
