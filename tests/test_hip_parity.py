@@ -348,3 +348,34 @@ def test_split_phase_api_on_a_torch_stream(hip_engine):
     assert np.array_equal(plan2.download(), want)
     plan.close()
     plan2.close()
+
+
+def test_concurrent_host_threads_one_handle_each():
+    """The reference calls the path from up to --threads rayon workers, each with its own engine clone
+    (assembly_region_walker.rs:227).  Same here: one phmm_handle per thread, calls overlap (ctypes drops the
+    GIL), every thread must get exactly the single-threaded answer."""
+    import threading
+    n_threads, n_iter = 8, 12
+    batches = [synthetic.make_regions(3, 24, 1 + (t % 5), 120 + 13 * t, [40, 77, 101], seed=500 + t) for t in range(n_threads)]
+    ref_eng = HipPairHMMEngine(0)
+    want = [ref_eng.compute(b) for b in batches]
+    ref_eng.close()
+    errors = []
+
+    def worker(t):
+        try:
+            eng = HipPairHMMEngine(0)
+            for i in range(n_iter):
+                got = eng.compute(batches[(t + i) % n_threads])
+                if not np.array_equal(got, want[(t + i) % n_threads]):
+                    errors.append((t, i))
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
