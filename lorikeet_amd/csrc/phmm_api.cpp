@@ -70,11 +70,18 @@ struct Arena {
     size_t cap = 0, used = 0;
 };
 
+constexpr int kSlots = 3;  // pipeline depth of the chunked host path
+
 struct phmm_handle {
-    Arena arena;
+    // Each slot is an independent (arena, stream) pair; single calls use slot 0, the chunked large-batch
+    // path rotates through all of them so that staging / H2D of chunk i+1 overlaps the kernels of chunk i.
+    Arena arenas[kSlots];
+    hipStream_t streams[kSlots] = {nullptr, nullptr, nullptr};
+    int slot = 0;
+    Arena &A() { return arenas[slot]; }
+    hipStream_t S() { return streams[slot]; }
     int device = 0;
     unsigned flags = 0;
-    hipStream_t stream = nullptr;
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr;
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
@@ -99,6 +106,7 @@ struct phmm_batch {
     double *d_out = nullptr;
     void *d_owned = nullptr;  // batch-owned payload + out (phmm_batch_upload)
     Arena *arena = nullptr;   // non-null: every device allocation of this batch lives in the handle's arena
+    hipStream_t home_stream = nullptr;  // the handle stream this batch was staged on
     std::vector<void *> mallocs;  // hipMalloc'ed pieces owned by this batch (persistent batches, generic scratch)
     size_t out_arena_off = 0;     // arena mode: offset of [status word | out]
     bool tight_out = true;        // out_off has no gaps (every slot is written by a kernel)
@@ -179,7 +187,10 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
     const auto &eps = table_eps();
     const auto &eps3 = table_eps_third();
     const auto &mm = table_match_to_match();
-    bool ok = hip_ok(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+    bool ok = true;
+    for (int i = 0; i < kSlots && ok; ++i)
+        ok = hip_ok(nullptr, hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking), "hipStreamCreate");
+    ok = ok &&
               hip_ok(nullptr, hipMalloc(&h->d_eps, 256 * sizeof(double)), "hipMalloc eps") &&
               hip_ok(nullptr, hipMalloc(&h->d_eps_mis, 256 * sizeof(double)), "hipMalloc eps_mis") &&
               hip_ok(nullptr, hipMalloc(&h->d_mm, mm.size() * sizeof(double)), "hipMalloc mm") &&
@@ -208,13 +219,16 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
 void phmm_destroy(phmm_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < kSlots; ++i)
+        if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
     if (h->d_eps) (void)hipFree(h->d_eps);
     if (h->d_eps_mis) (void)hipFree(h->d_eps_mis);
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->d_pcr_cache) (void)hipFree(h->d_pcr_cache);
-    if (h->arena.dev) (void)hipFree(h->arena.dev);
-    if (h->arena.host) (void)hipHostFree(h->arena.host);
+    for (int i = 0; i < kSlots; ++i) {
+        if (h->arenas[i].dev) (void)hipFree(h->arenas[i].dev);
+        if (h->arenas[i].host) (void)hipHostFree(h->arenas[i].host);
+    }
     delete h;
 }
 
@@ -287,6 +301,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     b->read_bytes = read_off[n_reads];
     b->hap_bytes = hap_off[n_haps];
     b->tight_out = tight;
+    b->home_stream = h->S();
 
     // ---- device memory provider ---------------------------------------------------------------
     // arena mode: bump-allocate from the handle's arena, "uploads" go to the pinned mirror and travel in
@@ -297,9 +312,9 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
                             align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
                             align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes;
-        Arena &A = h->arena;
+        Arena &A = h->A();
         if (A.cap < need) {
-            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->S());
             if (A.dev) (void)hipFree(A.dev);
             if (A.host) (void)hipHostFree(A.host);
             A.dev = A.host = nullptr;
@@ -336,7 +351,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (mirror) {
             memcpy(mirror, src, bytes);
         } else {
-            ok = hip_ok(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream), "H2D meta");
+            ok = hip_ok(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->S()), "H2D meta");
             async_pending = true;
         }
     };
@@ -445,7 +460,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     up(b->d_out_off, m_oo, out_off, (size_t)(n_regions + 1) * 8);
     if (!b->arena) {  // persistent batch: own status word (arena mode keeps it next to the results)
         b->d_status = (uint32_t *)dalloc(256, nullptr);
-        if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->stream), "memset status");
+        if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->S()), "memset status");
     }
 
     // ---- finalise classes -------------------------------------------------------------------
@@ -509,7 +524,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         b->classes.push_back(std::move(c));
     }
     // host staging vectors die at return: finish the async copies first (arena mode copied into the mirror)
-    if (ok && async_pending) ok = hip_ok(h, hipStreamSynchronize(h->stream), "sync(meta)");
+    if (ok && async_pending) ok = hip_ok(h, hipStreamSynchronize(h->S()), "sync(meta)");
     if (!ok) {
         phmm_batch_destroy(b);
         return nullptr;
@@ -564,7 +579,7 @@ int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *b
     const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
     for (int i = 0; i < 6; ++i) {
         const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
-        if (bytes) HIP_TRY(h, hipMemcpyAsync(d[i], src[i], bytes, hipMemcpyHostToDevice, h->stream), PHMM_ERR_HIP);
+        if (bytes) HIP_TRY(h, hipMemcpyAsync(d[i], src[i], bytes, hipMemcpyHostToDevice, b->home_stream), PHMM_ERR_HIP);
     }
     return phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
 }
@@ -576,7 +591,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         h->err = "phmm_batch_launch: no device buffers bound";
         return PHMM_ERR_NOT_BOUND;
     }
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : h->stream;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : b->home_stream;
     for (auto &c : b->classes) {
         ForwardParams p{};
         p.class_reads = c.identity ? nullptr : c.d_reads;
@@ -639,21 +654,25 @@ int phmm_batch_download(phmm_batch *b, double *out) {
     phmm_handle *h = b->h;
     if (!b->bound) return PHMM_ERR_NOT_BOUND;
     if (b->n_out)
-        HIP_TRY(h, hipMemcpyAsync(out, b->d_out, b->n_out * 8, hipMemcpyDeviceToHost, h->stream), PHMM_ERR_HIP);
-    HIP_TRY(h, hipStreamSynchronize(h->stream), PHMM_ERR_HIP);
+        HIP_TRY(h, hipMemcpyAsync(out, b->d_out, b->n_out * 8, hipMemcpyDeviceToHost, b->home_stream), PHMM_ERR_HIP);
+    HIP_TRY(h, hipStreamSynchronize(b->home_stream), PHMM_ERR_HIP);
     return phmm_batch_status(b);
 }
 
-int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
-                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
-                 const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
-                 const uint64_t *out_off, double *out) {
-    if (!h) return PHMM_ERR_INVALID_ARG;
-    static const bool trace = getenv("PHMM_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
+namespace {
+
+struct PendingCompute {
+    phmm_batch *b = nullptr;
+    int slot = 0;
+    double *out = nullptr;
+};
+
+// Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
+int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                    const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                    const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                    const uint64_t *out_off, double *out, PendingCompute *pending) {
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
-    const double t1 = now();
     if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
     if ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases) ||
@@ -661,7 +680,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
         h->err = "phmm_compute: null pointer";
         st = PHMM_ERR_INVALID_ARG;
     }
-    Arena &A = h->arena;
+    Arena &A = h->A();
     if (st == PHMM_OK) {
         // payload into the arena mirror, then [status | out] last so that one copy each way suffices
         const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
@@ -671,9 +690,9 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
             const size_t off = align_up(A.used, 256);
             A.used = off + bytes;
             // small arrays ride in the single mirror copy; large ones go straight from the caller's memory
-            // (a second pass over 100 MB on one host core costs more than the extra copy call)
+            // (the chunked path keeps every array below this limit so that its copies are truly asynchronous)
             if (bytes > kDirectCopyBytes) {
-                if (st == PHMM_OK && !hip_ok(h, hipMemcpyAsync(A.dev + off, src[i], bytes, hipMemcpyHostToDevice, h->stream),
+                if (st == PHMM_OK && !hip_ok(h, hipMemcpyAsync(A.dev + off, src[i], bytes, hipMemcpyHostToDevice, h->S()),
                                              "H2D payload"))
                     st = PHMM_ERR_HIP;
             } else if (bytes) {
@@ -687,38 +706,127 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
         memset(A.host + in_bytes, 0, 256);  // status word
         b->d_status = (uint32_t *)(A.dev + in_bytes);
         double *d_out = (double *)(A.dev + in_bytes + 256);
-        if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->stream), "H2D batch"))
+        if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch"))
             st = PHMM_ERR_HIP;
         // slots the kernels never write (gaps the caller left in out_off) come back as NaN
         if (st == PHMM_OK && !b->tight_out && b->n_out &&
-            !hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->stream), "memset out"))
+            !hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->S()), "memset out"))
             st = PHMM_ERR_HIP;
         if (st == PHMM_OK) st = phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
     }
-    const double t2 = now();
     if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
-    const double t3 = now();
-    if (st == PHMM_OK) {
-        char *hs = A.host + b->out_arena_off;
-        if (!hip_ok(h, hipMemcpyAsync(hs, A.dev + b->out_arena_off, 256 + b->n_out * 8, hipMemcpyDeviceToHost, h->stream),
-                    "D2H results") ||
-            !hip_ok(h, hipStreamSynchronize(h->stream), "sync"))
-            st = PHMM_ERR_HIP;
-        else {
-            if (b->n_out) memcpy(out, hs + 256, b->n_out * 8);
-            if (*(const uint32_t *)hs) {
-                h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
-                st = PHMM_ERR_POSITIVE_RESULT;
-            }
+    if (st == PHMM_OK &&
+        !hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
+                                  hipMemcpyDeviceToHost, h->S()),
+                "D2H results"))
+        st = PHMM_ERR_HIP;
+    if (st != PHMM_OK) {
+        std::string keep = h->err;
+        (void)hipStreamSynchronize(h->S());
+        phmm_batch_destroy(b);
+        h->err = keep;
+        return st;
+    }
+    pending->b = b;
+    pending->slot = h->slot;
+    pending->out = out;
+    return PHMM_OK;
+}
+
+// Wait for a pending batch, hand the results to the caller, release the batch.
+int finish_compute(phmm_handle *h, PendingCompute *p) {
+    if (!p->b) return PHMM_OK;
+    int st = PHMM_OK;
+    phmm_batch *b = p->b;
+    const Arena &A = h->arenas[p->slot];
+    if (!hip_ok(h, hipStreamSynchronize(h->streams[p->slot]), "sync")) {
+        st = PHMM_ERR_HIP;
+    } else {
+        const char *hs = A.host + b->out_arena_off;
+        if (b->n_out) memcpy(p->out, hs + 256, b->n_out * 8);
+        if (*(const uint32_t *)hs) {
+            h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+            st = PHMM_ERR_POSITIVE_RESULT;
         }
     }
-    const double t4 = now();
     std::string keep = h->err;
     phmm_batch_destroy(b);
     h->err = keep;
-    if (trace)
-        fprintf(stderr, "phmm_compute: plan %.1f us, stage+H2D %.1f us, launch %.1f us, wait+D2H %.1f us, destroy %.1f us\n",
-                t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+    p->b = nullptr;
+    return st;
+}
+
+}  // namespace
+
+int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                 const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                 const uint64_t *out_off, double *out) {
+    if (!h) return PHMM_ERR_INVALID_ARG;
+    static const bool trace = getenv("PHMM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
+        h->err = "phmm_compute: null offset array";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    const uint32_t n_reads = region_read_off[n_regions];
+    // ---- small / medium batch: one shot ------------------------------------------------------------
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kDirectCopyBytes || getenv("PHMM_NO_PIPELINE")) {
+        h->slot = 0;
+        PendingCompute p;
+        int st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
+                                 hap_off, hap_bases, out_off, out, &p);
+        const double t1 = now();
+        if (st == PHMM_OK) st = finish_compute(h, &p);
+        if (trace)
+            fprintf(stderr, "phmm_compute: plan+stage+enqueue %.1f us, wait+copy-out %.1f us\n", t1 - t0, now() - t1);
+        return st;
+    }
+    // ---- large batch: chunks of regions rotate through kSlots (arena, stream) pairs, so the host staging
+    //      and the H2D copy of chunk i+1 overlap the kernels of chunk i.  Results are identical: every
+    //      region is independent, the chunk only rebases the offsets. -----------------------------------
+    PendingCompute pend[kSlots];
+    int st = PHMM_OK;
+    std::vector<uint32_t> rro, rho, ro, ho;
+    std::vector<uint64_t> oo;
+    uint32_t g0 = 0;
+    int n_chunks = 0;
+    while (g0 < n_regions && st == PHMM_OK) {
+        // grow the chunk while every per-base array stays below the direct-copy limit
+        uint32_t g1 = g0 + 1;
+        const size_t base_r = read_off[region_read_off[g0]];
+        while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kDirectCopyBytes) ++g1;
+        const uint32_t r0 = region_read_off[g0], r1 = region_read_off[g1], h0 = region_hap_off[g0], h1 = region_hap_off[g1];
+        rro.resize(g1 - g0 + 1);
+        rho.resize(g1 - g0 + 1);
+        oo.resize(g1 - g0 + 1);
+        for (uint32_t g = g0; g <= g1; ++g) {
+            rro[g - g0] = region_read_off[g] - r0;
+            rho[g - g0] = region_hap_off[g] - h0;
+            oo[g - g0] = out_off[g] - out_off[g0];
+        }
+        ro.resize(r1 - r0 + 1);
+        for (uint32_t r = r0; r <= r1; ++r) ro[r - r0] = read_off[r] - read_off[r0];
+        ho.resize(h1 - h0 + 1);
+        for (uint32_t a = h0; a <= h1; ++a) ho[a - h0] = hap_off[a] - hap_off[h0];
+        const int slot = n_chunks % kSlots;
+        st = finish_compute(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
+        if (st != PHMM_OK) break;
+        h->slot = slot;
+        const size_t bo = read_off[r0], co = hap_off[h0];
+        st = enqueue_compute(h, g1 - g0, rro.data(), rho.data(), ro.data(), read_bases + bo, base_q + bo, ins_q + bo, del_q + bo,
+                             gcp + bo, ho.data(), hap_bases + co, oo.data(), out + out_off[g0], &pend[slot]);
+        g0 = g1;
+        ++n_chunks;
+    }
+    for (int i = 0; i < kSlots; ++i) {  // drain in submission order
+        const int slot = (n_chunks + i) % kSlots;
+        const int s2 = finish_compute(h, &pend[slot]);
+        if (st == PHMM_OK) st = s2;
+    }
+    h->slot = 0;
+    if (trace) fprintf(stderr, "phmm_compute: %d chunks pipelined over %d slots, total %.1f us\n", n_chunks, kSlots, now() - t0);
     return st;
 }
 
@@ -749,7 +857,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         h->err = "phmm_engine_compute: null pointer";
         st = PHMM_ERR_INVALID_ARG;
     }
-    Arena &A = h->arena;
+    Arena &A = h->A();
     if (st == PHMM_OK) {
         auto place = [&](const void *src, size_t bytes) -> char * {  // into the mirror (travels in the one H2D copy)
             const size_t off = align_up(A.used, 256);
@@ -776,9 +884,9 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         b->d_status = (uint32_t *)(A.dev + res_off);
         uint8_t *d_keep = (uint8_t *)(A.dev + res_off + 256);
         double *d_out = (double *)(A.dev + res_off + 256 + keep_bytes);
-        bool ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->stream), "H2D batch") &&
-                  hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->stream), "memset status");
-        if (ok && !b->tight_out && b->n_out) ok = hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->stream), "memset out");
+        bool ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->S()), "H2D batch") &&
+                  hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->S()), "memset status");
+        if (ok && !b->tight_out && b->n_out) ok = hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->S()), "memset out");
         uint32_t max_r = 0;
         for (uint32_t r = 0; r < n_reads; ++r) max_r = std::max(max_r, read_off[r + 1] - read_off[r]);
         PrepParams pp{};
@@ -808,7 +916,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
             ok = false;
             st = PHMM_ERR_INVALID_ARG;
         }
-        if (ok) ok = hip_ok(h, launch_prep(pp, h->stream), "phmm_prep_reads");
+        if (ok) ok = hip_ok(h, launch_prep(pp, h->S()), "phmm_prep_reads");
         if (ok) ok = phmm_batch_bind_device(b, d_bases, d_q, d_i, d_d, d_g, d_haps, d_out) == PHMM_OK;
         if (ok) ok = phmm_batch_launch(b, nullptr) == PHMM_OK;
         PostParams po{};
@@ -823,11 +931,11 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         po.keep = d_keep;
         po.max_likelihood_difference_cap = cfg->log10_global_read_mismapping_rate;
         po.symmetric = cfg->symmetrically_normalize_alleles_to_reference;
-        if (ok) ok = hip_ok(h, launch_post(po, h->stream), "phmm_post_reads");
+        if (ok) ok = hip_ok(h, launch_post(po, h->S()), "phmm_post_reads");
         const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
-        if (ok) ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->stream),
+        if (ok) ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->S()),
                             "D2H results") &&
-                     hip_ok(h, hipStreamSynchronize(h->stream), "sync");
+                     hip_ok(h, hipStreamSynchronize(h->S()), "sync");
         if (ok) {
             const char *hs = A.host + res_off;
             if (n_reads) memcpy(keep, hs + 256, n_reads);
