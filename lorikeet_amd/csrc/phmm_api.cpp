@@ -689,6 +689,11 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
             const size_t off = align_up(A.used, 256);
             A.used = off + bytes;
+            if (A.used > A.cap) {
+                h->err = "phmm_compute: internal error, arena too small";
+                st = PHMM_ERR_HIP;
+                break;
+            }
             // small arrays ride in the single mirror copy; large ones go straight from the caller's memory
             // (the chunked path keeps every array below this limit so that its copies are truly asynchronous)
             if (bytes > kDirectCopyBytes) {
@@ -703,6 +708,13 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         const size_t in_bytes = align_up(A.used, 256);
         b->out_arena_off = in_bytes;
         A.used = in_bytes + 256 + b->n_out * 8;
+        if (st != PHMM_OK || A.used > A.cap) {  // cannot happen: batch_create_impl reserved for exactly this layout
+            h->err = "phmm_compute: internal error, arena too small";
+            std::string keep = h->err;
+            phmm_batch_destroy(b);
+            h->err = keep;
+            return PHMM_ERR_HIP;
+        }
         memset(A.host + in_bytes, 0, 256);  // status word
         b->d_status = (uint32_t *)(A.dev + in_bytes);
         double *d_out = (double *)(A.dev + in_bytes + 256);
@@ -859,8 +871,13 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     }
     Arena &A = h->A();
     if (st == PHMM_OK) {
+        bool fits = true;
         auto place = [&](const void *src, size_t bytes) -> char * {  // into the mirror (travels in the one H2D copy)
             const size_t off = align_up(A.used, 256);
+            if (off + bytes > A.cap) {
+                fits = false;
+                return A.dev;
+            }
             A.used = off + bytes;
             if (src && bytes) memcpy(A.host + off, src, bytes);
             return A.dev + off;
@@ -881,6 +898,13 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         const size_t res_off = align_up(A.used, 256);
         const size_t keep_bytes = align_up((size_t)n_reads, 256);
         A.used = res_off + 256 + keep_bytes + b->n_out * 8;
+        if (!fits || A.used > A.cap) {  // cannot happen: `extra` above reserves for exactly this layout
+            h->err = "phmm_engine_compute: internal error, arena too small";
+            std::string keep_err = h->err;
+            phmm_batch_destroy(b);
+            h->err = keep_err;
+            return PHMM_ERR_HIP;
+        }
         b->d_status = (uint32_t *)(A.dev + res_off);
         uint8_t *d_keep = (uint8_t *)(A.dev + res_off + 256);
         double *d_out = (double *)(A.dev + res_off + 256 + keep_bytes);
