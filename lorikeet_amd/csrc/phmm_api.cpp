@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -50,6 +51,11 @@ struct ShapeClass {
     size_t lds_bytes = 0;
     dim3 grid;
     uint32_t exec_select = 0;
+    // chained class: items are (region, haplotype group, run of reads) instead of single reads
+    bool chain = false;
+    std::vector<uint32_t> regions;  // member regions (chain classes)
+    std::vector<ChainItem> chain_items;
+    ChainItem *d_chain_items = nullptr;
     // device
     uint32_t *d_reads = nullptr;
     // generic only
@@ -311,7 +317,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         const size_t need = align_up((size_t)n_reads * 4, 256) * 2 + align_up((size_t)(n_regions + 1) * 4, 256) * 2 +
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
                             align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
-                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes;
+                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes +
+                            (size_t)n_reads * 16 /* chain items: at most one per two (read, haplotype group) sweeps */;
         Arena &A = h->A();
         if (A.cap < need) {
             (void)hipStreamSynchronize(h->S());
@@ -358,7 +365,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
 
     // ---- per-region shape, totals -----------------------------------------------------------
     struct RegionShape {
-        uint32_t nr, nh, max_r, max_h, mean_r;
+        uint32_t nr, nh, max_r, max_h, mean_r, min_r = 0xffffffffu, min_h = 0xffffffffu;
         uint64_t cells;
     };
     std::vector<RegionShape> shape(n_regions);
@@ -371,12 +378,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) {
             const uint32_t len = read_off[r + 1] - read_off[r];
             s.max_r = std::max(s.max_r, len);
+            s.min_r = std::min(s.min_r, len);
             sum_r += len;
             read_region[r] = g;
         }
         for (uint32_t a = region_hap_off[g]; a < region_hap_off[g + 1]; ++a) {
             const uint32_t len = hap_off[a + 1] - hap_off[a];
             s.max_h = std::max(s.max_h, len);
+            s.min_h = std::min(s.min_h, len);
             sum_h += len;
         }
         s.mean_r = s.nr ? (uint32_t)(sum_r / s.nr) : 0;
@@ -424,7 +433,25 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         min_L *= 2;
     }
 
-    std::map<std::pair<int, int>, ShapeClass> by_shape;
+    // Chained kernel (phmm_chain_kernels.hip): reads of a region stream back to back through the lane
+    // pipeline, which removes the per-read fill/drain steps.  Worth it (and balanced) only when there is
+    // enough work to give every wave a run of reads: decide per batch, qualify per region.
+    uint64_t units16 = 0;  // (read, haplotype group) sweeps of the regions that run with 16 lanes per pair
+    for (uint32_t g = 0; g < n_regions; ++g)
+        if (reg_L[g] == 16) units16 += (uint64_t)shape[g].nr * ((shape[g].nh + 3) / 4);
+    uint32_t chain_reads = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, units16 / (8ull * 2 * kNumSimd));
+    if (const char *e = getenv("PHMM_FORCE_CHAIN")) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, std::max(0, atoi(e)));
+    auto chain_k = [&](const RegionShape &s) {  // one extra column right of the haplotype carries the last term of the sum
+        return round_up_k((int)((s.max_h + 1 + 15) / 16));
+    };
+    auto chainable = [&](uint32_t g) {
+        const RegionShape &s = shape[g];
+        const int k = chain_k(s);
+        return chain_reads >= 2 && reg_L[g] == 16 && k > 0 && k <= chain_max_k() && s.min_r >= 1 && s.min_h >= 1 &&
+               (int)s.max_r <= chain_max_read_rows();
+    };
+
+    std::map<std::tuple<int, int, int>, ShapeClass> by_shape;
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (reg_L[g] < 0) continue;
         const RegionShape &s = shape[g];
@@ -432,9 +459,13 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         // LDS staging must hold the longest read of the region, one wave per block at least
         const size_t rows = align_up((size_t)s.max_r + 1, 8);
         if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
-        ShapeClass &c = by_shape[{L, K}];
+        const bool chain = L && chainable(g);
+        if (chain) K = chain_k(s);
+        ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? 1 : 0)];
         c.L = L;
         c.K = K;
+        c.chain = chain;
+        if (chain) c.regions.push_back(g);
         for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.reads.push_back(r);
         c.max_r = std::max(c.max_r, s.max_r);
         c.max_h = std::max(c.max_h, s.max_h);
@@ -470,12 +501,24 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         const uint32_t n_items = (uint32_t)c.reads.size();
         c.identity = (n_items == n_reads);
         for (uint32_t i = 0; c.identity && i < n_items; ++i) c.identity = (c.reads[i] == i);
-        if (!c.identity) {
+        if (!c.identity && !c.chain) {
             void *mirror;
             c.d_reads = (uint32_t *)dalloc((size_t)n_items * 4, &mirror);
             up(c.d_reads, mirror, c.reads.data(), (size_t)n_items * 4);
         }
-        if (c.L) {
+        if (c.chain) {
+            for (uint32_t g : c.regions) {
+                const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1];
+                const uint32_t nq = (shape[g].nh + 3) / 4;
+                for (uint32_t q = 0; q < nq; ++q)
+                    for (uint32_t r = r0; r < r1; r += chain_reads)
+                        c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + chain_reads)});
+            }
+            void *mirror;
+            c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
+            up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
+            snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d>", c.K);
+        } else if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
             const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
             // One wave per workgroup: waves are independent (no barrier, private LDS), and a multi-wave block
@@ -619,7 +662,13 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.status = b->d_status;
         if (!p.n_items) continue;
         hipError_t e;
-        if (c.L) {
+        if (c.chain) {
+            ChainParams cp{};
+            cp.f = p;
+            cp.items = c.d_chain_items;
+            cp.n_items = (uint32_t)c.chain_items.size();
+            e = launch_chain(c.K, cp, stream);
+        } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
         } else {
             GenericParams gp{};

@@ -1,0 +1,290 @@
+// gfx950 chained forward kernel: the same register-resident sweep as phmm_forward<16,K>, but a wave keeps
+// its four haplotypes and streams MANY reads through them back to back, so the 15-step fill / 15-step
+// drain of the lane pipeline is paid once per chain instead of once per read.
+//
+// The reads of a chain form one stream of rows in an LDS ring:
+//     [rows of read 0][SUM][RESET][rows of read 1][SUM][RESET] ...
+// and lane l simply works on stream position t - l at step t.  Nothing in the steady state is predicated
+// or per-lane conditional; the hand-over between reads happens through the recurrence itself:
+//   * the LAST row of a read is pre-scaled with sI = 1, sD = 0, so D^(R,.) == 0 and I^(R,.) == I(R,.);
+//   * the SUM row (mm = 1, dD = dd = 1, prior = 1 on valid columns and 0 on padding, via a base code that
+//     only padding columns match) turns M into M(R,j-1) + I(R,j-1) and lets the D chain -- which already
+//     runs left to right through columns AND lanes -- accumulate it: after the last lane's SUM step,
+//     M + D of its last column is sum_j M[R][j] + I[R][j] in exactly the reference's order
+//     (pair_hmm.rs:598-603); that lane takes the log10 and stores the result;
+//   * the RESET row (prior = 0, bI = gI = 0, dD = 0, dd = 1) rebuilds the row-0 state (0, 0, c0) of the next
+//     read: M and I^ vanish and the D chain copies the value injected at the group's first lane.
+// Rows are produced 64 at a time (one per lane) into a 256-row ring, 64..128 rows ahead of lane 0; the stream
+// is padded with CL-1 neutral rows in front and behind, so a lane's slot is just (position & 255).
+// D(0,j): every value of the recurrence is linear in the initial D(0,j) = 2^1020 / H (pair_hmm.rs:515-529), so
+// the chained kernel starts all haplotypes from the same 2^1010 (which lets the RESET row carry the injected
+// value itself) and subtracts log10(H) at the end; the difference to dividing first is one rounding.
+//
+// Chains with a haplotype containing 'N' or a read with gcp == 0 fall back, inside the same wave, to the
+// plain per-read sweep (sweep_general): rare, kept for exactness.
+#include "phmm_device.hpp"
+
+namespace phmm {
+
+namespace {
+
+constexpr int CL = 16;               // lanes per pair
+constexpr int RING = 256;            // ring rows (power of two); slot RING holds the neutral row
+constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (> H): only the SUM row's x equals it
+constexpr uint32_t X_EDGE = 0x101u;  // base code of the one extra column right of the haplotype
+constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
+constexpr int LEAD = CL - 1;          // neutral rows in front of the stream (lane l starts LEAD - l rows early)
+
+// Left neighbour's value; the group's first lane (no neighbour inside its row of 16) receives `inject`.
+__device__ __forceinline__ double from_left_inject(double v, double inject) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(inject), __double2loint(v), 0x111, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(inject), __double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K>
+__device__ __forceinline__ void chain_fallback(const ForwardParams &p, const ChainItem &it, RowConst *ring, int lane,
+                                               int grp, int l, const HapCols<K> &hc, int H, bool hv, int a, int Nh) {
+    // Per read: stage plain or pre-scaled rows linearly (slot 0 neutral, row r at r+1), general sweep, reduce.
+    const uint32_t reg = it.region;
+    for (uint32_t r = it.read_begin; r < it.read_end; ++r) {
+        const uint32_t ro = p.read_off[r];
+        const int R = (int)(p.read_off[r + 1] - ro);
+        bool z = false;
+        for (int row = lane; row < R; row += WAVE) z |= (p.gcp[ro + row] == 0);
+        const bool scaled = __ballot(z) == 0ull;
+        lds_wave_sync();
+        if (lane == 0) ring[0] = neutral_row();
+        for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled, false);
+        lds_wave_sync();
+        const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
+        const double c0 = p.initial_condition / (double)H * scale0;
+        const LdsView lds{ring};
+        double s = sweep_general<CL, K>(lds, R, l, false, hc, H, c0, scaled);
+#pragma unroll
+        for (int off = CL / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (l == 0 && hv) {
+            const double v = log10(s) - p.initial_condition_log10;
+            p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
+            if (!(v <= 0.0)) atomicOr(p.status, 1u);
+        }
+    }
+    (void)grp;
+}
+
+}  // namespace
+
+template <int K>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ForwardParams &p = cp.f;
+    const int lane = threadIdx.x;
+    const int grp = lane / CL, l = lane % CL;
+    const ChainItem it = cp.items[blockIdx.x];
+    const uint32_t reg = it.region;
+    const int n_chain = (int)(it.read_end - it.read_begin);
+    const uint32_t h0 = p.region_hap_off[reg];
+    const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
+    const int a = (int)it.quad * (WAVE / CL) + grp;
+    const bool hv = a < Nh;
+    uint32_t ho = 0;
+    int H = 0;
+    if (hv) {
+        ho = p.hap_off[h0 + a];
+        H = (int)(p.hap_off[h0 + a + 1] - ho);
+    }
+    RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING + 1 records
+    uint32_t *cum = reinterpret_cast<uint32_t *>(ring + RING + 1);  // [n_chain + 1] stream offset of each read
+    uint32_t *roff = cum + (CHAIN_MAX_READS + 1);                   // [n_chain + 1] byte offset of each read
+
+    // ---- haplotype columns: real bases, one EDGE column, then padding -------------------------------
+    HapCols<K> hc;
+    bool lane_n = false;
+#pragma unroll
+    for (int w = 0; w < HapCols<K>::W; ++w) {
+        hc.y[w] = 0u;
+        hc.m[w] = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int col = l * K + k;
+        uint32_t y = col < H ? (uint32_t)p.hap_bases[ho + col] : (col == H ? X_EDGE : X_PAD);
+        const bool is_n = (y == 'N');
+        lane_n |= is_n;
+        hc.set(k, y, 0xffffu);
+    }
+
+    // ---- the chain: stream offsets, and whether every read can be pre-scaled ------------------------
+    const uint32_t rb = it.read_begin;
+    const uint32_t byte0 = p.read_off[rb];
+    const uint32_t bytes = p.read_off[it.read_end] - byte0;
+    bool z = false;
+    for (uint32_t i = lane; i < bytes; i += WAVE) z |= (p.gcp[byte0 + i] == 0);
+    if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
+        if (lane_n) {  // general compare: 'N' columns become wildcards (mask 0), everything else full mask
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (hc.base(k) == 'N') {
+                    hc.y[k >> 1] &= ~(0xffffu << (16 * (k & 1)));
+                    hc.m[k >> 1] &= ~(0xffffu << (16 * (k & 1)));
+                }
+        }
+        chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
+        return;
+    }
+    {
+        uint32_t len = lane < n_chain ? p.read_off[rb + lane + 1] - p.read_off[rb + lane] + 2u : 0u;  // + SUM + RESET
+        uint32_t incl = len;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 0) cum[0] = 0u;
+        if (lane < n_chain) cum[lane + 1] = incl;
+        if (lane <= n_chain) roff[lane] = p.read_off[rb + lane];
+        if (lane == 0) ring[RING] = neutral_row();
+    }
+    lds_wave_sync();
+    const int S_total = (int)cum[n_chain];
+    const double c_unit = ldexp(1.0, 1010);  // common D(0,j) of every haplotype, see the header
+
+    // ---- row producer: stream positions [P0, P0 + 64) -> ring ----------------------------------------
+    // Two-phase producer, one ring row per lane: `issue` starts the (cold) loads of a row's quality bytes, `finish`
+    // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
+    // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
+    uint32_t pb_x = 0, pb_q = 0, pb_i = 0, pb_d = 0, pb_g = 0, pb_gn = 0;
+    auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the chain, row)
+        const int P = Q - LEAD;
+        if (P < 0 || P >= S_total) return false;
+        lo = 0;
+        int hi = n_chain;  // cum[lo] <= P < cum[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)cum[mid] <= P) lo = mid; else hi = mid;
+        }
+        ro = roff[lo];
+        R = (int)(roff[lo + 1] - ro);
+        row = P - (int)cum[lo];
+        return true;
+    };
+    auto issue = [&](int Q0) {
+        int lo, row, R;
+        uint32_t ro;
+        if (locate(Q0 + lane, lo, row, R, ro) && row < R) {
+            pb_x = p.read_bases[ro + row];
+            pb_q = p.base_q[ro + row];
+            pb_i = p.ins_q[ro + row];
+            pb_d = p.del_q[ro + row];
+            pb_g = p.gcp[ro + row];
+            pb_gn = row + 1 < R ? (uint32_t)p.gcp[ro + row + 1] : 0u;
+        }
+    };
+    auto finish = [&](int Q0) {  // ring positions [Q0, Q0 + 64); stream position = ring position - LEAD
+        const int Q = Q0 + lane;
+        int lo, row, R;
+        uint32_t ro;
+        RowConst n;
+        if (locate(Q, lo, row, R, ro)) {
+            if (row < R) {
+                n = make_row_bytes(p, pb_x, pb_q, pb_i, pb_d, pb_g, pb_gn, row + 1 >= R, true, true);
+            } else if (row == R) {  // SUM row; pad0 = read index inside the chain
+                n.mm = 1.0; n.bI = 0.0; n.gI = 0.0; n.dD = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 1.0;
+                n.x = X_PAD; n.pad0 = (uint32_t)lo; n.pad1 = 0.0;
+            } else {                // RESET row; pad1 = D^(0,.) of the next read = 2^1010 * im of its first row
+                n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dD = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+                n.x = X_NONE; n.pad0 = 0;
+                n.pad1 = c_unit * (lo + 1 < n_chain ? 1.0 - p.eps[p.gcp[roff[lo + 1]]] : 1.0);
+            }
+        } else {
+            n = neutral_row();
+        }
+        ring[Q & (RING - 1)] = n;
+    };
+    issue(0);
+    finish(0);
+    issue(64);
+    finish(64);
+    issue(128);
+    finish(128);
+    lds_wave_sync();
+    issue(192);
+
+    // ---- state ---------------------------------------------------------------------------------------
+    const double c0 = c_unit * (1.0 - p.eps[p.gcp[byte0]]);  // planner guarantees every read has >= 1 base
+    double Mp[K], Ip[K], Dp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        Mp[k] = 0.0;
+        Ip[k] = 0.0;
+        Dp[k] = c0;
+    }
+    double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c0;
+    const bool last_lane = (l == CL - 1);
+    const double log10_scale = log10(c_unit) + log10((double)H);  // result = log10(sum) - log10(2^1010 * H)
+    auto emit = [&](const RowConst &c) {
+        // after the last lane's SUM step: D^ = running sum of the gated M over everything to its left, M = own term
+        {
+            if (last_lane && c.x == X_PAD && hv) {
+                const uint32_t r = rb + c.pad0;
+                const double v = log10(Dp[K - 1] + Mp[K - 1]) - log10_scale;
+                p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
+                if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
+            }
+        }
+    };
+
+    // lane l works on ring position q = t + LEAD - l  (stream position t - l); rows outside the stream are neutral
+    int q = LEAD - l;
+    RowConst cA = ring[q & (RING - 1)], cB;
+    const int T = (S_total + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
+    // Outer loop = one producer tick (64 steps), inner loop = the sweep.  The producer's pending bytes are
+    // defined before the inner loop and first used after it, so their loads have 64 steps to land.
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        if (t0 >= 64) {  // keep the ring 64..128 rows ahead of the first lane
+            finish(t0 + 128);
+            lds_wave_sync();
+            issue(t0 + 192);
+        }
+        const int t1 = min(T, t0 + 64);
+        for (int t = t0; t < t1; t += 2) {
+            cB = ring[(q + 1) & (RING - 1)];
+            aM = from_left<CL>(Mp[K - 1], false);
+            aI = from_left<CL>(Ip[K - 1], false);
+            aD = from_left_inject(Dp[K - 1], cA.pad1);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
+            row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
+            // a read's SUM row reaches the last lane once per read: one wave-uniform test per two steps
+            const bool any_sum = __ballot(last_lane && (cA.x == X_PAD || cB.x == X_PAD)) != 0ull;
+            if (any_sum) emit(cA);
+            cA = ring[(q + 2) & (RING - 1)];
+            bM = from_left<CL>(Mp[K - 1], false);
+            bI = from_left<CL>(Ip[K - 1], false);
+            bD = from_left_inject(Dp[K - 1], cB.pad1);
+            row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
+            if (any_sum) emit(cB);
+            q += 2;
+        }
+    }
+}
+
+// ---- launch ----------------------------------------------------------------------------------------
+#define PHMM_CHAIN_K_LIST(X) \
+    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+
+size_t chain_lds_bytes() { return (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t); }
+int chain_max_k() { return 20; }
+int chain_max_read_rows() { return RING - 8; }  // the in-wave fallback stages a whole read linearly in the ring
+
+hipError_t launch_chain(int K, const ChainParams &cp, hipStream_t stream) {
+    if (!cp.n_items) return hipSuccess;
+#define PHMM_CASE(KK)                                                                                     \
+    if (K == KK) {                                                                                        \
+        hipLaunchKernelGGL(phmm_forward_chain<KK>, dim3(cp.n_items), dim3(WAVE), chain_lds_bytes(), stream, cp); \
+        return hipGetLastError();                                                                         \
+    }
+    PHMM_CHAIN_K_LIST(PHMM_CASE)
+#undef PHMM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace phmm

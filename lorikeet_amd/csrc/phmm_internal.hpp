@@ -52,6 +52,22 @@ struct GenericParams {
 };
 hipError_t launch_generic(const GenericParams &p, hipStream_t stream);
 
+// ---- chained forward kernel (phmm_chain_kernels.hip) ------------------------------------------------
+constexpr int CHAIN_MAX_READS = 64;  // reads per chain (one lane per read when the stream offsets are scanned)
+struct ChainItem {
+    uint32_t region, quad;          // region index, haplotype group (4 haplotypes) inside it
+    uint32_t read_begin, read_end;  // global read indices [begin, end), all of that region
+};
+struct ChainParams {
+    ForwardParams f;
+    const ChainItem *items;
+    uint32_t n_items;
+};
+hipError_t launch_chain(int K, const ChainParams &p, hipStream_t stream);
+size_t chain_lds_bytes();
+int chain_max_k();          // largest instantiated K
+int chain_max_read_rows();  // longest read a chained region may contain
+
 // ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------
 struct PrepParams {
     uint32_t n_reads;

@@ -379,3 +379,68 @@ def test_concurrent_host_threads_one_handle_each():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+# ---------------------------------------------------------------------------------------------
+# chained kernel (phmm_forward_chain<K>): reads of a region stream back to back through the lanes
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture()
+def force_chain():
+    os.environ["PHMM_FORCE_CHAIN"] = "5"  # runs of 5 reads per wave regardless of batch size
+    yield
+    os.environ.pop("PHMM_FORCE_CHAIN", None)
+
+
+def test_chained_kernel_matches_oracle(engines, force_chain, kat_rows):
+    hip_engine = engines[16]  # chaining applies to the 16-lanes-per-pair shape (small batches would pick 64)
+    rng = np.random.default_rng(77)
+    regions = [_random_region(rng, int(rng.integers(1, 14)), int(rng.integers(1, 10)), (1, 140), (1, 300)) for _ in range(30)]
+    b = RegionBatch.from_regions(regions)
+    plan = hip_engine.plan(b)
+    assert plan.dominant_kernel.startswith("phmm_forward_chain<")
+    plan.close()
+    _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
+    # the reference's known-answer vectors, all in ONE region per haplotype so that reads really chain
+    by_hap = {}
+    for r in kat_rows:
+        by_hap.setdefault(r["hap"], []).append(r)
+    regs = [([Read(r["read"], r["qual"], r["ins"], r["dele"], r["gcp"]) for r in rows], [hap]) for hap, rows in by_hap.items()]
+    kb = RegionBatch.from_regions(regs)
+    got = hip_engine.compute(kb)
+    exp = np.array([r["expected"] for rows in by_hap.values() for r in rows])
+    assert np.max(np.abs(got - exp)) < TOL_REFERENCE
+    # mixed read lengths at full shape, sample of regions against the oracle
+    c3 = synthetic.config3(6, seed=11)
+    _close(hip_engine.compute(c3), oracle.compute_batch(c3.as_dict(), n_threads=8))
+
+
+def test_chained_kernel_falls_back_exactly(engines, force_chain):
+    hip_engine = engines[16]
+    """Haplotypes with 'N' and reads with gcp == 0 cannot use the chained fast path: same wave, plain sweep."""
+    rng = np.random.default_rng(78)
+    regions = [_random_region(rng, 7, 4, (5, 90), (30, 200), alphabet=b"ACGTN"),  # N in haplotypes (and reads)
+               _random_region(rng, 7, 3, (5, 90), (30, 200))]
+    for rd in regions[1][0][::2]:
+        rd.gcp[len(rd.gcp) // 2] = 0  # im = 0 on one row
+    b = RegionBatch.from_regions(regions)
+    plan = hip_engine.plan(b)
+    assert plan.dominant_kernel.startswith("phmm_forward_chain<")
+    plan.close()
+    _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=4))
+
+
+def test_chained_and_plain_kernels_agree(engines):
+    hip_engine = engines[16]
+    b = synthetic.config2(24, seed=9)
+    plain = hip_engine.compute(b)
+    os.environ["PHMM_FORCE_CHAIN"] = "16"
+    try:
+        chained = hip_engine.compute(b)
+    finally:
+        os.environ.pop("PHMM_FORCE_CHAIN", None)
+    _close(chained, plain, tol=1e-12)
+    os.environ["PHMM_FORCE_CHAIN"] = "0"
+    try:
+        assert np.array_equal(hip_engine.compute(b), plain)
+    finally:
+        os.environ.pop("PHMM_FORCE_CHAIN", None)

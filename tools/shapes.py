@@ -18,7 +18,7 @@ def timed(eng, batch, reps=3):
         e0.record(st)
         for _ in range(reps): plan.launch(st.cuda_stream)
         e1.record(st); st.synchronize()
-    plan.status()
+    if not os.environ.get('SHAPES_NOSTATUS'): plan.status()
     return e0.elapsed_time(e1) / reps, plan.cells, plan.dominant_kernel
 
 cfgs = {"config2x1024": lambda: synthetic.config2(1024, seed=1),
