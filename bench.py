@@ -168,6 +168,37 @@ def main():
                   "kernel": p1.dominant_kernel, "note": "one region per launch, back-to-back launches on one stream"}
         p1.close()
 
+    engine_row = None
+    if rank == 0:  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
+        import ctypes as C
+        import math
+        import numpy as np
+        from lorikeet_amd import _lib
+        nreg = min(256, batch.n_regions)
+        sub = batch.region_slice(0, nreg)
+        cfg = _lib.EngineConfig()
+        cfg.constant_gcp, cfg.pcr_error_model, cfg.base_quality_score_threshold = 10, 3, 18
+        cfg.dynamic_read_disqualification, cfg.symmetrically_normalize_alleles_to_reference = 1, 1
+        cfg.log10_global_read_mismapping_rate = -4.5 * math.log10(math.e)
+        cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = 1.0, 0.02
+        mapq = np.full(sub.n_reads, 60, np.uint8)
+        ref = np.zeros(nreg, np.int32)
+        eout = np.empty(sub.n_out, np.float64)
+        keep = np.zeros(sub.n_reads, np.uint8)
+        pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+        args = (eng._h, C.byref(cfg), nreg, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p),
+                pp(sub.read_off, _lib.u32p), pp(sub.read_bases, _lib.u8p), pp(sub.base_q, _lib.u8p), None, None,
+                pp(mapq, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p),
+                pp(ref, C.POINTER(C.c_int32)), pp(sub.out_off, _lib.u64p), pp(eout, _lib.f64p), pp(keep, _lib.u8p))
+        assert eng.lib.phmm_engine_compute(*args) == 0, eng.last_error()
+        te = time.perf_counter()
+        for _ in range(5):
+            assert eng.lib.phmm_engine_compute(*args) == 0
+        te = (time.perf_counter() - te) / 5
+        engine_row = {"call": "phmm_engine_compute (PCR model conservative, dynamic disqualification), host buffers, "
+                              "PCIe included", "regions": nreg, "ms_per_call": round(te * 1e3, 3),
+                      "gcups_incl_pcie": round(sub.cells() / te / 1e9, 1), "reads_kept_fraction": round(float(keep.mean()), 4)}
+
     if rank == 0:
         res = out.cpu().numpy()
         assert (res <= 0).all(), "non-finite or positive likelihoods"
@@ -201,6 +232,7 @@ def main():
                          "flop_per_cell": FLOP_PER_CELL},
         }
         line["single_region"] = single
+        line["engine_call"] = engine_row
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(line), flush=True)

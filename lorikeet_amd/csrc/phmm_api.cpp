@@ -91,6 +91,7 @@ struct phmm_handle {
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr;
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
+    int err_code = PHMM_OK;  // status of the last failure (set together with err)
     int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
     int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
 };
@@ -102,7 +103,6 @@ struct phmm_batch {
     uint64_t cells = 0, alg_bytes = 0;
     std::vector<ShapeClass> classes;
     // device metadata (one allocation)
-    void *d_meta = nullptr;
     uint32_t *d_read_region = nullptr, *d_region_read_off = nullptr, *d_region_hap_off = nullptr, *d_read_off = nullptr,
              *d_hap_off = nullptr, *d_status = nullptr;
     uint64_t *d_out_off = nullptr;
@@ -126,7 +126,10 @@ bool hip_ok(phmm_handle *h, hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     char buf[256];
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    if (h) h->err = buf;
+    if (h) {
+        h->err = buf;
+        h->err_code = PHMM_ERR_HIP;
+    }
     else {
         std::lock_guard<std::mutex> g(g_err_mu);
         g_create_err = buf;
@@ -260,12 +263,15 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                                      size_t extra_arena_bytes = 0) {
     if (!h) return nullptr;
     h->err.clear();
+    h->err_code = PHMM_OK;
     if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
         h->err = "phmm_batch_create: null offset array";
+        h->err_code = PHMM_ERR_INVALID_ARG;
         return nullptr;
     }
     if (region_read_off[0] != 0 || region_hap_off[0] != 0 || read_off[0] != 0 || hap_off[0] != 0 || out_off[0] != 0) {
         h->err = "phmm_batch_create: offset arrays must start at 0";
+        h->err_code = PHMM_ERR_INVALID_ARG;
         return nullptr;
     }
     const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
@@ -273,12 +279,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (region_read_off[g + 1] < region_read_off[g] || region_hap_off[g + 1] < region_hap_off[g]) {
             h->err = "phmm_batch_create: region offsets not monotonic";
+            h->err_code = PHMM_ERR_INVALID_ARG;
             return nullptr;
         }
         const uint64_t need = (uint64_t)(region_read_off[g + 1] - region_read_off[g]) *
                               (uint64_t)(region_hap_off[g + 1] - region_hap_off[g]);
         if (out_off[g + 1] < out_off[g] || out_off[g + 1] - out_off[g] < need) {
             h->err = "phmm_batch_create: out_off leaves too little room for a region (needs Nr*Nh doubles)";
+            h->err_code = PHMM_ERR_INVALID_ARG;
             return nullptr;
         }
         if (out_off[g + 1] - out_off[g] != need) tight = false;
@@ -286,11 +294,13 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     for (uint32_t r = 0; r < n_reads; ++r)
         if (read_off[r + 1] < read_off[r]) {
             h->err = "phmm_batch_create: read_off not monotonic";
+            h->err_code = PHMM_ERR_INVALID_ARG;
             return nullptr;
         }
     for (uint32_t a = 0; a < n_haps; ++a)
         if (hap_off[a + 1] < hap_off[a]) {
             h->err = "phmm_batch_create: hap_off not monotonic";
+            h->err_code = PHMM_ERR_INVALID_ARG;
             return nullptr;
         }
     if (hipSetDevice(h->device) != hipSuccess) {
@@ -722,7 +732,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                     const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
                     const uint64_t *out_off, double *out, PendingCompute *pending) {
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
-    if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
+    if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
     if ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases) ||
         (b->n_out && !out)) {
@@ -911,7 +921,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     const size_t extra = 4 * rbytes + 4 * rbytes + align_up((size_t)n_reads, 256) * 2 + align_up((size_t)n_reads * 8, 256) +
                          align_up((size_t)n_regions * 4, 256) + 16 * 256;
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true, extra);
-    if (!b) return h->err.rfind("hip", 0) == 0 ? PHMM_ERR_HIP : PHMM_ERR_INVALID_ARG;
+    if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
     if ((b->read_bytes && (!read_bases || !base_q)) || (n_reads && (!mapq || !keep)) || (b->hap_bytes && !hap_bases) ||
         (b->n_out && !out)) {
