@@ -102,14 +102,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # barrier + max-over-ranks only; no data-path collective
+    # one process per GPU; BENCH_DIST_BACKEND=gloo (ranks may then share a device) exists only to exercise the
+    # N>1 code path on a single-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:  # barrier + max-over-ranks only; no data-path collective
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from lorikeet_amd import HipPairHMMEngine
     batch, shape = make_workload(a.workload, a.regions, a.seed + rank)
-    eng = HipPairHMMEngine(local_rank)
+    eng = HipPairHMMEngine(dev_index)
     plan = eng.plan(batch)
     tens = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in
             ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
@@ -121,7 +128,7 @@ def main():
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
@@ -139,7 +146,7 @@ def main():
     plan.status()  # raises if any likelihood came out > 0
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -237,7 +244,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 
