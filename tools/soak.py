@@ -1,0 +1,81 @@
+"""Developer tool: soak parity run -- random batches of widely varying shape through the C ABI vs the oracle
+(all host cores), for a wall-clock budget.  usage: python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from lorikeet_amd import HipPairHMMEngine
+from lorikeet_amd.batch import Read, RegionBatch
+from oracle import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+alpha = np.frombuffer(b"ACGT", np.uint8)
+alphan = np.frombuffer(b"ACGTN", np.uint8)
+cores = os.cpu_count() or 8
+eng = HipPairHMMEngine(0)
+t_end = time.time() + budget
+worst, n_batches, n_pairs, n_cells = 0.0, 0, 0, 0
+kinds = {}
+while time.time() < t_end:
+    kind = rng.choice(["typical", "typical", "typical", "tiny", "longhap", "longread", "manyhaps", "withN", "lowq"])
+    regions = []
+    n_regions = int(rng.integers(1, 40)) if kind in ("typical", "tiny", "withN", "lowq") else int(rng.integers(1, 4))
+    for _ in range(n_regions):
+        if kind == "tiny":
+            nr, nh, hl, rl = int(rng.integers(0, 5)), int(rng.integers(1, 4)), (1, 40), (0, 30)
+        elif kind == "longhap":
+            nr, nh, hl, rl = int(rng.integers(1, 6)), int(rng.integers(1, 4)), (1500, 2600), (50, 200)
+        elif kind == "longread":
+            nr, nh, hl, rl = int(rng.integers(1, 4)), int(rng.integers(1, 3)), (100, 700), (800, 3300)
+        elif kind == "manyhaps":
+            nr, nh, hl, rl = int(rng.integers(4, 30)), int(rng.integers(20, 70)), (200, 420), (80, 160)
+        else:
+            nr, nh, hl, rl = int(rng.integers(1, 40)), int(rng.integers(1, 10)), (60, 450), (20, 260)
+        a = alphan if kind == "withN" else alpha
+        root = a[rng.integers(0, len(a), int(rng.integers(*hl)))]
+        haps = []
+        for j in range(nh):
+            h = root.copy()
+            if j:
+                for _ in range(int(rng.integers(1, 4))):
+                    h[int(rng.integers(0, len(h)))] = a[int(rng.integers(0, len(a)))]
+                if rng.random() < 0.3 and len(h) > 10:  # an indel haplotype
+                    p = int(rng.integers(1, len(h) - 1))
+                    h = np.concatenate([h[:p], h[p + int(rng.integers(1, 4)):]])
+            haps.append(h)
+        reads = []
+        for _ in range(nr):
+            n = int(rng.integers(*rl))
+            if n <= len(root):
+                s = int(rng.integers(0, len(root) - n + 1))
+                b = root[s:s + n].copy()
+            else:
+                b = a[rng.integers(0, len(a), n)]
+            flips = rng.random(n) < 0.02
+            b[flips] = a[rng.integers(0, len(a), int(flips.sum()))]
+            qlo = 0 if kind == "lowq" else 6
+            reads.append(Read(b, rng.integers(qlo, 42, n), rng.integers(6, 46, n), rng.integers(6, 46, n),
+                              rng.integers(1 if kind != "lowq" else 0, 41, n)))
+        regions.append((reads, haps))
+    batch = RegionBatch.from_regions(regions)
+    want = oracle.compute_batch(batch.as_dict(), n_threads=cores)
+    for env in ({}, {"PHMM_FORCE_CHAIN": "6", "PHMM_FORCE_L": "16"}):
+        os.environ.update(env)
+        try:
+            got = eng.compute(batch)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        inf = np.isinf(want)
+        assert np.array_equal(np.isinf(got), inf), kind
+        assert not np.isnan(got).any(), kind
+        if (~inf).any():
+            d = float(np.max(np.abs(got[~inf] - want[~inf])))
+            worst = max(worst, d)
+            assert d <= 1e-9, (kind, d)
+    n_batches += 1
+    n_pairs += batch.n_out
+    n_cells += batch.cells()
+    kinds[kind] = kinds.get(kind, 0) + 1
+print("soak ok: %d batches, %d pairs, %.3g cells, worst |hip - oracle| = %.3g, kinds %s" % (n_batches, n_pairs, n_cells, worst, kinds))
