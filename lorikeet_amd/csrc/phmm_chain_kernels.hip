@@ -6,13 +6,14 @@
 //     [rows of read 0][SUM][RESET][rows of read 1][SUM][RESET] ...
 // and lane l simply works on stream position t - l at step t.  Nothing in the steady state is predicated
 // or per-lane conditional; the hand-over between reads happens through the recurrence itself:
-//   * the LAST row of a read is pre-scaled with sI = 1, sD = 0, so D^(R,.) == 0 and I^(R,.) == I(R,.);
-//   * the SUM row (mm = 1, dD = dd = 1, prior = 1 on valid columns and 0 on padding, via a base code that
+//   * the SUM row's dDp (the previous row's M->D coefficient, applied by the consumer) is 0, so the last row's
+//     deletion state drops out, and its I^ is I itself (im(R+1) = 1);
+//   * the SUM row (mm = 1, dd = 1, prior = 1 on valid columns and 0 on padding, via a base code that
 //     only padding columns match) turns M into M(R,j-1) + I(R,j-1) and lets the D chain -- which already
 //     runs left to right through columns AND lanes -- accumulate it: after the last lane's SUM step,
 //     M + D of its last column is sum_j M[R][j] + I[R][j] in exactly the reference's order
 //     (pair_hmm.rs:598-603); that lane takes the log10 and stores the result;
-//   * the RESET row (prior = 0, bI = gI = 0, dD = 0, dd = 1) rebuilds the row-0 state (0, 0, c0) of the next
+//   * the RESET row (prior = 0, bI = gI = 0, dd = 1) rebuilds the row-0 state (0, 0, c0) of the next
 //     read: M and I^ vanish and the D chain copies the value injected at the group's first lane.
 // Rows are produced 64 at a time (one per lane) into a 256-row ring, 64..128 rows ahead of lane 0; the stream
 // is padded with CL-1 neutral rows in front and behind, so a lane's slot is just (position & 255).
@@ -55,7 +56,7 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
         const bool scaled = __ballot(z) == 0ull;
         lds_wave_sync();
         if (lane == 0) ring[0] = neutral_row();
-        for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled, false);
+        for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled);
         lds_wave_sync();
         const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
         const double c0 = p.initial_condition / (double)H * scale0;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     // Two-phase producer, one ring row per lane: `issue` starts the (cold) loads of a row's quality bytes, `finish`
     // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
     // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
-    uint32_t pb_x = 0, pb_q = 0, pb_i = 0, pb_d = 0, pb_g = 0, pb_gn = 0;
+    uint32_t pb_x = 0, pb_q = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
     auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the chain, row)
         const int P = Q - LEAD;
         if (P < 0 || P >= S_total) return false;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             pb_q = p.base_q[ro + row];
             pb_i = p.ins_q[ro + row];
             pb_d = p.del_q[ro + row];
+            pb_dp = row > 0 ? (uint32_t)p.del_q[ro + row - 1] : 0u;
             pb_g = p.gcp[ro + row];
             pb_gn = row + 1 < R ? (uint32_t)p.gcp[ro + row + 1] : 0u;
         }
@@ -187,12 +189,13 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         RowConst n;
         if (locate(Q, lo, row, R, ro)) {
             if (row < R) {
-                n = make_row_bytes(p, pb_x, pb_q, pb_i, pb_d, pb_g, pb_gn, row + 1 >= R, true, true);
+                n = make_row_bytes(p, pb_x, pb_q, pb_i, pb_dp, pb_g, pb_gn, row == 0, row + 1 >= R, true);
+                n.mm = match_to_match(p, pb_i, pb_d);
             } else if (row == R) {  // SUM row; pad0 = read index inside the chain
-                n.mm = 1.0; n.bI = 0.0; n.gI = 0.0; n.dD = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 1.0;
+                n.mm = 1.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 1.0;
                 n.x = X_PAD; n.pad0 = (uint32_t)lo; n.pad1 = 0.0;
             } else {                // RESET row; pad1 = D^(0,.) of the next read = 2^1010 * im of its first row
-                n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dD = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+                n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
                 n.x = X_NONE; n.pad0 = 0;
                 n.pad1 = c_unit * (lo + 1 < n_chain ? 1.0 - p.eps[p.gcp[roff[lo + 1]]] : 1.0);
             }

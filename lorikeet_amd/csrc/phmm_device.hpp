@@ -44,15 +44,18 @@ __device__ __forceinline__ double from_left(double v, bool group_head) {
 // conflict-free, and lanes of different haplotype groups reading the same row broadcast.
 //
 // The record holds the coefficients of the row update in the form the kernel evaluates it:
-//   M(i,k) = prior * ( M(i-1,k-1)*mm + (I^(i-1,k-1) + D^(i-1,k-1)) * imx )
+//   M(i,k)  = prior * ( M(i-1,k-1)*mm + (I^(i-1,k-1) + D'(i-1,k-1)*dDp) * imx )
 //   I^(i,k) = M(i-1,k)*bI + I^(i-1,k)*gI
-//   D^(i,k) = M(i,k-1)*dD + D^(i,k-1)*dd
+//   D'(i,k) = M(i,k-1)    + D'(i,k-1)*dd            (one FMA: the row's M->D factor is applied by the consumer)
+// where D'(i,.) = D^(i,.) / dD(i) and dDp = dD(i-1) is the PREVIOUS row's match->deletion coefficient
+// (1 for the first row: D'(0,.) = D(0,.)).
 // Plain rows (any read):       I^ = I, D^ = D, bI = mi, gI = ii, dD = md, dd = ii, imx = im = 1 - dd.
 // Pre-scaled rows (no gcp==0): I^(i) = I(i)*im(i+1), D^(i) = D(i)*im(i+1) with im(R+1) = 1, so the
-//   indel->match factor is already folded in (imx == 1, one f64 op less per cell):
+//   indel->match factor is already folded in (imx == 1):
 //   bI = mi*im(i+1), gI = ii*im(i+1)/im(i), dD = md*im(i+1), dd = ii.
+// 8 f64-rate VALU ops per cell in the fast body: fma, fma, mul, mul (prior), mul, fma (I^), fma (D'), compare.
 struct alignas(8) RowConst {
-    double mm, bI, gI, dD, dd, pm, px;  // pm = 1 - eps(q) (match prior), px = mismatch prior
+    double mm, bI, gI, dDp, dd, pm, px;  // dDp: previous row's M->D coefficient; pm = 1 - eps(q), px = mismatch prior
     uint32_t x, pad0;                   // read base
     double pad1;
 };
@@ -111,7 +114,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         const double dM = k > 0 ? Mp[km1] : plM;  // (i-1, k-1)
         const double dI = k > 0 ? Ip[km1] : plI;
         const double dD = k > 0 ? Dp[km1] : plD;
-        double t = dI + dD;
+        double t = fma(dD, c.dDp, dI);  // I^(i-1,k-1) + D^(i-1,k-1), with D^ = D' * dD(i-1)
         if constexpr (MODE == ROW_GENERAL) t *= imx;
         const double a = fma(dM, c.mm, t);
         if constexpr (MODE == ROW_FAST_EXEC) {
@@ -135,11 +138,11 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
             Mp[k] = prior * a;
         }
     });
-    // Pass 2, left-to-right: the serial chain D(i,k) = M(i,k-1)*dD + D(i,k-1)*dd.
+    // Pass 2, left-to-right: the serial chain D'(i,k) = M(i,k-1) + D'(i,k-1)*dd.
     double leftM = lM, leftD = lD;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        Dp[k] = fma(leftD, c.dd, leftM * c.dD);
+        Dp[k] = fma(leftD, c.dd, leftM);
         leftM = Mp[k];
         leftD = Dp[k];
     }
@@ -249,28 +252,29 @@ __device__ __forceinline__ double sweep_general(const LdsView &lds, const int R,
 
 // One row record from the read's quality bytes (tables live in HBM / L2).
 //   plain      : coefficients as the reference writes them (bI = mi, gI = ii, dD = md)
-//   pre-scaled : I^ = I*im(i+1), D^ = D*im(i+1).  `last_special` (chained kernel) scales the read's last
-//                row with sI = 1, sD = 0 so that D^(R,.) == 0 and the sum row can add M + I only.
-// `g_next` is the gcp of the following row (ignored when `last`).
-__device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint32_t x, uint32_t q, uint32_t iq, uint32_t dq,
-                                                   uint32_t g, uint32_t g_next, bool last, bool scaled, bool last_special) {
-    const uint32_t mx = max(iq, dq), mn = min(iq, dq);
-    const double eq = p.eps[q], mi = p.eps[iq], md = p.eps[dq], ii = p.eps[g];
+//   pre-scaled : I^ = I*im(i+1), D^ = D*im(i+1), im(R+1) = 1
+// `dq_prev` is the deletion quality of the previous row (ignored when `first`), `g_next` the gcp of the
+// following row (ignored when `last`).
+__device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint32_t x, uint32_t q, uint32_t iq,
+                                                   uint32_t dq_prev, uint32_t g, uint32_t g_next, bool first, bool last,
+                                                   bool scaled) {
+    const uint32_t dq = 0;  // the row's own deletion quality only enters through mm (below) -- see callers
+    (void)dq;
+    const double eq = p.eps[q], mi = p.eps[iq], ii = p.eps[g];
     RowConst n;
-    n.mm = p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
-    n.pm = 1.0 - eq;                           // qual_to_prob(q)
-    n.px = (x == 'N') ? n.pm : p.eps_mis[q];   // read 'N' matches everything (pair_hmm.rs:643)
+    n.pm = 1.0 - eq;                          // qual_to_prob(q)
+    n.px = (x == 'N') ? n.pm : p.eps_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
     n.dd = ii;
+    const double im = 1.0 - ii;
     if (scaled) {
-        const double im = 1.0 - ii;
         const double im_next = last ? 1.0 : 1.0 - p.eps[g_next];
         n.bI = mi * im_next;
         n.gI = ii * (im_next / im);
-        n.dD = (last && last_special) ? 0.0 : md * im_next;
+        n.dDp = first ? 1.0 : p.eps[dq_prev] * im;  // dD(i-1) = md(i-1) * im(i)
     } else {
         n.bI = mi;
         n.gI = ii;
-        n.dD = md;
+        n.dDp = first ? 1.0 : p.eps[dq_prev];
     }
     n.x = x;
     n.pad0 = 0;
@@ -278,16 +282,24 @@ __device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint3
     return n;
 }
 
-__device__ __forceinline__ RowConst make_row(const ForwardParams &p, uint32_t ro, int row, int R, bool scaled,
-                                             bool last_special) {
-    const bool last = row + 1 >= R;
-    return make_row_bytes(p, p.read_bases[ro + row], p.base_q[ro + row], p.ins_q[ro + row], p.del_q[ro + row],
-                          p.gcp[ro + row], last ? 0u : (uint32_t)p.gcp[ro + row + 1], last, scaled, last_special);
+__device__ __forceinline__ double match_to_match(const ForwardParams &p, uint32_t iq, uint32_t dq) {
+    const uint32_t mx = max(iq, dq), mn = min(iq, dq);
+    return p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
 }
 
-__device__ __forceinline__ RowConst neutral_row() {  // keeps (M, I^, D^) = (0, 0, c0) fixed
+__device__ __forceinline__ RowConst make_row(const ForwardParams &p, uint32_t ro, int row, int R, bool scaled) {
+    const bool first = row == 0, last = row + 1 >= R;
+    const uint32_t iq = p.ins_q[ro + row];
+    RowConst n = make_row_bytes(p, p.read_bases[ro + row], p.base_q[ro + row], iq,
+                                first ? 0u : (uint32_t)p.del_q[ro + row - 1], p.gcp[ro + row],
+                                last ? 0u : (uint32_t)p.gcp[ro + row + 1], first, last, scaled);
+    n.mm = match_to_match(p, iq, p.del_q[ro + row]);
+    return n;
+}
+
+__device__ __forceinline__ RowConst neutral_row() {  // keeps (M, I^, D') = (0, 0, c0) fixed
     RowConst n;
-    n.mm = 0.0; n.bI = 0.0; n.gI = 1.0; n.dD = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+    n.mm = 0.0; n.bI = 0.0; n.gI = 1.0; n.dDp = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
     n.x = 0; n.pad0 = 0; n.pad1 = 0.0;
     return n;
 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
     for (int row = lane; row < R; row += WAVE) lane_zero_gcp |= (p.gcp[ro + row] == 0);
     const bool scaled = __ballot(lane_zero_gcp) == 0ull;
     if (lane == 0) srow[0] = neutral_row();  // lanes that have not started yet run this row
-    for (int row = lane; row < R; row += WAVE) srow[row + 1] = make_row(p, ro, row, R, scaled, false);
+    for (int row = lane; row < R; row += WAVE) srow[row + 1] = make_row(p, ro, row, R, scaled);
     // D(0,j) scale: pre-scaled rows carry im of the first read row
     const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
     lds_wave_sync();
