@@ -88,7 +88,7 @@ struct phmm_handle {
     hipStream_t S() { return streams[slot]; }
     int device = 0;
     unsigned flags = 0;
-    double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr;
+    double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr, *d_ratio_mis = nullptr, *d_inv_om = nullptr;
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
     int err_code = PHMM_OK;  // status of the last failure (set together with err)
@@ -209,6 +209,18 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
                                256 * sizeof(double), hipMemcpyHostToDevice),
                      "copy eps_mis") &&
               hip_ok(nullptr, hipMemcpy(h->d_mm, mm.data(), mm.size() * sizeof(double), hipMemcpyHostToDevice), "copy mm");
+    if (ok) {  // derived tables of the pre-scaled row form (phmm_device.hpp, RowConst)
+        std::vector<double> ratio(256, 0.0), inv_om(256, 0.0);
+        const auto &mis = (flags & PHMM_FLAG_NO_TRISTATE) ? eps : eps3;
+        for (int q = 1; q < 256; ++q) {
+            ratio[q] = mis[q] / (1.0 - eps[q]);
+            inv_om[q] = 1.0 / (1.0 - eps[q]);
+        }
+        ok = hip_ok(nullptr, hipMalloc(&h->d_ratio_mis, 256 * sizeof(double)), "hipMalloc ratio_mis") &&
+             hip_ok(nullptr, hipMalloc(&h->d_inv_om, 256 * sizeof(double)), "hipMalloc inv_om") &&
+             hip_ok(nullptr, hipMemcpy(h->d_ratio_mis, ratio.data(), 256 * sizeof(double), hipMemcpyHostToDevice), "copy ratio_mis") &&
+             hip_ok(nullptr, hipMemcpy(h->d_inv_om, inv_om.data(), 256 * sizeof(double), hipMemcpyHostToDevice), "copy inv_om");
+    }
     if (ok) {
         std::vector<unsigned char> all(4 * 128, 0);
         for (int m = 1; m <= 3; ++m) {
@@ -233,6 +245,8 @@ void phmm_destroy(phmm_handle *h) {
     if (h->d_eps) (void)hipFree(h->d_eps);
     if (h->d_eps_mis) (void)hipFree(h->d_eps_mis);
     if (h->d_mm) (void)hipFree(h->d_mm);
+    if (h->d_ratio_mis) (void)hipFree(h->d_ratio_mis);
+    if (h->d_inv_om) (void)hipFree(h->d_inv_om);
     if (h->d_pcr_cache) (void)hipFree(h->d_pcr_cache);
     for (int i = 0; i < kSlots; ++i) {
         if (h->arenas[i].dev) (void)hipFree(h->arenas[i].dev);
@@ -665,6 +679,8 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.eps = h->d_eps;
         p.eps_mis = h->d_eps_mis;
         p.mm = h->d_mm;
+        p.ratio_mis = h->d_ratio_mis;
+        p.inv_om = h->d_inv_om;
         p.initial_condition = initial_condition();
         p.initial_condition_log10 = initial_condition_log10();
         p.lds_rows = c.lds_rows;

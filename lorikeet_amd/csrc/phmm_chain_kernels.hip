@@ -8,11 +8,11 @@
 // or per-lane conditional; the hand-over between reads happens through the recurrence itself:
 //   * the SUM row's dDp (the previous row's M->D coefficient, applied by the consumer) is 0, so the last row's
 //     deletion state drops out, and its I^ is I itself (im(R+1) = 1);
-//   * the SUM row (mm = 1, dd = 1, prior = 1 on valid columns and 0 on padding, via a base code that
-//     only padding columns match) turns M into M(R,j-1) + I(R,j-1) and lets the D chain -- which already
-//     runs left to right through columns AND lanes -- accumulate it: after the last lane's SUM step,
-//     M + D of its last column is sum_j M[R][j] + I[R][j] in exactly the reference's order
-//     (pair_hmm.rs:598-603); that lane takes the log10 and stores the result;
+//   * the SUM row (mm = pm(R), dd = 1, prior 1) turns M into M(R,j-1) + I(R,j-1) and lets the D chain -- which
+//     already runs left to right through columns AND lanes -- accumulate it: after the SUM step of the lane that
+//     owns the EDGE column (index H, one right of the haplotype), M + D' of that column is
+//     sum_j M[R][j] + I[R][j] in exactly the reference's order (pair_hmm.rs:598-603); that lane takes the
+//     log10 and stores the result;
 //   * the RESET row (prior = 0, bI = gI = 0, dd = 1) rebuilds the row-0 state (0, 0, c0) of the next
 //     read: M and I^ vanish and the D chain copies the value injected at the group's first lane.
 // Rows are produced 64 at a time (one per lane) into a 256-row ring, 64..128 rows ahead of lane 0; the stream
@@ -52,16 +52,17 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
         const uint32_t ro = p.read_off[r];
         const int R = (int)(p.read_off[r + 1] - ro);
         bool z = false;
-        for (int row = lane; row < R; row += WAVE) z |= (p.gcp[ro + row] == 0);
+        for (int row = lane; row < R; row += WAVE) z |= row_blocks_prescale(p, ro + row);
         const bool scaled = __ballot(z) == 0ull;
         lds_wave_sync();
         if (lane == 0) ring[0] = neutral_row();
         for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled);
         lds_wave_sync();
         const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
+        const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;
         const double c0 = p.initial_condition / (double)H * scale0;
         const LdsView lds{ring};
-        double s = sweep_general<CL, K>(lds, R, l, false, hc, H, c0, scaled);
+        double s = sweep_general<CL, K>(lds, R, l, false, hc, H, c0, scaled, fin);
 #pragma unroll
         for (int off = CL / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     const uint32_t byte0 = p.read_off[rb];
     const uint32_t bytes = p.read_off[it.read_end] - byte0;
     bool z = false;
-    for (uint32_t i = lane; i < bytes; i += WAVE) z |= (p.gcp[byte0 + i] == 0);
+    for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
         if (lane_n) {  // general compare: 'N' columns become wildcards (mask 0), everything else full mask
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     // Two-phase producer, one ring row per lane: `issue` starts the (cold) loads of a row's quality bytes, `finish`
     // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
     // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
-    uint32_t pb_x = 0, pb_q = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
+    uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
     auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the chain, row)
         const int P = Q - LEAD;
         if (P < 0 || P >= S_total) return false;
@@ -172,14 +173,17 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     auto issue = [&](int Q0) {
         int lo, row, R;
         uint32_t ro;
-        if (locate(Q0 + lane, lo, row, R, ro) && row < R) {
-            pb_x = p.read_bases[ro + row];
-            pb_q = p.base_q[ro + row];
-            pb_i = p.ins_q[ro + row];
-            pb_d = p.del_q[ro + row];
-            pb_dp = row > 0 ? (uint32_t)p.del_q[ro + row - 1] : 0u;
-            pb_g = p.gcp[ro + row];
-            pb_gn = row + 1 < R ? (uint32_t)p.gcp[ro + row + 1] : 0u;
+        if (locate(Q0 + lane, lo, row, R, ro) && row <= R) {
+            pb_qp = row > 0 ? (uint32_t)p.base_q[ro + row - 1] : 0u;  // row == R: the SUM row needs pm(R)
+            if (row < R) {
+                pb_x = p.read_bases[ro + row];
+                pb_q = p.base_q[ro + row];
+                pb_i = p.ins_q[ro + row];
+                pb_d = p.del_q[ro + row];
+                pb_dp = row > 0 ? (uint32_t)p.del_q[ro + row - 1] : 0u;
+                pb_g = p.gcp[ro + row];
+                pb_gn = row + 1 < R ? (uint32_t)p.gcp[ro + row + 1] : 0u;
+            }
         }
     };
     auto finish = [&](int Q0) {  // ring positions [Q0, Q0 + 64); stream position = ring position - LEAD
@@ -189,13 +193,12 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         RowConst n;
         if (locate(Q, lo, row, R, ro)) {
             if (row < R) {
-                n = make_row_bytes(p, pb_x, pb_q, pb_i, pb_dp, pb_g, pb_gn, row == 0, row + 1 >= R, true);
-                n.mm = match_to_match(p, pb_i, pb_d);
-            } else if (row == R) {  // SUM row; pad0 = read index inside the chain
-                n.mm = 1.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 1.0;
+                n = make_row_bytes(p, pb_x, pb_q, pb_qp, pb_i, pb_d, pb_dp, pb_g, pb_gn, row == 0, row + 1 >= R, true);
+            } else if (row == R) {  // SUM row: M~_S(k) = M~(R,k-1)*pm(R) + I(R,k-1); pad0 = read index inside the chain
+                n.mm = 1.0 - p.eps[pb_qp]; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 1.0; n.px = 1.0;
                 n.x = X_PAD; n.pad0 = (uint32_t)lo; n.pad1 = 0.0;
-            } else {                // RESET row; pad1 = D^(0,.) of the next read = 2^1010 * im of its first row
-                n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+            } else {                // RESET row; pad1 = D'(0,.) of the next read = 2^1010 * im of its first row
+                n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
                 n.x = X_NONE; n.pad0 = 0;
                 n.pad1 = c_unit * (lo + 1 < n_chain ? 1.0 - p.eps[p.gcp[roff[lo + 1]]] : 1.0);
             }
@@ -223,14 +226,21 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         Dp[k] = c0;
     }
     double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c0;
-    const bool last_lane = (l == CL - 1);
+    // The EDGE column (index H) of the SUM row holds M~_S = M(R,H)+I(R,H) and D' = the sum over the columns to its
+    // left: the lane that owns it emits the result (columns right of it carry don't-care values until RESET).
+    const int edge_lane = H / K, edge_k = H % K;
+    const bool last_lane = (l == edge_lane);
     const double log10_scale = log10(c_unit) + log10((double)H);  // result = log10(sum) - log10(2^1010 * H)
     auto emit = [&](const RowConst &c) {
-        // after the last lane's SUM step: D^ = running sum of the gated M over everything to its left, M = own term
+        // after the EDGE lane's SUM step: D' = running sum of M~_S over everything to its left, M~_S = own term
         {
             if (last_lane && c.x == X_PAD && hv) {
                 const uint32_t r = rb + c.pad0;
-                const double v = log10(Dp[K - 1] + Mp[K - 1]) - log10_scale;
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (k == edge_k) sum = Dp[k] + Mp[k];
+                const double v = log10(sum) - log10_scale;
                 p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
                 if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
             }

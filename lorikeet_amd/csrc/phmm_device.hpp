@@ -44,18 +44,22 @@ __device__ __forceinline__ double from_left(double v, bool group_head) {
 // conflict-free, and lanes of different haplotype groups reading the same row broadcast.
 //
 // The record holds the coefficients of the row update in the form the kernel evaluates it:
-//   M(i,k)  = prior * ( M(i-1,k-1)*mm + (I^(i-1,k-1) + D'(i-1,k-1)*dDp) * imx )
-//   I^(i,k) = M(i-1,k)*bI + I^(i-1,k)*gI
-//   D'(i,k) = M(i,k-1)    + D'(i,k-1)*dd            (one FMA: the row's M->D factor is applied by the consumer)
-// where D'(i,.) = D^(i,.) / dD(i) and dDp = dD(i-1) is the PREVIOUS row's match->deletion coefficient
-// (1 for the first row: D'(0,.) = D(0,.)).
-// Plain rows (any read):       I^ = I, D^ = D, bI = mi, gI = ii, dD = md, dd = ii, imx = im = 1 - dd.
-// Pre-scaled rows (no gcp==0): I^(i) = I(i)*im(i+1), D^(i) = D(i)*im(i+1) with im(R+1) = 1, so the
-//   indel->match factor is already folded in (imx == 1):
-//   bI = mi*im(i+1), gI = ii*im(i+1)/im(i), dD = md*im(i+1), dd = ii.
-// 8 f64-rate VALU ops per cell in the fast body: fma, fma, mul, mul (prior), mul, fma (I^), fma (D'), compare.
+//   M~(i,k) = sel * ( M~(i-1,k-1)*mm + (I^(i-1,k-1) + D'(i-1,k-1)*dDp) * imx ),  sel = x==y ? pm : px
+//   I^(i,k) = M~(i-1,k)*bI + I^(i-1,k)*gI
+//   D'(i,k) = M~(i,k-1)    + D'(i,k-1)*dd          (one FMA: the row's M->D factor is applied by the consumer)
+// Plain rows (any read; used when a read has gcp == 0 or a base quality 0):
+//   M~ = M, I^ = I, D' = D/md(i); mm, bI = mi, gI = ii, dd = ii as the reference writes them, dDp = md(i-1)
+//   (1 for the first row: D'(0,.) = D(0,.)), pm/px = the match / mismatch priors, imx = im = 1 - ii.
+// Pre-scaled rows (everything else): three factors are folded into neighbouring coefficients so that the
+// steady-state body is 7 f64-rate VALU ops per cell (fma, fma, masked mul, mul, fma, fma, compare):
+//   * I^(i) = I(i)*im(i+1), D^(i) = D(i)*im(i+1) with im(R+1) = 1: the indel->match factor (imx == 1):
+//       bI = mi*im(i+1), gI = ii*im(i+1)/im(i), dD = md*im(i+1)
+//   * D'(i) = D^(i)/dD(i): the match->deletion factor moves to the consumer (dDp = dD(i-1))
+//   * M~(i) = M(i)/pm(i): a matching cell needs no prior multiply at all (pm field = 1.0) and a mismatching
+//       cell is multiplied by px = prior_mismatch/prior_match; pm(i-1) is folded into mm, bI and dDp of row i.
+//       The final sum is sum_j M~(R,j)*pm(R) + I^(R,j).
 struct alignas(8) RowConst {
-    double mm, bI, gI, dDp, dd, pm, px;  // dDp: previous row's M->D coefficient; pm = 1 - eps(q), px = mismatch prior
+    double mm, bI, gI, dDp, dd, pm, px;  // see above
     uint32_t x, pad0;                   // read base
     double pad1;
 };
@@ -118,15 +122,15 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         if constexpr (MODE == ROW_GENERAL) t *= imx;
         const double a = fma(dM, c.mm, t);
         if constexpr (MODE == ROW_FAST_EXEC) {
-            // prior select without v_cndmask: multiply by the mismatch prior everywhere, then redo the
-            // multiply with the match prior under EXEC = (x == y).  Two VALU + one SALU instead of four
-            // VALU (compare, two v_cndmask, multiply).  Only valid where all 64 lanes are active.
-            double m = c.px * a;
-            asm volatile("v_cmpx_eq_u32_e32 vcc, %1, %2\n\t"
-                         "v_mul_f64 %0, %3, %4\n\t"
+            // prior select without v_cndmask (pre-scaled rows: pm == 1): matching cells keep `a`, mismatching
+            // cells are multiplied by px under EXEC = (x != y).  Two VALU + one SALU instead of four VALU
+            // (compare, two v_cndmask, multiply).  Only valid where all 64 lanes are active.
+            double m = a;
+            asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
+                         "v_mul_f64 %0, %3, %0\n\t"
                          "s_mov_b64 exec, -1"
                          : "+v"(m)
-                         : "v"(c.x), "v"((uint32_t)hc.base(k)), "v"(c.pm), "v"(a)
+                         : "v"(c.x), "v"((uint32_t)hc.base(k)), "v"(c.px)
                          : "vcc");
             Mp[k] = m;
         } else {
@@ -158,7 +162,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
 // so nothing is copied between steps.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
 template <int L, int K, int STEADY>
 __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, const int l, const bool group_head,
-                                             const HapCols<K> &hc, const int H, const double c0) {
+                                             const HapCols<K> &hc, const int H, const double c0, const double fin) {
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -212,7 +216,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-        if (l * K + k < H) s += Mp[k] + Ip[k];
+        if (l * K + k < H) s += fma(Mp[k], fin, Ip[k]);  // fin = pm(R) for pre-scaled rows, else 1
     return s;
 }
 
@@ -220,7 +224,8 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
 // one compact predicated loop, kept small on purpose -- it is rare.
 template <int L, int K>
 __device__ __forceinline__ double sweep_general(const LdsView &lds, const int R, const int l, const bool group_head,
-                                             const HapCols<K> &hc, const int H, const double c0, const bool scaled) {
+                                             const HapCols<K> &hc, const int H, const double c0, const bool scaled,
+                                             const double fin) {
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -245,36 +250,41 @@ __device__ __forceinline__ double sweep_general(const LdsView &lds, const int R,
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-        if (l * K + k < H) s += Mp[k] + Ip[k];
+        if (l * K + k < H) s += fma(Mp[k], fin, Ip[k]);  // fin = pm(R) for pre-scaled rows, else 1
     return s;
 }
 
 
-// One row record from the read's quality bytes (tables live in HBM / L2).
-//   plain      : coefficients as the reference writes them (bI = mi, gI = ii, dD = md)
-//   pre-scaled : I^ = I*im(i+1), D^ = D*im(i+1), im(R+1) = 1
-// `dq_prev` is the deletion quality of the previous row (ignored when `first`), `g_next` the gcp of the
-// following row (ignored when `last`).
-__device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint32_t x, uint32_t q, uint32_t iq,
-                                                   uint32_t dq_prev, uint32_t g, uint32_t g_next, bool first, bool last,
-                                                   bool scaled) {
-    const uint32_t dq = 0;  // the row's own deletion quality only enters through mm (below) -- see callers
-    (void)dq;
-    const double eq = p.eps[q], mi = p.eps[iq], ii = p.eps[g];
+// One row record from the read's quality bytes (tables live in HBM / L2); forms as described at RowConst.
+// `q_prev` / `dq_prev` belong to the previous row (ignored when `first`), `g_next` to the following row
+// (ignored when `last`).
+__device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint32_t x, uint32_t q, uint32_t q_prev,
+                                                   uint32_t iq, uint32_t dq, uint32_t dq_prev, uint32_t g,
+                                                   uint32_t g_next, bool first, bool last, bool scaled) {
+    const double mi = p.eps[iq], ii = p.eps[g];
+    const uint32_t mx = max(iq, dq), mn = min(iq, dq);
+    const double mm = p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
     RowConst n;
-    n.pm = 1.0 - eq;                          // qual_to_prob(q)
-    n.px = (x == 'N') ? n.pm : p.eps_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
     n.dd = ii;
-    const double im = 1.0 - ii;
-    if (scaled) {
+    if (scaled) {  // division-free: the quotients come from host-built tables
+        const double im = 1.0 - ii;
         const double im_next = last ? 1.0 : 1.0 - p.eps[g_next];
-        n.bI = mi * im_next;
-        n.gI = ii * (im_next / im);
-        n.dDp = first ? 1.0 : p.eps[dq_prev] * im;  // dD(i-1) = md(i-1) * im(i)
+        const double pm_prev = first ? 1.0 : 1.0 - p.eps[q_prev];
+        n.mm = mm * pm_prev;
+        n.bI = mi * im_next * pm_prev;
+        n.gI = ii * (im_next * p.inv_om[g]);
+        n.dDp = first ? 1.0 : p.eps[dq_prev] * im * pm_prev;  // dD(i-1) = md(i-1) * im(i)
+        n.pm = 1.0;
+        n.px = (x == 'N') ? 1.0 : p.ratio_mis[q];  // read 'N' matches everything (pair_hmm.rs:643)
     } else {
+        const double pm = 1.0 - p.eps[q];                  // qual_to_prob(q)
+        const double px = (x == 'N') ? pm : p.eps_mis[q];
+        n.mm = mm;
         n.bI = mi;
         n.gI = ii;
         n.dDp = first ? 1.0 : p.eps[dq_prev];
+        n.pm = pm;
+        n.px = px;
     }
     n.x = x;
     n.pad0 = 0;
@@ -282,24 +292,21 @@ __device__ __forceinline__ RowConst make_row_bytes(const ForwardParams &p, uint3
     return n;
 }
 
-__device__ __forceinline__ double match_to_match(const ForwardParams &p, uint32_t iq, uint32_t dq) {
-    const uint32_t mx = max(iq, dq), mn = min(iq, dq);
-    return p.mm[((mx * (mx + 1)) >> 1) + mn];  // pair_hmm_model.rs:442-461
-}
-
 __device__ __forceinline__ RowConst make_row(const ForwardParams &p, uint32_t ro, int row, int R, bool scaled) {
     const bool first = row == 0, last = row + 1 >= R;
-    const uint32_t iq = p.ins_q[ro + row];
-    RowConst n = make_row_bytes(p, p.read_bases[ro + row], p.base_q[ro + row], iq,
-                                first ? 0u : (uint32_t)p.del_q[ro + row - 1], p.gcp[ro + row],
-                                last ? 0u : (uint32_t)p.gcp[ro + row + 1], first, last, scaled);
-    n.mm = match_to_match(p, iq, p.del_q[ro + row]);
-    return n;
+    return make_row_bytes(p, p.read_bases[ro + row], p.base_q[ro + row], first ? 0u : (uint32_t)p.base_q[ro + row - 1],
+                          p.ins_q[ro + row], p.del_q[ro + row], first ? 0u : (uint32_t)p.del_q[ro + row - 1],
+                          p.gcp[ro + row], last ? 0u : (uint32_t)p.gcp[ro + row + 1], first, last, scaled);
+}
+
+// A read can use pre-scaled rows unless one of its rows has gcp == 0 (im = 0) or base quality 0 (pm = 0).
+__device__ __forceinline__ bool row_blocks_prescale(const ForwardParams &p, uint32_t byte) {
+    return p.gcp[byte] == 0 || p.base_q[byte] == 0;
 }
 
 __device__ __forceinline__ RowConst neutral_row() {  // keeps (M, I^, D') = (0, 0, c0) fixed
     RowConst n;
-    n.mm = 0.0; n.bI = 0.0; n.gI = 1.0; n.dDp = 1.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
+    n.mm = 0.0; n.bI = 0.0; n.gI = 1.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
     n.x = 0; n.pad0 = 0; n.pad1 = 0.0;
     return n;
 }

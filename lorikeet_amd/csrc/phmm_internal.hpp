@@ -29,6 +29,8 @@ struct ForwardParams {
     const double *eps;    // [256]  10^(-q/10)
     const double *eps_mis;  // [256]  mismatch prior: eps/3 (tristate) or eps
     const double *mm;     // triangular [256*257/2] match->match
+    const double *ratio_mis;  // [256]  eps_mis[q] / (1 - eps[q]): mismatch/match prior ratio of pre-scaled rows (0 at q = 0)
+    const double *inv_om;     // [256]  1 / (1 - eps[q]) (0 at q = 0)
     // scalars
     double initial_condition;        // 2^1020
     double initial_condition_log10;  // log10(2^1020), host libm

@@ -40,14 +40,16 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
 
     // ---- stage this read's per-row constants in wave-private LDS (72-byte records, conflict-free) ----------
     RowConst *srow = reinterpret_cast<RowConst *>(smem) + (size_t)wave * p.lds_rows;
-    // gcp == 0 means im = 1 - eps(0) = 0: such a read keeps plain rows (rare; production gcp is 10)
+    // gcp == 0 means im = 1 - eps(0) = 0 (and base quality 0 means pm = 0): such a read keeps plain rows
+    // (rare; production gcp is 10 and the engine caps base qualities at >= 6)
     bool lane_zero_gcp = false;
-    for (int row = lane; row < R; row += WAVE) lane_zero_gcp |= (p.gcp[ro + row] == 0);
+    for (int row = lane; row < R; row += WAVE) lane_zero_gcp |= row_blocks_prescale(p, ro + row);
     const bool scaled = __ballot(lane_zero_gcp) == 0ull;
     if (lane == 0) srow[0] = neutral_row();  // lanes that have not started yet run this row
     for (int row = lane; row < R; row += WAVE) srow[row + 1] = make_row(p, ro, row, R, scaled);
     // D(0,j) scale: pre-scaled rows carry im of the first read row
     const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
+    const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;  // pm(R), see RowConst
     lds_wave_sync();
     const LdsView lds{srow};
     const bool group_head = (L == 32) && (lane == 32);
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
         const double c0 = p.initial_condition / (double)H * scale0;
         double s;
         if (scaled && __ballot(lane_n) == 0ull)
-            s = p.exec_select ? sweep_fast<L, K, ROW_FAST_EXEC>(lds, R, l, group_head, hc, H, c0)
-                              : sweep_fast<L, K, ROW_FAST>(lds, R, l, group_head, hc, H, c0);
+            s = p.exec_select ? sweep_fast<L, K, ROW_FAST_EXEC>(lds, R, l, group_head, hc, H, c0, fin)
+                              : sweep_fast<L, K, ROW_FAST>(lds, R, l, group_head, hc, H, c0, fin);
         else  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0
-            s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled);
+            s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled, fin);
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {

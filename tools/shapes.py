@@ -28,10 +28,20 @@ cfgs = {"config2x1024": lambda: synthetic.config2(1024, seed=1),
         "R250_H300x512": lambda: synthetic.make_regions(512, 128, 8, 300, 250, 6),
         "Nh2_R150_H300x2048": lambda: synthetic.make_regions(2048, 128, 2, 300, 150, 7),
         "ragged_small": lambda: synthetic.make_regions(4096, 12, 3, 220, [80, 120, 151], 8)}
-only = sys.argv[1:] 
+only = [a for a in sys.argv[1:] if not a.startswith("--")]
+chain_mode = "--chain" in sys.argv  # compare planner default / chained kernel off / forced on instead of forcing L
 for name, mk in cfgs.items():
     if only and name not in only: continue
     b = mk()
+    if chain_mode:
+        for ch in (None, "0", "1"):
+            if ch is None: os.environ.pop("PHMM_FORCE_CHAIN", None)
+            else: os.environ["PHMM_FORCE_CHAIN"] = ch
+            eng = HipPairHMMEngine(0)
+            ms, cells, k = timed(eng, b)
+            print("%-20s chain=%-4s %-26s %8.3f ms %8.1f GCUPS" % (name, ch, k, ms, cells / ms / 1e6), flush=True)
+            eng.close()
+        continue
     for L in (0, 16, 32, 64):
         if L: os.environ["PHMM_FORCE_L"] = str(L)
         else: os.environ.pop("PHMM_FORCE_L", None)

@@ -18,9 +18,9 @@ t_end = time.time() + budget
 worst, n_batches, n_pairs, n_cells = 0.0, 0, 0, 0
 kinds = {}
 while time.time() < t_end:
-    kind = rng.choice(["typical", "typical", "typical", "tiny", "longhap", "longread", "manyhaps", "withN", "lowq"])
+    kind = rng.choice(["typical", "typical", "typical", "tiny", "longhap", "longread", "manyhaps", "withN", "lowq", "wideq"])
     regions = []
-    n_regions = int(rng.integers(1, 40)) if kind in ("typical", "tiny", "withN", "lowq") else int(rng.integers(1, 4))
+    n_regions = int(rng.integers(1, 40)) if kind in ("typical", "tiny", "withN", "lowq", "wideq") else int(rng.integers(1, 4))
     for _ in range(n_regions):
         if kind == "tiny":
             nr, nh, hl, rl = int(rng.integers(0, 5)), int(rng.integers(1, 4)), (1, 40), (0, 30)
@@ -54,6 +54,10 @@ while time.time() < t_end:
                 b = a[rng.integers(0, len(a), n)]
             flips = rng.random(n) < 0.02
             b[flips] = a[rng.integers(0, len(a), int(flips.sum()))]
+            if kind == "wideq":  # the whole quality range a BAM can carry (HiFi-style Q93, gap penalties from 1)
+                reads.append(Read(b, rng.integers(1, 94, n), rng.integers(1, 94, n), rng.integers(1, 94, n),
+                                  rng.integers(1, 61, n)))
+                continue
             qlo = 0 if kind == "lowq" else 6
             reads.append(Read(b, rng.integers(qlo, 42, n), rng.integers(6, 46, n), rng.integers(6, 46, n),
                               rng.integers(1 if kind != "lowq" else 0, 41, n)))
