@@ -230,6 +230,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     // left: the lane that owns it emits the result (columns right of it carry don't-care values until RESET).
     const int edge_lane = H / K, edge_k = H % K;
     const bool last_lane = (l == edge_lane);
+    const uint32_t sum_code = last_lane ? X_PAD : 0xffffffffu;  // == c.x exactly when this lane has to emit
     const double log10_scale = log10(c_unit) + log10((double)H);  // result = log10(sum) - log10(2^1010 * H)
     auto emit = [&](const RowConst &c) {
         // after the EDGE lane's SUM step: D' = running sum of M~_S over everything to its left, M~_S = own term
@@ -253,13 +254,15 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     const int T = (S_total + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
     // Outer loop = one producer tick (64 steps), inner loop = the sweep.  The producer's pending bytes are
     // defined before the inner loop and first used after it, so their loads have 64 steps to land.
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        if (t0 >= 64) {  // keep the ring 64..128 rows ahead of the first lane
-            finish(t0 + 128);
+    // The first tick is shortened by a per-block even phase (the ring only gets further ahead), so that the two
+    // waves sharing a SIMD do not run their producers -- the one latency-exposed part -- at the same time.
+    const int phase = (int)((blockIdx.x * 2654435761u) >> 26) & 62;
+    for (int t0 = 0, t1 = min(T, 64 - phase), tick = 0; t0 < T; t0 = t1, t1 = min(T, t1 + 64), ++tick) {
+        if (tick >= 1) {  // keep the ring 64..128 (+ phase) rows ahead of the first lane
+            finish(64 * tick + 128);
             lds_wave_sync();
-            issue(t0 + 192);
+            issue(64 * tick + 192);
         }
-        const int t1 = min(T, t0 + 64);
         for (int t = t0; t < t1; t += 2) {
             cB = ring[(q + 1) & (RING - 1)];
             aM = from_left<CL>(Mp[K - 1], false);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             aD = from_left_inject(Dp[K - 1], cA.pad1);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
             // a read's SUM row reaches the last lane once per read: one wave-uniform test per two steps
-            const bool any_sum = __ballot(last_lane && (cA.x == X_PAD || cB.x == X_PAD)) != 0ull;
+            const bool any_sum = (__ballot(cA.x == sum_code) | __ballot(cB.x == sum_code)) != 0ull;
             if (any_sum) emit(cA);
             cA = ring[(q + 2) & (RING - 1)];
             bM = from_left<CL>(Mp[K - 1], false);

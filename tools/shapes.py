@@ -34,7 +34,7 @@ for name, mk in cfgs.items():
     if only and name not in only: continue
     b = mk()
     if chain_mode:
-        for ch in (None, "0", "1"):
+        for ch in (None, "0", "16"):
             if ch is None: os.environ.pop("PHMM_FORCE_CHAIN", None)
             else: os.environ["PHMM_FORCE_CHAIN"] = ch
             eng = HipPairHMMEngine(0)

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 __global__ __launch_bounds__(256) void k_ind_fma(double *out, int iters, double b, double c) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     for (int i = 0; i < iters; ++i) {
         asm volatile(
@@ -17,6 +18,10 @@ __global__ __launch_bounds__(256) void k_ind_fma(double *out, int iters, double 
             : "v"(b), "v"(c));
     }
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[0] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // shader-clock ticks vs 100 MHz wall ticks over the kernel
+        out[1] = (double)(clock64() - c0);
+        out[2] = (double)(wall_clock64() - w0);
+    }
 }
 __global__ __launch_bounds__(256) void k_ind_fma32(float *out, int iters, float b, float c) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -47,6 +52,8 @@ int main() {
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double instr_per_simd = (double)iters * 16 * wps;
+            double cw[3]; hipMemcpy(cw, out, 24, hipMemcpyDeviceToHost);
+            if (pass == 0) printf("   clock64/wall_clock64 = %.3f (x100 MHz if wall is the 100 MHz counter)\n", cw[1] / cw[2]);
             printf("%s waves/SIMD=%d  %.1f ms  %.3f G wave-instr/s per SIMD -> %.2f GHz if 4 clk/instr; %.1f TFLOP/s\n",
                    pass ? "f32" : "f64", wps, ms, instr_per_simd / ms / 1e6, 4 * instr_per_simd / ms / 1e6,
                    instr_per_simd * 1024 * 128 / ms / 1e9);
