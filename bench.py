@@ -31,6 +31,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_F64_PEAK_TFLOPS = 78.6  # vector FP64 peak (256 CU * 2.4 GHz * 128 flop/clk)
+NUM_SIMD = 1024              # 256 CUs x 4
+VALU_ISSUE_PEAK = 0.6        # G wave64 VALU instructions / s / SIMD at 2.4 GHz, one per 4 clk
+VALU_ISSUE_UBENCH = 0.488    # what the kernel's own instruction mix sustains (tools/ubench/issue.hip)
 FLOP_PER_CELL = 12           # M 4 mul + 2 add, I 2+1, D 2+1
 
 
@@ -43,6 +46,8 @@ def parse():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed loop (no single_region / engine_call / cpu_baseline rows): for PMC passes")
     return ap.parse_args()
 
 
@@ -82,15 +87,16 @@ def cpu_baseline(batch, budget_s=20.0):
 
 
 def pmc_traffic(workload, regions):
-    """(HBM bytes per launch, L2 hit rate) measured with rocprofv3 PMC passes (profiles/pmc_traffic.json)."""
+    """(HBM bytes per launch, L2 hit rate, wave64 VALU instructions per launch) measured with rocprofv3 PMC
+    passes of this very command (profiles/pmc_traffic.json; tools/profile.sh + tools/rocpd_summary.py)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         for e in json.load(open(path)):
             if e["workload"] == workload and e["regions"] == regions:
-                return e["hbm_bytes_per_launch"], e.get("l2_hit_rate")
+                return e["hbm_bytes_per_launch"], e.get("l2_hit_rate"), e.get("valu_insts_per_launch")
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def main():
@@ -154,7 +160,7 @@ def main():
     regions_total = batch.n_regions * world
 
     single = None
-    if rank == 0:  # configs[1] literally: ONE region per launch (latency mode: the planner spreads it over all SIMDs)
+    if rank == 0 and not a.main_only:  # configs[1] literally: ONE region per launch (latency mode: the planner spreads it over all SIMDs)
         one, _ = make_workload(a.workload, 1, a.seed + 7919)
         p1 = eng.plan(one)
         t1 = {k: torch.from_numpy(getattr(one, k)).to(dev) for k in
@@ -176,7 +182,7 @@ def main():
         p1.close()
 
     engine_row = None
-    if rank == 0:  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
+    if rank == 0 and not a.main_only:  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
         import ctypes as C
         import math
         import numpy as np
@@ -236,11 +242,22 @@ def main():
             "valu_f64": {"achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
                          "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
-                         "flop_per_cell": FLOP_PER_CELL},
+                         "flop_per_cell": FLOP_PER_CELL,
+                         "note": "flop_per_cell counts the reference recurrence (pair_hmm.rs:561-587); the kernel "
+                                 "executes 10 (4 FMA + 2 MUL) after folding three factors into the row constants"},
         }
+        valu_insts = pmc_traffic(a.workload, a.regions)[2]
+        if valu_insts:  # the bound that actually binds: wave64 VALU issue slots (every VALU op costs one, FP64 or not)
+            rate = valu_insts / mean_kernel_s / NUM_SIMD / 1e9
+            line["valu_issue"] = {
+                "achieved": round(rate, 4), "peak": VALU_ISSUE_PEAK, "unit": "G wave64-instr/s per SIMD",
+                "frac": round(rate / VALU_ISSUE_PEAK, 4), "valu_per_cell": round(valu_insts * 64 / plan.cells, 3),
+                "same_mix_ubench": VALU_ISSUE_UBENCH,
+                "note": "peak = 2.4 GHz / 4 clk; same_mix_ubench = the 7-op cell body alone at 2 waves/SIMD on the whole "
+                        "chip (tools/ubench/issue.hip: 4.76 clk per instruction at the 2.3 GHz the chip sustains)"}
         line["single_region"] = single
         line["engine_call"] = engine_row
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.main_only:
             line["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -54,15 +54,18 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
         bool z = false;
         for (int row = lane; row < R; row += WAVE) z |= row_blocks_prescale(p, ro + row);
         const bool scaled = __ballot(z) == 0ull;
+        const bool staged = R + 1 <= RING;  // longer reads build their rows on the fly (slow, but this path is rare)
         lds_wave_sync();
-        if (lane == 0) ring[0] = neutral_row();
-        for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled);
+        if (staged) {
+            if (lane == 0) ring[0] = neutral_row();
+            for (int row = lane; row < R; row += WAVE) ring[row + 1] = make_row(p, ro, row, R, scaled);
+        }
         lds_wave_sync();
         const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
         const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;
         const double c0 = p.initial_condition / (double)H * scale0;
-        const LdsView lds{ring};
-        double s = sweep_general<CL, K>(lds, R, l, false, hc, H, c0, scaled, fin);
+        double s = staged ? sweep_general<CL, K>(LdsView{ring}, R, l, false, hc, H, c0, scaled, fin)
+                          : sweep_general<CL, K>(GlobalRowView{p, ro, R, scaled}, R, l, false, hc, H, c0, scaled, fin);
 #pragma unroll
         for (int off = CL / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 
 size_t chain_lds_bytes() { return (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t); }
 int chain_max_k() { return 20; }
-int chain_max_read_rows() { return RING - 8; }  // the in-wave fallback stages a whole read linearly in the ring
+int chain_max_read_rows() { return 1 << 20; }  // the stream has no length limit (the in-wave fallback neither)
 
 hipError_t launch_chain(int K, const ChainParams &cp, hipStream_t stream) {
     if (!cp.n_items) return hipSuccess;

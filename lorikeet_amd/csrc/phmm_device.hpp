@@ -108,6 +108,50 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
                                            const double plI, const double plD, const double lM, const double lD,
                                            const RowConst &c, const HapCols<K> &hc, const double imx) {
     const uint16_t x16 = (uint16_t)c.x;
+    if constexpr (MODE == ROW_FAST_EXEC) {
+        // Pre-scaled rows (pm == 1), all 64 lanes active.  One cell = one asm statement in a fixed order that keeps
+        // independent work between consecutive EXEC writes (back-to-back v_cmpx blocks serialise the SIMD, see
+        // tools/ubench/issue.hip):
+        //   M~(k)  = D'(k-1)*dDp + I^(k-1);  M~(k) += M~(k-1)*mm          (row i-1 values of column k-1)
+        //   EXEC = (x != y_k);  M~(k) *= px;  EXEC = all                  (matching cells keep the value)
+        //   I^(k-1) = I^(k-1)*gI + M~(k-1)*bI                             (column k-1 moves on to row i)
+        // Columns right-to-left, so every register is updated in place; I^(K-1) is updated up front.
+        Ip[K - 1] = fma(Mp[K - 1], c.bI, Ip[K - 1] * c.gI);
+        static_for_down<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t y = (uint32_t)hc.base(k);
+            if constexpr (k > 0) {
+                asm volatile("v_fma_f64 %[M], %[Dl], %[dDp], %[Il]\n\t"
+                             "v_fmac_f64_e32 %[M], %[Ml], %[mm]\n\t"
+                             "v_cmpx_ne_u32_e32 vcc, %[x], %[y]\n\t"
+                             "v_mul_f64 %[M], %[px], %[M]\n\t"
+                             "s_mov_b64 exec, -1\n\t"
+                             "v_mul_f64 %[Il], %[Il], %[gI]\n\t"
+                             "v_fmac_f64_e32 %[Il], %[Ml], %[bI]"
+                             : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[k - 1])
+                             : [Dl] "v"(Dp[k - 1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[k - 1]), [mm] "v"(c.mm), [x] "v"(c.x),
+                               [y] "v"(y), [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI)
+                             : "vcc");
+            } else {
+                double m = fma(plM, c.mm, fma(plD, c.dDp, plI));
+                asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
+                             "v_mul_f64 %0, %3, %0\n\t"
+                             "s_mov_b64 exec, -1"
+                             : "+v"(m)
+                             : "v"(c.x), "v"(y), "v"(c.px)
+                             : "vcc");
+                Mp[0] = m;
+            }
+        });
+        double leftM = lM, leftD = lD;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            Dp[k] = fma(leftD, c.dd, leftM);
+            leftM = Mp[k];
+            leftD = Dp[k];
+        }
+        return;
+    }
     // Pass 1, columns right-to-left: I(i,k) reads the old M/I of column k, then M(i,k) overwrites
     // M[k] using the still-old column k-1.
     static_for_down<K>([&](auto kc) {
@@ -222,8 +266,8 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
 
 // General sweep (haplotype with 'N', or a read with gcp == 0 whose rows cannot be pre-scaled):
 // one compact predicated loop, kept small on purpose -- it is rare.
-template <int L, int K>
-__device__ __forceinline__ double sweep_general(const LdsView &lds, const int R, const int l, const bool group_head,
+template <int L, int K, class RowView>
+__device__ __forceinline__ double sweep_general(const RowView &lds, const int R, const int l, const bool group_head,
                                              const HapCols<K> &hc, const int H, const double c0, const bool scaled,
                                              const double fin) {
     double Mp[K], Ip[K], Dp[K];
@@ -298,6 +342,20 @@ __device__ __forceinline__ RowConst make_row(const ForwardParams &p, uint32_t ro
                           p.ins_q[ro + row], p.del_q[ro + row], first ? 0u : (uint32_t)p.del_q[ro + row - 1],
                           p.gcp[ro + row], last ? 0u : (uint32_t)p.gcp[ro + row + 1], first, last, scaled);
 }
+
+__device__ __forceinline__ RowConst neutral_row();
+
+// Row source that builds each record from HBM on the fly (no staging): for the rare general path of the chained
+// kernel when a read does not fit its LDS ring.  Same indexing as LdsView (0 = neutral row).
+struct GlobalRowView {
+    const ForwardParams &p;
+    uint32_t ro;
+    int R;
+    bool scaled;
+    __device__ __forceinline__ RowConst load(int idx) const {
+        return idx == 0 ? neutral_row() : make_row(p, ro, idx - 1, R, scaled);
+    }
+};
 
 // A read can use pre-scaled rows unless one of its rows has gcp == 0 (im = 0) or base quality 0 (pm = 0).
 __device__ __forceinline__ bool row_blocks_prescale(const ForwardParams &p, uint32_t byte) {

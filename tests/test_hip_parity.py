@@ -151,7 +151,7 @@ def test_haplotype_indexing_inputs_equal_oracle(engine_no_tristate):
 # ---------------------------------------------------------------------------------------------
 # seeded random inputs, edge cases
 # ---------------------------------------------------------------------------------------------
-def _random_region(rng, n_reads, n_haps, rlen, hlen, alphabet=b"ACGT", qmax=60):
+def _random_region(rng, n_reads, n_haps, rlen, hlen, alphabet=b"ACGT", qmax=60, qmin=0):
     alpha = np.frombuffer(alphabet, np.uint8)
     haps = [alpha[rng.integers(0, len(alpha), int(rng.integers(*hlen)))] for _ in range(n_haps)]
     reads = []
@@ -159,8 +159,8 @@ def _random_region(rng, n_reads, n_haps, rlen, hlen, alphabet=b"ACGT", qmax=60):
         n = int(rng.integers(*rlen))
         # ins/del quals >= 6 as the engine guarantees (...engine.rs:446-456): below Q4 the transition model is
         # improper (mi + md > 1) and results may exceed 0, which the reference asserts on (tested separately)
-        reads.append(Read(alpha[rng.integers(0, len(alpha), n)], rng.integers(0, qmax + 1, n),
-                          rng.integers(6, qmax + 1, n), rng.integers(6, qmax + 1, n), rng.integers(0, qmax + 1, n)))
+        reads.append(Read(alpha[rng.integers(0, len(alpha), n)], rng.integers(qmin, qmax + 1, n),
+                          rng.integers(6, qmax + 1, n), rng.integers(6, qmax + 1, n), rng.integers(qmin, qmax + 1, n)))
     return reads, haps
 
 
@@ -427,6 +427,23 @@ def test_chained_kernel_falls_back_exactly(engines, force_chain):
     assert plan.dominant_kernel.startswith("phmm_forward_chain<")
     plan.close()
     _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=4))
+
+
+def test_chained_kernel_long_reads(engines, force_chain):
+    """Reads longer than the 256-row LDS ring stream through it; with an 'N' haplotype, a gcp == 0 or a base
+    quality 0 in the chain, the in-wave general path builds the rows of such reads on the fly."""
+    hip_engine = engines[16]
+    rng = np.random.default_rng(79)
+    regions = [_random_region(rng, 6, 3, (230, 700), (40, 250), qmin=1),                      # streamed
+               _random_region(rng, 5, 2, (230, 700), (40, 250), alphabet=b"ACGTN", qmin=1),   # general path, unstaged
+               _random_region(rng, 5, 3, (250, 600), (40, 250), qmin=1)]
+    regions[2][0][1].gcp[3] = 0
+    regions[2][0][3].quals[100] = 0  # match prior 0: the row form with the prior folded out cannot be used
+    b = RegionBatch.from_regions(regions)
+    plan = hip_engine.plan(b)
+    assert plan.dominant_kernel.startswith("phmm_forward_chain<")
+    plan.close()
+    _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
 
 
 def test_chained_and_plain_kernels_agree(engines):
