@@ -50,7 +50,6 @@ struct ShapeClass {
     int waves_per_block = MAX_WAVES_PER_BLOCK;
     size_t lds_bytes = 0;
     dim3 grid;
-    uint32_t exec_select = 0;
     // chained class: items are (region, haplotype group, run of reads) instead of single reads
     bool chain = false;
     std::vector<uint32_t> regions;  // member regions (chain classes)
@@ -147,20 +146,21 @@ int round_up_k(int k) {
     return 0;
 }
 
-// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates; K <= 21 is
-// compiled for 2 waves).
-int waves_per_simd(int K) { return K <= 6 ? 3 : K <= 21 ? 2 : 1; }
+// Registers cap the resident waves per SIMD (3*K f64 of DP state per lane dominates; K <= 25 is
+// compiled for 2 waves, PHMM_TWO_WAVE_MAX_K).
+int waves_per_simd(int K) { return K <= 25 ? 2 : 1; }
 
 // Throughput model of a region under <L,K>, calibrated on MI355X (tools/shapes.py): useful fraction of
-// issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~12 of 9.5*K+12 VALU ops per
-// step) x a small bonus for a second resident wave (measured ~1-3 %).
+// issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~11 of 7*K+11 VALU ops per
+// step) x the issue rate one resident wave reaches alone (a wave issues a VALU op every ~6 clk, two waves
+// together one every ~4.7: tools/ubench/issue.hip; measured 0.81 on <16,25>).
 double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h) {
     const int G = WAVE / L;
     const double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
     const double ramp = (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
     const double col_fill = (double)max_h / (double)(L * K);
-    const double step = 9.5 * K / (9.5 * K + 12.0);
-    const double occ = waves_per_simd(K) >= 2 ? 1.0 : 0.97;
+    const double step = 7.0 * K / (7.0 * K + 11.0);
+    const double occ = waves_per_simd(K) >= 2 ? 1.0 : 0.84;
     return hap_fill * ramp * col_fill * step * occ;
 }
 
@@ -465,9 +465,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (reg_L[g] == 16) units16 += (uint64_t)shape[g].nr * ((shape[g].nh + 3) / 4);
     uint32_t chain_reads = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, units16 / (8ull * 2 * kNumSimd));
     if (const char *e = getenv("PHMM_FORCE_CHAIN")) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, std::max(0, atoi(e)));
-    auto chain_k = [&](const RegionShape &s) {  // one extra column right of the haplotype carries the last term of the sum
-        return round_up_k((int)((s.max_h + 1 + 15) / 16));
-    };
+    auto chain_k = [&](const RegionShape &s) { return round_up_k((int)((s.max_h + 15) / 16)); };
     auto chainable = [&](uint32_t g) {
         const RegionShape &s = shape[g];
         const int k = chain_k(s);
@@ -475,6 +473,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                (int)s.max_r <= chain_max_read_rows();
     };
 
+    if (getenv("PHMM_TRACE"))
+        fprintf(stderr, "phmm plan: %u regions, min_L %d, units16 %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
+                min_L, (unsigned long long)units16, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
+                n_regions ? (int)chainable(0) : 0);
     std::map<std::tuple<int, int, int>, ShapeClass> by_shape;
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (reg_L[g] < 0) continue;
@@ -538,6 +540,11 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     for (uint32_t r = r0; r < r1; r += chain_reads)
                         c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + chain_reads)});
             }
+            // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
+            // be filled by the short ones (stable, so equal-length batches keep their order)
+            std::stable_sort(c.chain_items.begin(), c.chain_items.end(), [&](const ChainItem &x, const ChainItem &y) {
+                return read_off[x.read_end] - read_off[x.read_begin] > read_off[y.read_end] - read_off[y.read_begin];
+            });
             void *mirror;
             c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
             up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
@@ -557,11 +564,6 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             bool split = (uint64_t)n_items < 4ull * kNumSimd;
             if (h->force_split >= 0) split = h->force_split != 0;
             c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
-            // the EXEC-masked prior select trades a VALU op for an SALU op: a win only when a second wave on
-            // the SIMD can use the freed VALU slot (measured: +3 % at 2 waves/SIMD, -8 % at 1)
-            const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
-            c.exec_select = (waves >= 2ull * kNumSimd && c.K <= 21) ? 1u : 0u;
-            if (const char *e = getenv("PHMM_FORCE_EXEC_SELECT")) c.exec_select = atoi(e) ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {
             // generic: exclusive prefix of pairs per read, scratch for a bounded grid
@@ -684,7 +686,6 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.initial_condition = initial_condition();
         p.initial_condition_log10 = initial_condition_log10();
         p.lds_rows = c.lds_rows;
-        p.exec_select = c.exec_select;
         p.status = b->d_status;
         if (!p.n_items) continue;
         hipError_t e;

@@ -8,11 +8,11 @@
 // or per-lane conditional; the hand-over between reads happens through the recurrence itself:
 //   * the SUM row's dDp (the previous row's M->D coefficient, applied by the consumer) is 0, so the last row's
 //     deletion state drops out, and its I^ is I itself (im(R+1) = 1);
-//   * the SUM row (mm = pm(R), dd = 1, prior 1) turns M into M(R,j-1) + I(R,j-1) and lets the D chain -- which
-//     already runs left to right through columns AND lanes -- accumulate it: after the SUM step of the lane that
-//     owns the EDGE column (index H, one right of the haplotype), M + D' of that column is
-//     sum_j M[R][j] + I[R][j] in exactly the reference's order (pair_hmm.rs:598-603); that lane takes the
-//     log10 and stores the result;
+//   * the SUM row (mm = bI = pm(R), gI = dd = 1, prior 1) turns M(k) into M(R,k-1) + I(R,k-1) and I(k) into
+//     M(R,k) + I(R,k), and lets the D chain -- which already runs left to right through columns AND lanes --
+//     accumulate the M's: after the SUM step of the lane that owns the last haplotype column c, D' + M + I of that
+//     column is sum_j M[R][j] + I[R][j] in the reference's order (pair_hmm.rs:598-603); that lane takes the
+//     log10 and stores the result (columns right of c carry don't-care values until the RESET row);
 //   * the RESET row (prior = 0, bI = gI = 0, dd = 1) rebuilds the row-0 state (0, 0, c0) of the next
 //     read: M and I^ vanish and the D chain copies the value injected at the group's first lane.
 // Rows are produced 64 at a time (one per lane) into a 256-row ring, 64..128 rows ahead of lane 0; the stream
@@ -31,8 +31,7 @@ namespace {
 
 constexpr int CL = 16;               // lanes per pair
 constexpr int RING = 256;            // ring rows (power of two); slot RING holds the neutral row
-constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (> H): only the SUM row's x equals it
-constexpr uint32_t X_EDGE = 0x101u;  // base code of the one extra column right of the haplotype
+constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
 constexpr int LEAD = CL - 1;          // neutral rows in front of the stream (lane l starts LEAD - l rows early)
 
@@ -106,17 +105,14 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     HapCols<K> hc;
     bool lane_n = false;
 #pragma unroll
-    for (int w = 0; w < HapCols<K>::W; ++w) {
-        hc.y[w] = 0u;
-        hc.m[w] = 0u;
-    }
+    for (int w = 0; w < HapCols<K>::W; ++w) hc.y[w] = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int col = l * K + k;
-        uint32_t y = col < H ? (uint32_t)p.hap_bases[ho + col] : (col == H ? X_EDGE : X_PAD);
+        uint32_t y = col < H ? (uint32_t)p.hap_bases[ho + col] : X_PAD;
         const bool is_n = (y == 'N');
         lane_n |= is_n;
-        hc.set(k, y, 0xffffu);
+        hc.set(k, y);
     }
 
     // ---- the chain: stream offsets, and whether every read can be pre-scaled ------------------------
@@ -126,14 +122,6 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     bool z = false;
     for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
-        if (lane_n) {  // general compare: 'N' columns become wildcards (mask 0), everything else full mask
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (hc.base(k) == 'N') {
-                    hc.y[k >> 1] &= ~(0xffffu << (16 * (k & 1)));
-                    hc.m[k >> 1] &= ~(0xffffu << (16 * (k & 1)));
-                }
-        }
         chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
         return;
     }
@@ -197,8 +185,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         if (locate(Q, lo, row, R, ro)) {
             if (row < R) {
                 n = make_row_bytes(p, pb_x, pb_q, pb_qp, pb_i, pb_d, pb_dp, pb_g, pb_gn, row == 0, row + 1 >= R, true);
-            } else if (row == R) {  // SUM row: M~_S(k) = M~(R,k-1)*pm(R) + I(R,k-1); pad0 = read index inside the chain
-                n.mm = 1.0 - p.eps[pb_qp]; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 1.0; n.px = 1.0;
+            } else if (row == R) {  // SUM row: M_S(k) = M(R,k-1) + I(R,k-1), I_S(k) = M(R,k) + I(R,k); pad0 = read index in the chain
+                n.mm = 1.0 - p.eps[pb_qp]; n.bI = n.mm; n.gI = 1.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 1.0; n.px = 1.0;
                 n.x = X_PAD; n.pad0 = (uint32_t)lo; n.pad1 = 0.0;
             } else {                // RESET row; pad1 = D'(0,.) of the next read = 2^1010 * im of its first row
                 n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
@@ -229,21 +217,21 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         Dp[k] = c0;
     }
     double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c0;
-    // The EDGE column (index H) of the SUM row holds M~_S = M(R,H)+I(R,H) and D' = the sum over the columns to its
-    // left: the lane that owns it emits the result (columns right of it carry don't-care values until RESET).
-    const int edge_lane = H / K, edge_k = H % K;
+    // After the SUM row the last haplotype column c = H-1 holds I_S = M(R,c)+I(R,c), M_S = M(R,c-1)+I(R,c-1) and
+    // D' = the sum over everything further left: the lane that owns it emits the result.
+    const int edge_lane = (H > 0 ? H - 1 : 0) / K, edge_k = (H > 0 ? H - 1 : 0) % K;
     const bool last_lane = (l == edge_lane);
     const uint32_t sum_code = last_lane ? X_PAD : 0xffffffffu;  // == c.x exactly when this lane has to emit
     const double log10_scale = log10(c_unit) + log10((double)H);  // result = log10(sum) - log10(2^1010 * H)
     auto emit = [&](const RowConst &c) {
-        // after the EDGE lane's SUM step: D' = running sum of M~_S over everything to its left, M~_S = own term
+        // after the owning lane's SUM step, see above
         {
             if (last_lane && c.x == X_PAD && hv) {
                 const uint32_t r = rb + c.pad0;
                 double sum = 0.0;
 #pragma unroll
                 for (int k = 0; k < K; ++k)
-                    if (k == edge_k) sum = Dp[k] + Mp[k];
+                    if (k == edge_k) sum = (Dp[k] + Mp[k]) + Ip[k];
                 const double v = log10(sum) - log10_scale;
                 p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
                 if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
@@ -288,10 +276,11 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 
 // ---- launch ----------------------------------------------------------------------------------------
 #define PHMM_CHAIN_K_LIST(X) \
-    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
+    X(23) X(24) X(25)
 
 size_t chain_lds_bytes() { return (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t); }
-int chain_max_k() { return 20; }
+int chain_max_k() { return 25; }
 int chain_max_read_rows() { return 1 << 20; }  // the stream has no length limit (the in-wave fallback neither)
 
 hipError_t launch_chain(int K, const ChainParams &cp, hipStream_t stream) {

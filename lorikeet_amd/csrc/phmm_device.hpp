@@ -8,7 +8,7 @@
 
 // K up to this value is compiled for two resident waves per SIMD (<= 256 VGPRs, no spills)
 #ifndef PHMM_TWO_WAVE_MAX_K
-#define PHMM_TWO_WAVE_MAX_K 21
+#define PHMM_TWO_WAVE_MAX_K 25
 #endif
 
 namespace phmm {
@@ -79,66 +79,70 @@ __device__ __forceinline__ void static_for_down(F &&f) {
     }
 }
 
-// Haplotype columns of a lane, two 16-bit fields per dword (column k of the lane = l*K+k): the
-// compare then is a single v_cmp_eq_u16 with a half-word select, no extraction ops.
+// Haplotype columns of a lane, two 16-bit fields per dword (column k of the lane = l*K+k): the fast body compares
+// straight out of the packed half-word (SDWA operand select), so a column costs half a register.
 template <int K>
 struct HapCols {
     static constexpr int W = (K + 1) / 2;
-    uint32_t y[W];  // base (0 where the haplotype has 'N' and HAPN is set)
-    uint32_t m[W];  // HAPN only: 0xff = compare, 0x00 = wildcard column
+    uint32_t y[W];  // raw haplotype byte (or a chained kernel's EDGE / PAD code)
     __device__ __forceinline__ uint16_t base(int k) const { return (uint16_t)(y[k >> 1] >> (16 * (k & 1))); }
-    __device__ __forceinline__ uint16_t mask(int k) const { return (uint16_t)(m[k >> 1] >> (16 * (k & 1))); }
-    __device__ __forceinline__ void set(int k, uint32_t yv, uint32_t mv) {
-        y[k >> 1] |= yv << (16 * (k & 1));
-        m[k >> 1] |= mv << (16 * (k & 1));
-    }
+    __device__ __forceinline__ void set(int k, uint32_t yv) { y[k >> 1] |= yv << (16 * (k & 1)); }
 };
 
 // One read row for the K columns of this lane, every register updated in place.
 //   in : Mp/Ip/Dp = row i-1;  (plM,plI,plD) = left neighbour's last column, row i-1;
 //        (lM,lD) = left neighbour's last column, row i
 //   out: Mp/Ip/Dp = row i
-// FAST: pre-scaled rows and a haplotype without 'N' (the common case).  Otherwise the general form:
-// `imx` multiplies the indel->match term (1.0 for pre-scaled rows) and the compare honours the
-// haplotype wildcard mask.
-enum : int { ROW_GENERAL = 0, ROW_FAST = 1, ROW_FAST_EXEC = 2 };
+// FAST_EXEC: pre-scaled rows and a haplotype without 'N' (the common case), every lane of the wave active;
+// FAST_EXEC_PRED: the same under a predicate (`live` = the EXEC mask the caller runs under, wave-uniform).
+// Otherwise the general form: `imx` multiplies the indel->match term (1.0 for pre-scaled rows) and the
+// compare honours the haplotype wildcard mask.
+enum : int { ROW_GENERAL = 0, ROW_FAST_EXEC = 2, ROW_FAST_EXEC_PRED = 3 };
 
 template <int K, int MODE>
 __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], double (&Dp)[K], const double plM,
                                            const double plI, const double plD, const double lM, const double lD,
-                                           const RowConst &c, const HapCols<K> &hc, const double imx) {
+                                           const RowConst &c, const HapCols<K> &hc, const double imx,
+                                           const uint64_t live = ~0ull) {
     const uint16_t x16 = (uint16_t)c.x;
-    if constexpr (MODE == ROW_FAST_EXEC) {
-        // Pre-scaled rows (pm == 1), all 64 lanes active.  One cell = one asm statement in a fixed order that keeps
+    if constexpr (MODE == ROW_FAST_EXEC || MODE == ROW_FAST_EXEC_PRED) {
+        // Pre-scaled rows (pm == 1).  One cell = one asm statement in a fixed order that keeps
         // independent work between consecutive EXEC writes (back-to-back v_cmpx blocks serialise the SIMD, see
         // tools/ubench/issue.hip):
         //   M~(k)  = D'(k-1)*dDp + I^(k-1);  M~(k) += M~(k-1)*mm          (row i-1 values of column k-1)
-        //   EXEC = (x != y_k);  M~(k) *= px;  EXEC = all                  (matching cells keep the value)
+        //   EXEC &= (x != y_k);  M~(k) *= px;  EXEC = live                (matching cells keep the value)
         //   I^(k-1) = I^(k-1)*gI + M~(k-1)*bI                             (column k-1 moves on to row i)
         // Columns right-to-left, so every register is updated in place; I^(K-1) is updated up front.
+        const uint64_t restore = (MODE == ROW_FAST_EXEC) ? ~0ull : live;
         Ip[K - 1] = fma(Mp[K - 1], c.bI, Ip[K - 1] * c.gI);
         static_for_down<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const uint32_t y = (uint32_t)hc.base(k);
-            if constexpr (k > 0) {
-                asm volatile("v_fma_f64 %[M], %[Dl], %[dDp], %[Il]\n\t"
-                             "v_fmac_f64_e32 %[M], %[Ml], %[mm]\n\t"
-                             "v_cmpx_ne_u32_e32 vcc, %[x], %[y]\n\t"
-                             "v_mul_f64 %[M], %[px], %[M]\n\t"
-                             "s_mov_b64 exec, -1\n\t"
-                             "v_mul_f64 %[Il], %[Il], %[gI]\n\t"
-                             "v_fmac_f64_e32 %[Il], %[Ml], %[bI]"
-                             : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[k - 1])
-                             : [Dl] "v"(Dp[k - 1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[k - 1]), [mm] "v"(c.mm), [x] "v"(c.x),
-                               [y] "v"(y), [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI)
-                             : "vcc");
+            const uint32_t y = hc.y[k >> 1];
+#define PHMM_CELL(SEL)                                                                                              \
+    asm volatile("v_fma_f64 %[M], %[Dl], %[dDp], %[Il]\n\t"                                                        \
+                 "v_fmac_f64_e32 %[M], %[Ml], %[mm]\n\t"                                                           \
+                 "v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:" SEL "\n\t"                          \
+                 "v_mul_f64 %[M], %[px], %[M]\n\t"                                                                 \
+                 "s_mov_b64 exec, %[live]\n\t"                                                                     \
+                 "v_mul_f64 %[Il], %[Il], %[gI]\n\t"                                                               \
+                 "v_fmac_f64_e32 %[Il], %[Ml], %[bI]"                                                               \
+                 : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1])                                                            \
+                 : [Dl] "v"(Dp[km1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[km1]), [mm] "v"(c.mm), [x] "v"(c.x), [y] "v"(y), \
+                   [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI), [live] "s"(restore)                               \
+                 : "vcc")
+            constexpr int km1 = k > 0 ? k - 1 : 0;
+            if constexpr (k > 0 && (k & 1)) {
+                PHMM_CELL("WORD_1");
+            } else if constexpr (k > 0) {
+                PHMM_CELL("WORD_0");
+#undef PHMM_CELL
             } else {
                 double m = fma(plM, c.mm, fma(plD, c.dDp, plI));
-                asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
+                asm volatile("v_cmpx_ne_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:WORD_0\n\t"
                              "v_mul_f64 %0, %3, %0\n\t"
-                             "s_mov_b64 exec, -1"
+                             "s_mov_b64 exec, %4"
                              : "+v"(m)
-                             : "v"(c.x), "v"(y), "v"(c.px)
+                             : "v"(c.x), "v"(y), "v"(c.px), "s"(restore)
                              : "vcc");
                 Mp[0] = m;
             }
@@ -152,7 +156,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         }
         return;
     }
-    // Pass 1, columns right-to-left: I(i,k) reads the old M/I of column k, then M(i,k) overwrites
+    // General form (rare).  Pass 1, columns right-to-left: I(i,k) reads the old M/I of column k, then M(i,k) overwrites
     // M[k] using the still-old column k-1.
     static_for_down<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -165,26 +169,9 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         double t = fma(dD, c.dDp, dI);  // I^(i-1,k-1) + D^(i-1,k-1), with D^ = D' * dD(i-1)
         if constexpr (MODE == ROW_GENERAL) t *= imx;
         const double a = fma(dM, c.mm, t);
-        if constexpr (MODE == ROW_FAST_EXEC) {
-            // prior select without v_cndmask (pre-scaled rows: pm == 1): matching cells keep `a`, mismatching
-            // cells are multiplied by px under EXEC = (x != y).  Two VALU + one SALU instead of four VALU
-            // (compare, two v_cndmask, multiply).  Only valid where all 64 lanes are active.
-            double m = a;
-            asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
-                         "v_mul_f64 %0, %3, %0\n\t"
-                         "s_mov_b64 exec, -1"
-                         : "+v"(m)
-                         : "v"(c.x), "v"((uint32_t)hc.base(k)), "v"(c.px)
-                         : "vcc");
-            Mp[k] = m;
-        } else {
-            double prior;
-            if constexpr (MODE == ROW_FAST)
-                prior = (x16 == hc.base(k)) ? c.pm : c.px;
-            else
-                prior = ((uint16_t)(x16 & hc.mask(k)) == hc.base(k)) ? c.pm : c.px;
-            Mp[k] = prior * a;
-        }
+        const uint16_t yb = hc.base(k);  // haplotype 'N' is a wildcard too (pair_hmm.rs:643)
+        const double prior = (x16 == yb || yb == (uint16_t)'N') ? c.pm : c.px;
+        Mp[k] = prior * a;
     });
     // Pass 2, left-to-right: the serial chain D'(i,k) = M(i,k-1) + D'(i,k-1)*dd.
     double leftM = lM, leftD = lD;
@@ -204,7 +191,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
 
 // Fast sweep: two steps per trip with the roles of the (constants, left-column) register sets swapped,
 // so nothing is copied between steps.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
-template <int L, int K, int STEADY>
+template <int L, int K>
 __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, const int l, const bool group_head,
                                              const HapCols<K> &hc, const int H, const double c0, const double fin) {
     double Mp[K], Ip[K], Dp[K];
@@ -223,12 +210,12 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         aM = from_left<L>(Mp[K - 1], group_head);
         aI = from_left<L>(Ip[K - 1], group_head);
         aD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, STEADY>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
+        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
         cA = lds.load(max(row + 3, 0));
         bM = from_left<L>(Mp[K - 1], group_head);
         bI = from_left<L>(Ip[K - 1], group_head);
         bD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, STEADY>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
+        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
         row += 2;
     }
     RowConst cur = cA;
@@ -238,7 +225,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, STEADY>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
+        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
@@ -250,7 +237,8 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        if (row < R) row_update<K, ROW_FAST>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
+        const uint64_t live = __ballot(row < R);
+        if (row < R) row_update<K, ROW_FAST_EXEC_PRED>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0, live);
         plM = lM;
         plI = lI;
         plD = lD;

@@ -35,8 +35,6 @@ struct ForwardParams {
     double initial_condition;        // 2^1020
     double initial_condition_log10;  // log10(2^1020), host libm
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
-    uint32_t exec_select;            // 1: prior select by EXEC-masked multiply (pays off with >= 2 resident
-                                     // waves per SIMD), 0: v_cndmask (latency-bound small launches)
     uint32_t *status;                // device status word (bit0: positive result)
 };
 

@@ -67,23 +67,19 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
         HapCols<K> hc;
         bool lane_n = false;
 #pragma unroll
-        for (int w = 0; w < HapCols<K>::W; ++w) {
-            hc.y[w] = 0u;
-            hc.m[w] = 0u;
-        }
+        for (int w = 0; w < HapCols<K>::W; ++w) hc.y[w] = 0u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int col = l * K + k;
             const uint32_t y = (col < H) ? (uint32_t)p.hap_bases[ho + col] : 0u;
             const bool is_n = (y == 'N');
             lane_n |= is_n;
-            hc.set(k, is_n ? 0u : y, is_n ? 0u : 0xffu);
+            hc.set(k, y);
         }
         const double c0 = p.initial_condition / (double)H * scale0;
         double s;
         if (scaled && __ballot(lane_n) == 0ull)
-            s = p.exec_select ? sweep_fast<L, K, ROW_FAST_EXEC>(lds, R, l, group_head, hc, H, c0, fin)
-                              : sweep_fast<L, K, ROW_FAST>(lds, R, l, group_head, hc, H, c0, fin);
+            s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
         else  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0
             s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled, fin);
 #pragma unroll
