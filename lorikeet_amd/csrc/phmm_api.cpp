@@ -55,6 +55,7 @@ struct ShapeClass {
     std::vector<uint32_t> regions;  // member regions (chain classes)
     std::vector<ChainItem> chain_items;
     ChainItem *d_chain_items = nullptr;
+    uint32_t cnd_select = 0;
     // device
     uint32_t *d_reads = nullptr;
     // generic only
@@ -564,6 +565,11 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             bool split = (uint64_t)n_items < 4ull * kNumSimd;
             if (h->force_split >= 0) split = h->force_split != 0;
             c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
+            // a wave alone on its SIMD is latency-bound: the v_cndmask select (one more VALU op, no EXEC round
+            // trip) is ~8 % faster there; with two resident waves the EXEC-masked select wins
+            const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
+            c.cnd_select = waves < 2ull * kNumSimd ? 1u : 0u;
+            if (const char *e = getenv("PHMM_FORCE_CND_SELECT")) c.cnd_select = atoi(e) ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {
             // generic: exclusive prefix of pairs per read, scratch for a bounded grid
@@ -686,6 +692,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.initial_condition = initial_condition();
         p.initial_condition_log10 = initial_condition_log10();
         p.lds_rows = c.lds_rows;
+        p.cnd_select = c.cnd_select;
         p.status = b->d_status;
         if (!p.n_items) continue;
         hipError_t e;

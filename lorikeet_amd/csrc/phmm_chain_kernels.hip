@@ -260,15 +260,15 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             aI = from_left<CL>(Ip[K - 1], false);
             aD = from_left_inject(Dp[K - 1], cA.pad1);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
-            // a read's SUM row reaches the last lane once per read: one wave-uniform test per two steps
-            const bool any_sum = (__ballot(cA.x == sum_code) | __ballot(cB.x == sum_code)) != 0ull;
-            if (any_sum) emit(cA);
+            // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
+            // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
+            if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
             cA = ring[(q + 2) & (RING - 1)];
             bM = from_left<CL>(Mp[K - 1], false);
             bI = from_left<CL>(Ip[K - 1], false);
             bD = from_left_inject(Dp[K - 1], cB.pad1);
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
-            if (any_sum) emit(cB);
+            if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
             q += 2;
         }
     }

@@ -7,6 +7,13 @@
 #include <type_traits>
 
 // K up to this value is compiled for two resident waves per SIMD (<= 256 VGPRs, no spills)
+#ifndef PHMM_SDWA_MIN_K
+#define PHMM_SDWA_MIN_K 21
+#endif
+// K up to this value also gets the v_cndmask body for launches that leave a wave alone on its SIMD
+#ifndef PHMM_CND_MAX_K
+#define PHMM_CND_MAX_K 13
+#endif
 #ifndef PHMM_TWO_WAVE_MAX_K
 #define PHMM_TWO_WAVE_MAX_K 25
 #endif
@@ -94,10 +101,12 @@ struct HapCols {
 //        (lM,lD) = left neighbour's last column, row i
 //   out: Mp/Ip/Dp = row i
 // FAST_EXEC: pre-scaled rows and a haplotype without 'N' (the common case), every lane of the wave active;
-// FAST_EXEC_PRED: the same under a predicate (`live` = the EXEC mask the caller runs under, wave-uniform).
+// FAST_EXEC_PRED: the same under a predicate (`live` = the EXEC mask the caller runs under, wave-uniform);
+// FAST_CND: the same arithmetic with a v_cndmask select, scheduled by the compiler -- one VALU op more per cell but
+// no EXEC round trip, which is faster when a wave has a SIMD to itself (small launches; compiled for small K only).
 // Otherwise the general form: `imx` multiplies the indel->match term (1.0 for pre-scaled rows) and the
 // compare honours the haplotype wildcard mask.
-enum : int { ROW_GENERAL = 0, ROW_FAST_EXEC = 2, ROW_FAST_EXEC_PRED = 3 };
+enum : int { ROW_GENERAL = 0, ROW_FAST_CND = 1, ROW_FAST_EXEC = 2, ROW_FAST_EXEC_PRED = 3 };
 
 template <int K, int MODE>
 __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], double (&Dp)[K], const double plM,
@@ -113,36 +122,51 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         //   EXEC &= (x != y_k);  M~(k) *= px;  EXEC = live                (matching cells keep the value)
         //   I^(k-1) = I^(k-1)*gI + M~(k-1)*bI                             (column k-1 moves on to row i)
         // Columns right-to-left, so every register is updated in place; I^(K-1) is updated up front.
+        // The accumulating FMAs are written in the VOP3 form on purpose: the 2-address VOP2 v_fmac_f64_e32 issues
+        // at ~60 % of the VOP3 rate on gfx950 (tools/ubench/banks.hip).
         const uint64_t restore = (MODE == ROW_FAST_EXEC) ? ~0ull : live;
         Ip[K - 1] = fma(Mp[K - 1], c.bI, Ip[K - 1] * c.gI);
         static_for_down<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const uint32_t y = hc.y[k >> 1];
-#define PHMM_CELL(SEL)                                                                                              \
+            // K > PHMM_SDWA_MIN_K: the haplotype base is compared straight out of its packed half-word (SDWA operand
+            // select) so that no unpacked copy per column lives in registers -- that is what lets K = 22..25 keep
+            // two waves per SIMD; smaller K can afford the copies and the plain compare issues a little faster.
+            constexpr bool packed = K > PHMM_SDWA_MIN_K;
+            const uint32_t y = packed ? hc.y[k >> 1] : (uint32_t)hc.base(k);
+#define PHMM_CELL(CMPX, RESTORE)                                                                                             \
     asm volatile("v_fma_f64 %[M], %[Dl], %[dDp], %[Il]\n\t"                                                        \
-                 "v_fmac_f64_e32 %[M], %[Ml], %[mm]\n\t"                                                           \
-                 "v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:" SEL "\n\t"                          \
+                 "v_fma_f64 %[M], %[Ml], %[mm], %[M]\n\t"                                                          \
+                 CMPX "\n\t"                                                                                     \
                  "v_mul_f64 %[M], %[px], %[M]\n\t"                                                                 \
-                 "s_mov_b64 exec, %[live]\n\t"                                                                     \
+                 "s_mov_b64 exec, " RESTORE "\n\t"                                                                 \
                  "v_mul_f64 %[Il], %[Il], %[gI]\n\t"                                                               \
-                 "v_fmac_f64_e32 %[Il], %[Ml], %[bI]"                                                               \
+                 "v_fma_f64 %[Il], %[Ml], %[bI], %[Il]"                                                             \
                  : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1])                                                            \
                  : [Dl] "v"(Dp[km1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[km1]), [mm] "v"(c.mm), [x] "v"(c.x), [y] "v"(y), \
                    [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI), [live] "s"(restore)                               \
                  : "vcc")
             constexpr int km1 = k > 0 ? k - 1 : 0;
-            if constexpr (k > 0 && (k & 1)) {
-                PHMM_CELL("WORD_1");
+            constexpr bool pred = MODE == ROW_FAST_EXEC_PRED;
+            if constexpr (k > 0 && pred && packed && (k & 1)) {
+                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "%[live]");
+            } else if constexpr (k > 0 && pred && packed) {
+                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "%[live]");
+            } else if constexpr (k > 0 && pred) {
+                PHMM_CELL("v_cmpx_ne_u32_e32 vcc, %[x], %[y]", "%[live]");
+            } else if constexpr (k > 0 && packed && (k & 1)) {
+                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "-1");
+            } else if constexpr (k > 0 && packed) {
+                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "-1");
             } else if constexpr (k > 0) {
-                PHMM_CELL("WORD_0");
+                PHMM_CELL("v_cmpx_ne_u32_e32 vcc, %[x], %[y]", "-1");
 #undef PHMM_CELL
             } else {
                 double m = fma(plM, c.mm, fma(plD, c.dDp, plI));
-                asm volatile("v_cmpx_ne_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:WORD_0\n\t"
+                asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
                              "v_mul_f64 %0, %3, %0\n\t"
                              "s_mov_b64 exec, %4"
                              : "+v"(m)
-                             : "v"(c.x), "v"(y), "v"(c.px), "s"(restore)
+                             : "v"(c.x), "v"((uint32_t)hc.base(0)), "v"(c.px), "s"(restore)
                              : "vcc");
                 Mp[0] = m;
             }
@@ -170,7 +194,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
         if constexpr (MODE == ROW_GENERAL) t *= imx;
         const double a = fma(dM, c.mm, t);
         const uint16_t yb = hc.base(k);  // haplotype 'N' is a wildcard too (pair_hmm.rs:643)
-        const double prior = (x16 == yb || yb == (uint16_t)'N') ? c.pm : c.px;
+        const double prior = (x16 == yb || (MODE == ROW_GENERAL && yb == (uint16_t)'N')) ? c.pm : c.px;
         Mp[k] = prior * a;
     });
     // Pass 2, left-to-right: the serial chain D'(i,k) = M(i,k-1) + D'(i,k-1)*dd.
@@ -191,7 +215,7 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
 
 // Fast sweep: two steps per trip with the roles of the (constants, left-column) register sets swapped,
 // so nothing is copied between steps.  Returns this lane's partial of sum_j M[R][j]+I[R][j].
-template <int L, int K>
+template <int L, int K, int STEADY = ROW_FAST_EXEC>
 __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, const int l, const bool group_head,
                                              const HapCols<K> &hc, const int H, const double c0, const double fin) {
     double Mp[K], Ip[K], Dp[K];
@@ -210,12 +234,12 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         aM = from_left<L>(Mp[K - 1], group_head);
         aI = from_left<L>(Ip[K - 1], group_head);
         aD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
         cA = lds.load(max(row + 3, 0));
         bM = from_left<L>(Mp[K - 1], group_head);
         bI = from_left<L>(Ip[K - 1], group_head);
         bD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
         row += 2;
     }
     RowConst cur = cA;
@@ -225,7 +249,7 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lM = from_left<L>(Mp[K - 1], group_head);
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
-        row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
+        row_update<K, STEADY>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0);
         plM = lM;
         plI = lI;
         plD = lD;
@@ -238,7 +262,9 @@ __device__ __forceinline__ double sweep_fast(const LdsView &lds, const int R, co
         const double lI = from_left<L>(Ip[K - 1], group_head);
         const double lD = from_left<L>(Dp[K - 1], group_head);
         const uint64_t live = __ballot(row < R);
-        if (row < R) row_update<K, ROW_FAST_EXEC_PRED>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur, hc, 1.0, live);
+        if (row < R)
+            row_update<K, STEADY == ROW_FAST_CND ? ROW_FAST_CND : ROW_FAST_EXEC_PRED>(Mp, Ip, Dp, plM, plI, plD, lM, lD, cur,
+                                                                                     hc, 1.0, live);
         plM = lM;
         plI = lI;
         plD = lD;

@@ -35,6 +35,7 @@ struct ForwardParams {
     double initial_condition;        // 2^1020
     double initial_condition_log10;  // log10(2^1020), host libm
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
+    uint32_t cnd_select;             // 1: v_cndmask prior select (launches with < 2 waves per SIMD, K <= PHMM_CND_MAX_K)
     uint32_t *status;                // device status word (bit0: positive result)
 };
 

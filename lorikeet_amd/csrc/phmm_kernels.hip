@@ -78,10 +78,16 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
         }
         const double c0 = p.initial_condition / (double)H * scale0;
         double s;
-        if (scaled && __ballot(lane_n) == 0ull)
-            s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
-        else  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0
+        if (scaled && __ballot(lane_n) == 0ull) {
+            if constexpr (K <= PHMM_CND_MAX_K) {
+                s = p.cnd_select ? sweep_fast<L, K, ROW_FAST_CND>(lds, R, l, group_head, hc, H, c0, fin)
+                                 : sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
+            } else {
+                s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
+            }
+        } else {  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0 / base quality 0
             s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled, fin);
+        }
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
