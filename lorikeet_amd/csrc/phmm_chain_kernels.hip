@@ -228,10 +228,14 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         {
             if (last_lane && c.x == X_PAD && hv) {
                 const uint32_t r = rb + c.pad0;
+                // the column is a per-lane value: a K-way select.  `ek` is made opaque so that the K compare masks are
+                // built here, once per read, instead of living in 2*K SGPRs across the sweep loop
+                int ek = edge_k;
+                asm volatile("" : "+v"(ek));
                 double sum = 0.0;
 #pragma unroll
                 for (int k = 0; k < K; ++k)
-                    if (k == edge_k) sum = (Dp[k] + Mp[k]) + Ip[k];
+                    if (k == ek) sum = (Dp[k] + Mp[k]) + Ip[k];
                 const double v = log10(sum) - log10_scale;
                 p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
                 if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
