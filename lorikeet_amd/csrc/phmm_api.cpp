@@ -155,10 +155,11 @@ int waves_per_simd(int K) { return K <= 25 ? 2 : 1; }
 // issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~11 of 7*K+11 VALU ops per
 // step) x the issue rate one resident wave reaches alone (a wave issues a VALU op every ~6 clk, two waves
 // together one every ~4.7: tools/ubench/issue.hip; measured 0.81 on <16,25>).
-double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h) {
+double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h, bool chained) {
     const int G = WAVE / L;
     const double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
-    const double ramp = (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
+    // fill / drain steps of the lane pipeline: per read, or (chained kernel) amortised over a run of reads
+    const double ramp = chained ? 1.0 : (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
     const double col_fill = (double)max_h / (double)(L * K);
     const double step = 7.0 * K / (7.0 * K + 11.0);
     const double occ = waves_per_simd(K) >= 2 ? 1.0 : 0.84;
@@ -343,7 +344,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
                             align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
                             align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes +
-                            (size_t)n_reads * 16 /* chain items: at most one per two (read, haplotype group) sweeps */;
+                            (size_t)n_reads * 64 /* chain items (16 B): up to four per read fit; more spill to hipMalloc (dalloc) */;
         Arena &A = h->A();
         if (A.cap < need) {
             (void)hipStreamSynchronize(h->S());
@@ -424,6 +425,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     // Candidates L in {16,32,64}; K = ceil(max_h / L) rounded up to an instantiated value.
     // Pick the most efficient one, then trade lanes-per-pair for more waves while the batch is
     // too small to fill the chip.
+    // The chained kernel holds a 19 KB LDS ring per wave (two waves per SIMD): a win wherever the per-read kernel
+    // runs two waves per SIMD anyway, a loss against the three or four waves small K gets at 32 / 64 lanes per
+    // pair (measured: <32,10> 3150 per-read vs 2860 chained; <32,13> 3030 vs 3450; <32,19> 3220 vs 3470).
+    const bool chain_forced = getenv("PHMM_FORCE_CHAIN") != nullptr;  // tests: every chainable shape chains
+    auto chain_shape_ok = [&](int L, int k, const RegionShape &s) {
+        return k > 0 && k <= chain_max_k() && (L == 16 || k >= 13 || chain_forced) && s.min_r >= 1 && s.min_h >= 1;
+    };
+    bool assume_chain = false;  // second planning pass: the batch is large enough for the chained kernel
     auto pick = [&](const RegionShape &s, int min_L, int &L_out, int &K_out) {
         double best = -1.0;
         L_out = 0;
@@ -433,7 +442,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             if (h->force_L && L != h->force_L) continue;
             const int k = round_up_k((int)((std::max<uint32_t>(s.max_h, 1) + L - 1) / L));
             if (!k) continue;
-            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h);
+            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h, assume_chain && chain_shape_ok(L, k, s));
             if (e > best) {
                 best = e;
                 L_out = L;
@@ -443,6 +452,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     };
     std::vector<int> reg_L(n_regions), reg_K(n_regions);
     int min_L = 16;
+    auto plan_shapes = [&]() {
+    min_L = 16;
     for (;;) {
         uint64_t waves = 0;
         for (uint32_t g = 0; g < n_regions; ++g) {
@@ -457,26 +468,46 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (waves >= 2ull * kNumSimd || min_L == 64 || h->force_L) break;
         min_L *= 2;
     }
+    };
+    plan_shapes();
 
     // Chained kernel (phmm_chain_kernels.hip): reads of a region stream back to back through the lane
     // pipeline, which removes the per-read fill/drain steps.  Worth it (and balanced) only when there is
     // enough work to give every wave a run of reads: decide per batch, qualify per region.
-    uint64_t units16 = 0;  // (read, haplotype group) sweeps of the regions that run with 16 lanes per pair
-    for (uint32_t g = 0; g < n_regions; ++g)
-        if (reg_L[g] == 16) units16 += (uint64_t)shape[g].nr * ((shape[g].nh + 3) / 4);
-    uint32_t chain_reads = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, units16 / (8ull * 2 * kNumSimd));
+    auto count_units = [&]() {  // (read, haplotype group) sweeps of the batch under the chosen shapes
+        uint64_t u = 0;
+        for (uint32_t g = 0; g < n_regions; ++g)
+            if (reg_L[g] > 0) u += (uint64_t)shape[g].nr * ((shape[g].nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
+        return u;
+    };
+    uint64_t units = count_units();
+    auto runs_for = [&](uint64_t u) { return (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, u / (8ull * 2 * kNumSimd)); };
+    uint32_t chain_reads = runs_for(units);
     if (const char *e = getenv("PHMM_FORCE_CHAIN")) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, std::max(0, atoi(e)));
-    auto chain_k = [&](const RegionShape &s) { return round_up_k((int)((s.max_h + 15) / 16)); };
+    if (chain_reads >= 2 && !h->force_L) {
+        // chained sweeps pay no per-read fill/drain: choose the shapes again without that term (more lanes per pair
+        // become attractive for regions with few haplotypes), and keep the result if the batch still chains
+        std::vector<int> L0 = reg_L, K0 = reg_K;
+        assume_chain = true;
+        plan_shapes();
+        const uint32_t cr = getenv("PHMM_FORCE_CHAIN") ? chain_reads : runs_for(count_units());
+        if (cr >= 2 && min_L == 16) {
+            chain_reads = cr;
+            units = count_units();
+        } else {
+            reg_L = L0;
+            reg_K = K0;
+        }
+        assume_chain = false;
+    }
     auto chainable = [&](uint32_t g) {
         const RegionShape &s = shape[g];
-        const int k = chain_k(s);
-        return chain_reads >= 2 && reg_L[g] == 16 && k > 0 && k <= chain_max_k() && s.min_r >= 1 && s.min_h >= 1 &&
-               (int)s.max_r <= chain_max_read_rows();
+        return chain_reads >= 2 && reg_L[g] > 0 && chain_shape_ok(reg_L[g], reg_K[g], s);
     };
 
     if (getenv("PHMM_TRACE"))
-        fprintf(stderr, "phmm plan: %u regions, min_L %d, units16 %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
-                min_L, (unsigned long long)units16, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
+        fprintf(stderr, "phmm plan: %u regions, min_L %d, units %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
+                min_L, (unsigned long long)units, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
                 n_regions ? (int)chainable(0) : 0);
     std::map<std::tuple<int, int, int>, ShapeClass> by_shape;
     for (uint32_t g = 0; g < n_regions; ++g) {
@@ -487,7 +518,6 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         const size_t rows = align_up((size_t)s.max_r + 1, 8);
         if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
         const bool chain = L && chainable(g);
-        if (chain) K = chain_k(s);
         ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? 1 : 0)];
         c.L = L;
         c.K = K;
@@ -536,7 +566,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (c.chain) {
             for (uint32_t g : c.regions) {
                 const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1];
-                const uint32_t nq = (shape[g].nh + 3) / 4;
+                const uint32_t nq = (shape[g].nh + WAVE / c.L - 1) / (WAVE / c.L);
                 for (uint32_t q = 0; q < nq; ++q)
                     for (uint32_t r = r0; r < r1; r += chain_reads)
                         c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + chain_reads)});
@@ -549,7 +579,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             void *mirror;
             c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
             up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
-            snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d>", c.K);
+            snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d>", c.L, c.K);
         } else if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
             const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
@@ -701,7 +731,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             cp.f = p;
             cp.items = c.d_chain_items;
             cp.n_items = (uint32_t)c.chain_items.size();
-            e = launch_chain(c.K, cp, stream);
+            e = launch_chain(c.L, c.K, cp, stream);
         } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
         } else {

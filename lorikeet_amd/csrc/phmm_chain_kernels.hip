@@ -1,6 +1,7 @@
-// gfx950 chained forward kernel: the same register-resident sweep as phmm_forward<16,K>, but a wave keeps
-// its four haplotypes and streams MANY reads through them back to back, so the 15-step fill / 15-step
-// drain of the lane pipeline is paid once per chain instead of once per read.
+// gfx950 chained forward kernel: the same register-resident sweep as phmm_forward<L,K>, but a wave keeps
+// its 64/L haplotypes and streams MANY reads through them back to back, so the (L-1)-step fill / drain of the
+// lane pipeline is paid once per chain instead of once per read.  Compiled once per lanes-per-pair value
+// (-DPHMM_CHAIN_L=16|32|64), like phmm_kernels.hip.
 //
 // The reads of a chain form one stream of rows in an LDS ring:
 //     [rows of read 0][SUM][RESET][rows of read 1][SUM][RESET] ...
@@ -29,16 +30,26 @@ namespace phmm {
 
 namespace {
 
-constexpr int CL = 16;               // lanes per pair
+#ifndef PHMM_CHAIN_L
+#define PHMM_CHAIN_L 16
+#endif
+constexpr int CL = PHMM_CHAIN_L;     // lanes per pair
 constexpr int RING = 256;            // ring rows (power of two); slot RING holds the neutral row
 constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
 constexpr int LEAD = CL - 1;          // neutral rows in front of the stream (lane l starts LEAD - l rows early)
 
-// Left neighbour's value; the group's first lane (no neighbour inside its row of 16) receives `inject`.
-__device__ __forceinline__ double from_left_inject(double v, double inject) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(inject), __double2loint(v), 0x111, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(inject), __double2hiint(v), 0x111, 0xf, 0xf, false);
+// Left neighbour's value; the group's first lane (no neighbour inside its group) receives `inject`: through the
+// DPP `old` operand where the shift has no source lane (row_shr:1 for 16-lane groups, wave_shr:1 for lane 0),
+// through a select for lane 32 of two 32-lane groups.
+__device__ __forceinline__ double from_left_inject(double v, double inject, bool group_head) {
+    constexpr int ctrl = CL == 16 ? 0x111 : 0x138;
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(inject), __double2loint(v), ctrl, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(inject), __double2hiint(v), ctrl, 0xf, 0xf, false);
+    if constexpr (CL == 32) {
+        lo = group_head ? __double2loint(inject) : lo;
+        hi = group_head ? __double2hiint(inject) : hi;
+    }
     return __hiloint2double(hi, lo);
 }
 
@@ -63,8 +74,9 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
         const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
         const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;
         const double c0 = p.initial_condition / (double)H * scale0;
-        double s = staged ? sweep_general<CL, K>(LdsView{ring}, R, l, false, hc, H, c0, scaled, fin)
-                          : sweep_general<CL, K>(GlobalRowView{p, ro, R, scaled}, R, l, false, hc, H, c0, scaled, fin);
+        const bool group_head = (CL == 32) && (lane == 32);
+        double s = staged ? sweep_general<CL, K>(LdsView{ring}, R, l, group_head, hc, H, c0, scaled, fin)
+                          : sweep_general<CL, K>(GlobalRowView{p, ro, R, scaled}, R, l, group_head, hc, H, c0, scaled, fin);
 #pragma unroll
         for (int off = CL / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
@@ -78,12 +90,14 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
 
 }  // namespace
 
-template <int K>
+template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the three units' kernel symbols apart)
 __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams cp) {
+    static_assert(CLT == CL, "one lanes-per-pair value per compilation unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ForwardParams &p = cp.f;
     const int lane = threadIdx.x;
     const int grp = lane / CL, l = lane % CL;
+    const bool group_head = (CL == 32) && (lane == 32);
     const ChainItem it = cp.items[blockIdx.x];
     const uint32_t reg = it.region;
     const int n_chain = (int)(it.read_end - it.read_begin);
@@ -260,17 +274,17 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         }
         for (int t = t0; t < t1; t += 2) {
             cB = ring[(q + 1) & (RING - 1)];
-            aM = from_left<CL>(Mp[K - 1], false);
-            aI = from_left<CL>(Ip[K - 1], false);
-            aD = from_left_inject(Dp[K - 1], cA.pad1);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
+            aM = from_left<CL>(Mp[K - 1], group_head);
+            aI = from_left<CL>(Ip[K - 1], group_head);
+            aD = from_left_inject(Dp[K - 1], cA.pad1, group_head);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
             // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
             // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
             cA = ring[(q + 2) & (RING - 1)];
-            bM = from_left<CL>(Mp[K - 1], false);
-            bI = from_left<CL>(Ip[K - 1], false);
-            bD = from_left_inject(Dp[K - 1], cB.pad1);
+            bM = from_left<CL>(Mp[K - 1], group_head);
+            bI = from_left<CL>(Ip[K - 1], group_head);
+            bD = from_left_inject(Dp[K - 1], cB.pad1, group_head);
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
             if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
             q += 2;
@@ -283,20 +297,31 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
     X(23) X(24) X(25)
 
-size_t chain_lds_bytes() { return (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t); }
-int chain_max_k() { return 25; }
-int chain_max_read_rows() { return 1 << 20; }  // the stream has no length limit (the in-wave fallback neither)
+#define PHMM_CHAIN_CAT2(a, b) a##b
+#define PHMM_CHAIN_CAT(a, b) PHMM_CHAIN_CAT2(a, b)
+#define PHMM_CHAIN_LAUNCH PHMM_CHAIN_CAT(launch_chain_L, PHMM_CHAIN_L)
 
-hipError_t launch_chain(int K, const ChainParams &cp, hipStream_t stream) {
-    if (!cp.n_items) return hipSuccess;
-#define PHMM_CASE(KK)                                                                                     \
-    if (K == KK) {                                                                                        \
-        hipLaunchKernelGGL(phmm_forward_chain<KK>, dim3(cp.n_items), dim3(WAVE), chain_lds_bytes(), stream, cp); \
-        return hipGetLastError();                                                                         \
+hipError_t PHMM_CHAIN_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
+    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t);
+#define PHMM_CASE(KK)                                                                                  \
+    if (K == KK) {                                                                                     \
+        hipLaunchKernelGGL((phmm_forward_chain<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \
+        return hipGetLastError();                                                                      \
     }
     PHMM_CHAIN_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
     return hipErrorInvalidValue;
 }
+
+#if PHMM_CHAIN_L == 16
+hipError_t launch_chain_L32(int K, const ChainParams &cp, hipStream_t stream);
+hipError_t launch_chain_L64(int K, const ChainParams &cp, hipStream_t stream);
+int chain_max_k() { return 25; }
+hipError_t launch_chain(int L, int K, const ChainParams &cp, hipStream_t stream) {
+    if (!cp.n_items) return hipSuccess;
+    return L == 16 ? launch_chain_L16(K, cp, stream) : L == 32 ? launch_chain_L32(K, cp, stream)
+         : L == 64 ? launch_chain_L64(K, cp, stream) : hipErrorInvalidValue;
+}
+#endif
 
 }  // namespace phmm

@@ -56,7 +56,7 @@ hipError_t launch_generic(const GenericParams &p, hipStream_t stream);
 // ---- chained forward kernel (phmm_chain_kernels.hip) ------------------------------------------------
 constexpr int CHAIN_MAX_READS = 64;  // reads per chain (one lane per read when the stream offsets are scanned)
 struct ChainItem {
-    uint32_t region, quad;          // region index, haplotype group (4 haplotypes) inside it
+    uint32_t region, quad;          // region index, haplotype group (64/L haplotypes) inside it
     uint32_t read_begin, read_end;  // global read indices [begin, end), all of that region
 };
 struct ChainParams {
@@ -64,10 +64,8 @@ struct ChainParams {
     const ChainItem *items;
     uint32_t n_items;
 };
-hipError_t launch_chain(int K, const ChainParams &p, hipStream_t stream);
-size_t chain_lds_bytes();
-int chain_max_k();          // largest instantiated K
-int chain_max_read_rows();  // longest read a chained region may contain
+hipError_t launch_chain(int L, int K, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
+int chain_max_k();  // largest instantiated K
 
 // ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------
 struct PrepParams {

@@ -382,7 +382,7 @@ def test_concurrent_host_threads_one_handle_each():
 
 
 # ---------------------------------------------------------------------------------------------
-# chained kernel (phmm_forward_chain<K>): reads of a region stream back to back through the lanes
+# chained kernel (phmm_forward_chain<L,K>): reads of a region stream back to back through the lanes
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture()
 def force_chain():
@@ -391,13 +391,14 @@ def force_chain():
     os.environ.pop("PHMM_FORCE_CHAIN", None)
 
 
-def test_chained_kernel_matches_oracle(engines, force_chain, kat_rows):
-    hip_engine = engines[16]  # chaining applies to the 16-lanes-per-pair shape (small batches would pick 64)
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_chained_kernel_matches_oracle(engines, force_chain, kat_rows, lanes):
+    hip_engine = engines[lanes]  # forced lanes per pair (the planner would give these small batches 64)
     rng = np.random.default_rng(77)
     regions = [_random_region(rng, int(rng.integers(1, 14)), int(rng.integers(1, 10)), (1, 140), (1, 300)) for _ in range(30)]
     b = RegionBatch.from_regions(regions)
     plan = hip_engine.plan(b)
-    assert plan.dominant_kernel.startswith("phmm_forward_chain<")
+    assert plan.dominant_kernel.startswith("phmm_forward_chain<%d," % lanes)
     plan.close()
     _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
     # the reference's known-answer vectors, all in ONE region per haplotype so that reads really chain
@@ -414,8 +415,9 @@ def test_chained_kernel_matches_oracle(engines, force_chain, kat_rows):
     _close(hip_engine.compute(c3), oracle.compute_batch(c3.as_dict(), n_threads=8))
 
 
-def test_chained_kernel_falls_back_exactly(engines, force_chain):
-    hip_engine = engines[16]
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_chained_kernel_falls_back_exactly(engines, force_chain, lanes):
+    hip_engine = engines[lanes]
     """Haplotypes with 'N' and reads with gcp == 0 cannot use the chained fast path: same wave, plain sweep."""
     rng = np.random.default_rng(78)
     regions = [_random_region(rng, 7, 4, (5, 90), (30, 200), alphabet=b"ACGTN"),  # N in haplotypes (and reads)
@@ -429,10 +431,11 @@ def test_chained_kernel_falls_back_exactly(engines, force_chain):
     _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=4))
 
 
-def test_chained_kernel_long_reads(engines, force_chain):
+@pytest.mark.parametrize("lanes", [16, 32])
+def test_chained_kernel_long_reads(engines, force_chain, lanes):
     """Reads longer than the 256-row LDS ring stream through it; with an 'N' haplotype, a gcp == 0 or a base
     quality 0 in the chain, the in-wave general path builds the rows of such reads on the fly."""
-    hip_engine = engines[16]
+    hip_engine = engines[lanes]
     rng = np.random.default_rng(79)
     regions = [_random_region(rng, 6, 3, (230, 700), (40, 250), qmin=1),                      # streamed
                _random_region(rng, 5, 2, (230, 700), (40, 250), alphabet=b"ACGTN", qmin=1),   # general path, unstaged

@@ -27,6 +27,7 @@ cfgs = {"config2x1024": lambda: synthetic.config2(1024, seed=1),
         "R100_H300x1024": lambda: synthetic.make_regions(1024, 128, 8, 300, 100, 5),
         "R250_H300x512": lambda: synthetic.make_regions(512, 128, 8, 300, 250, 6),
         "Nh2_R150_H300x2048": lambda: synthetic.make_regions(2048, 128, 2, 300, 150, 7),
+        "R150_H600x512": lambda: synthetic.make_regions(512, 64, 8, 600, 150, 9),
         "ragged_small": lambda: synthetic.make_regions(4096, 12, 3, 220, [80, 120, 151], 8)}
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
 chain_mode = "--chain" in sys.argv  # compare planner default / chained kernel off / forced on instead of forcing L
