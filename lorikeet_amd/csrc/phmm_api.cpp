@@ -56,6 +56,7 @@ struct ShapeClass {
     std::vector<ChainItem> chain_items;
     ChainItem *d_chain_items = nullptr;
     uint32_t cnd_select = 0;
+    int streams = 1;  // chained classes: sub-runs swept side by side (phmm_chain_kernels.hip)
     // device
     uint32_t *d_reads = nullptr;
     // generic only
@@ -155,9 +156,29 @@ int waves_per_simd(int K) { return K <= 25 ? 2 : 1; }
 // issued lane-steps x the per-step overhead (DPP shifts, LDS fetch, loop: ~11 of 7*K+11 VALU ops per
 // step) x the issue rate one resident wave reaches alone (a wave issues a VALU op every ~6 clk, two waves
 // together one every ~4.7: tools/ubench/issue.hip; measured 0.81 on <16,25>).
+// Chained kernel at 16 lanes per pair: the four haplotype slots of a wave can be shared by S = 1, 2 or 4 streams of
+// reads (phmm_chain_kernels.hip), so any haplotype count fills them.  Every extra stream costs row-producer work
+// (rows are built per stream, in shorter ticks): measured 3990 / 3700 / 3300 GCUPS at 1 / 2 / 4 streams with all
+// slots busy, i.e. ~6 % per extra stream.  Returns S, and the slot fill (times that factor) it achieves.
+int chain_streams(uint32_t nh, double *fill_out) {
+    int best_s = 1;
+    double best = 0.0;
+    for (int S : {1, 2, 4}) {
+        const uint32_t gs = 4 / S;
+        const double fill = (double)nh / (double)(((nh + gs - 1) / gs) * gs) * (1.0 - 0.06 * (S - 1));
+        if (fill > best + 1e-9) {
+            best = fill;
+            best_s = S;
+        }
+    }
+    if (fill_out) *fill_out = best;
+    return best_s;
+}
+
 double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max_h, bool chained) {
     const int G = WAVE / L;
-    const double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
+    double hap_fill = (double)nh / (double)(((nh + G - 1) / G) * G);
+    if (chained && L == 16) (void)chain_streams(nh, &hap_fill);
     // fill / drain steps of the lane pipeline: per read, or (chained kernel) amortised over a run of reads
     const double ramp = chained ? 1.0 : (double)std::max<uint32_t>(mean_r, 1) / (double)(std::max<uint32_t>(mean_r, 1) + L - 1);
     const double col_fill = (double)max_h / (double)(L * K);
@@ -474,10 +495,20 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     // Chained kernel (phmm_chain_kernels.hip): reads of a region stream back to back through the lane
     // pipeline, which removes the per-read fill/drain steps.  Worth it (and balanced) only when there is
     // enough work to give every wave a run of reads: decide per batch, qualify per region.
-    auto count_units = [&]() {  // (read, haplotype group) sweeps of the batch under the chosen shapes
+    int force_streams = 0;  // tests: PHMM_FORCE_STREAMS = 1 | 2 | 4
+    if (const char *e = getenv("PHMM_FORCE_STREAMS")) force_streams = atoi(e);
+    auto streams_of = [&](uint32_t g) {
+        if (reg_L[g] != 16) return 1;
+        if (force_streams == 1 || force_streams == 2 || force_streams == 4) return force_streams;
+        return chain_streams(shape[g].nh, nullptr);
+    };
+    auto count_units = [&]() {  // wave-sweeps (one read against one wave-load of haplotypes) under the chosen shapes
         uint64_t u = 0;
         for (uint32_t g = 0; g < n_regions; ++g)
-            if (reg_L[g] > 0) u += (uint64_t)shape[g].nr * ((shape[g].nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
+            if (reg_L[g] > 0) {
+                const uint32_t S = (uint32_t)streams_of(g), gs = (uint32_t)(WAVE / reg_L[g]) / S;
+                u += (uint64_t)shape[g].nr * ((shape[g].nh + gs - 1) / gs) / S;
+            }
         return u;
     };
     uint64_t units = count_units();
@@ -509,7 +540,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         fprintf(stderr, "phmm plan: %u regions, min_L %d, units %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
                 min_L, (unsigned long long)units, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
                 n_regions ? (int)chainable(0) : 0);
-    std::map<std::tuple<int, int, int>, ShapeClass> by_shape;
+    std::map<std::tuple<int, int, int>, ShapeClass> by_shape;  // (L, K, 0 = per-read kernel | streams of the chained kernel)
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (reg_L[g] < 0) continue;
         const RegionShape &s = shape[g];
@@ -518,10 +549,12 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         const size_t rows = align_up((size_t)s.max_r + 1, 8);
         if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
         const bool chain = L && chainable(g);
-        ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? 1 : 0)];
+        const int streams = chain ? streams_of(g) : 1;
+        ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? streams : 0)];
         c.L = L;
         c.K = K;
         c.chain = chain;
+        c.streams = streams;
         if (chain) c.regions.push_back(g);
         for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.reads.push_back(r);
         c.max_r = std::max(c.max_r, s.max_r);
@@ -566,10 +599,12 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         if (c.chain) {
             for (uint32_t g : c.regions) {
                 const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1];
-                const uint32_t nq = (shape[g].nh + WAVE / c.L - 1) / (WAVE / c.L);
+                const uint32_t gs = (uint32_t)(WAVE / c.L) / (uint32_t)c.streams;  // haplotypes per work item
+                const uint32_t nq = (shape[g].nh + gs - 1) / gs;
+                const uint32_t run = std::min<uint32_t>(CHAIN_MAX_READS, chain_reads * (uint32_t)c.streams);
                 for (uint32_t q = 0; q < nq; ++q)
-                    for (uint32_t r = r0; r < r1; r += chain_reads)
-                        c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + chain_reads)});
+                    for (uint32_t r = r0; r < r1; r += run)
+                        c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + run)});
             }
             // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
             // be filled by the short ones (stable, so equal-length batches keep their order)
@@ -579,7 +614,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             void *mirror;
             c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
             up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
-            snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d>", c.L, c.K);
+            if (c.streams > 1)
+                snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d> x%d streams", c.L, c.K, c.streams);
+            else
+                snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d>", c.L, c.K);
         } else if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
             const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
@@ -731,6 +769,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             cp.f = p;
             cp.items = c.d_chain_items;
             cp.n_items = (uint32_t)c.chain_items.size();
+            cp.streams = (uint32_t)c.streams;
             e = launch_chain(c.L, c.K, cp, stream);
         } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);

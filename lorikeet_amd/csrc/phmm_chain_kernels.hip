@@ -22,8 +22,14 @@
 // the chained kernel starts all haplotypes from the same 2^1010 (which lets the RESET row carry the injected
 // value itself) and subtracts log10(H) at the end; the difference to dividing first is one rounding.
 //
-// Chains with a haplotype containing 'N' or a read with gcp == 0 fall back, inside the same wave, to the
-// plain per-read sweep (sweep_general): rare, kept for exactness.
+// Streams.  With 16 lanes per pair a wave has four haplotype slots; a region with 1, 2, 3, 5, ... haplotypes would
+// leave slots idle.  So the run of reads of a work item can be split into S = 1, 2 or 4 sub-runs ("streams") that are
+// swept side by side: stream s owns 4/S slots (the same haplotypes as the other streams, its own reads), its own
+// quarter/half of the ring (RING/S rows), and the producer makes 64/S rows per stream and tick (a tick is then 64/S
+// steps), so everything scales and the sweep loop itself is unchanged.
+//
+// Chains with a haplotype containing 'N' or a read with gcp == 0 / base quality 0 fall back, inside the same wave,
+// to the plain per-read sweep (sweep_general): rare, kept for exactness.
 #include "phmm_device.hpp"
 
 namespace phmm {
@@ -34,7 +40,8 @@ namespace {
 #define PHMM_CHAIN_L 16
 #endif
 constexpr int CL = PHMM_CHAIN_L;     // lanes per pair
-constexpr int RING = 256;            // ring rows (power of two); slot RING holds the neutral row
+constexpr int RING = 256;            // ring rows (power of two), shared by the streams; slot RING holds the neutral row
+constexpr int CHAIN_META = CHAIN_MAX_READS + 8;  // per-read offsets of all streams: n_chain + S entries
 constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
 constexpr int LEAD = CL - 1;          // neutral rows in front of the stream (lane l starts LEAD - l rows early)
@@ -88,6 +95,35 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
     (void)grp;
 }
 
+// The same for a work item split into streams: every 16-lane group walks the reads of ITS stream, rows built on the
+// fly from HBM (no staging: the groups of a wave are at different reads).  Slow and rare.
+template <int K>
+__device__ __forceinline__ void chain_fallback_streams(const ForwardParams &p, uint32_t reg, uint32_t r_begin, int n_mine,
+                                                       int n_iter, int lane, int l, const HapCols<K> &hc, int H, bool hv,
+                                                       int a, int Nh) {
+    const uint64_t group_bits = 0xffffull << (lane & ~15);
+    for (int i = 0; i < n_iter; ++i) {  // wave-uniform trip count; groups past their last read idle
+        const bool valid = i < n_mine;
+        const uint32_t r = r_begin + (uint32_t)i;
+        const uint32_t ro = valid ? p.read_off[r] : 0u;
+        const int R = valid ? (int)(p.read_off[r + 1] - ro) : 0;
+        bool z = false;
+        for (int row = l; row < R; row += 16) z |= row_blocks_prescale(p, ro + row);
+        const bool scaled = (__ballot(z) & group_bits) == 0ull;
+        const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
+        const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;
+        const double c0 = p.initial_condition / (double)H * scale0;
+        double s = sweep_general<16, K>(GlobalRowView{p, ro, R, scaled}, R, l, false, hc, H, c0, scaled, fin);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (l == 0 && hv && valid) {
+            const double v = log10(s) - p.initial_condition_log10;
+            p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
+            if (!(v <= 0.0)) atomicOr(p.status, 1u);
+        }
+    }
+}
+
 }  // namespace
 
 template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the three units' kernel symbols apart)
@@ -103,8 +139,17 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
-    const int a = (int)it.quad * (WAVE / CL) + grp;
+    // streams (see the header): S sub-runs of reads side by side, each on G/S haplotype slots
+    const int S = (CL == 16) ? (int)cp.streams : 1;
+    const int GS = (WAVE / CL) / S;             // haplotype slots per stream
+    const int sid = grp / GS;                   // stream of this lane's group
+    const int a = (int)it.quad * GS + grp % GS;
     const bool hv = a < Nh;
+    const int n_sub = (n_chain + S - 1) / S;    // reads per stream (the last streams may get fewer, or none)
+    const int TPS = WAVE / S;                   // rows produced per stream and tick == steps per tick
+    const int NM = RING / S - 1;                // ring rows per stream - 1 (mask)
+    auto n_of = [&](int s) { return max(0, min(n_sub, n_chain - s * n_sub)); };
+    const int n_mine = n_of(sid);
     uint32_t ho = 0;
     int H = 0;
     if (hv) {
@@ -112,8 +157,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
     RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING + 1 records
-    uint32_t *cum = reinterpret_cast<uint32_t *>(ring + RING + 1);  // [n_chain + 1] stream offset of each read
-    uint32_t *roff = cum + (CHAIN_MAX_READS + 1);                   // [n_chain + 1] byte offset of each read
+    uint32_t *cum = reinterpret_cast<uint32_t *>(ring + RING + 1);  // per stream s at s*(n_sub+1): row offset of each read
+    uint32_t *roff = cum + CHAIN_META;                              // same layout: byte offset of each read
 
     // ---- haplotype columns: real bases, one EDGE column, then padding -------------------------------
     HapCols<K> hc;
@@ -136,10 +181,14 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     bool z = false;
     for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
-        chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
+        if (S == 1)
+            chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
+        else if constexpr (CL == 16)
+            chain_fallback_streams<K>(p, reg, rb + (uint32_t)(sid * n_sub), n_mine, n_sub, lane, l, hc, H, hv, a, Nh);
         return;
     }
-    {
+    {   // lane j describes read j of the run: its stream sj and index ij there; offsets by a wave scan
+        const int sj = lane / n_sub, ij = lane % n_sub;
         uint32_t len = lane < n_chain ? p.read_off[rb + lane + 1] - p.read_off[rb + lane] + 2u : 0u;  // + SUM + RESET
         uint32_t incl = len;
 #pragma unroll
@@ -147,13 +196,19 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             const uint32_t v = __shfl_up(incl, off, WAVE);
             if (lane >= off) incl += v;
         }
-        if (lane == 0) cum[0] = 0u;
-        if (lane < n_chain) cum[lane + 1] = incl;
-        if (lane <= n_chain) roff[lane] = p.read_off[rb + lane];
+        const uint32_t before = __shfl(incl, max(sj * n_sub - 1, 0), WAVE);  // scan value just before my stream starts
+        const int cb = sj * (n_sub + 1);
+        if (lane < S) cum[lane * (n_sub + 1)] = 0u;
+        if (lane < n_chain) {
+            cum[cb + ij + 1] = incl - (sj > 0 ? before : 0u);
+            roff[cb + ij] = p.read_off[rb + lane];
+            if (ij + 1 == n_of(sj)) roff[cb + ij + 1] = p.read_off[rb + lane + 1];
+        }
         if (lane == 0) ring[RING] = neutral_row();
     }
     lds_wave_sync();
-    const int S_total = (int)cum[n_chain];
+    int S_max = 0;  // longest stream (rows)
+    for (int s = 0; s < S; ++s) S_max = max(S_max, (int)cum[s * (n_sub + 1) + n_of(s)]);
     const double c_unit = ldexp(1.0, 1010);  // common D(0,j) of every haplotype, see the header
 
     // ---- row producer: stream positions [P0, P0 + 64) -> ring ----------------------------------------
@@ -161,24 +216,28 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
     // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
     uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
-    auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the chain, row)
+    // producer side of this lane: row (lane % TPS) of stream (lane / TPS) of each tick
+    const int ps = lane / TPS, pj = lane % TPS;
+    const int pcb = ps * (n_sub + 1), pn = n_of(ps);
+    const int pS_total = (int)cum[pcb + pn];
+    auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the stream, row)
         const int P = Q - LEAD;
-        if (P < 0 || P >= S_total) return false;
+        if (P < 0 || P >= pS_total) return false;
         lo = 0;
-        int hi = n_chain;  // cum[lo] <= P < cum[hi]
+        int hi = pn;  // cum[lo] <= P < cum[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if ((int)cum[mid] <= P) lo = mid; else hi = mid;
+            if ((int)cum[pcb + mid] <= P) lo = mid; else hi = mid;
         }
-        ro = roff[lo];
-        R = (int)(roff[lo + 1] - ro);
-        row = P - (int)cum[lo];
+        ro = roff[pcb + lo];
+        R = (int)(roff[pcb + lo + 1] - ro);
+        row = P - (int)cum[pcb + lo];
         return true;
     };
     auto issue = [&](int Q0) {
         int lo, row, R;
         uint32_t ro;
-        if (locate(Q0 + lane, lo, row, R, ro) && row <= R) {
+        if (locate(Q0 + pj, lo, row, R, ro) && row <= R) {
             pb_qp = row > 0 ? (uint32_t)p.base_q[ro + row - 1] : 0u;  // row == R: the SUM row needs pm(R)
             if (row < R) {
                 pb_x = p.read_bases[ro + row];
@@ -191,8 +250,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             }
         }
     };
-    auto finish = [&](int Q0) {  // ring positions [Q0, Q0 + 64); stream position = ring position - LEAD
-        const int Q = Q0 + lane;
+    auto finish = [&](int Q0) {  // ring positions [Q0, Q0 + TPS) of every stream; stream position = ring position - LEAD
+        const int Q = Q0 + pj;
         int lo, row, R;
         uint32_t ro;
         RowConst n;
@@ -205,24 +264,25 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             } else {                // RESET row; pad1 = D'(0,.) of the next read = 2^1010 * im of its first row
                 n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
                 n.x = X_NONE; n.pad0 = 0;
-                n.pad1 = c_unit * (lo + 1 < n_chain ? 1.0 - p.eps[p.gcp[roff[lo + 1]]] : 1.0);
+                n.pad1 = c_unit * (lo + 1 < pn ? 1.0 - p.eps[p.gcp[roff[pcb + lo + 1]]] : 1.0);
             }
         } else {
             n = neutral_row();
         }
-        ring[Q & (RING - 1)] = n;
+        ring[ps * (NM + 1) + (Q & NM)] = n;
     };
     issue(0);
     finish(0);
-    issue(64);
-    finish(64);
-    issue(128);
-    finish(128);
+    issue(TPS);
+    finish(TPS);
+    issue(2 * TPS);
+    finish(2 * TPS);
     lds_wave_sync();
-    issue(192);
+    issue(3 * TPS);
 
     // ---- state ---------------------------------------------------------------------------------------
-    const double c0 = c_unit * (1.0 - p.eps[p.gcp[byte0]]);  // planner guarantees every read has >= 1 base
+    // planner guarantees every read has >= 1 base; a stream without reads only ever sees neutral rows
+    const double c0 = c_unit * (n_mine > 0 ? 1.0 - p.eps[p.gcp[roff[sid * (n_sub + 1)]]] : 1.0);
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -241,7 +301,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         // after the owning lane's SUM step, see above
         {
             if (last_lane && c.x == X_PAD && hv) {
-                const uint32_t r = rb + c.pad0;
+                const uint32_t r = rb + (uint32_t)(sid * n_sub) + c.pad0;
                 // the column is a per-lane value: a K-way select.  `ek` is made opaque so that the K compare masks are
                 // built here, once per read, instead of living in 2*K SGPRs across the sweep loop
                 int ek = edge_k;
@@ -259,21 +319,22 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 
     // lane l works on ring position q = t + LEAD - l  (stream position t - l); rows outside the stream are neutral
     int q = LEAD - l;
-    RowConst cA = ring[q & (RING - 1)], cB;
-    const int T = (S_total + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
-    // Outer loop = one producer tick (64 steps), inner loop = the sweep.  The producer's pending bytes are
-    // defined before the inner loop and first used after it, so their loads have 64 steps to land.
+    const RowConst *my_ring = ring + sid * (NM + 1);
+    RowConst cA = my_ring[q & NM], cB;
+    const int T = (S_max + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
+    // Outer loop = one producer tick (TPS steps), inner loop = the sweep.  The producer's pending bytes are
+    // defined before the inner loop and first used after it, so their loads have a tick to land.
     // The first tick is shortened by a per-block even phase (the ring only gets further ahead), so that the two
     // waves sharing a SIMD do not run their producers -- the one latency-exposed part -- at the same time.
-    const int phase = (int)((blockIdx.x * 2654435761u) >> 26) & 62;
-    for (int t0 = 0, t1 = min(T, 64 - phase), tick = 0; t0 < T; t0 = t1, t1 = min(T, t1 + 64), ++tick) {
-        if (tick >= 1) {  // keep the ring 64..128 (+ phase) rows ahead of the first lane
-            finish(64 * tick + 128);
+    const int phase = (int)((blockIdx.x * 2654435761u) >> 26) & (TPS - 2);
+    for (int t0 = 0, t1 = min(T, TPS - phase), tick = 0; t0 < T; t0 = t1, t1 = min(T, t1 + TPS), ++tick) {
+        if (tick >= 1) {  // keep the ring one to two ticks (+ phase) ahead of the first lane
+            finish(TPS * tick + 2 * TPS);
             lds_wave_sync();
-            issue(64 * tick + 192);
+            issue(TPS * tick + 3 * TPS);
         }
         for (int t = t0; t < t1; t += 2) {
-            cB = ring[(q + 1) & (RING - 1)];
+            cB = my_ring[(q + 1) & NM];
             aM = from_left<CL>(Mp[K - 1], group_head);
             aI = from_left<CL>(Ip[K - 1], group_head);
             aD = from_left_inject(Dp[K - 1], cA.pad1, group_head);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
@@ -281,7 +342,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
             // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
-            cA = ring[(q + 2) & (RING - 1)];
+            cA = my_ring[(q + 2) & NM];
             bM = from_left<CL>(Mp[K - 1], group_head);
             bI = from_left<CL>(Ip[K - 1], group_head);
             bD = from_left_inject(Dp[K - 1], cB.pad1, group_head);
@@ -302,7 +363,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 #define PHMM_CHAIN_LAUNCH PHMM_CHAIN_CAT(launch_chain_L, PHMM_CHAIN_L)
 
 hipError_t PHMM_CHAIN_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
-    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + 2 * (CHAIN_MAX_READS + 1) * sizeof(uint32_t);
+    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + 2 * CHAIN_META * sizeof(uint32_t);
 #define PHMM_CASE(KK)                                                                                  \
     if (K == KK) {                                                                                     \
         hipLaunchKernelGGL((phmm_forward_chain<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \

@@ -63,6 +63,8 @@ struct ChainParams {
     ForwardParams f;
     const ChainItem *items;
     uint32_t n_items;
+    uint32_t streams;  // 16 lanes per pair only: the run of reads is split into 1, 2 or 4 sub-runs swept side by side,
+                       // each on 4/streams haplotype slots (ChainItem::quad then counts groups of 4/streams haplotypes)
 };
 hipError_t launch_chain(int L, int K, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
 int chain_max_k();  // largest instantiated K

@@ -449,6 +449,52 @@ def test_chained_kernel_long_reads(engines, force_chain, lanes):
     _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
 
 
+@pytest.mark.parametrize("streams", [2, 4])
+def test_chained_kernel_streams(engines, force_chain, streams, kat_rows):
+    """16 lanes per pair: the run of reads is split into 2 or 4 streams swept side by side on 2 or 1 haplotype slots
+    each (what the planner does for regions whose haplotype count is not a multiple of four)."""
+    hip_engine = engines[16]
+    os.environ["PHMM_FORCE_STREAMS"] = str(streams)
+    try:
+        rng = np.random.default_rng(80 + streams)
+        # 1..9 haplotypes, 1..14 reads (fewer reads than streams, uneven sub-runs), reads beyond the per-stream ring
+        regions = [_random_region(rng, int(rng.integers(1, 15)), int(rng.integers(1, 10)), (1, 140), (1, 300), qmin=1)
+                   for _ in range(30)]
+        regions.append(_random_region(rng, 7, 3, (60, 400), (40, 250), qmin=1))
+        b = RegionBatch.from_regions(regions)
+        plan = hip_engine.plan(b)
+        assert plan.dominant_kernel.endswith("x%d streams" % streams), plan.dominant_kernel
+        plan.close()
+        _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
+        # the general path inside a split run: 'N' haplotypes, gcp == 0, base quality 0
+        regions = [_random_region(rng, 9, 3, (5, 90), (30, 200), alphabet=b"ACGTN"), _random_region(rng, 9, 2, (5, 90), (30, 200))]
+        b = RegionBatch.from_regions(regions)
+        _close(hip_engine.compute(b), oracle.compute_batch(b.as_dict(), n_threads=4))
+        # the reference's known-answer vectors, one region per haplotype (a single haplotype: 4 streams fill the wave)
+        by_hap = {}
+        for r in kat_rows:
+            by_hap.setdefault(r["hap"], []).append(r)
+        regs = [([Read(r["read"], r["qual"], r["ins"], r["dele"], r["gcp"]) for r in rows], [hap]) for hap, rows in by_hap.items()]
+        got = hip_engine.compute(RegionBatch.from_regions(regs))
+        exp = np.array([r["expected"] for rows in by_hap.values() for r in rows])
+        assert np.max(np.abs(got - exp)) < TOL_REFERENCE
+    finally:
+        os.environ.pop("PHMM_FORCE_STREAMS", None)
+
+
+def test_planner_fills_the_wave_for_any_haplotype_count(hip_engine):
+    """Large batches of regions with 1, 2, 3, 5 and 6 haplotypes: chained with 4, 2, 4, 4 and 2 streams."""
+    for nh, streams in ((1, 4), (2, 2), (3, 4), (5, 4), (6, 2), (8, 1)):
+        b = synthetic.make_regions(2400, 64, nh, 120, 60, seed=100 + nh)  # enough wave-sweeps for the batch to chain
+        plan = hip_engine.plan(b)
+        want = "x%d streams" % streams if streams > 1 else ">"
+        assert plan.dominant_kernel.startswith("phmm_forward_chain<16,") and plan.dominant_kernel.endswith(want), (nh, plan.dominant_kernel)
+        plan.close()
+        sub = b.region_slice(0, 6)
+        got = hip_engine.compute(b)
+        _close(got[:int(b.out_off[6])], oracle.compute_batch(sub.as_dict(), n_threads=8))
+
+
 def test_chained_and_plain_kernels_agree(engines):
     hip_engine = engines[16]
     b = synthetic.config2(24, seed=9)

@@ -27,6 +27,10 @@ cfgs = {"config2x1024": lambda: synthetic.config2(1024, seed=1),
         "R100_H300x1024": lambda: synthetic.make_regions(1024, 128, 8, 300, 100, 5),
         "R250_H300x512": lambda: synthetic.make_regions(512, 128, 8, 300, 250, 6),
         "Nh2_R150_H300x2048": lambda: synthetic.make_regions(2048, 128, 2, 300, 150, 7),
+        "Nh1_R150_H300x4096": lambda: synthetic.make_regions(4096, 128, 1, 300, 150, 11),
+        "Nh3_R150_H300x1536": lambda: synthetic.make_regions(1536, 128, 3, 300, 150, 12),
+        "Nh5_R150_H300x1024": lambda: synthetic.make_regions(1024, 128, 5, 300, 150, 13),
+        "Nh6_R150_H300x1024": lambda: synthetic.make_regions(1024, 128, 6, 300, 150, 14),
         "R150_H600x512": lambda: synthetic.make_regions(512, 64, 8, 600, 150, 9),
         "ragged_small": lambda: synthetic.make_regions(4096, 12, 3, 220, [80, 120, 151], 8)}
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -35,8 +39,11 @@ for name, mk in cfgs.items():
     if only and name not in only: continue
     b = mk()
     if chain_mode:
-        for ch in (None, "0", "16"):
+        for ch in (None, "0", "16", "streams1"):
+            os.environ.pop("PHMM_FORCE_STREAMS", None)
             if ch is None: os.environ.pop("PHMM_FORCE_CHAIN", None)
+            elif ch == "streams1":  # chained, but one stream per wave (idle haplotype slots)
+                os.environ.pop("PHMM_FORCE_CHAIN", None); os.environ["PHMM_FORCE_STREAMS"] = "1"
             else: os.environ["PHMM_FORCE_CHAIN"] = ch
             eng = HipPairHMMEngine(0)
             ms, cells, k = timed(eng, b)
