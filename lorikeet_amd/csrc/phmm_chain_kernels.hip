@@ -157,8 +157,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
     RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING + 1 records
-    uint32_t *cum = reinterpret_cast<uint32_t *>(ring + RING + 1);  // per stream s at s*(n_sub+1): row offset of each read
-    uint32_t *roff = cum + CHAIN_META;                              // same layout: byte offset of each read
+    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING + 1);  // per stream s at s*(n_sub+1): byte offset of each read
+    uint32_t *stot = roff + CHAIN_META;                              // [4] rows of each stream
 
     // ---- haplotype columns: real bases, one EDGE column, then padding -------------------------------
     HapCols<K> hc;
@@ -198,17 +198,18 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         }
         const uint32_t before = __shfl(incl, max(sj * n_sub - 1, 0), WAVE);  // scan value just before my stream starts
         const int cb = sj * (n_sub + 1);
-        if (lane < S) cum[lane * (n_sub + 1)] = 0u;
+        if (lane < 4) stot[lane] = 0u;  // rows of each stream (streams without reads stay 0)
         if (lane < n_chain) {
-            cum[cb + ij + 1] = incl - (sj > 0 ? before : 0u);
             roff[cb + ij] = p.read_off[rb + lane];
-            if (ij + 1 == n_of(sj)) roff[cb + ij + 1] = p.read_off[rb + lane + 1];
+            if (ij + 1 == n_of(sj)) {
+                roff[cb + ij + 1] = p.read_off[rb + lane + 1];
+                stot[sj] = incl - (sj > 0 ? before : 0u);
+            }
         }
         if (lane == 0) ring[RING] = neutral_row();
     }
     lds_wave_sync();
-    int S_max = 0;  // longest stream (rows)
-    for (int s = 0; s < S; ++s) S_max = max(S_max, (int)cum[s * (n_sub + 1) + n_of(s)]);
+    const int S_max = (int)max(max(stot[0], stot[1]), max(stot[2], stot[3]));  // longest stream (rows)
     const double c_unit = ldexp(1.0, 1010);  // common D(0,j) of every haplotype, see the header
 
     // ---- row producer: stream positions [P0, P0 + 64) -> ring ----------------------------------------
@@ -216,28 +217,29 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
     // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
     uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
-    // producer side of this lane: row (lane % TPS) of stream (lane / TPS) of each tick
+    // producer side of this lane: row (lane % TPS) of stream (lane / TPS) of each tick.  Its position in that stream,
+    // (p_lo = read of the stream, p_row = row of that read, counting SUM and RESET), moves on by TPS rows per tick.
     const int ps = lane / TPS, pj = lane % TPS;
     const int pcb = ps * (n_sub + 1), pn = n_of(ps);
-    const int pS_total = (int)cum[pcb + pn];
-    auto locate = [&](int Q, int &lo, int &row, int &R, uint32_t &ro) {  // ring position -> (read of the stream, row)
-        const int P = Q - LEAD;
-        if (P < 0 || P >= pS_total) return false;
-        lo = 0;
-        int hi = pn;  // cum[lo] <= P < cum[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)cum[pcb + mid] <= P) lo = mid; else hi = mid;
+    int p_lo = 0, p_row = pj - LEAD - TPS;  // before the first advance(); rows < 0 are the neutral lead-in
+    uint32_t p_ro = pn > 0 ? roff[pcb] : 0u;
+    int p_R = pn > 0 ? (int)(roff[pcb + 1] - p_ro) : 0;
+    auto advance = [&]() {
+        p_row += TPS;
+        while (p_lo < pn && p_row >= p_R + 2) {  // past SUM and RESET of the current read: on to the next one(s)
+            p_row -= p_R + 2;
+            ++p_lo;
+            if (p_lo < pn) {
+                p_ro = roff[pcb + p_lo];
+                p_R = (int)(roff[pcb + p_lo + 1] - p_ro);
+            }
         }
-        ro = roff[pcb + lo];
-        R = (int)(roff[pcb + lo + 1] - ro);
-        row = P - (int)cum[pcb + lo];
-        return true;
     };
-    auto issue = [&](int Q0) {
-        int lo, row, R;
-        uint32_t ro;
-        if (locate(Q0 + pj, lo, row, R, ro) && row <= R) {
+    auto issue = [&]() {  // next position of this lane: start the loads of its bytes
+        advance();
+        const int row = p_row, R = p_R;
+        const uint32_t ro = p_ro;
+        if (p_lo < pn && row >= 0 && row <= R) {
             pb_qp = row > 0 ? (uint32_t)p.base_q[ro + row - 1] : 0u;  // row == R: the SUM row needs pm(R)
             if (row < R) {
                 pb_x = p.read_bases[ro + row];
@@ -250,12 +252,11 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             }
         }
     };
-    auto finish = [&](int Q0) {  // ring positions [Q0, Q0 + TPS) of every stream; stream position = ring position - LEAD
-        const int Q = Q0 + pj;
-        int lo, row, R;
-        uint32_t ro;
+    auto finish = [&](int Q0) {  // the issued position = ring positions [Q0, Q0 + TPS) of every stream
+        const int Q = Q0 + pj;     // stream position = ring position - LEAD
+        const int lo = p_lo, row = p_row, R = p_R;
         RowConst n;
-        if (locate(Q, lo, row, R, ro)) {
+        if (lo < pn && row >= 0) {
             if (row < R) {
                 n = make_row_bytes(p, pb_x, pb_q, pb_qp, pb_i, pb_d, pb_dp, pb_g, pb_gn, row == 0, row + 1 >= R, true);
             } else if (row == R) {  // SUM row: M_S(k) = M(R,k-1) + I(R,k-1), I_S(k) = M(R,k) + I(R,k); pad0 = read index in the chain
@@ -271,14 +272,14 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         }
         ring[ps * (NM + 1) + (Q & NM)] = n;
     };
-    issue(0);
+    issue();
     finish(0);
-    issue(TPS);
+    issue();
     finish(TPS);
-    issue(2 * TPS);
+    issue();
     finish(2 * TPS);
     lds_wave_sync();
-    issue(3 * TPS);
+    issue();
 
     // ---- state ---------------------------------------------------------------------------------------
     // planner guarantees every read has >= 1 base; a stream without reads only ever sees neutral rows
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
         if (tick >= 1) {  // keep the ring one to two ticks (+ phase) ahead of the first lane
             finish(TPS * tick + 2 * TPS);
             lds_wave_sync();
-            issue(TPS * tick + 3 * TPS);
+            issue();
         }
         for (int t = t0; t < t1; t += 2) {
             cB = my_ring[(q + 1) & NM];
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 #define PHMM_CHAIN_LAUNCH PHMM_CHAIN_CAT(launch_chain_L, PHMM_CHAIN_L)
 
 hipError_t PHMM_CHAIN_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
-    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + 2 * CHAIN_META * sizeof(uint32_t);
+    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
 #define PHMM_CASE(KK)                                                                                  \
     if (K == KK) {                                                                                     \
         hipLaunchKernelGGL((phmm_forward_chain<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \
