@@ -64,7 +64,10 @@ while time.time() < t_end:
         regions.append((reads, haps))
     batch = RegionBatch.from_regions(regions)
     want = oracle.compute_batch(batch.as_dict(), n_threads=cores)
-    for env in ({}, {"PHMM_FORCE_CHAIN": "6", "PHMM_FORCE_L": "16"}):
+    # the planner's choice; the chained kernel forced at 16 lanes per pair, with 1 and with 2 or 4 streams; and at 32
+    for env in ({}, {"PHMM_FORCE_CHAIN": "6", "PHMM_FORCE_L": "16", "PHMM_FORCE_STREAMS": "1"},
+                {"PHMM_FORCE_CHAIN": "5", "PHMM_FORCE_L": "16", "PHMM_FORCE_STREAMS": str(rng.choice([2, 4]))},
+                {"PHMM_FORCE_CHAIN": "7", "PHMM_FORCE_L": "32"}):
         os.environ.update(env)
         try:
             got = eng.compute(batch)
