@@ -512,7 +512,13 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         return u;
     };
     uint64_t units = count_units();
-    auto runs_for = [&](uint64_t u) { return (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, u / (8ull * 2 * kNumSimd)); };
+    // run length: about eight runs per wave slot (balance), but never runs shorter than four reads (measured on 128
+    // regions of config 2: runs of 2 reads 3380, of 4 reads 3530, per-read kernel 3450 GCUPS); below two runs of two
+    // per slot the batch stays with the per-read kernel
+    auto runs_for = [&](uint64_t u) {
+        const uint32_t r = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, u / (8ull * 2 * kNumSimd));
+        return r >= 2 && r < 4 ? 4u : r;
+    };
     uint32_t chain_reads = runs_for(units);
     if (const char *e = getenv("PHMM_FORCE_CHAIN")) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, std::max(0, atoi(e)));
     if (chain_reads >= 2 && !h->force_L) {

@@ -21,7 +21,8 @@ def timed(eng, batch, reps=3):
     if not os.environ.get('SHAPES_NOSTATUS'): plan.status()
     return e0.elapsed_time(e1) / reps, plan.cells, plan.dominant_kernel
 
-cfgs = {"config2x1024": lambda: synthetic.config2(1024, seed=1),
+cfgs = {"config2x256": lambda: synthetic.config2(256, seed=21), "config2x128": lambda: synthetic.config2(128, seed=22), "config2x64": lambda: synthetic.config2(64, seed=23),
+        "config2x1024": lambda: synthetic.config2(1024, seed=1),
         "config3x1024": lambda: synthetic.config3(1024, seed=2),
         "config5x32": lambda: synthetic.config5(32, seed=3),
         "R100_H300x1024": lambda: synthetic.make_regions(1024, 128, 8, 300, 100, 5),
