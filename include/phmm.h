@@ -25,8 +25,9 @@
  *     gives -inf; an empty read list is a no-op (:224);
  *   - every result satisfies <= 0.0; a violation (the reference asserts, :478-481) is reported
  *     as PHMM_ERR_POSITIVE_RESULT.
- * Results agree with the reference's scalar f64 path to ~1e-12 relative (FMA contraction and the
- * order of the final row sum are the only differences); the reference's own gate is 1e-5 abs.
+ * Results agree with the reference's scalar f64 path to ~1e-13 absolute in log10 (FMA contraction,
+ * exact rescalings of the DP state and the order of the final row sum are the only differences,
+ * DESIGN.md section 4); the reference's own gate is 1e-5 abs.
  *
  * Threading: a handle may be used by one thread at a time; create one per host thread (the
  * reference clones its engine per rayon task, assembly_region_walker.rs:227) or serialise.
