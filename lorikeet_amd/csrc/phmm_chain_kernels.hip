@@ -320,8 +320,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 
     // lane l works on ring position q = t + LEAD - l  (stream position t - l); rows outside the stream are neutral
     int q = LEAD - l;
-    const RowConst *my_ring = ring + sid * (NM + 1);
-    RowConst cA = my_ring[q & NM], cB;
+    const int my_ring = sid * (NM + 1);  // first slot of this lane's stream (an index, so the LDS address stays 32-bit math)
+    RowConst cA = lds_row(ring, my_ring + (q & NM)), cB;
     const int T = (S_max + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
     // Outer loop = one producer tick (TPS steps), inner loop = the sweep.  The producer's pending bytes are
     // defined before the inner loop and first used after it, so their loads have a tick to land.
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             issue();
         }
         for (int t = t0; t < t1; t += 2) {
-            cB = my_ring[(q + 1) & NM];
+            cB = lds_row(ring, my_ring + ((q + 1) & NM));
             aM = from_left<CL>(Mp[K - 1], group_head);
             aI = from_left<CL>(Ip[K - 1], group_head);
             aD = from_left_inject(Dp[K - 1], cA.pad1, group_head);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
             // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
             // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
-            cA = my_ring[(q + 2) & NM];
+            cA = lds_row(ring, my_ring + ((q + 2) & NM));
             bM = from_left<CL>(Mp[K - 1], group_head);
             bI = from_left<CL>(Ip[K - 1], group_head);
             bD = from_left_inject(Dp[K - 1], cB.pad1, group_head);

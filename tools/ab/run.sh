@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 cp lorikeet_amd/libphmm.so /tmp/libphmm_cur.so
 for rep in 1 2; do
-for v in b7a2 vop3 sum2; do
+for v in prev mul24; do
   cp tools/ab/libphmm_$v.so lorikeet_amd/libphmm.so
   echo "== $v"; python tools/shapes.py --chain config2x1024 2>&1 | grep -v "^phmm plan" | tail -2
 done
