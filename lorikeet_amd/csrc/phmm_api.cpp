@@ -903,6 +903,45 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     return PHMM_OK;
 }
 
+// Regions [g0, g1) of a caller's batch with every offset array rebased to zero: what one pipelined chunk is made of.
+struct ChunkView {
+    uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
+    size_t read_byte0 = 0, hap_byte0 = 0;
+    std::vector<uint32_t> rro, rho, ro, ho;
+    std::vector<uint64_t> oo;
+};
+
+// Next chunk after `c` (start with c.g1 == 0): grows while every per-base array stays below the direct-copy limit.
+bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off) {
+    const uint32_t g0 = c.g1;
+    if (g0 >= n_regions) return false;
+    uint32_t g1 = g0 + 1;
+    const size_t base_r = read_off[region_read_off[g0]];
+    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kDirectCopyBytes) ++g1;
+    c.g0 = g0;
+    c.g1 = g1;
+    c.r0 = region_read_off[g0];
+    c.r1 = region_read_off[g1];
+    c.h0 = region_hap_off[g0];
+    c.h1 = region_hap_off[g1];
+    c.read_byte0 = read_off[c.r0];
+    c.hap_byte0 = hap_off[c.h0];
+    c.rro.resize(g1 - g0 + 1);
+    c.rho.resize(g1 - g0 + 1);
+    c.oo.resize(g1 - g0 + 1);
+    for (uint32_t g = g0; g <= g1; ++g) {
+        c.rro[g - g0] = region_read_off[g] - c.r0;
+        c.rho[g - g0] = region_hap_off[g] - c.h0;
+        c.oo[g - g0] = out_off[g] - out_off[g0];
+    }
+    c.ro.resize(c.r1 - c.r0 + 1);
+    for (uint32_t r = c.r0; r <= c.r1; ++r) c.ro[r - c.r0] = read_off[r] - read_off[c.r0];
+    c.ho.resize(c.h1 - c.h0 + 1);
+    for (uint32_t a = c.h0; a <= c.h1; ++a) c.ho[a - c.h0] = hap_off[a] - hap_off[c.h0];
+    return true;
+}
+
 // Wait for a pending batch, hand the results to the caller, release the batch.
 int finish_compute(phmm_handle *h, PendingCompute *p) {
     if (!p->b) return PHMM_OK;
@@ -958,36 +997,16 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     //      region is independent, the chunk only rebases the offsets. -----------------------------------
     PendingCompute pend[kSlots];
     int st = PHMM_OK;
-    std::vector<uint32_t> rro, rho, ro, ho;
-    std::vector<uint64_t> oo;
-    uint32_t g0 = 0;
+    ChunkView c;
     int n_chunks = 0;
-    while (g0 < n_regions && st == PHMM_OK) {
-        // grow the chunk while every per-base array stays below the direct-copy limit
-        uint32_t g1 = g0 + 1;
-        const size_t base_r = read_off[region_read_off[g0]];
-        while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kDirectCopyBytes) ++g1;
-        const uint32_t r0 = region_read_off[g0], r1 = region_read_off[g1], h0 = region_hap_off[g0], h1 = region_hap_off[g1];
-        rro.resize(g1 - g0 + 1);
-        rho.resize(g1 - g0 + 1);
-        oo.resize(g1 - g0 + 1);
-        for (uint32_t g = g0; g <= g1; ++g) {
-            rro[g - g0] = region_read_off[g] - r0;
-            rho[g - g0] = region_hap_off[g] - h0;
-            oo[g - g0] = out_off[g] - out_off[g0];
-        }
-        ro.resize(r1 - r0 + 1);
-        for (uint32_t r = r0; r <= r1; ++r) ro[r - r0] = read_off[r] - read_off[r0];
-        ho.resize(h1 - h0 + 1);
-        for (uint32_t a = h0; a <= h1; ++a) ho[a - h0] = hap_off[a] - hap_off[h0];
+    while (st == PHMM_OK && next_chunk(c, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
         const int slot = n_chunks % kSlots;
         st = finish_compute(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
         if (st != PHMM_OK) break;
         h->slot = slot;
-        const size_t bo = read_off[r0], co = hap_off[h0];
-        st = enqueue_compute(h, g1 - g0, rro.data(), rho.data(), ro.data(), read_bases + bo, base_q + bo, ins_q + bo, del_q + bo,
-                             gcp + bo, ho.data(), hap_bases + co, oo.data(), out + out_off[g0], &pend[slot]);
-        g0 = g1;
+        const size_t bo = c.read_byte0, co = c.hap_byte0;
+        st = enqueue_compute(h, c.g1 - c.g0, c.rro.data(), c.rho.data(), c.ro.data(), read_bases + bo, base_q + bo, ins_q + bo,
+                             del_q + bo, gcp + bo, c.ho.data(), hap_bases + co, c.oo.data(), out + out_off[c.g0], &pend[slot]);
         ++n_chunks;
     }
     for (int i = 0; i < kSlots; ++i) {  // drain in submission order
@@ -1000,20 +1019,24 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     return st;
 }
 
-int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions,
-                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
-                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
-                        const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases,
-                        const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep) {
-    if (!h || !cfg) return PHMM_ERR_INVALID_ARG;
-    if (cfg->pcr_error_model > 3) {
-        h->err = "phmm_engine_compute: Unknown PCR Error Model";  // engine.rs:89
-        return PHMM_ERR_INVALID_ARG;
-    }
-    if (!region_read_off || !read_off) {
-        h->err = "phmm_engine_compute: null offset array";
-        return PHMM_ERR_INVALID_ARG;
-    }
+namespace {
+
+struct PendingEngine {
+    phmm_batch *b = nullptr;
+    int slot = 0;
+    double *out = nullptr;
+    uint8_t *keep = nullptr;
+    size_t res_off = 0, keep_bytes = 0;
+    uint32_t n_reads = 0;
+};
+
+// Stage one batch of the engine-level call in the current slot's arena and enqueue H2D, pre-step, PairHMM, post-step
+// and D2H on its stream.  No sync.
+int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions, const uint32_t *region_read_off,
+                   const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                   const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
+                   const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep,
+                   PendingEngine *pending) {
     const uint32_t n_reads = region_read_off[n_regions];
     const size_t rbytes = align_up((size_t)read_off[n_reads], 256);
     // originals (4 x read bytes + mapq + ref index) and device-only copies (4 x read bytes, thresholds, keep)
@@ -1116,23 +1139,101 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         if (ok) ok = hip_ok(h, launch_post(po, h->S()), "phmm_post_reads");
         const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
         if (ok) ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->S()),
-                            "D2H results") &&
-                     hip_ok(h, hipStreamSynchronize(h->S()), "sync");
+                            "D2H results");
         if (ok) {
-            const char *hs = A.host + res_off;
-            if (n_reads) memcpy(keep, hs + 256, n_reads);
-            if (b->n_out) memcpy(out, hs + 256 + keep_bytes, b->n_out * 8);
-            if (*(const uint32_t *)hs) {
-                h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
-                st = PHMM_ERR_POSITIVE_RESULT;
-            }
-        } else if (st == PHMM_OK) {
-            st = PHMM_ERR_HIP;
+            pending->b = b;
+            pending->slot = h->slot;
+            pending->out = out;
+            pending->keep = keep;
+            pending->res_off = res_off;
+            pending->keep_bytes = keep_bytes;
+            pending->n_reads = n_reads;
+            return PHMM_OK;
+        }
+        if (st == PHMM_OK) st = PHMM_ERR_HIP;
+    }
+    std::string keep_err = h->err;
+    (void)hipStreamSynchronize(h->S());
+    phmm_batch_destroy(b);
+    h->err = keep_err;
+    return st;
+}
+
+// Wait for a pending engine batch, hand keep flags and likelihoods to the caller, release the batch.
+int engine_finish(phmm_handle *h, PendingEngine *p) {
+    if (!p->b) return PHMM_OK;
+    int st = PHMM_OK;
+    phmm_batch *b = p->b;
+    const Arena &A = h->arenas[p->slot];
+    if (!hip_ok(h, hipStreamSynchronize(h->streams[p->slot]), "sync")) {
+        st = PHMM_ERR_HIP;
+    } else {
+        const char *hs = A.host + p->res_off;
+        if (p->n_reads) memcpy(p->keep, hs + 256, p->n_reads);
+        if (b->n_out) memcpy(p->out, hs + 256 + p->keep_bytes, b->n_out * 8);
+        if (*(const uint32_t *)hs) {
+            h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+            st = PHMM_ERR_POSITIVE_RESULT;
         }
     }
     std::string keep_err = h->err;
     phmm_batch_destroy(b);
     h->err = keep_err;
+    p->b = nullptr;
+    return st;
+}
+
+}  // namespace
+
+int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions,
+                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                        const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases,
+                        const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep) {
+    if (!h || !cfg) return PHMM_ERR_INVALID_ARG;
+    if (cfg->pcr_error_model > 3) {
+        h->err = "phmm_engine_compute: Unknown PCR Error Model";  // engine.rs:89
+        return PHMM_ERR_INVALID_ARG;
+    }
+    if (!region_read_off || !read_off) {
+        h->err = "phmm_engine_compute: null offset array";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    const uint32_t n_reads = region_read_off[n_regions];
+    // ---- small / medium batch: one shot ------------------------------------------------------------
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kDirectCopyBytes || !region_hap_off || !hap_off || !out_off ||
+        getenv("PHMM_NO_PIPELINE")) {
+        h->slot = 0;
+        PendingEngine p;
+        int st = engine_enqueue(h, cfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q,
+                                mapq, hap_off, hap_bases, region_ref_hap, out_off, out, keep, &p);
+        if (st == PHMM_OK) st = engine_finish(h, &p);
+        return st;
+    }
+    // ---- large batch: chunks of regions through the kSlots (arena, stream) pairs, like phmm_compute ----
+    PendingEngine pend[kSlots];
+    int st = PHMM_OK;
+    ChunkView c;
+    int n_chunks = 0;
+    while (st == PHMM_OK && next_chunk(c, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
+        const int slot = n_chunks % kSlots;
+        st = engine_finish(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
+        if (st != PHMM_OK) break;
+        h->slot = slot;
+        const size_t bo = c.read_byte0, co = c.hap_byte0;
+        st = engine_enqueue(h, cfg, c.g1 - c.g0, c.rro.data(), c.rho.data(), c.ro.data(), read_bases ? read_bases + bo : nullptr,
+                            base_q ? base_q + bo : nullptr, ins_q ? ins_q + bo : nullptr, del_q ? del_q + bo : nullptr,
+                            mapq ? mapq + c.r0 : nullptr, c.ho.data(), hap_bases ? hap_bases + co : nullptr,
+                            region_ref_hap ? region_ref_hap + c.g0 : nullptr, c.oo.data(), out ? out + out_off[c.g0] : nullptr,
+                            keep ? keep + c.r0 : nullptr, &pend[slot]);
+        ++n_chunks;
+    }
+    for (int i = 0; i < kSlots; ++i) {  // drain in submission order
+        const int slot = (n_chunks + i) % kSlots;
+        const int s2 = engine_finish(h, &pend[slot]);
+        if (st == PHMM_OK) st = s2;
+    }
+    h->slot = 0;
     return st;
 }
 

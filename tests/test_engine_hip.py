@@ -136,3 +136,47 @@ def test_engine_surface_filters_and_compacts():
     assert m0.shape == (2, 3) and m1.shape == (2, 2)
     assert not np.isnan(m0[:, :2]).any() and np.isnan(m0[:, 2]).all() and np.isnan(m1[:, 1]).all()
     assert (m0[0, :2] >= m0[1, :2]).all()  # reads copied from the reference prefer it
+
+
+def test_large_engine_call_is_pipelined_transparently():
+    """A call big enough to be cut into chunks (three (arena, stream) slots, staging of chunk i+1 overlapping the
+    kernels of chunk i) returns exactly what the one-shot path returns: regions are independent."""
+    import ctypes as C
+    import os
+
+    from lorikeet_amd import HipPairHMMEngine, _lib, synthetic
+    b = synthetic.config2(600, seed=77)  # 11.5 MB per per-base array: three chunks
+    eng = HipPairHMMEngine(0)
+    cfg = _lib.EngineConfig()
+    cfg.constant_gcp, cfg.pcr_error_model, cfg.base_quality_score_threshold = 10, 3, 18
+    cfg.dynamic_read_disqualification, cfg.symmetrically_normalize_alleles_to_reference = 1, 1
+    cfg.log10_global_read_mismapping_rate = -4.5 * math.log10(math.e)
+    cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = 1.0, 0.02
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    mapq[::7] = 20
+    ref = np.zeros(b.n_regions, np.int32)
+    pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+
+    def run():
+        out = np.empty(b.n_out, np.float64)
+        keep = np.zeros(b.n_reads, np.uint8)
+        st = eng.lib.phmm_engine_compute(
+            eng._h, C.byref(cfg), b.n_regions, pp(b.region_read_off, _lib.u32p), pp(b.region_hap_off, _lib.u32p),
+            pp(b.read_off, _lib.u32p), pp(b.read_bases, _lib.u8p), pp(b.base_q, _lib.u8p), None, None, pp(mapq, _lib.u8p),
+            pp(b.hap_off, _lib.u32p), pp(b.hap_bases, _lib.u8p), pp(ref, C.POINTER(C.c_int32)), pp(b.out_off, _lib.u64p),
+            pp(out, _lib.f64p), pp(keep, _lib.u8p))
+        assert st == 0, eng.last_error()
+        return out, keep
+
+    out_p, keep_p = run()
+    os.environ["PHMM_NO_PIPELINE"] = "1"
+    try:
+        out_1, keep_1 = run()
+    finally:
+        os.environ.pop("PHMM_NO_PIPELINE", None)
+    # chunks plan their own shapes (run lengths differ with the batch size): same numbers up to the last-row
+    # summation order, identical keep decisions
+    assert np.max(np.abs(out_p - out_1)) <= 1e-12
+    assert np.array_equal(keep_p, keep_1)
+    assert 0.9 < keep_p.mean() <= 1.0
+    eng.close()
