@@ -60,10 +60,29 @@ def make_workload(name, n_regions, seed):
     return synthetic.config5(n_regions, seed=seed), "512 reads x 64 haps, R=150, H=400"
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that
+    sees 256 logical CPUs may be limited to 16 cores' worth of time; more threads than that only oversubscribe)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(batch, budget_s=20.0):
-    """Oracle ("port" of the reference's scalar path) on all host cores, bounded sample."""
+    """Oracle ("port" of the reference's scalar path) on all usable host cores, bounded sample."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     try:
         oracle.build(native=True)
         native = True
@@ -83,7 +102,8 @@ def cpu_baseline(batch, budget_s=20.0):
     dt = time.perf_counter() - t
     return {"value": round(sub.cells() / dt / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
             "sample": "first %d regions of rank 0's batch (%.3g cells, %.1f s); oracle/pairhmm_oracle.c, f64 scalar, "
-                      "one region per pthread task%s" % (n1, sub.cells(), dt, ", -march=native" if native else "")}
+                      "one region per pthread task%s; cores = min(affinity, cgroup cpu quota) of %d logical CPUs"
+                      % (n1, sub.cells(), dt, ", -march=native" if native else "", os.cpu_count() or 1)}
 
 
 def pmc_traffic(workload, regions):

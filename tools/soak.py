@@ -12,7 +12,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 alpha = np.frombuffer(b"ACGT", np.uint8)
 alphan = np.frombuffer(b"ACGTN", np.uint8)
-cores = os.cpu_count() or 8
+from bench import usable_cores
+cores = usable_cores()  # affinity capped by the cgroup CPU quota: more oracle threads only oversubscribe
 eng = HipPairHMMEngine(0)
 t_end = time.time() + budget
 worst, n_batches, n_pairs, n_cells = 0.0, 0, 0, 0
