@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flush-caches", action="store_true",
+                    help="PMC calibration only: overwrite a 1 GiB buffer before every launch so that no input byte "
+                         "survives in L2 / Infinity Cache from the previous launch (the timing then includes the fill)")
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed loop (no single_region / engine_call / cpu_baseline rows): for PMC passes")
     return ap.parse_args()
@@ -157,6 +160,7 @@ def main():
             dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(dev)
 
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if a.flush_caches else None
     with torch.cuda.stream(stream):
         for _ in range(a.warmup):
             plan.launch(sh)
@@ -165,6 +169,8 @@ def main():
         t0 = time.perf_counter()
         ev[0].record(stream)
         for i in range(a.steps):
+            if flush is not None:
+                flush.fill_(float(i))
             plan.launch(sh)
             ev[i + 1].record(stream)
         barrier()
