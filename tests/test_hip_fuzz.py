@@ -31,13 +31,13 @@ def region_st(draw):
 
 @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(regions=st.lists(region_st(), min_size=1, max_size=5), force_l=st.sampled_from([None, "16", "32", "64"]),
-       chain=st.sampled_from([None, "3"]))
-def test_hip_equals_oracle_on_drawn_batches(regions, force_l, chain):
+       chain=st.sampled_from([None, "3"]), streams=st.sampled_from([None, "1", "2", "4"]))
+def test_hip_equals_oracle_on_drawn_batches(regions, force_l, chain, streams):
     import os
     from lorikeet_amd import HipPairHMMEngine
     b = RegionBatch.from_regions(regions)
     want = oracle.compute_batch(b.as_dict())
-    for k, v in (("PHMM_FORCE_L", force_l), ("PHMM_FORCE_CHAIN", chain)):
+    for k, v in (("PHMM_FORCE_L", force_l), ("PHMM_FORCE_CHAIN", chain), ("PHMM_FORCE_STREAMS", streams)):
         if v is None:
             os.environ.pop(k, None)
         else:
@@ -49,6 +49,7 @@ def test_hip_equals_oracle_on_drawn_batches(regions, force_l, chain):
     finally:
         os.environ.pop("PHMM_FORCE_L", None)
         os.environ.pop("PHMM_FORCE_CHAIN", None)
+        os.environ.pop("PHMM_FORCE_STREAMS", None)
     assert got.shape == want.shape
     inf = np.isinf(want)
     assert np.array_equal(np.isinf(got), inf)
