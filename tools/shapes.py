@@ -6,6 +6,7 @@ import numpy as np, torch
 from lorikeet_amd import HipPairHMMEngine, synthetic
 
 def timed(eng, batch, reps=3):
+    reps = max(reps, min(200, int(2e9 / max(batch.cells(), 1))))  # small batches: many launches per measurement
     plan = eng.plan(batch)
     dev = torch.device("cuda:0")
     t = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
@@ -21,7 +22,9 @@ def timed(eng, batch, reps=3):
     if not os.environ.get('SHAPES_NOSTATUS'): plan.status()
     return e0.elapsed_time(e1) / reps, plan.cells, plan.dominant_kernel
 
-cfgs = {"config2x256": lambda: synthetic.config2(256, seed=21), "config2x128": lambda: synthetic.config2(128, seed=22), "config2x64": lambda: synthetic.config2(64, seed=23),
+cfgs = {"config2x1": lambda: synthetic.config2(1, seed=31), "config2x2": lambda: synthetic.config2(2, seed=32), "config2x4": lambda: synthetic.config2(4, seed=33),
+        "config2x8": lambda: synthetic.config2(8, seed=34), "config2x16": lambda: synthetic.config2(16, seed=35),
+        "config2x256": lambda: synthetic.config2(256, seed=21), "config2x128": lambda: synthetic.config2(128, seed=22), "config2x64": lambda: synthetic.config2(64, seed=23),
         "config2x1024": lambda: synthetic.config2(1024, seed=1),
         "config3x1024": lambda: synthetic.config3(1024, seed=2),
         "config5x32": lambda: synthetic.config5(32, seed=3),
