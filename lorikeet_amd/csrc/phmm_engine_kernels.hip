@@ -73,60 +73,62 @@ __device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, boo
 
 // find_tandem_repeat_units (engine.rs:528-611) -> length of the tandem repeat around `offset`.
 //
-// A unit of length `str` <= 20 repeats (count > 1) iff the adjacent block of the same length equals it,
-// and both blocks lie within 40 bases of the offset.  So the 40 bases on either side are fetched up front
-// with independent LDS reads and all 2 x 20 candidate unit lengths are decided in registers, branch-free
-// (no divergence between the 64 positions a wave works on); the exact, data-dependent count runs only at
-// positions that really sit in a tandem repeat.  Same results as the plain loops.
+// The reference tries unit lengths str = 1..20 in order and stops at the first one whose adjacent copy equals the
+// unit (count > 1).  "Adjacent copy equals the unit" is a periodicity test on 2*str bases next to the offset; it is
+// decided in two levels so that the common case (no repeat) costs ~40 register compares per direction instead of
+// 210: a branch-free screen on the first two positions of every candidate length (bit mask per lane), then the
+// exact test, from LDS, only for the ~6 % of lengths that pass it.  Positions outside the read never compare equal
+// (the screen uses distinct sentinels, the exact test a range check), which is what the reference's bounds do.
+// The exact, data-dependent count runs only at positions that really sit in a tandem repeat.  Same results as the
+// plain loops (tests/test_engine_oracle.py pins the oracle to them, tests/test_engine_hip.py this kernel to the oracle).
 __device__ int tandem_repeat_length(const uint8_t *s, int n, int offset) {
-    constexpr int W = 2 * MAX_STR_UNIT_LENGTH;
-    uint32_t wb[W], wf[W];  // wb[d] = s[offset - d], wf[d] = s[offset + 1 + d]; distinct sentinels outside the read
+    constexpr int W = MAX_STR_UNIT_LENGTH + 2;
+    uint32_t wb[W], wf[W];  // wb[d] = s[offset - d], wf[d] = s[offset + 1 + d]
 #pragma unroll
     for (int d = 0; d < W; ++d) {
         wb[d] = (offset - d >= 0) ? (uint32_t)s[offset - d] : 0x100u + d;
         wf[d] = (offset + 1 + d < n) ? (uint32_t)s[offset + 1 + d] : 0x200u + d;
     }
-    int max_bw = 0, bw_u = offset, bw_len = 1;
-    bool bw_done = false;
+    uint32_t cand_b = 0, cand_f = 0;  // bit str-1: unit length str passes the screen
 #pragma unroll
     for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
-        if (!bw_done && offset + 1 >= str) {
-            // unit = s[offset+1-str, offset+1); the copy before it starts at offset+1-2str
-            max_bw = 1;
-            bool twice = true;
-#pragma unroll
-            for (int d = 0; d < str; ++d) twice &= (wb[d] == wb[d + str]);
-            if (twice) max_bw = repetitions(s, offset + 1 - str, str, 0, offset + 1, false, true);
-            if (max_bw > 1) {
-                bw_u = offset + 1 - str;
-                bw_len = str;
-                bw_done = true;
-            }
-        } else {
-            bw_done = true;  // (offset + 1).checked_sub(str) failed: stop (:535-537)
+        bool b = wb[0] == wb[str], f = wf[0] == wf[str];
+        if (str >= 2) {
+            b &= wb[1] == wb[1 + str];
+            f &= wf[1] == wf[1 + str];
         }
+        cand_b |= b ? 1u << (str - 1) : 0u;
+        cand_f |= f ? 1u << (str - 1) : 0u;
+    }
+    // backward: unit = s[offset+1-str, offset+1), the copy before it starts at offset+1-2str (:531-560)
+    int max_bw = 1, bw_u = offset, bw_len = 1;
+    while (cand_b) {
+        const int str = __ffs(cand_b);
+        bool twice = offset + 1 - 2 * str >= 0;
+        for (int d = 2; d < str && twice; ++d) twice = s[offset - d] == s[offset - d - str];
+        if (twice) {
+            max_bw = repetitions(s, offset + 1 - str, str, 0, offset + 1, false, true);
+            bw_u = offset + 1 - str;
+            bw_len = str;
+            break;
+        }
+        cand_b &= cand_b - 1;
     }
     int max_rl = max_bw;
     if (offset < n - 1) {
-        int max_fw = 0, fw_len = 1;
+        // forward: unit = s[offset+1, offset+1+str), the copy after it starts at offset+1+str (:562-587)
+        int max_fw = 1, fw_len = 1;
         const int fw_u = offset + 1;
-        bool fw_done = false;
-#pragma unroll
-        for (int str = 1; str <= MAX_STR_UNIT_LENGTH; ++str) {
-            if (!fw_done && offset + str + 1 <= n) {
-                // unit = s[offset+1, offset+1+str); the copy after it starts at offset+1+str
-                max_fw = 1;
-                bool twice = true;
-#pragma unroll
-                for (int d = 0; d < str; ++d) twice &= (wf[d] == wf[d + str]);
-                if (twice) max_fw = repetitions(s, offset + 1, str, offset + 1, n - offset - 1, true, true);
-                if (max_fw > 1) {
-                    fw_len = str;
-                    fw_done = true;
-                }
-            } else {
-                fw_done = true;
+        while (cand_f) {
+            const int str = __ffs(cand_f);
+            bool twice = offset + 1 + 2 * str <= n;
+            for (int d = 2; d < str && twice; ++d) twice = s[offset + 1 + d] == s[offset + 1 + d + str];
+            if (twice) {
+                max_fw = repetitions(s, offset + 1, str, offset + 1, n - offset - 1, true, true);
+                fw_len = str;
+                break;
             }
+            cand_f &= cand_f - 1;
         }
         if (fw_len == bw_len && same(s, fw_u, bw_u, bw_len)) {
             max_rl = max_bw + max_fw;
