@@ -63,6 +63,21 @@ K(k_cmpx, F_CMPX)
 K(k_cmp, F_CMP)
 K(k_cell, F_CELL)
 
+// the same cell body in f32 (what an f32-first mode like the reference's gkl arm would issue) and with packed f32
+// for the four FMAs / the I multiply (two columns per instruction; select and D chain stay per column)
+__global__ __launch_bounds__(256) void k_cell_f32(double *out, int iters, double B, double C, uint32_t ux) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = (float)B, c = (float)C; uint32_t vy = threadIdx.x & 3;
+    const long long c0 = clock64(), w0 = wall_clock64();
+#define F_CELL32(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n v_cmpx_ne_u32_e32 vcc, %11, %12\n v_mul_f32 %" #i ", %" #i ", %8\n s_mov_b64 exec, -1\n v_mul_f32 %" #i ", %" #i ", %8\n v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+    for (int i = 0; i < iters; ++i)
+        asm volatile(OPS8(F_CELL32) OPS8(F_CELL32)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy) : "vcc");
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[0] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (double)(clock64() - c0); out[2] = (double)(wall_clock64() - w0); }
+}
+
 typedef void (*kern_t)(double *, int, double, double, uint32_t);
 static void run(const char *name, kern_t k, double valu_per_group) {
     double *out; hipMalloc(&out, 64);
@@ -100,5 +115,6 @@ int main() {
     run("v_cmp->sgpr, s_mov exec, mul, s_mov", k_smask, 2);
     run("same, groups of 4 (one restore)", (kern_t)k_smask4, 1);  // 16 VALU per iteration: count as 8+8 over 16 groups
     run("cmpx block + 1 independent fma", k_cmpx_il, 3);
+    run("7-op cell body in f32", k_cell_f32, 7);
     return 0;
 }
