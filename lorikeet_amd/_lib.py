@@ -16,6 +16,7 @@ u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
 
 PHMM_FLAG_NO_TRISTATE = 1
+PHMM_FLAG_F32_FIRST = 2  # opt-in: f32 sweep first, f64 redo of what f32 cannot be trusted with (include/phmm.h)
 PHMM_OK = 0
 PHMM_ERR_INVALID_ARG = 1
 PHMM_ERR_NO_DEVICE = 2

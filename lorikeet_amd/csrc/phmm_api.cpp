@@ -35,7 +35,7 @@ constexpr size_t kLdsBytesPerCU = 160 * 1024;
 constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
 constexpr uint32_t kNumSimd = 256 * 4;
 constexpr uint64_t kGenericScratchBytes = 1ull << 30;
-constexpr size_t kDirectCopyBytes = 4u << 20;
+constexpr size_t kChunkBytes = 4u << 20;  // per-array bytes of one pipelined chunk; batches up to twice that go in one shot
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -57,6 +57,8 @@ struct ShapeClass {
     ChainItem *d_chain_items = nullptr;
     uint32_t cnd_select = 0;
     int streams = 1;  // chained classes: sub-runs swept side by side (phmm_chain_kernels.hip)
+    bool f32_first = false;  // chained class at 16 lanes per pair of a PHMM_FLAG_F32_FIRST handle: f32 sweep, then the
+                             // f64 per-read kernel over the reads it flagged (the per-read launch geometry is filled in too)
     // device
     uint32_t *d_reads = nullptr;
     // generic only
@@ -107,6 +109,7 @@ struct phmm_batch {
     uint32_t *d_read_region = nullptr, *d_region_read_off = nullptr, *d_region_hap_off = nullptr, *d_read_off = nullptr,
              *d_hap_off = nullptr, *d_status = nullptr;
     uint64_t *d_out_off = nullptr;
+    uint8_t *d_redo = nullptr;  // [n_reads] f32-first mode: reads the f64 per-read kernel has to redo
     // payload
     const uint8_t *d_read_bases = nullptr, *d_base_q = nullptr, *d_ins_q = nullptr, *d_del_q = nullptr, *d_gcp = nullptr,
                   *d_hap_bases = nullptr;
@@ -365,7 +368,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
                             align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
                             align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes +
-                            (size_t)n_reads * 64 /* chain items (16 B): up to four per read fit; more spill to hipMalloc (dalloc) */;
+                            (size_t)n_reads * 64 /* chain items (16 B): up to four per read fit; more spill to hipMalloc (dalloc) */ +
+                            align_up((size_t)n_reads, 256) /* redo flags of the f32-first mode */;
         Arena &A = h->A();
         if (A.cap < need) {
             (void)hipStreamSynchronize(h->S());
@@ -622,10 +626,25 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             void *mirror;
             c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
             up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
+            c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && c.L == 16;
+            if (c.f32_first) {  // the f64 per-read kernel runs behind the f32 sweep over the reads it flags
+                if (!c.identity) {
+                    void *mr;
+                    c.d_reads = (uint32_t *)dalloc((size_t)n_items * 4, &mr);
+                    up(c.d_reads, mr, c.reads.data(), (size_t)n_items * 4);
+                }
+                c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
+                c.waves_per_block = 1;
+                c.lds_bytes = (size_t)c.lds_rows * kLdsRowBytes;
+                c.grid = dim3(n_items, 1, 1);
+                c.cnd_select = 0;
+                if (!b->d_redo) b->d_redo = (uint8_t *)dalloc(align_up((size_t)n_reads, 256), nullptr);
+            }
+            const char *f32 = c.f32_first ? "_f32" : "";
             if (c.streams > 1)
-                snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d> x%d streams", c.L, c.K, c.streams);
+                snprintf(c.name, sizeof c.name, "phmm_forward_chain%s<%d,%d> x%d streams", f32, c.L, c.K, c.streams);
             else
-                snprintf(c.name, sizeof c.name, "phmm_forward_chain<%d,%d>", c.L, c.K);
+                snprintf(c.name, sizeof c.name, "phmm_forward_chain%s<%d,%d>", f32, c.L, c.K);
         } else if (c.L) {
             c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
             const size_t per_wave = (size_t)c.lds_rows * kLdsRowBytes;
@@ -743,6 +762,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         return PHMM_ERR_NOT_BOUND;
     }
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : b->home_stream;
+    if (b->d_redo && !hip_ok(h, hipMemsetAsync(b->d_redo, 0, b->n_reads, stream), "memset redo")) return PHMM_ERR_HIP;
     for (auto &c : b->classes) {
         ForwardParams p{};
         p.class_reads = c.identity ? nullptr : c.d_reads;
@@ -778,7 +798,16 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             cp.items = c.d_chain_items;
             cp.n_items = (uint32_t)c.chain_items.size();
             cp.streams = (uint32_t)c.streams;
-            e = launch_chain(c.L, c.K, cp, stream);
+            if (c.f32_first) {  // f32 sweep, then the f64 per-read kernel over exactly the reads it flagged
+                cp.redo = b->d_redo;
+                e = launch_chain_f32(c.K, cp, stream);
+                if (e == hipSuccess) {
+                    p.redo = b->d_redo;
+                    e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
+                }
+            } else {
+                e = launch_chain(c.L, c.K, cp, stream);
+            }
         } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
         } else {
@@ -854,15 +883,9 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                 st = PHMM_ERR_HIP;
                 break;
             }
-            // small arrays ride in the single mirror copy; large ones go straight from the caller's memory
-            // (the chunked path keeps every array below this limit so that its copies are truly asynchronous)
-            if (bytes > kDirectCopyBytes) {
-                if (st == PHMM_OK && !hip_ok(h, hipMemcpyAsync(A.dev + off, src[i], bytes, hipMemcpyHostToDevice, h->S()),
-                                             "H2D payload"))
-                    st = PHMM_ERR_HIP;
-            } else if (bytes) {
-                memcpy(A.host + off, src[i], bytes);
-            }
+            // everything rides in the single copy of the pinned mirror (the chunked path keeps every array of a
+            // chunk at or below kChunkBytes so that staging chunk i+1 overlaps the kernels of chunk i)
+            if (bytes) memcpy(A.host + off, src[i], bytes);
             d[i] = (const uint8_t *)(A.dev + off);
         }
         const size_t in_bytes = align_up(A.used, 256);
@@ -920,7 +943,7 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     if (g0 >= n_regions) return false;
     uint32_t g1 = g0 + 1;
     const size_t base_r = read_off[region_read_off[g0]];
-    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kDirectCopyBytes) ++g1;
+    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kChunkBytes) ++g1;
     c.g0 = g0;
     c.g1 = g1;
     c.r0 = region_read_off[g0];
@@ -983,7 +1006,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     }
     const uint32_t n_reads = region_read_off[n_regions];
     // ---- small / medium batch: one shot ------------------------------------------------------------
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kDirectCopyBytes || getenv("PHMM_NO_PIPELINE")) {
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kChunkBytes || getenv("PHMM_NO_PIPELINE")) {
         h->slot = 0;
         PendingCompute p;
         int st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
@@ -1203,7 +1226,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     }
     const uint32_t n_reads = region_read_off[n_regions];
     // ---- small / medium batch: one shot ------------------------------------------------------------
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kDirectCopyBytes || !region_hap_off || !hap_off || !out_off ||
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kChunkBytes || !region_hap_off || !hap_off || !out_off ||
         getenv("PHMM_NO_PIPELINE")) {
         h->slot = 0;
         PendingEngine p;

@@ -35,6 +35,7 @@ struct ForwardParams {
     double initial_condition;        // 2^1020
     double initial_condition_log10;  // log10(2^1020), host libm
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
+    const uint8_t *redo;             // not null: only reads with redo[r] != 0 are computed (f64 pass of the f32-first mode)
     uint32_t cnd_select;             // 1: v_cndmask prior select (launches with < 2 waves per SIMD, K <= PHMM_CND_MAX_K)
     uint32_t *status;                // device status word (bit0: positive result)
 };
@@ -63,10 +64,12 @@ struct ChainParams {
     ForwardParams f;
     const ChainItem *items;
     uint32_t n_items;
+    uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
     uint32_t streams;  // 16 lanes per pair only: the run of reads is split into 1, 2 or 4 sub-runs swept side by side,
                        // each on 4/streams haplotype slots (ChainItem::quad then counts groups of 4/streams haplotypes)
 };
 hipError_t launch_chain(int L, int K, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
+hipError_t launch_chain_f32(int K, const ChainParams &p, hipStream_t stream);     // phmm_chain32_kernels.hip, 16 lanes
 int chain_max_k();  // largest instantiated K
 
 // ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
     const uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= p.n_items) return;  // wave-uniform
     const uint32_t r = p.class_reads ? p.class_reads[item] : item;
+    if (p.redo && p.redo[r] == 0) return;  // f32-first mode: this launch only redoes the flagged reads (wave-uniform)
     const uint32_t reg = p.read_region[r];
     const uint32_t ro = p.read_off[r];
     const int R = (int)(p.read_off[r + 1] - ro);

@@ -91,9 +91,11 @@ class DevicePlan:
 class HipPairHMMEngine:
     """phmm_create / phmm_destroy.  Raises if there is no HIP device (no CPU fallback)."""
 
-    def __init__(self, device_id=0, do_not_use_tristate_correction=False):
+    def __init__(self, device_id=0, do_not_use_tristate_correction=False, f32_first=False):
         self.lib = _lib.load()
         flags = _lib.PHMM_FLAG_NO_TRISTATE if do_not_use_tristate_correction else 0
+        if f32_first:  # opt-in, see PHMM_FLAG_F32_FIRST in include/phmm.h
+            flags |= _lib.PHMM_FLAG_F32_FIRST
         self._h = self.lib.phmm_create(int(device_id), flags)
         if not self._h:
             raise PhmmError(_lib.PHMM_ERR_NO_DEVICE, self.lib.phmm_last_error(None).decode())

@@ -325,6 +325,25 @@ def test_config5_stress_shape(hip_engine):
     _close(np.concatenate(rows), want)
 
 
+def test_host_path_size_classes(hip_engine):
+    """phmm_compute stages small batches in one shot and cuts large ones into pipelined chunks (per-array limit
+    4 MB, one shot up to 8 MB): every size class, and the one-shot path forced on a large batch, against the oracle
+    and against each other."""
+    b = synthetic.config2(600, seed=41)      # 11.5 MB per per-base array: three chunks
+    chunked = hip_engine.compute(b)
+    os.environ["PHMM_NO_PIPELINE"] = "1"
+    try:
+        one_shot = hip_engine.compute(b)     # the same batch in one shot (arrays above the chunk limit)
+    finally:
+        os.environ.pop("PHMM_NO_PIPELINE", None)
+    _close(one_shot, chunked, tol=1e-12)     # chunks plan their own run lengths: last-row summation order only
+    _close(chunked[:int(b.out_off[3])], oracle.compute_batch(b.region_slice(0, 3).as_dict(), n_threads=8))
+    for n in (40, 300):                      # 0.8 MB; 5.8 MB per array (one shot, above the chunk limit)
+        sub = b.region_slice(100, 100 + n)
+        got = hip_engine.compute(sub)
+        _close(got, chunked[int(b.out_off[100]):int(b.out_off[100 + n])], tol=1e-12)
+
+
 def test_split_phase_api_on_a_torch_stream(hip_engine):
     import torch
     b = synthetic.config2(8, seed=3)
