@@ -80,7 +80,7 @@ __device__ int repetitions(const uint8_t *s, int u, int len, int lo, int tl, boo
 // exact test, from LDS, only for the ~6 % of lengths that pass it.  Positions outside the read never compare equal
 // (the screen uses distinct sentinels, the exact test a range check), which is what the reference's bounds do.
 // The exact, data-dependent count runs only at positions that really sit in a tandem repeat.  Same results as the
-// plain loops (tests/test_engine_oracle.py pins the oracle to them, tests/test_engine_hip.py this kernel to the oracle).
+// plain loops (the GPU parity tests of the engine-level call pin this kernel to a CPU restatement of them).
 __device__ int tandem_repeat_length(const uint8_t *s, int n, int offset) {
     constexpr int W = MAX_STR_UNIT_LENGTH + 2;
     uint32_t wb[W], wf[W];  // wb[d] = s[offset - d], wf[d] = s[offset + 1 + d]
