@@ -207,6 +207,30 @@ def main():
                   "kernel": p1.dominant_kernel, "note": "one region per launch, back-to-back launches on one stream"}
         p1.close()
 
+    f32_row = None
+    if rank == 0 and not a.main_only:  # the opt-in PHMM_FLAG_F32_FIRST mode on the same resident batch (never `value`)
+        e32 = HipPairHMMEngine(dev_index, f32_first=True)
+        p32 = e32.plan(batch)
+        out32 = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
+        p32.bind_torch(tens, out32)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                p32.launch(sh)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(a.steps):
+                p32.launch(sh)
+            e1.record(stream)
+            stream.synchronize()
+        p32.status()
+        ms32 = e0.elapsed_time(e1) / a.steps
+        f32_row = {"value": round(p32.cells / ms32 / 1e6, 2), "unit": "GCUPS", "ms_per_step": round(ms32, 4),
+                   "kernel": p32.dominant_kernel, "dtype": "f32 first, f64 redo of what f32 cannot be trusted with",
+                   "max_abs_diff_vs_f64": float((out32 - out).abs().max().item()), "tolerance": 1e-5,
+                   "note": "opt-in flag of phmm_create, what the reference's vector arm (gkl) does; default and `value` are f64"}
+        p32.close()
+        e32.close()
+
     engine_row = None
     if rank == 0 and not a.main_only:  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
         import ctypes as C
@@ -282,6 +306,7 @@ def main():
                 "note": "peak = 2.4 GHz / 4 clk; same_mix_ubench = the 7-op cell body alone at 2 waves/SIMD on the whole "
                         "chip (tools/ubench/issue.hip: 4.76 clk per instruction at the 2.3 GHz the chip sustains)"}
         line["single_region"] = single
+        line["f32_first"] = f32_row
         line["engine_call"] = engine_row
         if world == 1 and not a.no_cpu_baseline and not a.main_only:
             line["cpu_baseline"] = cpu_baseline(batch)

@@ -15,6 +15,8 @@ alphan = np.frombuffer(b"ACGTN", np.uint8)
 from bench import usable_cores
 cores = usable_cores()  # affinity capped by the cgroup CPU quota: more oracle threads only oversubscribe
 eng = HipPairHMMEngine(0)
+eng32 = HipPairHMMEngine(0, f32_first=True)  # opt-in mode: same batches, gate 1e-5 (north_star) instead of 1e-9
+worst32 = 0.0
 t_end = time.time() + budget
 worst, n_batches, n_pairs, n_cells = 0.0, 0, 0, 0
 kinds = {}
@@ -82,8 +84,23 @@ while time.time() < t_end:
             d = float(np.max(np.abs(got[~inf] - want[~inf])))
             worst = max(worst, d)
             assert d <= 1e-9, (kind, d)
+    # f32-first mode, chained kernel forced so that the f32 sweep (and its f64 redo) really runs on these small batches
+    os.environ.update({"PHMM_FORCE_CHAIN": "4", "PHMM_FORCE_L": "16"})
+    try:
+        got = eng32.compute(batch)
+    finally:
+        os.environ.pop("PHMM_FORCE_CHAIN", None)
+        os.environ.pop("PHMM_FORCE_L", None)
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf), (kind, "f32 first")
+    assert not np.isnan(got).any(), (kind, "f32 first")
+    if (~inf).any():
+        d = float(np.max(np.abs(got[~inf] - want[~inf])))
+        worst32 = max(worst32, d)
+        assert d <= 1e-5, (kind, "f32 first", d)
     n_batches += 1
     n_pairs += batch.n_out
     n_cells += batch.cells()
     kinds[kind] = kinds.get(kind, 0) + 1
-print("soak ok: %d batches, %d pairs, %.3g cells, worst |hip - oracle| = %.3g, kinds %s" % (n_batches, n_pairs, n_cells, worst, kinds))
+print("soak ok: %d batches, %d pairs, %.3g cells, worst |hip - oracle| = %.3g (f32-first mode: %.3g), kinds %s"
+      % (n_batches, n_pairs, n_cells, worst, worst32, kinds))
