@@ -5,8 +5,8 @@
 // This file is that scheme for the chained sweep of phmm_chain_kernels.hip (16 lanes per pair):
 //   * same stream-of-rows design, same folded 7-instruction cell, state and row constants in f32 (the constants are
 //     still derived in f64 from the f64 tables and rounded once when a row record is written);
-//   * half the registers and a 36-byte row record: four waves per SIMD instead of two, and the f32 form of the cell
-//     issues at ~3 clk per instruction instead of ~4.7 (tools/ubench/issue.hip);
+//   * half the state registers and a 36-byte row record: three waves per SIMD instead of two (152 VGPRs at K = 19),
+//     and the f32 form of the cell issues at ~3 clk per instruction instead of ~4.7 (tools/ubench/issue.hip);
 //   * every haplotype starts from D(0,j) = 2^100; a pair whose scaled row sum comes out below 2^-60 (or not finite,
 //     or whose log10 would be positive), i.e. likelihood x haplotype length < 2^-160 ~ 7e-49, is not trusted (every
 //     term that matters for a larger sum is >= 2^-84, far inside the f32 range): the kernel sets redo[read] and the host
