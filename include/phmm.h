@@ -49,7 +49,7 @@ extern "C" {
 #define PHMM_FLAG_NO_TRISTATE 1u /* PairHMM::do_not_use_tristate_correction (pair_hmm.rs:189) */
 #define PHMM_FLAG_F32_FIRST 2u   /* opt-in: what the reference's vector arm does (gkl, called at pair_hmm.rs:345-375):
                                   * large batches are swept in f32 first and every read whose result is too small to
-                                  * trust in f32 (< ~7e-49 / haplotype length), or that needs the general path, is
+                                  * trust in f32 (< ~1e-59 / haplotype length), or that needs the general path, is
                                   * recomputed in f64.  Results of the f32 pairs differ from the f64 path by f32
                                   * rounding (<= 2e-6 in log10 measured, the reference's gate is 1e-5); default OFF:
                                   * everything in f64. */

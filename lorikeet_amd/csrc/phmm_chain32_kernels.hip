@@ -7,9 +7,10 @@
 //     still derived in f64 from the f64 tables and rounded once when a row record is written);
 //   * half the state registers and a 36-byte row record: three waves per SIMD instead of two (152 VGPRs at K = 19),
 //     and the f32 form of the cell issues at ~3 clk per instruction instead of ~4.7 (tools/ubench/issue.hip);
-//   * every haplotype starts from D(0,j) = 2^100; a pair whose scaled row sum comes out below 2^-60 (or not finite,
-//     or whose log10 would be positive), i.e. likelihood x haplotype length < 2^-160 ~ 7e-49, is not trusted (every
-//     term that matters for a larger sum is >= 2^-84, far inside the f32 range): the kernel sets redo[read] and the host
+//   * every haplotype starts from D(0,j) = 2^100; a pair whose scaled row sum comes out below 2^-96 (or not finite,
+//     or whose log10 would be positive), i.e. likelihood x haplotype length < 2^-196 ~ 1e-59, is not trusted (every
+//     term that matters for a larger sum is >= 2^-120, still a normal f32; gkl draws its line at a scaled 1e-28 under
+//     2^120, i.e. ~1e-64): the kernel sets redo[read] and the host
 //     enqueues the f64 per-read kernel (phmm_forward<16,K>) right behind it, which recomputes exactly the flagged
 //     reads -- all their haplotypes -- and overwrites their results;
 //   * runs that need the general path (a haplotype with 'N', a gcp == 0, a base quality 0) are flagged wholesale
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainPar
                 if (k == ek) sum = (Dp[k] + Mp[k]) + Ip[k];
             // too small (or not a number) to trust in f32: the f64 kernel behind this one redoes the read
             const double v = log10((double)sum) - log10_scale;
-            if (!(sum >= 0x1p-60f && sum < __builtin_huge_valf()) || !(v <= 0.0)) cp.redo[r] = 1;
+            if (!(sum >= 0x1p-96f && sum < __builtin_huge_valf()) || !(v <= 0.0)) cp.redo[r] = 1;
             p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
         }
     };

@@ -13,7 +13,7 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 TOL_F32 = 1e-5      # north_star / the reference's own gate for its vector path
-F32_TRUST = -45.0   # log10: pairs above this are comfortably inside the f32 trust range (kernel: L*H >= 2^-160)
+F32_TRUST = -50.0   # log10: pairs above this are comfortably inside the f32 trust range (kernel: L*H >= 2^-196 ~ 1e-59)
 
 
 @pytest.fixture(scope="module")
@@ -104,7 +104,7 @@ def test_what_f32_cannot_be_trusted_with_is_redone_in_f64(engines):
         os.environ.pop("PHMM_FORCE_CHAIN", None)
     m = r64.reshape(-1, 4)
     m32 = r32.reshape(-1, 4)
-    redone = (m.min(axis=1) < F32_TRUST - 10)          # reads with a pair far below the trust range are redone entirely
+    redone = (m.min(axis=1) < F32_TRUST - 25)          # reads with a pair far below the trust range are redone entirely
     assert redone.sum() > 15000
     assert np.array_equal(m32[redone], per_read[redone])  # ... and are that kernel's f64 results, bit for bit
     assert np.max(np.abs(r32 - r64)) <= TOL_F32
