@@ -48,9 +48,13 @@ __device__ __forceinline__ float from_left_inject32(float v, float inject) {  //
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inject), __float_as_int(v), 0x111, 0xf, 0xf, false));
 }
 
-// One read row for the K columns of a lane, f32, every register updated in place.  Same cell, same order as
-// row_update<K, ROW_FAST_EXEC> (phmm_device.hpp):
-//   M~(k)  = D'(k-1)*dDp + I^(k-1);  M~(k) += M~(k-1)*mm;  EXEC &= (x != y_k);  M~(k) *= px;  EXEC = all
+// One read row for the K columns of a lane, f32, every register updated in place.  Same cell, same fixed order as
+// row_update<K, ROW_FAST_EXEC> (phmm_device.hpp) -- the compiler's own schedule of this loop is 1.75x slower -- except
+// for the prior select: a 32-bit value needs only ONE v_cndmask, and compare + select + multiply (three plain
+// instructions, ~2 clk each) beat the EXEC-masked multiply, whose EXEC round trip costs the f32 cell more than it saves
+// (tools/ubench/issue.hip: 17 vs 23 clk per cell at two waves; +5 % in the kernel) -- the opposite of the f64 case,
+// where the select needs two v_cndmask and the arithmetic is slower anyway.
+//   M~(k)  = D'(k-1)*dDp + I^(k-1);  M~(k) += M~(k-1)*mm;  M~(k) *= (x != y_k ? px : 1)
 //   I^(k-1) = I^(k-1)*gI + M~(k-1)*bI;                       then the serial chain D'(k) = D'(k-1)*dd + M~(k-1)
 // Haplotype columns: two 16-bit codes per dword for K > 21 (compared through an SDWA half-word select: keeps K = 22..25
 // at three waves per SIMD), one per dword otherwise.
@@ -64,34 +68,29 @@ __device__ __forceinline__ void row_update32(float (&Mp)[K], float (&Ip)[K], flo
         constexpr bool packed = K > PHMM_SDWA_MIN_K;
         const uint32_t yk = packed ? hc.y[k >> 1] : (uint32_t)hc.base(k);
         constexpr int km1 = k > 0 ? k - 1 : 0;
-#define PHMM_CELL32(CMPX)                                                                                           \
+        float sel;  // 1 where the bases match, px (= mismatch / match prior) where they do not
+#define PHMM_CELL32(CMP)                                                                                            \
     asm volatile("v_fma_f32 %[M], %[Dl], %[dDp], %[Il]\n\t"                                                        \
                  "v_fma_f32 %[M], %[Ml], %[mm], %[M]\n\t"                                                          \
-                 CMPX "\n\t"                                                                                     \
-                 "v_mul_f32 %[M], %[px], %[M]\n\t"                                                                 \
-                 "s_mov_b64 exec, -1\n\t"                                                                          \
+                 CMP "\n\t"                                                                                      \
+                 "v_cndmask_b32_e32 %[sel], 1.0, %[px], vcc\n\t"                                                   \
+                 "v_mul_f32 %[M], %[sel], %[M]\n\t"                                                                \
                  "v_mul_f32 %[Il], %[Il], %[gI]\n\t"                                                               \
                  "v_fma_f32 %[Il], %[Ml], %[bI], %[Il]"                                                             \
-                 : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1])                                                            \
+                 : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1]), [sel] "=&v"(sel)                                           \
                  : [Dl] "v"(Dp[km1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[km1]), [mm] "v"(c.mm), [x] "v"(c.x), [y] "v"(yk), \
                    [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI)                                                    \
                  : "vcc")
         if constexpr (k > 0 && packed && (k & 1)) {
-            PHMM_CELL32("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1");
+            PHMM_CELL32("v_cmp_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1");
         } else if constexpr (k > 0 && packed) {
-            PHMM_CELL32("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0");
+            PHMM_CELL32("v_cmp_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0");
         } else if constexpr (k > 0) {
-            PHMM_CELL32("v_cmpx_ne_u32_e32 vcc, %[x], %[y]");
+            PHMM_CELL32("v_cmp_ne_u32_e32 vcc, %[x], %[y]");
 #undef PHMM_CELL32
         } else {
-            float m = fmaf(plM, c.mm, fmaf(plD, c.dDp, plI));
-            asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
-                         "v_mul_f32 %0, %3, %0\n\t"
-                         "s_mov_b64 exec, -1"
-                         : "+v"(m)
-                         : "v"(c.x), "v"((uint32_t)hc.base(0)), "v"(c.px)
-                         : "vcc");
-            Mp[0] = m;
+            const float a0 = fmaf(plM, c.mm, fmaf(plD, c.dDp, plI));
+            Mp[0] = (c.x != (uint32_t)hc.base(0)) ? a0 * c.px : a0;
         }
     });
     float leftM = lM, leftD = lD;

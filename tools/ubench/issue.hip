@@ -78,6 +78,33 @@ __global__ __launch_bounds__(256) void k_cell_f32(double *out, int iters, double
     if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (double)(clock64() - c0); out[2] = (double)(wall_clock64() - w0); }
 }
 
+// f32 cell with a v_cndmask select (32-bit values need only one): cmp, cndmask, mul instead of cmpx, masked mul, s_mov
+__global__ __launch_bounds__(256) void k_cell_f32_cnd(double *out, int iters, double B, double C, uint32_t ux) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = (float)B, c = (float)C; uint32_t vy = threadIdx.x & 3;
+    const long long c0 = clock64(), w0 = wall_clock64();
+#define F_CELL32C(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n v_cmp_ne_u32_e32 vcc, %11, %12\n v_cndmask_b32_e32 v60, 1.0, %8, vcc\n v_mul_f32 %" #i ", %" #i ", v60\n v_mul_f32 %" #i ", %" #i ", %8\n v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+    for (int i = 0; i < iters; ++i)
+        asm volatile(OPS8(F_CELL32C) OPS8(F_CELL32C)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy) : "vcc", "v60");
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[0] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (double)(clock64() - c0); out[2] = (double)(wall_clock64() - w0); }
+}
+
+// f64 cell with a v_cndmask select: fma fma cmp cnd cnd mul mul fma fma (9 VALU, three of them 32-bit)
+__global__ __launch_bounds__(256) void k_cell_f64_cnd(double *out, int iters, double B, double C, uint32_t ux) {
+    DECL
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    for (int i = 0; i < iters; ++i) {
+#define F_C64(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n v_fma_f64 %" #i ", %" #i ", %8, %9\n v_cmp_ne_u32_e32 vcc, %11, %12\n v_cndmask_b32_e32 v60, 0, %13, vcc\n v_cndmask_b32_e32 v61, %15, %14, vcc\n v_mul_f64 %" #i ", %" #i ", v[60:61]\n v_mul_f64 %" #i ", %" #i ", %8\n v_fma_f64 %" #i ", %" #i ", %8, %9\n v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+        asm volatile(OPS8(F_C64) OPS8(F_C64)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy), "v"(blo), "v"(bhi), "v"(0x3ff00000u) : "vcc", "v60", "v61");
+    }
+    FIN
+}
+
 typedef void (*kern_t)(double *, int, double, double, uint32_t);
 static void run(const char *name, kern_t k, double valu_per_group) {
     double *out; hipMalloc(&out, 64);
@@ -116,5 +143,7 @@ int main() {
     run("same, groups of 4 (one restore)", (kern_t)k_smask4, 1);  // 16 VALU per iteration: count as 8+8 over 16 groups
     run("cmpx block + 1 independent fma", k_cmpx_il, 3);
     run("7-op cell body in f32", k_cell_f32, 7);
+    run("f32 cell, cndmask select (8 VALU)", k_cell_f32_cnd, 8);
+    run("f64 cell, cndmask select (9 VALU)", k_cell_f64_cnd, 9);
     return 0;
 }
