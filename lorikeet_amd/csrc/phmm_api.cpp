@@ -626,7 +626,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             void *mirror;
             c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
             up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
-            c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && c.L == 16;
+            c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && (c.L == 16 || c.L == 32);
             if (c.f32_first) {  // the f64 per-read kernel runs behind the f32 sweep over the reads it flags
                 if (!c.identity) {
                     void *mr;
@@ -636,7 +636,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 c.lds_rows = (uint32_t)align_up((size_t)c.max_r + 1, 8);
                 c.waves_per_block = 1;
                 c.lds_bytes = (size_t)c.lds_rows * kLdsRowBytes;
-                c.grid = dim3(n_items, 1, 1);
+                c.grid = dim3(n_items, 1, 1);  // one wave per read, it walks all haplotype groups
                 c.cnd_select = 0;
                 if (!b->d_redo) b->d_redo = (uint8_t *)dalloc(align_up((size_t)n_reads, 256), nullptr);
             }
@@ -800,7 +800,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             cp.streams = (uint32_t)c.streams;
             if (c.f32_first) {  // f32 sweep, then the f64 per-read kernel over exactly the reads it flagged
                 cp.redo = b->d_redo;
-                e = launch_chain_f32(c.K, cp, stream);
+                e = launch_chain_f32(c.L, c.K, cp, stream);
                 if (e == hipSuccess) {
                     p.redo = b->d_redo;
                     e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);

@@ -2,7 +2,8 @@
 //
 // The reference's production arm (gkl, Cargo.toml:42; called at src/pair_hmm/pair_hmm.rs:345-375) computes every
 // pair in f32 with a 2^120 scale first and recomputes it in f64 only when the f32 result is too small to trust.
-// This file is that scheme for the chained sweep of phmm_chain_kernels.hip (16 lanes per pair):
+// This file is that scheme for the chained sweep of phmm_chain_kernels.hip (16 or 32 lanes per pair, one compilation
+// unit each: -DPHMM_CHAIN32_L=16|32):
 //   * same stream-of-rows design, same folded 7-instruction cell, state and row constants in f32 (the constants are
 //     still derived in f64 from the f64 tables and rounded once when a row record is written);
 //   * half the state registers and a 36-byte row record: three waves per SIMD instead of two (152 VGPRs at K = 19),
@@ -23,7 +24,10 @@ namespace phmm {
 
 namespace {
 
-constexpr int CL = 16;                // lanes per pair
+#ifndef PHMM_CHAIN32_L
+#define PHMM_CHAIN32_L 16
+#endif
+constexpr int CL = PHMM_CHAIN32_L;    // lanes per pair
 constexpr int RING = 256;             // ring rows (power of two), shared by the streams; slot RING holds the neutral row
 constexpr int CHAIN_META = CHAIN_MAX_READS + 8;
 constexpr uint32_t X_PAD = 0x100u;    // base code of padding columns (>= H) and read-side code of the SUM row
@@ -41,12 +45,16 @@ __device__ __forceinline__ Row32 lds_row32(const Row32 *rows, int idx) {
     return *reinterpret_cast<const Row32 *>(reinterpret_cast<const unsigned char *>(rows) + __mul24(idx, (int)sizeof(Row32)));
 }
 
-__device__ __forceinline__ float from_left32(float v) {  // lane n <- lane n-1 inside each row of 16, 0 at the first lane
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+// lane n <- lane n-1 inside each group; the group's first lane gets `inject` (0 for M and I): through the DPP `old`
+// operand where the shift has no source lane (row_shr:1 for 16-lane groups, wave_shr:1 for lane 0), through a select
+// for lane 32 of two 32-lane groups
+__device__ __forceinline__ float from_left_inject32(float v, float inject, bool group_head) {
+    constexpr int ctrl = CL == 16 ? 0x111 : 0x138;
+    float r = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inject), __float_as_int(v), ctrl, 0xf, 0xf, false));
+    if constexpr (CL == 32) r = group_head ? inject : r;
+    return r;
 }
-__device__ __forceinline__ float from_left_inject32(float v, float inject) {  // ... `inject` at the first lane
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inject), __float_as_int(v), 0x111, 0xf, 0xf, false));
-}
+__device__ __forceinline__ float from_left32(float v, bool group_head) { return from_left_inject32(v, 0.f, group_head); }
 
 // One read row for the K columns of a lane, f32, every register updated in place.  Same cell, same fixed order as
 // row_update<K, ROW_FAST_EXEC> (phmm_device.hpp) -- the compiler's own schedule of this loop is 1.75x slower -- except
@@ -111,18 +119,20 @@ __device__ __forceinline__ Row32 neutral_row32() {
 
 }  // namespace
 
-template <int K>
+template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the units' kernel symbols apart)
 __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainParams cp) {
+    static_assert(CLT == CL, "one lanes-per-pair value per compilation unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ForwardParams &p = cp.f;
     const int lane = threadIdx.x;
     const int grp = lane / CL, l = lane % CL;
+    const bool group_head = (CL == 32) && (lane == 32);
     const ChainItem it = cp.items[blockIdx.x];
     const uint32_t reg = it.region;
     const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
-    const int S = (int)cp.streams;
+    const int S = (CL == 16) ? (int)cp.streams : 1;
     const int GS = (WAVE / CL) / S;
     const int sid = grp / GS;
     const int a = (int)it.quad * GS + grp % GS;
@@ -297,15 +307,15 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainPar
         }
         for (int t = t0; t < t1; t += 2) {
             cB = lds_row32(ring, my_ring + ((q + 1) & NM));
-            aM = from_left32(Mp[K - 1]);
-            aI = from_left32(Ip[K - 1]);
-            aD = from_left_inject32(Dp[K - 1], cA.inj);
+            aM = from_left32(Mp[K - 1], group_head);
+            aI = from_left32(Ip[K - 1], group_head);
+            aD = from_left_inject32(Dp[K - 1], cA.inj, group_head);
             row_update32<K>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc);
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
             cA = lds_row32(ring, my_ring + ((q + 2) & NM));
-            bM = from_left32(Mp[K - 1]);
-            bI = from_left32(Ip[K - 1]);
-            bD = from_left_inject32(Dp[K - 1], cB.inj);
+            bM = from_left32(Mp[K - 1], group_head);
+            bI = from_left32(Ip[K - 1], group_head);
+            bD = from_left_inject32(Dp[K - 1], cB.inj, group_head);
             row_update32<K>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc);
             if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
             q += 2;
@@ -318,17 +328,28 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainPar
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
     X(23) X(24) X(25)
 
-hipError_t launch_chain_f32(int K, const ChainParams &cp, hipStream_t stream) {
-    if (!cp.n_items) return hipSuccess;
+#define PHMM_C32_CAT2(a, b) a##b
+#define PHMM_C32_CAT(a, b) PHMM_C32_CAT2(a, b)
+#define PHMM_C32_LAUNCH PHMM_C32_CAT(launch_chain_f32_L, PHMM_CHAIN32_L)
+
+hipError_t PHMM_C32_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
     const size_t lds = (size_t)(RING + 1) * sizeof(Row32) + (CHAIN_META + 4) * sizeof(uint32_t);
-#define PHMM_CASE(KK)                                                                                   \
-    if (K == KK) {                                                                                      \
-        hipLaunchKernelGGL(phmm_forward_chain_f32<KK>, dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \
-        return hipGetLastError();                                                                       \
+#define PHMM_CASE(KK)                                                                                         \
+    if (K == KK) {                                                                                            \
+        hipLaunchKernelGGL((phmm_forward_chain_f32<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);   \
+        return hipGetLastError();                                                                             \
     }
     PHMM_CHAIN32_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
     return hipErrorInvalidValue;
 }
+
+#if PHMM_CHAIN32_L == 16
+hipError_t launch_chain_f32_L32(int K, const ChainParams &cp, hipStream_t stream);
+hipError_t launch_chain_f32(int L, int K, const ChainParams &cp, hipStream_t stream) {
+    if (!cp.n_items) return hipSuccess;
+    return L == 16 ? launch_chain_f32_L16(K, cp, stream) : L == 32 ? launch_chain_f32_L32(K, cp, stream) : hipErrorInvalidValue;
+}
+#endif
 
 }  // namespace phmm

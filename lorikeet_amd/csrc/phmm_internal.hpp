@@ -69,7 +69,7 @@ struct ChainParams {
                        // each on 4/streams haplotype slots (ChainItem::quad then counts groups of 4/streams haplotypes)
 };
 hipError_t launch_chain(int L, int K, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
-hipError_t launch_chain_f32(int K, const ChainParams &p, hipStream_t stream);     // phmm_chain32_kernels.hip, 16 lanes
+hipError_t launch_chain_f32(int L, int K, const ChainParams &p, hipStream_t stream);  // phmm_chain32_kernels.hip, L = 16 | 32
 int chain_max_k();  // largest instantiated K
 
 // ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------

@@ -39,6 +39,15 @@ def test_f32_first_on_synthetic_regions(engines):
     # mixed read lengths, and the stress shape (packed haplotype columns)
     for bb in (synthetic.config3(400, seed=32), synthetic.config5(8, seed=33)):
         assert np.max(np.abs(e32.compute(bb) - e64.compute(bb))) <= TOL_F32
+    # haplotypes of 600 columns: 32 lanes per pair
+    long_haps = synthetic.make_regions(400, 64, 8, 600, 150, seed=36)
+    plan = e32.plan(long_haps)
+    assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<32,"), plan.dominant_kernel
+    plan.close()
+    r32 = e32.compute(long_haps)
+    assert np.max(np.abs(r32 - e64.compute(long_haps))) <= TOL_F32
+    want = oracle.compute_batch(long_haps.region_slice(0, 4).as_dict(), n_threads=8)
+    assert np.max(np.abs(r32[:int(long_haps.out_off[4])] - want)) <= TOL_F32
 
 
 def test_f32_first_known_answer_vectors(engines, kat_rows):
@@ -50,12 +59,12 @@ def test_f32_first_known_answer_vectors(engines, kat_rows):
     regs = [([Read(r["read"], r["qual"], r["ins"], r["dele"], r["gcp"]) for r in rows], [hap]) for hap, rows in by_hap.items()]
     kb = RegionBatch.from_regions(regs)
     exp = np.array([r["expected"] for rows in by_hap.values() for r in rows])
-    for streams in ("1", "2", "4"):
-        os.environ.update({"PHMM_FORCE_CHAIN": "5", "PHMM_FORCE_L": "16", "PHMM_FORCE_STREAMS": streams})
+    for lanes, streams in (("16", "1"), ("16", "2"), ("16", "4"), ("32", "1")):
+        os.environ.update({"PHMM_FORCE_CHAIN": "5", "PHMM_FORCE_L": lanes, "PHMM_FORCE_STREAMS": streams})
         try:
             eng = HipPairHMMEngine(0, f32_first=True)
             plan = eng.plan(kb)
-            assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<16,"), plan.dominant_kernel
+            assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<%s," % lanes), plan.dominant_kernel
             plan.close()
             got = eng.compute(kb)
             eng.close()
