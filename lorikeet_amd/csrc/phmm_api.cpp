@@ -478,23 +478,23 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     std::vector<int> reg_L(n_regions), reg_K(n_regions);
     int min_L = 16;
     auto plan_shapes = [&]() {
-    min_L = 16;
-    for (;;) {
-        uint64_t waves = 0;
-        for (uint32_t g = 0; g < n_regions; ++g) {
-            const RegionShape &s = shape[g];
-            if (!s.nr || !s.nh) {
-                reg_L[g] = reg_K[g] = -1;  // nothing to do
-                continue;
+        min_L = 16;
+        for (;;) {
+            uint64_t waves = 0;
+            for (uint32_t g = 0; g < n_regions; ++g) {
+                const RegionShape &s = shape[g];
+                if (!s.nr || !s.nh) {
+                    reg_L[g] = reg_K[g] = -1;  // nothing to do
+                    continue;
+                }
+                pick(s, min_L, reg_L[g], reg_K[g]);
+                if (reg_L[g]) waves += (uint64_t)s.nr * ((s.nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
             }
-            pick(s, min_L, reg_L[g], reg_K[g]);
-            if (reg_L[g]) waves += (uint64_t)s.nr * ((s.nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
+            // one wave per SIMD is enough to stop trading lanes for waves (measured on 1, 2, 4 regions of config 2:
+            // <64,5> 41 us, <32,10> 54 us vs <64,5> 60 us, <16,19> 87 us vs <32,10> 88 us)
+            if (waves >= 1ull * kNumSimd || min_L == 64 || h->force_L) break;
+            min_L *= 2;
         }
-        // one wave per SIMD is enough to stop trading lanes for waves (measured on 1, 2, 4 regions of config 2:
-        // <64,5> 41 us, <32,10> 54 us vs <64,5> 60 us, <16,19> 87 us vs <32,10> 88 us)
-        if (waves >= 1ull * kNumSimd || min_L == 64 || h->force_L) break;
-        min_L *= 2;
-    }
     };
     plan_shapes();
 
