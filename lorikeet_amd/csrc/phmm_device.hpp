@@ -123,61 +123,79 @@ __device__ __forceinline__ void row_update(double (&Mp)[K], double (&Ip)[K], dou
                                            const uint64_t live = ~0ull) {
     const uint16_t x16 = (uint16_t)c.x;
     if constexpr (MODE == ROW_FAST_EXEC || MODE == ROW_FAST_EXEC_PRED) {
-        // Pre-scaled rows (pm == 1).  One cell = one asm statement in a fixed order that keeps
-        // independent work between consecutive EXEC writes (back-to-back v_cmpx blocks serialise the SIMD, see
-        // tools/ubench/issue.hip):
+        // Pre-scaled rows (pm == 1).  One cell = one asm statement in a fixed order:
         //   M~(k)  = D'(k-1)*dDp + I^(k-1);  M~(k) += M~(k-1)*mm          (row i-1 values of column k-1)
-        //   EXEC &= (x != y_k);  M~(k) *= px;  EXEC = live                (matching cells keep the value)
+        //   EXEC = mask_k;  M~(k) *= px;  EXEC = live                     (mask_k = lanes where x != y_k: matching
+        //                                                                  cells keep the value)
+        //   mask_(k-1) = (x != y_(k-1))                                   (v_cmp into an SGPR pair, one cell ahead)
         //   I^(k-1) = I^(k-1)*gI + M~(k-1)*bI                             (column k-1 moves on to row i)
-        // Columns right-to-left, so every register is updated in place; I^(K-1) is updated up front.
+        // Columns right-to-left, so every register is updated in place; I^(K-1) and mask_(K-1) come first.
+        // The mismatch mask is made by a plain v_cmp one cell AHEAD of its use and moved into EXEC by the scalar
+        // unit: a VALU instruction that writes EXEC itself (v_cmpx) stalls the SIMD for the round trip -- 4.8 vs 3.9
+        // clk per instruction for this very cell at two waves per SIMD (tools/ubench/issue.hip).  The compare runs
+        // under EXEC = live, so the mask never has a bit outside it.
         // The accumulating FMAs are written in the VOP3 form on purpose: the 2-address VOP2 v_fmac_f64_e32 issues
         // at ~60 % of the VOP3 rate on gfx950 (tools/ubench/banks.hip).
         const uint64_t restore = (MODE == ROW_FAST_EXEC) ? ~0ull : live;
+        // K > PHMM_SDWA_MIN_K: the haplotype base is compared straight out of its packed half-word (SDWA operand
+        // select) so that no unpacked copy per column lives in registers -- that is what lets K = 22..25 keep
+        // two waves per SIMD; smaller K can afford the copies and the plain compare issues a little faster.
+        constexpr bool packed = K > PHMM_SDWA_MIN_K;
+        constexpr bool pred = MODE == ROW_FAST_EXEC_PRED;
+        uint64_t mask;  // mismatch mask of the column about to be updated
+        {
+            constexpr int k = K - 1;
+            const uint32_t y = packed ? hc.y[k >> 1] : (uint32_t)hc.base(k);
+            if constexpr (packed && (k & 1))
+                asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:WORD_1" : "=s"(mask) : "v"(c.x), "v"(y));
+            else if constexpr (packed)
+                asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:WORD_0" : "=s"(mask) : "v"(c.x), "v"(y));
+            else
+                asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(mask) : "v"(c.x), "v"(y));
+        }
         Ip[K - 1] = fma(Mp[K - 1], c.bI, Ip[K - 1] * c.gI);
         static_for_down<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            // K > PHMM_SDWA_MIN_K: the haplotype base is compared straight out of its packed half-word (SDWA operand
-            // select) so that no unpacked copy per column lives in registers -- that is what lets K = 22..25 keep
-            // two waves per SIMD; smaller K can afford the copies and the plain compare issues a little faster.
-            constexpr bool packed = K > PHMM_SDWA_MIN_K;
-            const uint32_t y = packed ? hc.y[k >> 1] : (uint32_t)hc.base(k);
-#define PHMM_CELL(CMPX, RESTORE)                                                                                             \
+            constexpr int km1 = k > 0 ? k - 1 : 0;
+            const uint32_t yn = packed ? hc.y[km1 >> 1] : (uint32_t)hc.base(km1);  // the NEXT column to be updated
+            uint64_t next;
+#define PHMM_CELL(CMP, RESTORE)                                                                                      \
     asm volatile("v_fma_f64 %[M], %[Dl], %[dDp], %[Il]\n\t"                                                        \
                  "v_fma_f64 %[M], %[Ml], %[mm], %[M]\n\t"                                                          \
-                 CMPX "\n\t"                                                                                     \
+                 "s_mov_b64 exec, %[mk]\n\t"                                                                       \
                  "v_mul_f64 %[M], %[px], %[M]\n\t"                                                                 \
                  "s_mov_b64 exec, " RESTORE "\n\t"                                                                 \
+                 CMP "\n\t"                                                                                      \
                  "v_mul_f64 %[Il], %[Il], %[gI]\n\t"                                                               \
                  "v_fma_f64 %[Il], %[Ml], %[bI], %[Il]"                                                             \
-                 : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1])                                                            \
-                 : [Dl] "v"(Dp[km1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[km1]), [mm] "v"(c.mm), [x] "v"(c.x), [y] "v"(y), \
-                   [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI), [live] "s"(restore)                               \
-                 : "vcc")
-            constexpr int km1 = k > 0 ? k - 1 : 0;
-            constexpr bool pred = MODE == ROW_FAST_EXEC_PRED;
-            if constexpr (k > 0 && pred && packed && (k & 1)) {
-                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "%[live]");
+                 : [M] "=&v"(Mp[k]), [Il] "+v"(Ip[km1]), [mn] "=&s"(next)                                           \
+                 : [Dl] "v"(Dp[km1]), [dDp] "v"(c.dDp), [Ml] "v"(Mp[km1]), [mm] "v"(c.mm), [x] "v"(c.x), [y] "v"(yn), \
+                   [px] "v"(c.px), [gI] "v"(c.gI), [bI] "v"(c.bI), [live] "s"(restore), [mk] "s"(mask))
+            if constexpr (k > 0 && pred && packed && (km1 & 1)) {
+                PHMM_CELL("v_cmp_ne_u32_sdwa %[mn], %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "%[live]");
             } else if constexpr (k > 0 && pred && packed) {
-                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "%[live]");
+                PHMM_CELL("v_cmp_ne_u32_sdwa %[mn], %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "%[live]");
             } else if constexpr (k > 0 && pred) {
-                PHMM_CELL("v_cmpx_ne_u32_e32 vcc, %[x], %[y]", "%[live]");
-            } else if constexpr (k > 0 && packed && (k & 1)) {
-                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "-1");
+                PHMM_CELL("v_cmp_ne_u32_e64 %[mn], %[x], %[y]", "%[live]");
+            } else if constexpr (k > 0 && packed && (km1 & 1)) {
+                PHMM_CELL("v_cmp_ne_u32_sdwa %[mn], %[x], %[y] src0_sel:DWORD src1_sel:WORD_1", "-1");
             } else if constexpr (k > 0 && packed) {
-                PHMM_CELL("v_cmpx_ne_u32_sdwa vcc, %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "-1");
+                PHMM_CELL("v_cmp_ne_u32_sdwa %[mn], %[x], %[y] src0_sel:DWORD src1_sel:WORD_0", "-1");
             } else if constexpr (k > 0) {
-                PHMM_CELL("v_cmpx_ne_u32_e32 vcc, %[x], %[y]", "-1");
+                PHMM_CELL("v_cmp_ne_u32_e64 %[mn], %[x], %[y]", "-1");
 #undef PHMM_CELL
             } else {
+                (void)yn;
                 double m = fma(plM, c.mm, fma(plD, c.dDp, plI));
-                asm volatile("v_cmpx_ne_u32_e32 vcc, %1, %2\n\t"
-                             "v_mul_f64 %0, %3, %0\n\t"
-                             "s_mov_b64 exec, %4"
+                asm volatile("s_mov_b64 exec, %2\n\t"
+                             "v_mul_f64 %0, %1, %0\n\t"
+                             "s_mov_b64 exec, %3"
                              : "+v"(m)
-                             : "v"(c.x), "v"((uint32_t)hc.base(0)), "v"(c.px), "s"(restore)
-                             : "vcc");
+                             : "v"(c.px), "s"(mask), "s"(restore));
                 Mp[0] = m;
+                next = 0;
             }
+            mask = next;
         });
         double leftM = lM, leftD = lD;
 #pragma unroll

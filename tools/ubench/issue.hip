@@ -105,6 +105,20 @@ __global__ __launch_bounds__(256) void k_cell_f64_cnd(double *out, int iters, do
     FIN
 }
 
+// f64 cell with the compare hoisted one cell ahead into an SGPR pair (no VALU write of EXEC): per cell
+//   fma, fma, s_mov exec <- mask, masked mul, s_mov exec <- -1, v_cmp (next cell's mask), mul, fma
+__global__ __launch_bounds__(256) void k_cell_f64_hoist(double *out, int iters, double B, double C, uint32_t ux) {
+    DECL
+#define F_HA(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n v_fma_f64 %" #i ", %" #i ", %8, %9\n s_mov_b64 exec, s[20:21]\n v_mul_f64 %" #i ", %" #i ", %8\n s_mov_b64 exec, -1\n v_cmp_ne_u32_e64 s[22:23], %11, %12\n v_mul_f64 %" #i ", %" #i ", %8\n v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define F_HB(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n v_fma_f64 %" #i ", %" #i ", %8, %9\n s_mov_b64 exec, s[22:23]\n v_mul_f64 %" #i ", %" #i ", %8\n s_mov_b64 exec, -1\n v_cmp_ne_u32_e64 s[20:21], %11, %12\n v_mul_f64 %" #i ", %" #i ", %8\n v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+    asm volatile("v_cmp_ne_u32_e64 s[20:21], %0, %1" : : "s"(ux), "v"(vy) : "s20", "s21");
+    for (int i = 0; i < iters; ++i)
+        asm volatile(F_HA(0) F_HB(1) F_HA(2) F_HB(3) F_HA(4) F_HB(5) F_HA(6) F_HB(7) F_HA(0) F_HB(1) F_HA(2) F_HB(3) F_HA(4) F_HB(5) F_HA(6) F_HB(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy) : "vcc", "s20", "s21", "s22", "s23");
+    FIN
+}
+
 typedef void (*kern_t)(double *, int, double, double, uint32_t);
 static void run(const char *name, kern_t k, double valu_per_group) {
     double *out; hipMalloc(&out, 64);
@@ -145,5 +159,6 @@ int main() {
     run("7-op cell body in f32", k_cell_f32, 7);
     run("f32 cell, cndmask select (8 VALU)", k_cell_f32_cnd, 8);
     run("f64 cell, cndmask select (9 VALU)", k_cell_f64_cnd, 9);
+    run("f64 cell, hoisted v_cmp -> SGPR mask (7 VALU)", k_cell_f64_hoist, 7);
     return 0;
 }
