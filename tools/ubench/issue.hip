@@ -119,6 +119,25 @@ __global__ __launch_bounds__(256) void k_cell_f64_hoist(double *out, int iters, 
     FIN
 }
 
+// as above, but the masked multiplies of four cells are done back to back (four SGPR masks, ONE exec restore)
+__global__ __launch_bounds__(256) void k_cell_f64_hoist4(double *out, int iters, double B, double C, uint32_t ux) {
+    DECL
+#define F_P1(i, m) "v_fma_f64 %" #i ", %" #i ", %8, %9\n v_fma_f64 %" #i ", %" #i ", %8, %9\n v_cmp_ne_u32_e64 " m ", %11, %12\n v_mul_f64 %" #i ", %" #i ", %8\n v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define F_P2(i, m) "s_mov_b64 exec, " m "\n v_mul_f64 %" #i ", %" #i ", %8\n"
+    for (int i = 0; i < iters; ++i)
+        asm volatile(F_P1(0, "s[20:21]") F_P1(1, "s[22:23]") F_P1(2, "s[24:25]") F_P1(3, "s[26:27]")
+                     F_P2(0, "s[20:21]") F_P2(1, "s[22:23]") F_P2(2, "s[24:25]") F_P2(3, "s[26:27]") "s_mov_b64 exec, -1\n"
+                     F_P1(4, "s[20:21]") F_P1(5, "s[22:23]") F_P1(6, "s[24:25]") F_P1(7, "s[26:27]")
+                     F_P2(4, "s[20:21]") F_P2(5, "s[22:23]") F_P2(6, "s[24:25]") F_P2(7, "s[26:27]") "s_mov_b64 exec, -1\n"
+                     F_P1(0, "s[20:21]") F_P1(1, "s[22:23]") F_P1(2, "s[24:25]") F_P1(3, "s[26:27]")
+                     F_P2(0, "s[20:21]") F_P2(1, "s[22:23]") F_P2(2, "s[24:25]") F_P2(3, "s[26:27]") "s_mov_b64 exec, -1\n"
+                     F_P1(4, "s[20:21]") F_P1(5, "s[22:23]") F_P1(6, "s[24:25]") F_P1(7, "s[26:27]")
+                     F_P2(4, "s[20:21]") F_P2(5, "s[22:23]") F_P2(6, "s[24:25]") F_P2(7, "s[26:27]") "s_mov_b64 exec, -1\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy) : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    FIN
+}
+
 typedef void (*kern_t)(double *, int, double, double, uint32_t);
 static void run(const char *name, kern_t k, double valu_per_group) {
     double *out; hipMalloc(&out, 64);
@@ -160,5 +179,6 @@ int main() {
     run("f32 cell, cndmask select (8 VALU)", k_cell_f32_cnd, 8);
     run("f64 cell, cndmask select (9 VALU)", k_cell_f64_cnd, 9);
     run("f64 cell, hoisted v_cmp -> SGPR mask (7 VALU)", k_cell_f64_hoist, 7);
+    run("f64 cell, masks of 4 cells, one restore (7 VALU)", k_cell_f64_hoist4, 7);
     return 0;
 }
