@@ -138,6 +138,22 @@ __global__ __launch_bounds__(256) void k_cell_f64_hoist4(double *out, int iters,
     FIN
 }
 
+// f32 cell with the hoisted SGPR mask (the form that wins in f64)
+__global__ __launch_bounds__(256) void k_cell_f32_hoist(double *out, int iters, double B, double C, uint32_t ux) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = (float)B, c = (float)C; uint32_t vy = threadIdx.x & 3;
+    const long long c0 = clock64(), w0 = wall_clock64();
+#define G_HA(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n s_mov_b64 exec, s[20:21]\n v_mul_f32 %" #i ", %" #i ", %8\n s_mov_b64 exec, -1\n v_cmp_ne_u32_e64 s[22:23], %11, %12\n v_mul_f32 %" #i ", %" #i ", %8\n v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define G_HB(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n v_fma_f32 %" #i ", %" #i ", %8, %9\n s_mov_b64 exec, s[22:23]\n v_mul_f32 %" #i ", %" #i ", %8\n s_mov_b64 exec, -1\n v_cmp_ne_u32_e64 s[20:21], %11, %12\n v_mul_f32 %" #i ", %" #i ", %8\n v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+    asm volatile("v_cmp_ne_u32_e64 s[20:21], %0, %1" : : "s"(ux), "v"(vy) : "s20", "s21");
+    for (int i = 0; i < iters; ++i)
+        asm volatile(G_HA(0) G_HB(1) G_HA(2) G_HB(3) G_HA(4) G_HB(5) G_HA(6) G_HB(7) G_HA(0) G_HB(1) G_HA(2) G_HB(3) G_HA(4) G_HB(5) G_HA(6) G_HB(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c), "s"(B), "s"(ux), "v"(vy) : "vcc", "s20", "s21", "s22", "s23");
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[0] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (double)(clock64() - c0); out[2] = (double)(wall_clock64() - w0); }
+}
+
 typedef void (*kern_t)(double *, int, double, double, uint32_t);
 static void run(const char *name, kern_t k, double valu_per_group) {
     double *out; hipMalloc(&out, 64);
@@ -177,6 +193,7 @@ int main() {
     run("cmpx block + 1 independent fma", k_cmpx_il, 3);
     run("7-op cell body in f32", k_cell_f32, 7);
     run("f32 cell, cndmask select (8 VALU)", k_cell_f32_cnd, 8);
+    run("f32 cell, hoisted v_cmp -> SGPR mask (7 VALU)", k_cell_f32_hoist, 7);
     run("f64 cell, cndmask select (9 VALU)", k_cell_f64_cnd, 9);
     run("f64 cell, hoisted v_cmp -> SGPR mask (7 VALU)", k_cell_f64_hoist, 7);
     run("f64 cell, masks of 4 cells, one restore (7 VALU)", k_cell_f64_hoist4, 7);
