@@ -100,6 +100,32 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
                  const uint32_t *hap_off, const uint8_t *hap_bases, const uint64_t *out_off, double *out);
 
 /*
+ * Cross-thread batching: the same call as phmm_compute, split into submit + wait, and -- unlike every other entry
+ * point -- safe to call from many threads on ONE shared handle.  This is the call pattern of the reference as it
+ * stands: every rayon worker calls PairHMM::compute_likelihoods (pair_hmm.rs:345-375) with one region at a time
+ * (assembly_region_walker.rs:210-273).  A submission is only queued.  The first thread to wait while an engine lane is
+ * free leads one flush: it takes everything queued so far (its own region plus those of the workers that arrived in
+ * the meantime), computes it as one batch and hands every region's results to its owner; the other threads sleep until
+ * theirs are in.  No timer, no background thread: batches become as large as the number of workers that were waiting
+ * anyway, a lone caller pays nothing.  Results are those of phmm_compute on the same regions (every region is
+ * independent; which regions share a launch only selects the kernel shape, like batch size does in phmm_compute).
+ *
+ *   phmm_submit   same arrays as phmm_compute; ALL of them, inputs and `out`, stay caller-owned and must remain valid
+ *                 until phmm_wait(ticket) has returned.  Argument errors are reported here (nothing is queued).
+ *   phmm_wait     blocks until the ticket's results are in `out`; returns that submission's own status (a failure in
+ *                 another thread's region does not leak into it).  Each ticket must be waited for exactly once.
+ * phmm_last_error() after a failed phmm_submit / phmm_wait returns the calling thread's message.
+ */
+int phmm_submit(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases,
+                const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp,
+                const uint32_t *hap_off, const uint8_t *hap_bases, const uint64_t *out_off, double *out,
+                uint64_t *ticket);
+int phmm_wait(phmm_handle *h, uint64_t ticket);
+/* How many flushes have run on this handle and how many submissions they carried (batching achieved). */
+void phmm_submit_stats(phmm_handle *h, uint64_t *n_flushes, uint64_t *n_submissions);
+
+/*
  * Split-phase interface for device-resident data and for overlapping transfers with compute.
  * A batch owns the launch plan (regions binned into kernel shape classes) and the device copy
  * of the offset arrays; the byte payload and the output live in device memory that is either

@@ -11,14 +11,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <tuple>
+#include <unordered_map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "phmm_internal.hpp"
@@ -30,6 +35,10 @@ namespace {
 
 std::mutex g_err_mu;
 std::string g_create_err = "";
+// phmm_submit / phmm_wait are the only entry points several threads may call on one handle, so their messages are kept
+// per calling thread; every other entry point resets the pair.
+thread_local std::string tl_err;
+thread_local const phmm_handle *tl_err_h = nullptr;
 
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
@@ -97,6 +106,8 @@ struct phmm_handle {
     int err_code = PHMM_OK;  // status of the last failure (set together with err)
     int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
     int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
+    struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
+    std::once_flag comb_once;
 };
 
 struct phmm_batch {
@@ -192,6 +203,8 @@ double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max
 
 }  // namespace
 
+static void combiner_destroy(struct Combiner *c);  // phmm_submit / phmm_wait state, defined with them below
+
 extern "C" {
 
 int phmm_device_count(void) {
@@ -201,6 +214,7 @@ int phmm_device_count(void) {
 }
 
 const char *phmm_last_error(phmm_handle *h) {
+    if (h && tl_err_h == h) return tl_err.c_str();
     if (h) return h->err.c_str();
     std::lock_guard<std::mutex> g(g_err_mu);
     return g_create_err.c_str();
@@ -265,6 +279,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
 
 void phmm_destroy(phmm_handle *h) {
     if (!h) return;
+    if (h->comb) combiner_destroy(h->comb);
     (void)hipSetDevice(h->device);
     for (int i = 0; i < kSlots; ++i)
         if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
@@ -297,6 +312,32 @@ void phmm_batch_destroy(phmm_batch *b) {
     delete b;
 }
 
+// What every entry point checks before it touches the arrays; returns the message of the first violation or nullptr.
+static const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                                    const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off,
+                                    bool *tight_out) {
+    if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) return "phmm_batch_create: null offset array";
+    if (region_read_off[0] != 0 || region_hap_off[0] != 0 || read_off[0] != 0 || hap_off[0] != 0 || out_off[0] != 0)
+        return "phmm_batch_create: offset arrays must start at 0";
+    const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
+    bool tight = true;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if (region_read_off[g + 1] < region_read_off[g] || region_hap_off[g + 1] < region_hap_off[g])
+            return "phmm_batch_create: region offsets not monotonic";
+        const uint64_t need = (uint64_t)(region_read_off[g + 1] - region_read_off[g]) *
+                              (uint64_t)(region_hap_off[g + 1] - region_hap_off[g]);
+        if (out_off[g + 1] < out_off[g] || out_off[g + 1] - out_off[g] < need)
+            return "phmm_batch_create: out_off leaves too little room for a region (needs Nr*Nh doubles)";
+        if (out_off[g + 1] - out_off[g] != need) tight = false;
+    }
+    for (uint32_t r = 0; r < n_reads; ++r)
+        if (read_off[r + 1] < read_off[r]) return "phmm_batch_create: read_off not monotonic";
+    for (uint32_t a = 0; a < n_haps; ++a)
+        if (hap_off[a + 1] < hap_off[a]) return "phmm_batch_create: hap_off not monotonic";
+    if (tight_out) *tight_out = tight;
+    return nullptr;
+}
+
 static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
                                      const uint32_t *region_hap_off, const uint32_t *read_off,
                                      const uint32_t *hap_off, const uint64_t *out_off, bool use_arena,
@@ -304,45 +345,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     if (!h) return nullptr;
     h->err.clear();
     h->err_code = PHMM_OK;
-    if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
-        h->err = "phmm_batch_create: null offset array";
-        h->err_code = PHMM_ERR_INVALID_ARG;
-        return nullptr;
-    }
-    if (region_read_off[0] != 0 || region_hap_off[0] != 0 || read_off[0] != 0 || hap_off[0] != 0 || out_off[0] != 0) {
-        h->err = "phmm_batch_create: offset arrays must start at 0";
+    if (tl_err_h == h) tl_err_h = nullptr;
+    bool tight = true;
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, &tight)) {
+        h->err = bad;
         h->err_code = PHMM_ERR_INVALID_ARG;
         return nullptr;
     }
     const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
-    bool tight = true;
-    for (uint32_t g = 0; g < n_regions; ++g) {
-        if (region_read_off[g + 1] < region_read_off[g] || region_hap_off[g + 1] < region_hap_off[g]) {
-            h->err = "phmm_batch_create: region offsets not monotonic";
-            h->err_code = PHMM_ERR_INVALID_ARG;
-            return nullptr;
-        }
-        const uint64_t need = (uint64_t)(region_read_off[g + 1] - region_read_off[g]) *
-                              (uint64_t)(region_hap_off[g + 1] - region_hap_off[g]);
-        if (out_off[g + 1] < out_off[g] || out_off[g + 1] - out_off[g] < need) {
-            h->err = "phmm_batch_create: out_off leaves too little room for a region (needs Nr*Nh doubles)";
-            h->err_code = PHMM_ERR_INVALID_ARG;
-            return nullptr;
-        }
-        if (out_off[g + 1] - out_off[g] != need) tight = false;
-    }
-    for (uint32_t r = 0; r < n_reads; ++r)
-        if (read_off[r + 1] < read_off[r]) {
-            h->err = "phmm_batch_create: read_off not monotonic";
-            h->err_code = PHMM_ERR_INVALID_ARG;
-            return nullptr;
-        }
-    for (uint32_t a = 0; a < n_haps; ++a)
-        if (hap_off[a + 1] < hap_off[a]) {
-            h->err = "phmm_batch_create: hap_off not monotonic";
-            h->err_code = PHMM_ERR_INVALID_ARG;
-            return nullptr;
-        }
     if (hipSetDevice(h->device) != hipSuccess) {
         h->err = "hipSetDevice failed";
         return nullptr;
@@ -850,22 +860,33 @@ int phmm_batch_download(phmm_batch *b, double *out) {
 
 namespace {
 
+// Inputs of several independent submissions that one launch computes together (phmm_submit): part s contributes
+// read_bytes[s] bytes to each of the five per-base read arrays, hap_bytes[s] to the haplotype bases, and receives
+// n_out[s] results.
+struct Parts {
+    std::vector<const uint8_t *> src[6];
+    std::vector<size_t> read_bytes, hap_bytes;
+    std::vector<double *> out;
+    std::vector<uint64_t> n_out;
+};
+
 struct PendingCompute {
     phmm_batch *b = nullptr;
     int slot = 0;
     double *out = nullptr;
+    const Parts *parts = nullptr;  // non-null: results go to parts->out[s] instead of `out`
 };
 
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
 int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                     const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
                     const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
-                    const uint64_t *out_off, double *out, PendingCompute *pending) {
+                    const uint64_t *out_off, double *out, PendingCompute *pending, const Parts *parts = nullptr) {
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
     if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
-    if ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases) ||
-        (b->n_out && !out)) {
+    if (!parts && ((b->read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (b->hap_bytes && !hap_bases) ||
+                   (b->n_out && !out))) {
         h->err = "phmm_compute: null pointer";
         st = PHMM_ERR_INVALID_ARG;
     }
@@ -885,7 +906,16 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             }
             // everything rides in the single copy of the pinned mirror (the chunked path keeps every array of a
             // chunk at or below kChunkBytes so that staging chunk i+1 overlaps the kernels of chunk i)
-            if (bytes) memcpy(A.host + off, src[i], bytes);
+            if (parts) {
+                size_t o = off;
+                for (size_t s = 0; s < parts->src[i].size(); ++s) {
+                    const size_t n = i < 5 ? parts->read_bytes[s] : parts->hap_bytes[s];
+                    if (n) memcpy(A.host + o, parts->src[i][s], n);
+                    o += n;
+                }
+            } else if (bytes) {
+                memcpy(A.host + off, src[i], bytes);
+            }
             d[i] = (const uint8_t *)(A.dev + off);
         }
         const size_t in_bytes = align_up(A.used, 256);
@@ -925,6 +955,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     pending->b = b;
     pending->slot = h->slot;
     pending->out = out;
+    pending->parts = parts;
     return PHMM_OK;
 }
 
@@ -977,7 +1008,15 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + b->out_arena_off;
-        if (b->n_out) memcpy(p->out, hs + 256, b->n_out * 8);
+        if (p->parts) {
+            const char *src = hs + 256;
+            for (size_t s = 0; s < p->parts->out.size(); ++s) {
+                if (p->parts->n_out[s]) memcpy(p->parts->out[s], src, p->parts->n_out[s] * 8);
+                src += p->parts->n_out[s] * 8;
+            }
+        } else if (b->n_out) {
+            memcpy(p->out, hs + 256, b->n_out * 8);
+        }
         if (*(const uint32_t *)hs) {
             h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
             st = PHMM_ERR_POSITIVE_RESULT;
@@ -1042,6 +1081,233 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     h->slot = 0;
     if (trace) fprintf(stderr, "phmm_compute: %d chunks pipelined over %d slots, total %.1f us\n", n_chunks, kSlots, now() - t0);
     return st;
+}
+
+// ---- phmm_submit / phmm_wait: cross-thread batching -------------------------------------------------------------------
+// The reference calls the PairHMM once per region from every rayon worker (assembly_region_walker.rs:210-273), and one
+// region fills a quarter of the chip for a few tens of microseconds.  Here the workers share one handle: a submission is
+// only queued; the first thread that waits while a lane is free becomes the leader of one flush, takes everything queued
+// so far -- its own region and those of the threads that arrived meanwhile -- and computes it as ONE batch (one H2D copy,
+// one set of launches, one D2H copy), then hands every region's results to its owner.  Nobody waits on a timer: batches
+// grow exactly as large as the number of threads that were waiting anyway.  Two lanes (private engine handles) let the
+// next flush stage and copy while the previous one computes.
+struct Submission {
+    uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
+    const uint32_t *region_read_off = nullptr, *region_hap_off = nullptr, *read_off = nullptr, *hap_off = nullptr;
+    const uint8_t *payload[6] = {};
+    const uint64_t *out_off = nullptr;
+    double *out = nullptr;
+    size_t read_bytes = 0, hap_bytes = 0;
+    uint64_t n_out = 0;
+    enum State { QUEUED, RUNNING, DONE } state = QUEUED;
+    int status = PHMM_OK;
+    std::string err;
+};
+
+struct Combiner {
+    static constexpr int kMaxLanes = 4;
+    static constexpr size_t kMaxParts = 256;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<uint64_t> queue;  // tickets nobody has picked up yet, in submission order
+    std::unordered_map<uint64_t, Submission> live;  // until phmm_wait returns them (element addresses are stable)
+    uint64_t next_ticket = 1;
+    int n_lanes = 2;
+    phmm_handle *lane[kMaxLanes] = {};
+    bool lane_busy[kMaxLanes] = {};
+    uint64_t n_flushes = 0, n_parts = 0;  // statistics (phmm_submit_stats)
+    struct Scratch {  // per lane, reused between flushes
+        std::vector<uint32_t> rro, rho, ro, ho;
+        std::vector<uint64_t> oo;
+        Parts parts;
+    } scratch[kMaxLanes];
+};
+
+}  // extern "C"
+
+static void combiner_destroy(Combiner *c) {
+    for (int l = 0; l < Combiner::kMaxLanes; ++l)
+        if (c->lane[l]) phmm_destroy(c->lane[l]);
+    delete c;
+}
+
+extern "C" {
+
+namespace {
+
+int submission_alone(phmm_handle *lane, Submission *s) {
+    s->status = phmm_compute(lane, s->n_regions, s->region_read_off, s->region_hap_off, s->read_off, s->payload[0], s->payload[1],
+                             s->payload[2], s->payload[3], s->payload[4], s->hap_off, s->payload[5], s->out_off, s->out);
+    if (s->status != PHMM_OK) s->err = lane->err;
+    return s->status;
+}
+
+// One flush on one lane, outside the combiner's lock: `subs` are RUNNING and belong to this call.
+void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *> &subs) {
+    if (subs.size() == 1) {
+        submission_alone(lane, subs[0]);
+        return;
+    }
+    // concatenate the offset arrays (every submission starts at 0, so each is shifted by what came before it)
+    w.rro.assign(1, 0);
+    w.rho.assign(1, 0);
+    w.ro.assign(1, 0);
+    w.ho.assign(1, 0);
+    w.oo.assign(1, 0);
+    Parts &parts = w.parts;
+    for (int i = 0; i < 6; ++i) parts.src[i].clear();
+    parts.read_bytes.clear();
+    parts.hap_bytes.clear();
+    parts.out.clear();
+    parts.n_out.clear();
+    for (const Submission *s : subs) {
+        const uint32_t r0 = w.rro.back(), h0 = w.rho.back(), rb0 = w.ro.back(), hb0 = w.ho.back();
+        const uint64_t o0 = w.oo.back();
+        for (uint32_t g = 1; g <= s->n_regions; ++g) {
+            w.rro.push_back(r0 + s->region_read_off[g]);
+            w.rho.push_back(h0 + s->region_hap_off[g]);
+            w.oo.push_back(o0 + s->out_off[g]);
+        }
+        for (uint32_t r = 1; r <= s->n_reads; ++r) w.ro.push_back(rb0 + s->read_off[r]);
+        for (uint32_t a = 1; a <= s->n_haps; ++a) w.ho.push_back(hb0 + s->hap_off[a]);
+        for (int i = 0; i < 6; ++i) parts.src[i].push_back(s->payload[i]);
+        parts.read_bytes.push_back(s->read_bytes);
+        parts.hap_bytes.push_back(s->hap_bytes);
+        parts.out.push_back(s->out);
+        parts.n_out.push_back(s->n_out);
+    }
+    lane->slot = 0;
+    PendingCompute p;
+    int st = enqueue_compute(lane, (uint32_t)w.rro.size() - 1, w.rro.data(), w.rho.data(), w.ro.data(), nullptr, nullptr, nullptr,
+                             nullptr, nullptr, w.ho.data(), nullptr, w.oo.data(), nullptr, &p, &parts);
+    if (st == PHMM_OK) st = finish_compute(lane, &p);
+    if (st == PHMM_ERR_POSITIVE_RESULT) {
+        // some region of the batch tripped the reference's assert (pair_hmm.rs:478-481): find out whose it was, the
+        // other submitters get their (valid) results
+        for (Submission *s : subs) submission_alone(lane, s);
+        return;
+    }
+    for (Submission *s : subs) {
+        s->status = st;
+        if (st != PHMM_OK) s->err = lane->err;
+    }
+}
+
+int submit_fail(phmm_handle *h, int code, const char *msg) {
+    tl_err = msg;
+    tl_err_h = h;
+    return code;
+}
+
+}  // namespace
+
+int phmm_submit(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                const uint64_t *out_off, double *out, uint64_t *ticket) {
+    if (!h || !ticket) return PHMM_ERR_INVALID_ARG;
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr))
+        return submit_fail(h, PHMM_ERR_INVALID_ARG, bad);
+    Submission s;
+    s.n_regions = n_regions;
+    s.n_reads = region_read_off[n_regions];
+    s.n_haps = region_hap_off[n_regions];
+    s.region_read_off = region_read_off;
+    s.region_hap_off = region_hap_off;
+    s.read_off = read_off;
+    s.hap_off = hap_off;
+    s.out_off = out_off;
+    s.out = out;
+    s.read_bytes = read_off[s.n_reads];
+    s.hap_bytes = hap_off[s.n_haps];
+    s.n_out = out_off[n_regions];
+    const uint8_t *pl[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
+    for (int i = 0; i < 6; ++i) s.payload[i] = pl[i];
+    if ((s.read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (s.hap_bytes && !hap_bases) ||
+        (s.n_out && !out))
+        return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_submit: null pointer");
+    std::call_once(h->comb_once, [h] {
+        Combiner *c = new Combiner();
+        if (const char *e = getenv("PHMM_SUBMIT_LANES")) c->n_lanes = std::min(std::max(atoi(e), 1), (int)Combiner::kMaxLanes);
+        h->comb = c;
+    });
+    Combiner *c = h->comb;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int l = 0; l < c->n_lanes; ++l)
+        if (!c->lane[l]) {  // first submission: the lanes are engines of their own on the same device
+            c->lane[l] = phmm_create(h->device, h->flags);
+            if (!c->lane[l]) return submit_fail(h, PHMM_ERR_HIP, phmm_last_error(nullptr));
+        }
+    const uint64_t t = c->next_ticket++;
+    c->live.emplace(t, std::move(s));
+    c->queue.push_back(t);
+    *ticket = t;
+    return PHMM_OK;
+}
+
+int phmm_wait(phmm_handle *h, uint64_t ticket) {
+    if (!h) return PHMM_ERR_INVALID_ARG;
+    Combiner *c = h->comb;
+    if (!c) return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_wait: nothing was submitted on this handle");
+    std::unique_lock<std::mutex> lk(c->mu);
+    auto it = c->live.find(ticket);
+    if (it == c->live.end()) return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_wait: unknown ticket (already waited for?)");
+    Submission *me = &it->second;
+    std::vector<Submission *> subs;
+    for (;;) {
+        if (me->state == Submission::DONE) {
+            const int st = me->status;
+            if (st != PHMM_OK) {
+                tl_err = me->err;
+                tl_err_h = h;
+            } else if (tl_err_h == h) {
+                tl_err_h = nullptr;
+            }
+            c->live.erase(ticket);
+            return st;
+        }
+        int lane = -1;
+        if (me->state == Submission::QUEUED)
+            for (int l = 0; l < c->n_lanes && lane < 0; ++l)
+                if (!c->lane_busy[l]) lane = l;
+        if (lane < 0) {  // my region is in somebody's flush, or every lane is taken: the finishing leader wakes me
+            c->cv.wait(lk);
+            continue;
+        }
+        // Lead one flush: everything queued so far, in order, while it fits one staging pass.  (Measured and dropped:
+        // polling instead of sleeping, and a leader that keeps the lane for further flushes -- neither changes the
+        // rates of tools/threads_bench, the flush itself is what takes the time.)
+        subs.clear();
+        size_t bytes = 0;
+        while (!c->queue.empty() && subs.size() < Combiner::kMaxParts) {
+            Submission *s = &c->live.find(c->queue.front())->second;
+            if (!subs.empty() && bytes + s->read_bytes > kChunkBytes) break;
+            bytes += s->read_bytes;
+            s->state = Submission::RUNNING;
+            subs.push_back(s);
+            c->queue.pop_front();
+        }
+        c->lane_busy[lane] = true;
+        c->n_flushes += 1;
+        c->n_parts += subs.size();
+        lk.unlock();
+        run_flush(c->lane[lane], c->scratch[lane], subs);
+        lk.lock();
+        c->lane_busy[lane] = false;
+        for (Submission *s : subs) s->state = Submission::DONE;
+        c->cv.notify_all();
+    }
+}
+
+void phmm_submit_stats(phmm_handle *h, uint64_t *n_flushes, uint64_t *n_submissions) {
+    uint64_t f = 0, n = 0;
+    if (h && h->comb) {
+        std::lock_guard<std::mutex> lk(h->comb->mu);
+        f = h->comb->n_flushes;
+        n = h->comb->n_parts;
+    }
+    if (n_flushes) *n_flushes = f;
+    if (n_submissions) *n_submissions = n;
 }
 
 namespace {

@@ -120,6 +120,37 @@ class HipPairHMMEngine:
         self._check(self.lib.phmm_compute(self._h, *args, _p(out, _lib.f64p)))
         return out
 
+    @staticmethod
+    def _abi_args(batch):
+        args = getattr(batch, "_abi_args", None)
+        if args is None:
+            args = (batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
+                    _p(batch.read_off, _lib.u32p), _p(batch.read_bases, _lib.u8p), _p(batch.base_q, _lib.u8p),
+                    _p(batch.ins_q, _lib.u8p), _p(batch.del_q, _lib.u8p), _p(batch.gcp, _lib.u8p),
+                    _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(batch.out_off, _lib.u64p))
+            batch._abi_args = args
+        return args
+
+    def submit(self, batch: RegionBatch):
+        """phmm_submit: queue `batch` on this (shared, thread-safe for submit/wait) engine.  Returns (ticket, out);
+        `out` holds the results once wait(ticket) has returned.  The batch must stay alive until then."""
+        import ctypes as C
+        out = np.empty(batch.n_out, dtype=np.float64)
+        ticket = C.c_uint64(0)
+        self._check(self.lib.phmm_submit(self._h, *self._abi_args(batch), _p(out, _lib.f64p), C.byref(ticket)))
+        return ticket.value, out
+
+    def wait(self, ticket):
+        """phmm_wait: block until the submission's results are in its `out`; raises PhmmError with its own status."""
+        self._check(self.lib.phmm_wait(self._h, int(ticket)))
+
+    def submit_stats(self):
+        """(flushes run, submissions they carried) of phmm_submit / phmm_wait on this engine."""
+        import ctypes as C
+        f, n = C.c_uint64(0), C.c_uint64(0)
+        self.lib.phmm_submit_stats(self._h, C.byref(f), C.byref(n))
+        return f.value, n.value
+
     def plan(self, batch: RegionBatch):
         return DevicePlan(self, batch)
 

@@ -1,0 +1,146 @@
+"""phmm_submit / phmm_wait: the reference's call pattern -- every rayon worker calls PairHMM::compute_likelihoods with
+one region at a time (pair_hmm.rs:345-375 from assembly_region_walker.rs:210-273) -- served by ONE shared handle that
+computes whatever regions are waiting as one batch.  Every submission must get exactly its own results and its own
+status, whichever thread led the flush it travelled in."""
+import threading
+
+import numpy as np
+import pytest
+
+from lorikeet_amd import HipPairHMMEngine, PhmmError, synthetic
+from lorikeet_amd import _lib
+from lorikeet_amd.batch import Read, RegionBatch
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _regions(n, seed):
+    """n one-region batches of different shapes (reads x haplotypes, lengths), with the oracle's answer for each."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        b = synthetic.make_regions(1, int(rng.integers(1, 40)), int(rng.integers(1, 9)), int(rng.integers(120, 420)),
+                                   int(rng.integers(30, 120)), seed=seed * 1000 + i)
+        out.append((b, oracle.compute_batch(b.as_dict(), n_threads=4)))
+    return out
+
+
+def test_many_threads_share_one_handle():
+    eng = HipPairHMMEngine(0)
+    T, per_thread = 8, 12
+    work = [_regions(per_thread, 50 + t) for t in range(T)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for b, want in work[t]:
+                    ticket, out = eng.submit(b)
+                    eng.wait(ticket)
+                    d = float(np.max(np.abs(out - want)))
+                    assert d <= TOL, (t, d)
+        except Exception as e:  # surfaced in the main thread
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[0]
+    flushes, subs = eng.submit_stats()
+    assert subs == T * per_thread * 3
+    assert 1 <= flushes <= subs
+    eng.close()
+
+
+def test_one_thread_many_tickets_any_wait_order():
+    eng = HipPairHMMEngine(0)
+    items = _regions(9, 77)
+    tickets = [eng.submit(b) for b, _ in items]
+    # the first wait flushes everything queued; the others only collect
+    for i in (4, 0, 8, 1, 2, 3, 7, 6, 5):
+        eng.wait(tickets[i][0])
+        assert np.max(np.abs(tickets[i][1] - items[i][1])) <= TOL
+    flushes, subs = eng.submit_stats()
+    assert (flushes, subs) == (1, 9)
+    # the same regions through phmm_compute give the same numbers (which regions share a launch is invisible)
+    own = HipPairHMMEngine(0)
+    for (b, _), (_, out) in zip(items, tickets):
+        assert np.max(np.abs(own.compute(b) - out)) <= 1e-12
+    own.close()
+    with pytest.raises(PhmmError) as e:  # a ticket is good for one wait
+        eng.wait(tickets[0][0])
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "ticket" in str(e.value)
+    eng.close()
+
+
+def test_multi_region_and_large_submissions_mix():
+    """Submissions may hold many regions; one that is too large to share a staging pass is computed on its own."""
+    eng = HipPairHMMEngine(0)
+    small = [synthetic.config2(3, seed=5), synthetic.config3(2, seed=6)]
+    big = synthetic.config2(300, seed=7)  # 5.8 MB per per-base array: more than one combined staging pass takes
+    subs = [eng.submit(b) for b in (small[0], big, small[1])]
+    for t, _ in subs:
+        eng.wait(t)
+    own = HipPairHMMEngine(0)
+    for b, (_, out) in zip((small[0], big, small[1]), subs):
+        assert np.all(out <= 0.0)
+        assert np.max(np.abs(own.compute(b) - out)) <= 1e-12
+    want = oracle.compute_batch(small[1].as_dict(), n_threads=8)
+    assert np.max(np.abs(subs[2][1] - want)) <= TOL
+    own.close()
+    eng.close()
+
+
+def test_argument_errors_stay_with_their_submitter():
+    eng = HipPairHMMEngine(0)
+    good = _regions(3, 91)
+    t0, out0 = eng.submit(good[0][0])
+    bad = synthetic.make_regions(1, 4, 2, 100, 50, seed=1)
+    bad.read_off = bad.read_off.copy()
+    bad.read_off[2] = bad.read_off[1] - 1  # not monotonic
+    bad.__dict__.pop("_abi_args", None)
+    with pytest.raises(PhmmError) as e:
+        eng.submit(bad)
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "monotonic" in str(e.value)
+    t1, out1 = eng.submit(good[1][0])
+    eng.wait(t1)
+    eng.wait(t0)
+    assert np.max(np.abs(out0 - good[0][1])) <= TOL and np.max(np.abs(out1 - good[1][1])) <= TOL
+    # empty submissions (no regions / a region without reads) are legal, as in phmm_compute
+    empty = RegionBatch.from_regions([([], [np.frombuffer(b"ACGT", np.uint8)])])
+    t, out = eng.submit(empty)
+    eng.wait(t)
+    assert out.size == 0
+    eng.close()
+
+
+def test_positive_result_is_reported_to_its_owner_only():
+    """A region that trips the reference's `<= 0` assert (pair_hmm.rs:478-481; reachable with gap-open qualities below 3,
+    where the transitions out of the match state sum to more than one) fails for its submitter -- for the oracle as for
+    phmm_compute -- and the regions that shared its flush are served."""
+    hap = np.full(40, ord("A"), np.uint8)
+    n = 8
+    weird = RegionBatch.from_regions([([Read(hap[:n].copy(), np.full(n, 93), np.zeros(n, int), np.zeros(n, int), np.full(n, 10))],
+                                       [hap])])
+    with pytest.raises(AssertionError):
+        oracle.compute_batch(weird.as_dict(), n_threads=1)
+    own = HipPairHMMEngine(0)
+    with pytest.raises(PhmmError) as e:
+        own.compute(weird)
+    assert e.value.code == _lib.PHMM_ERR_POSITIVE_RESULT
+    own.close()
+    eng = HipPairHMMEngine(0)
+    good = _regions(4, 123)
+    tickets = [eng.submit(good[0][0]), eng.submit(weird), eng.submit(good[1][0]), eng.submit(good[2][0])]
+    with pytest.raises(PhmmError) as e:
+        eng.wait(tickets[1][0])
+    assert e.value.code == _lib.PHMM_ERR_POSITIVE_RESULT and "greater than 0.0" in str(e.value)
+    for i, g in ((0, 0), (2, 1), (3, 2)):
+        eng.wait(tickets[i][0])
+        assert np.max(np.abs(tickets[i][1] - good[g][1])) <= TOL
+    assert eng.submit_stats() == (1, 4)
+    eng.close()

@@ -1,0 +1,161 @@
+// Developer tool: the reference's call pattern without an interpreter in the way -- T host threads, ONE region per call
+// (host buffers, PCIe included), as rayon workers call PairHMM::compute_likelihoods (reference pair_hmm.rs:345-375 from
+// assembly_region_walker.rs:210-273).  Two ways to serve it through include/phmm.h:
+//   own     every thread has its own handle and calls phmm_compute
+//   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
+// usage: threads_bench [seconds per point] [Nr Nh R H]      (default 1.0 s, 128 8 150 300 = config 2)
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "../include/phmm.h"
+
+struct Region {
+    std::vector<uint32_t> rro, rho, ro, ho;
+    std::vector<uint64_t> oo;
+    std::vector<uint8_t> bases, q, iq, dq, gcp, haps;
+    std::vector<double> out;
+    uint64_t cells = 0;
+};
+
+static uint64_t rng_state;
+static uint32_t rnd() {  // splitmix64
+    uint64_t z = (rng_state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+
+static Region make_region(uint64_t seed, int nr, int nh, int R, int H) {
+    rng_state = seed;
+    Region g;
+    const char acgt[] = "ACGT";
+    std::vector<uint8_t> root(H);
+    for (auto &b : root) b = acgt[rnd() & 3];
+    g.ho.push_back(0);
+    for (int a = 0; a < nh; ++a) {
+        std::vector<uint8_t> h = root;
+        if (a)
+            for (int k = 0; k < 1 + (int)(rnd() % 3); ++k) h[rnd() % H] = acgt[rnd() & 3];
+        g.haps.insert(g.haps.end(), h.begin(), h.end());
+        g.ho.push_back((uint32_t)g.haps.size());
+    }
+    g.ro.push_back(0);
+    for (int r = 0; r < nr; ++r) {
+        const int a = rnd() % nh, s = rnd() % (H - R + 1);
+        for (int i = 0; i < R; ++i) {
+            uint8_t b = g.haps[(size_t)a * H + s + i];
+            if (rnd() % 100 == 0) b = acgt[rnd() & 3];
+            g.bases.push_back(b);
+            const uint32_t u = rnd() % 100;
+            g.q.push_back(u < 60 ? 37 : u < 75 ? 32 : u < 85 ? 27 : u < 93 ? 22 : 6);
+            g.iq.push_back(rnd() % 10 ? 40 : 30 + rnd() % 10);
+            g.dq.push_back(rnd() % 10 ? 40 : 30 + rnd() % 10);
+            g.gcp.push_back(10);
+        }
+        g.ro.push_back((uint32_t)g.bases.size());
+    }
+    g.rro = {0, (uint32_t)nr};
+    g.rho = {0, (uint32_t)nh};
+    g.oo = {0, (uint64_t)nr * nh};
+    g.out.assign((size_t)nr * nh, 0.0);
+    g.cells = (uint64_t)nr * R * (uint64_t)nh * H;
+    return g;
+}
+
+static int call_own(phmm_handle *h, Region &g) {
+    return phmm_compute(h, 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
+                        g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data());
+}
+
+static int call_shared(phmm_handle *h, Region &g) {
+    uint64_t t = 0;
+    int st = phmm_submit(h, 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
+                         g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data(), &t);
+    return st ? st : phmm_wait(h, t);
+}
+
+int main(int argc, char **argv) {
+    const double dur = argc > 1 ? atof(argv[1]) : 1.0;
+    const int nr = argc > 5 ? atoi(argv[2]) : 128, nh = argc > 5 ? atoi(argv[3]) : 8, R = argc > 5 ? atoi(argv[4]) : 150,
+              H = argc > 5 ? atoi(argv[5]) : 300;
+    if (phmm_device_count() < 1) {
+        fprintf(stderr, "no HIP device\n");
+        return 2;
+    }
+    printf("one region per call: %d reads x %d haplotypes, R=%d, H=%d (%.3g cells), %.1f s per point\n", nr, nh, R, H,
+           (double)nr * R * nh * H, dur);
+    std::vector<int> Ts = {1, 2, 4, 8, 16, 32, 64};
+    if (const char *e = getenv("TB_THREADS")) {  // e.g. TB_THREADS=4,8,16
+        Ts.clear();
+        for (const char *q = e; *q; q += (*q == ',')) {
+            Ts.push_back((int)strtol(q, (char **)&q, 10));
+            if (Ts.back() < 1) return 2;
+        }
+    }
+    const char *only = getenv("TB_MODE");  // "own" or "shared": just that one
+    for (int mode = 0; mode < 2; ++mode) {
+        if (only && only[0] != (mode == 0 ? 'o' : 's')) continue;
+        for (int T : Ts) {
+            std::vector<phmm_handle *> hs;
+            for (int i = 0; i < (mode == 0 ? T : 1); ++i) {
+                hs.push_back(phmm_create(0, 0));
+                if (!hs.back()) {
+                    fprintf(stderr, "phmm_create: %s\n", phmm_last_error(nullptr));
+                    return 2;
+                }
+            }
+            // every thread cycles through regions of its own (different data, same shape)
+            std::vector<std::vector<Region>> regs(T);
+            for (int t = 0; t < T; ++t)
+                for (int k = 0; k < 4; ++k) regs[t].push_back(make_region(1000 + 16 * t + k, nr, nh, R, H));
+            std::atomic<uint64_t> n_calls{0};
+            std::atomic<int> failed{0};
+            std::atomic<bool> go{false}, stop{false};
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    phmm_handle *h = hs[mode == 0 ? t : 0];
+                    for (int k = 0; k < 3; ++k)  // warm the arenas
+                        if ((mode == 0 ? call_own : call_shared)(h, regs[t][k])) failed = 1;
+                    while (!go.load()) std::this_thread::yield();
+                    uint64_t n = 0;
+                    for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
+                        if ((mode == 0 ? call_own : call_shared)(h, regs[t][k & 3])) {
+                            failed = 1;
+                            break;
+                        }
+                        ++n;
+                    }
+                    n_calls += n;
+                });
+            std::this_thread::sleep_for(std::chrono::milliseconds(200));
+            uint64_t f0 = 0, s0 = 0, f1 = 0, s1 = 0;
+            if (mode == 1) phmm_submit_stats(hs[0], &f0, &s0);
+            const auto t0 = std::chrono::steady_clock::now();
+            go = true;
+            std::this_thread::sleep_for(std::chrono::duration<double>(dur));
+            stop = true;
+            for (auto &x : th) x.join();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (mode == 1) phmm_submit_stats(hs[0], &f1, &s1);
+            if (failed) {
+                fprintf(stderr, "a call failed: %s\n", phmm_last_error(hs[0]));
+                return 1;
+            }
+            const double rate = n_calls / dt;
+            printf("%-6s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : "shared", T,
+                   rate, rate * regs[0][0].cells / 1e9, dt * T / (double)n_calls * 1e6);
+            if (mode == 1) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
+            printf("\n");
+            fflush(stdout);
+            for (auto *h : hs) phmm_destroy(h);
+        }
+    }
+    return 0;
+}
