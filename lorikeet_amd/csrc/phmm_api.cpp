@@ -19,6 +19,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <tuple>
 #include <unordered_map>
 #include <mutex>
@@ -89,6 +90,7 @@ struct Arena {
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
+
 
 struct phmm_handle {
     // Each slot is an independent (arena, stream) pair; single calls use slot 0, the chunked large-batch
@@ -882,6 +884,10 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                     const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
                     const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
                     const uint64_t *out_off, double *out, PendingCompute *pending, const Parts *parts = nullptr) {
+    static const bool trace = getenv("PHMM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
+    double t_plan = 0, t_stage = 0, t_h2d = 0, t_launch = 0;
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
     if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
@@ -891,6 +897,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         st = PHMM_ERR_INVALID_ARG;
     }
     Arena &A = h->A();
+    t_plan = now();
     if (st == PHMM_OK) {
         // payload into the arena mirror, then [status | out] last so that one copy each way suffices
         const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
@@ -928,6 +935,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             h->err = keep;
             return PHMM_ERR_HIP;
         }
+        t_stage = now();
         memset(A.host + in_bytes, 0, 256);  // status word
         b->d_status = (uint32_t *)(A.dev + in_bytes);
         double *d_out = (double *)(A.dev + in_bytes + 256);
@@ -938,8 +946,10 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             !hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->S()), "memset out"))
             st = PHMM_ERR_HIP;
         if (st == PHMM_OK) st = phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
+        t_h2d = now();
     }
     if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
+    t_launch = now();
     if (st == PHMM_OK &&
         !hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
                                   hipMemcpyDeviceToHost, h->S()),
@@ -952,6 +962,9 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         h->err = keep;
         return st;
     }
+    if (trace)
+        fprintf(stderr, "  enqueue %u regions: plan %.0f us, stage %.0f us, H2D enqueue %.0f us, launch %.0f us, D2H enqueue %.0f us\n",
+                n_regions, t_plan - t_0, t_stage - t_plan, t_h2d - t_stage, t_launch - t_h2d, now() - t_launch);
     pending->b = b;
     pending->slot = h->slot;
     pending->out = out;
@@ -962,6 +975,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
 // Regions [g0, g1) of a caller's batch with every offset array rebased to zero: what one pipelined chunk is made of.
 struct ChunkView {
     uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
+    uint32_t index = 0;  // how many chunks came before this one
     size_t read_byte0 = 0, hap_byte0 = 0;
     std::vector<uint32_t> rro, rho, ro, ho;
     std::vector<uint64_t> oo;
@@ -974,7 +988,10 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     if (g0 >= n_regions) return false;
     uint32_t g1 = g0 + 1;
     const size_t base_r = read_off[region_read_off[g0]];
-    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= kChunkBytes) ++g1;
+    // the first chunks are short so that the GPU starts early; staging of the following ones hides behind its kernels
+    c.index = g0 == 0 ? 0 : c.index + 1;
+    const size_t limit = c.index == 0 ? kChunkBytes / 4 : c.index == 1 ? kChunkBytes / 2 : kChunkBytes;
+    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= limit) ++g1;
     c.g0 = g0;
     c.g1 = g1;
     c.r0 = region_read_off[g0];
@@ -1116,6 +1133,7 @@ struct Combiner {
     phmm_handle *lane[kMaxLanes] = {};
     bool lane_busy[kMaxLanes] = {};
     uint64_t n_flushes = 0, n_parts = 0;  // statistics (phmm_submit_stats)
+    double flush_us = 0;  // time spent inside flushes (PHMM_TRACE prints the mean when the handle is destroyed)
     struct Scratch {  // per lane, reused between flushes
         std::vector<uint32_t> rro, rho, ro, ho;
         std::vector<uint64_t> oo;
@@ -1126,6 +1144,9 @@ struct Combiner {
 }  // extern "C"
 
 static void combiner_destroy(Combiner *c) {
+    if (getenv("PHMM_TRACE") && c->n_flushes)
+        fprintf(stderr, "phmm_submit: %llu flushes carried %llu submissions, mean flush %.1f us\n",
+                (unsigned long long)c->n_flushes, (unsigned long long)c->n_parts, c->flush_us / c->n_flushes);
     for (int l = 0; l < Combiner::kMaxLanes; ++l)
         if (c->lane[l]) phmm_destroy(c->lane[l]);
     delete c;
@@ -1290,9 +1311,12 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
         c->lane_busy[lane] = true;
         c->n_flushes += 1;
         c->n_parts += subs.size();
+        auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tb = nowus();
         lk.unlock();
         run_flush(c->lane[lane], c->scratch[lane], subs);
         lk.lock();
+        c->flush_us += nowus() - tb;
         c->lane_busy[lane] = false;
         for (Submission *s : subs) s->state = Submission::DONE;
         c->cv.notify_all();

@@ -3,7 +3,8 @@
 // assembly_region_walker.rs:210-273).  Two ways to serve it through include/phmm.h:
 //   own     every thread has its own handle and calls phmm_compute
 //   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
-// usage: threads_bench [seconds per point] [Nr Nh R H]      (default 1.0 s, 128 8 150 300 = config 2)
+// usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
+// env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -31,13 +32,20 @@ static uint32_t rnd() {  // splitmix64
     return (uint32_t)((z ^ (z >> 31)) >> 16);
 }
 
-static Region make_region(uint64_t seed, int nr, int nh, int R, int H) {
+// `per_call` regions of the same shape, as one call's arrays
+static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_call) {
     rng_state = seed;
     Region g;
     const char acgt[] = "ACGT";
+    g.ho.push_back(0);
+    g.ro.push_back(0);
+    g.rro.push_back(0);
+    g.rho.push_back(0);
+    g.oo.push_back(0);
+  for (int reg = 0; reg < per_call; ++reg) {
     std::vector<uint8_t> root(H);
     for (auto &b : root) b = acgt[rnd() & 3];
-    g.ho.push_back(0);
+    const size_t hap0 = g.haps.size();
     for (int a = 0; a < nh; ++a) {
         std::vector<uint8_t> h = root;
         if (a)
@@ -45,11 +53,10 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H) {
         g.haps.insert(g.haps.end(), h.begin(), h.end());
         g.ho.push_back((uint32_t)g.haps.size());
     }
-    g.ro.push_back(0);
     for (int r = 0; r < nr; ++r) {
         const int a = rnd() % nh, s = rnd() % (H - R + 1);
         for (int i = 0; i < R; ++i) {
-            uint8_t b = g.haps[(size_t)a * H + s + i];
+            uint8_t b = g.haps[hap0 + (size_t)a * H + s + i];
             if (rnd() % 100 == 0) b = acgt[rnd() & 3];
             g.bases.push_back(b);
             const uint32_t u = rnd() % 100;
@@ -60,22 +67,23 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H) {
         }
         g.ro.push_back((uint32_t)g.bases.size());
     }
-    g.rro = {0, (uint32_t)nr};
-    g.rho = {0, (uint32_t)nh};
-    g.oo = {0, (uint64_t)nr * nh};
-    g.out.assign((size_t)nr * nh, 0.0);
-    g.cells = (uint64_t)nr * R * (uint64_t)nh * H;
+    g.rro.push_back(g.rro.back() + nr);
+    g.rho.push_back(g.rho.back() + nh);
+    g.oo.push_back(g.oo.back() + (uint64_t)nr * nh);
+  }
+    g.out.assign((size_t)nr * nh * per_call, 0.0);
+    g.cells = (uint64_t)nr * R * (uint64_t)nh * H * per_call;
     return g;
 }
 
 static int call_own(phmm_handle *h, Region &g) {
-    return phmm_compute(h, 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
+    return phmm_compute(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
                         g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data());
 }
 
 static int call_shared(phmm_handle *h, Region &g) {
     uint64_t t = 0;
-    int st = phmm_submit(h, 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
+    int st = phmm_submit(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
                          g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data(), &t);
     return st ? st : phmm_wait(h, t);
 }
@@ -83,13 +91,13 @@ static int call_shared(phmm_handle *h, Region &g) {
 int main(int argc, char **argv) {
     const double dur = argc > 1 ? atof(argv[1]) : 1.0;
     const int nr = argc > 5 ? atoi(argv[2]) : 128, nh = argc > 5 ? atoi(argv[3]) : 8, R = argc > 5 ? atoi(argv[4]) : 150,
-              H = argc > 5 ? atoi(argv[5]) : 300;
+              H = argc > 5 ? atoi(argv[5]) : 300, per_call = argc > 6 ? atoi(argv[6]) : 1;
     if (phmm_device_count() < 1) {
         fprintf(stderr, "no HIP device\n");
         return 2;
     }
-    printf("one region per call: %d reads x %d haplotypes, R=%d, H=%d (%.3g cells), %.1f s per point\n", nr, nh, R, H,
-           (double)nr * R * nh * H, dur);
+    printf("%d region(s) per call: %d reads x %d haplotypes, R=%d, H=%d (%.3g cells each), %.1f s per point\n", per_call, nr, nh,
+           R, H, (double)nr * R * nh * H, dur);
     std::vector<int> Ts = {1, 2, 4, 8, 16, 32, 64};
     if (const char *e = getenv("TB_THREADS")) {  // e.g. TB_THREADS=4,8,16
         Ts.clear();
@@ -113,7 +121,7 @@ int main(int argc, char **argv) {
             // every thread cycles through regions of its own (different data, same shape)
             std::vector<std::vector<Region>> regs(T);
             for (int t = 0; t < T; ++t)
-                for (int k = 0; k < 4; ++k) regs[t].push_back(make_region(1000 + 16 * t + k, nr, nh, R, H));
+                for (int k = 0; k < 4; ++k) regs[t].push_back(make_region(1000 + 16 * t + k, nr, nh, R, H, per_call));
             std::atomic<uint64_t> n_calls{0};
             std::atomic<int> failed{0};
             std::atomic<bool> go{false}, stop{false};
@@ -148,9 +156,9 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "a call failed: %s\n", phmm_last_error(hs[0]));
                 return 1;
             }
-            const double rate = n_calls / dt;
+            const double rate = n_calls * per_call / dt;
             printf("%-6s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : "shared", T,
-                   rate, rate * regs[0][0].cells / 1e9, dt * T / (double)n_calls * 1e6);
+                   rate, rate * regs[0][0].cells / per_call / 1e9, dt * T / (double)n_calls * 1e6);
             if (mode == 1) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
             printf("\n");
             fflush(stdout);
