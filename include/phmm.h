@@ -216,6 +216,17 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
                         const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
                         double *out, uint8_t *keep);
 
+/* phmm_engine_compute through the shared, thread-safe queue of phmm_submit (same rules: every array stays caller-owned
+ * until phmm_wait(ticket) has returned; phmm_wait is the one above).  Engine-level submissions share a flush when their
+ * configurations are equal and the same optional arrays (ins_q / del_q, region_ref_hap) are present; plain and
+ * engine-level submissions on one handle are flushed separately, in submission order. */
+int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions,
+                       const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                       const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                       const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
+                       const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
+                       double *out, uint8_t *keep, uint64_t *ticket);
+
 /* Host copies of the device tables, for parity tests against the oracle:
  * eps[q] = 10^(-q/10) for q in 0..=255, mm = triangular match->match table incl. row 255. */
 size_t phmm_table_eps(const double **eps);

@@ -58,6 +58,8 @@ SYMBOLS = [
     ("phmm_batch_dominant_kernel", C.c_char_p, [C.c_void_p]),
     ("phmm_engine_compute", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                       u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
+    ("phmm_engine_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
+                                     u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p, C.POINTER(C.c_uint64)]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),
     ("phmm_table_match_to_match", C.c_size_t, [C.POINTER(f64p)]),
 ]

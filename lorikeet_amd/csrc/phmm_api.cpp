@@ -1116,9 +1116,23 @@ struct Submission {
     double *out = nullptr;
     size_t read_bytes = 0, hap_bytes = 0;
     uint64_t n_out = 0;
+    // phmm_engine_submit: payload = {read_bases, base_q, ins_q | NULL, del_q | NULL, unused, hap_bases}
+    bool engine = false;
+    phmm_engine_config cfg{};
+    const uint8_t *mapq = nullptr;
+    const int32_t *ref_hap = nullptr;
+    uint8_t *keep = nullptr;
     enum State { QUEUED, RUNNING, DONE } state = QUEUED;
     int status = PHMM_OK;
     std::string err;
+    // may share a flush with `o`: same entry point and, for the engine-level call, the same configuration and the same
+    // optional arrays present
+    bool compatible(const Submission &o) const {
+        if (engine != o.engine) return false;
+        if (!engine) return true;
+        return memcmp(&cfg, &o.cfg, sizeof cfg) == 0 && !payload[2] == !o.payload[2] && !payload[3] == !o.payload[3] &&
+               !ref_hap == !o.ref_hap;
+    }
 };
 
 struct Combiner {
@@ -1138,6 +1152,10 @@ struct Combiner {
         std::vector<uint32_t> rro, rho, ro, ho;
         std::vector<uint64_t> oo;
         Parts parts;
+        // engine-level flushes are concatenated on the host (every array, the optional ones included) and scattered back
+        std::vector<uint8_t> bytes[5], mapq, keep;  // bytes: read_bases, base_q, ins_q, del_q, hap_bases
+        std::vector<int32_t> ref;
+        std::vector<double> out;
     } scratch[kMaxLanes];
 };
 
@@ -1157,7 +1175,12 @@ extern "C" {
 namespace {
 
 int submission_alone(phmm_handle *lane, Submission *s) {
-    s->status = phmm_compute(lane, s->n_regions, s->region_read_off, s->region_hap_off, s->read_off, s->payload[0], s->payload[1],
+    if (s->engine)
+        s->status = phmm_engine_compute(lane, &s->cfg, s->n_regions, s->region_read_off, s->region_hap_off, s->read_off,
+                                        s->payload[0], s->payload[1], s->payload[2], s->payload[3], s->mapq, s->hap_off,
+                                        s->payload[5], s->ref_hap, s->out_off, s->out, s->keep);
+    else
+        s->status = phmm_compute(lane, s->n_regions, s->region_read_off, s->region_hap_off, s->read_off, s->payload[0], s->payload[1],
                              s->payload[2], s->payload[3], s->payload[4], s->hap_off, s->payload[5], s->out_off, s->out);
     if (s->status != PHMM_OK) s->err = lane->err;
     return s->status;
@@ -1197,12 +1220,46 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
         parts.out.push_back(s->out);
         parts.n_out.push_back(s->n_out);
     }
+    if (subs[0]->engine) {
+        const Submission &f = *subs[0];
+        static const int which[5] = {0, 1, 2, 3, 5};
+        for (int i = 0; i < 5; ++i) w.bytes[i].clear();
+        w.mapq.clear();
+        w.ref.clear();
+        for (const Submission *s : subs) {
+            for (int i = 0; i < 5; ++i)
+                if (s->payload[which[i]])
+                    w.bytes[i].insert(w.bytes[i].end(), s->payload[which[i]], s->payload[which[i]] + (i < 4 ? s->read_bytes : s->hap_bytes));
+            w.mapq.insert(w.mapq.end(), s->mapq, s->mapq + s->n_reads);
+            if (s->ref_hap) w.ref.insert(w.ref.end(), s->ref_hap, s->ref_hap + s->n_regions);
+        }
+        w.out.resize(w.oo.back());
+        w.keep.resize(w.rro.back());
+        int st = phmm_engine_compute(lane, &f.cfg, (uint32_t)w.rro.size() - 1, w.rro.data(), w.rho.data(), w.ro.data(),
+                                     w.bytes[0].data(), w.bytes[1].data(), f.payload[2] ? w.bytes[2].data() : nullptr,
+                                     f.payload[3] ? w.bytes[3].data() : nullptr, w.mapq.data(), w.ho.data(), w.bytes[4].data(),
+                                     f.ref_hap ? w.ref.data() : nullptr, w.oo.data(), w.out.data(), w.keep.data());
+        if (st != PHMM_OK && st != PHMM_ERR_HIP) {  // somebody's region is at fault: find out whose
+            for (Submission *s : subs) submission_alone(lane, s);
+            return;
+        }
+        size_t o = 0, r = 0;
+        for (Submission *s : subs) {
+            s->status = st;
+            if (st != PHMM_OK) s->err = lane->err;
+            if (st == PHMM_OK && s->n_out) memcpy(s->out, w.out.data() + o, s->n_out * 8);
+            if (st == PHMM_OK && s->n_reads) memcpy(s->keep, w.keep.data() + r, s->n_reads);
+            o += s->n_out;
+            r += s->n_reads;
+        }
+        return;
+    }
     lane->slot = 0;
     PendingCompute p;
     int st = enqueue_compute(lane, (uint32_t)w.rro.size() - 1, w.rro.data(), w.rho.data(), w.ro.data(), nullptr, nullptr, nullptr,
                              nullptr, nullptr, w.ho.data(), nullptr, w.oo.data(), nullptr, &p, &parts);
     if (st == PHMM_OK) st = finish_compute(lane, &p);
-    if (st == PHMM_ERR_POSITIVE_RESULT) {
+    if (st != PHMM_OK && st != PHMM_ERR_HIP) {
         // some region of the batch tripped the reference's assert (pair_hmm.rs:478-481): find out whose it was, the
         // other submitters get their (valid) results
         for (Submission *s : subs) submission_alone(lane, s);
@@ -1221,6 +1278,26 @@ int submit_fail(phmm_handle *h, int code, const char *msg) {
 }
 
 }  // namespace
+
+static int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
+    std::call_once(h->comb_once, [h] {
+        Combiner *c = new Combiner();
+        if (const char *e = getenv("PHMM_SUBMIT_LANES")) c->n_lanes = std::min(std::max(atoi(e), 1), (int)Combiner::kMaxLanes);
+        h->comb = c;
+    });
+    Combiner *c = h->comb;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int l = 0; l < c->n_lanes; ++l)
+        if (!c->lane[l]) {  // first submission: the lanes are engines of their own on the same device
+            c->lane[l] = phmm_create(h->device, h->flags);
+            if (!c->lane[l]) return submit_fail(h, PHMM_ERR_HIP, phmm_last_error(nullptr));
+        }
+    const uint64_t t = c->next_ticket++;
+    c->live.emplace(t, std::move(s));
+    c->queue.push_back(t);
+    *ticket = t;
+    return PHMM_OK;
+}
 
 int phmm_submit(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
@@ -1247,23 +1324,42 @@ int phmm_submit(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_
     if ((s.read_bytes && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) || (s.hap_bytes && !hap_bases) ||
         (s.n_out && !out))
         return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_submit: null pointer");
-    std::call_once(h->comb_once, [h] {
-        Combiner *c = new Combiner();
-        if (const char *e = getenv("PHMM_SUBMIT_LANES")) c->n_lanes = std::min(std::max(atoi(e), 1), (int)Combiner::kMaxLanes);
-        h->comb = c;
-    });
-    Combiner *c = h->comb;
-    std::lock_guard<std::mutex> lk(c->mu);
-    for (int l = 0; l < c->n_lanes; ++l)
-        if (!c->lane[l]) {  // first submission: the lanes are engines of their own on the same device
-            c->lane[l] = phmm_create(h->device, h->flags);
-            if (!c->lane[l]) return submit_fail(h, PHMM_ERR_HIP, phmm_last_error(nullptr));
-        }
-    const uint64_t t = c->next_ticket++;
-    c->live.emplace(t, std::move(s));
-    c->queue.push_back(t);
-    *ticket = t;
-    return PHMM_OK;
+    return submit_impl(h, s, ticket);
+}
+
+int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_regions, const uint32_t *region_read_off,
+                       const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases,
+                       const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq,
+                       const uint32_t *hap_off, const uint8_t *hap_bases, const int32_t *region_ref_hap,
+                       const uint64_t *out_off, double *out, uint8_t *keep, uint64_t *ticket) {
+    if (!h || !cfg || !ticket) return PHMM_ERR_INVALID_ARG;
+    if (cfg->pcr_error_model > 3) return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_engine_compute: Unknown PCR Error Model");
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr))
+        return submit_fail(h, PHMM_ERR_INVALID_ARG, bad);
+    Submission s;
+    s.engine = true;
+    s.cfg = *cfg;
+    s.n_regions = n_regions;
+    s.n_reads = region_read_off[n_regions];
+    s.n_haps = region_hap_off[n_regions];
+    s.region_read_off = region_read_off;
+    s.region_hap_off = region_hap_off;
+    s.read_off = read_off;
+    s.hap_off = hap_off;
+    s.out_off = out_off;
+    s.out = out;
+    s.read_bytes = read_off[s.n_reads];
+    s.hap_bytes = hap_off[s.n_haps];
+    s.n_out = out_off[n_regions];
+    const uint8_t *pl[6] = {read_bases, base_q, ins_q, del_q, nullptr, hap_bases};
+    for (int i = 0; i < 6; ++i) s.payload[i] = pl[i];
+    s.mapq = mapq;
+    s.ref_hap = region_ref_hap;
+    s.keep = keep;
+    if ((s.read_bytes && (!read_bases || !base_q)) || (s.n_reads && (!mapq || !keep)) || (s.hap_bytes && !hap_bases) ||
+        (s.n_out && !out))
+        return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_engine_submit: null pointer");
+    return submit_impl(h, s, ticket);
 }
 
 int phmm_wait(phmm_handle *h, uint64_t ticket) {
@@ -1302,7 +1398,7 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
         size_t bytes = 0;
         while (!c->queue.empty() && subs.size() < Combiner::kMaxParts) {
             Submission *s = &c->live.find(c->queue.front())->second;
-            if (!subs.empty() && bytes + s->read_bytes > kChunkBytes) break;
+            if (!subs.empty() && (bytes + s->read_bytes > kChunkBytes || !s->compatible(*subs[0]))) break;
             bytes += s->read_bytes;
             s->state = Submission::RUNNING;
             subs.push_back(s);

@@ -72,7 +72,10 @@ class PairHMMLikelihoodCalculationEngine:
     def __init__(self, constant_gcp, log10_global_read_mismapping_rate, pcr_error_model, base_quality_score_threshold,
                  dynamic_read_disqualification, read_disqualification_scale, expected_error_rate_per_base,
                  symmetrically_normalize_alleles_to_reference, disable_cap_read_qualities_to_mapq,
-                 modify_soft_clipped_bases=True, avx_mode=AVXMode.Hip, device_id=0):
+                 modify_soft_clipped_bases=True, avx_mode=AVXMode.Hip, device_id=0, shared_engine=None):
+        """shared_engine: a HipPairHMMEngine that several of these objects (one per worker thread, as the reference
+        clones its engine per task, assembly_region_walker.rs:227) share; calls then go through phmm_engine_submit /
+        phmm_wait, which computes the regions of all waiting workers as one batch."""
         if not modify_soft_clipped_bases:
             # The other branch of modify_read_qualities (:390-422) only differs for reads that still carry soft
             # clips, which the assembler has already removed upstream (SURVEY.md 8a trap 8/10).
@@ -87,7 +90,8 @@ class PairHMMLikelihoodCalculationEngine:
         self.cfg.log10_global_read_mismapping_rate = float(log10_global_read_mismapping_rate)
         self.cfg.read_disqualification_scale = float(read_disqualification_scale)
         self.cfg.expected_error_rate_per_base = float(expected_error_rate_per_base)
-        self._engine = HipPairHMMEngine(device_id)
+        self._shared = shared_engine is not None
+        self._engine = shared_engine if self._shared else HipPairHMMEngine(device_id)
 
     # ---- low level: many regions, arrays in / arrays out -------------------------------------------------
     def compute_regions(self, regions):
@@ -125,11 +129,17 @@ class PairHMMLikelihoodCalculationEngine:
             a["ins"], a["dele"] = cat(ins), cat(dele)
             ins_p, del_p = p(a["ins"], _lib.u8p), p(a["dele"], _lib.u8p)
         eng = self._engine
-        code = eng.lib.phmm_engine_compute(
-            eng._h, C.byref(self.cfg), len(regions), p(a["rro"], _lib.u32p), p(a["rho"], _lib.u32p), p(a["ro"], _lib.u32p),
-            p(a["bases"], _lib.u8p), p(a["quals"], _lib.u8p), ins_p, del_p, p(a["mapq"], _lib.u8p), p(a["ho"], _lib.u32p),
-            p(a["haps"], _lib.u8p), p(a["ref"], C.POINTER(C.c_int32)), p(a["oo"], _lib.u64p), p(out, _lib.f64p),
-            p(keep, _lib.u8p))
+        args = (eng._h, C.byref(self.cfg), len(regions), p(a["rro"], _lib.u32p), p(a["rho"], _lib.u32p), p(a["ro"], _lib.u32p),
+                p(a["bases"], _lib.u8p), p(a["quals"], _lib.u8p), ins_p, del_p, p(a["mapq"], _lib.u8p), p(a["ho"], _lib.u32p),
+                p(a["haps"], _lib.u8p), p(a["ref"], C.POINTER(C.c_int32)), p(a["oo"], _lib.u64p), p(out, _lib.f64p),
+                p(keep, _lib.u8p))
+        if self._shared:
+            ticket = C.c_uint64(0)
+            code = eng.lib.phmm_engine_submit(*args, C.byref(ticket))
+            if code == _lib.PHMM_OK:
+                code = eng.lib.phmm_wait(eng._h, ticket.value)
+        else:
+            code = eng.lib.phmm_engine_compute(*args)
         if code != _lib.PHMM_OK:
             raise PhmmError(code, eng.last_error())
         res = []

@@ -144,3 +144,57 @@ def test_positive_result_is_reported_to_its_owner_only():
         assert np.max(np.abs(tickets[i][1] - good[g][1])) <= TOL
     assert eng.submit_stats() == (1, 4)
     eng.close()
+
+
+def test_engine_level_submissions_share_flushes():
+    """phmm_engine_submit: worker threads with an engine object each (as the reference clones its engine per task) on
+    one shared handle.  Regions of equal configuration are computed together; two configurations and plain phmm_submit
+    traffic on the same handle are kept apart and every caller gets the results of a private engine."""
+    import math
+    from lorikeet_amd.likelihood_engine import PairHMMLikelihoodCalculationEngine, PCRErrorModel
+    from test_engine_hip import _random_regions
+
+    shared = HipPairHMMEngine(0)
+    cap = -4.5 * math.log10(math.e)
+    confs = [(10, cap, PCRErrorModel.CONSERVATIVE, 18, True, 1.0, 0.02, True, False),
+             (10, cap, PCRErrorModel.NONE, 18, False, 1.0, 0.02, False, False)]
+    T = 6
+    work = [_random_regions(np.random.default_rng(900 + t), 10, with_tags=bool(t % 2)) for t in range(T)]
+    want = []
+    for t in range(T):
+        private = PairHMMLikelihoodCalculationEngine(*confs[t % 2])
+        want.append([private.compute_regions([reg])[0] for reg in work[t]])
+    plain = _regions(6, 321)
+    errors = []
+
+    def worker(t):
+        try:
+            eng = PairHMMLikelihoodCalculationEngine(*confs[t % 2], shared_engine=shared)
+            for rep in range(2):
+                for reg, (wm, wk) in zip(work[t], want[t]):
+                    (gm, gk), = eng.compute_regions([reg])
+                    assert gm.shape == wm.shape and np.array_equal(gk, wk)
+                    if gm.size:
+                        assert np.max(np.abs(gm - wm)) <= 1e-12
+        except Exception as e:
+            errors.append(e)
+
+    def plain_worker():
+        try:
+            for rep in range(4):
+                for b, w in plain:
+                    ticket, out = shared.submit(b)
+                    shared.wait(ticket)
+                    assert np.max(np.abs(out - w)) <= TOL
+        except Exception as e:
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)] + [threading.Thread(target=plain_worker)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[0]
+    flushes, subs = shared.submit_stats()
+    assert subs == T * 10 * 2 + 4 * 6 and flushes <= subs
+    shared.close()
