@@ -4,7 +4,7 @@
 //   own     every thread has its own handle and calls phmm_compute
 //   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
-// env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode)
+// env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
         for (int T : Ts) {
             std::vector<phmm_handle *> hs;
             for (int i = 0; i < (mode == 0 ? T : 1); ++i) {
-                hs.push_back(phmm_create(0, 0));
+                hs.push_back(phmm_create(0, getenv("TB_FLAGS") ? (unsigned)atoi(getenv("TB_FLAGS")) : 0u));
                 if (!hs.back()) {
                     fprintf(stderr, "phmm_create: %s\n", phmm_last_error(nullptr));
                     return 2;
