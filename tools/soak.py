@@ -1,6 +1,6 @@
 """Developer tool: soak parity run -- random batches of widely varying shape through the C ABI vs the oracle
 (all host cores), for a wall-clock budget.  usage: python tools/soak.py [seconds] [seed]"""
-import os, sys, time
+import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -16,6 +16,7 @@ from bench import usable_cores
 cores = usable_cores()  # affinity capped by the cgroup CPU quota: more oracle threads only oversubscribe
 eng = HipPairHMMEngine(0)
 eng32 = HipPairHMMEngine(0, f32_first=True)  # opt-in mode: same batches, gate 1e-5 (north_star) instead of 1e-9
+shared = HipPairHMMEngine(0)  # phmm_submit / phmm_wait from several threads
 worst32 = 0.0
 t_end = time.time() + budget
 worst, n_batches, n_pairs, n_cells = 0.0, 0, 0, 0
@@ -98,9 +99,31 @@ while time.time() < t_end:
         d = float(np.max(np.abs(got[~inf] - want[~inf])))
         worst32 = max(worst32, d)
         assert d <= 1e-5, (kind, "f32 first", d)
+    # phmm_submit / phmm_wait: the same regions, one per submission, from four threads on one shared handle
+    if batch.n_regions >= 2:
+        singles = [batch.region_slice(g, g + 1) for g in range(batch.n_regions)]
+        bad = []
+
+        def worker(k):
+            try:
+                for g in range(k, len(singles), 4):
+                    ticket, out = shared.submit(singles[g])
+                    shared.wait(ticket)
+                    w = want[int(batch.out_off[g]):int(batch.out_off[g + 1])]
+                    fin = ~np.isinf(w)
+                    assert np.array_equal(np.isinf(out), ~fin) and not np.isnan(out).any()
+                    if fin.any():
+                        assert float(np.max(np.abs(out[fin] - w[fin]))) <= 1e-9
+            except BaseException as e:
+                bad.append(e)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not bad, (kind, "submit/wait", bad[0])
     n_batches += 1
     n_pairs += batch.n_out
     n_cells += batch.cells()
     kinds[kind] = kinds.get(kind, 0) + 1
-print("soak ok: %d batches, %d pairs, %.3g cells, worst |hip - oracle| = %.3g (f32-first mode: %.3g), kinds %s"
-      % (n_batches, n_pairs, n_cells, worst, worst32, kinds))
+print("soak ok: %d batches, %d pairs, %.3g cells, worst |hip - oracle| = %.3g (f32-first mode: %.3g), kinds %s; "
+      "shared handle: %d flushes for %d submissions" % ((n_batches, n_pairs, n_cells, worst, worst32, kinds) + shared.submit_stats()))
