@@ -197,6 +197,15 @@ struct Flat {
     size_t n_out() const { return (size_t)region_read_off[1] * region_hap_off[1]; }
 };
 
+// The reference builds a PairHMM per region and clones its engine per rayon task (assembly_region_walker.rs:227), so
+// these objects are created and dropped all the time and used from many threads at once.  They therefore hold no device
+// state: every object of a process shares one engine handle per (device, flags) and goes through phmm_submit /
+// phmm_wait, the thread-safe pair of the ABI, which also computes the regions of all waiting threads as one batch.
+inline phmm_handle *shared_handle(unsigned flags) {
+    static Handle plain = make_handle(0, 0), no_tristate = make_handle(0, PHMM_FLAG_NO_TRISTATE);
+    return (flags & PHMM_FLAG_NO_TRISTATE) ? no_tristate.get() : plain.get();
+}
+
 inline void check(phmm_handle *h, int rc) {
     if (rc == PHMM_OK) return;
     const std::string msg = phmm_last_error(h);
@@ -209,15 +218,17 @@ inline void check(phmm_handle *h, int rc) {
 // gkl::pairhmm::forward()'s closure: one (read, haplotype) log10 likelihood, tristate correction on.
 inline double forward(const Bytes &hap, const Bytes &read, const Bytes &quals, const Bytes &ins, const Bytes &del,
                       const Bytes &gcp) {
-    static detail::Handle h = detail::make_handle(0, 0);
+    phmm_handle *h = detail::shared_handle(0);
     detail::Flat f;
     f.add_read(read, quals, ins, del, gcp);
     f.add_hap(hap);
     f.out_off[1] = 1;
     double out = 0.0;
-    detail::check(h.get(), phmm_compute(h.get(), 1, f.region_read_off.data(), f.region_hap_off.data(), f.read_off.data(),
-                                        f.read_bases.data(), f.base_q.data(), f.ins_q.data(), f.del_q.data(), f.gcp.data(),
-                                        f.hap_off.data(), f.hap_bases.data(), f.out_off.data(), &out));
+    uint64_t ticket = 0;
+    detail::check(h, phmm_submit(h, 1, f.region_read_off.data(), f.region_hap_off.data(), f.read_off.data(),
+                                 f.read_bases.data(), f.base_q.data(), f.ins_q.data(), f.del_q.data(), f.gcp.data(),
+                                 f.hap_off.data(), f.hap_bases.data(), f.out_off.data(), &out, &ticket));
+    detail::check(h, phmm_wait(h, ticket));
     return out;
 }
 
@@ -228,13 +239,8 @@ class PairHMM {
     std::vector<Bytes> m_haplotype_data_array;
     std::vector<Haplotype> haplotype_list;  // list index == position (haplotype_to_haplotype_list_index_map)
     AVXMode avx_mode = AVXMode::Hip;
-    detail::Handle handle, handle_no_tristate;
 
-    phmm_handle *engine() {
-        detail::Handle &h = no_tristate ? handle_no_tristate : handle;
-        if (!h) h = detail::make_handle(0, no_tristate ? PHMM_FLAG_NO_TRISTATE : 0);
-        return h.get();
-    }
+    phmm_handle *engine() { return detail::shared_handle(no_tristate ? PHMM_FLAG_NO_TRISTATE : 0); }
 
 public:
     // pair_hmm.rs:63-108 (the AVX arm's shape: haplotype byte slices + list-index map)
@@ -264,10 +270,12 @@ public:
         f.out_off[1] = f.n_out();
         m_log_likelihood_array.assign(f.n_out(), 0.0);
         if (f.n_out() == 0) return;
-        detail::check(engine(), phmm_compute(engine(), 1, f.region_read_off.data(), f.region_hap_off.data(), f.read_off.data(),
-                                             f.read_bases.data(), f.base_q.data(), f.ins_q.data(), f.del_q.data(),
-                                             f.gcp.data(), f.hap_off.data(), f.hap_bases.data(), f.out_off.data(),
-                                             m_log_likelihood_array.data()));
+        uint64_t ticket = 0;
+        detail::check(engine(), phmm_submit(engine(), 1, f.region_read_off.data(), f.region_hap_off.data(), f.read_off.data(),
+                                            f.read_bases.data(), f.base_q.data(), f.ins_q.data(), f.del_q.data(),
+                                            f.gcp.data(), f.hap_off.data(), f.hap_bases.data(), f.out_off.data(),
+                                            m_log_likelihood_array.data(), &ticket));
+        detail::check(engine(), phmm_wait(engine(), ticket));
     }
 
     // pair_hmm.rs:217-267
@@ -323,7 +331,6 @@ public:
 
 class PairHMMLikelihoodCalculationEngine {
     phmm_engine_config cfg{};
-    detail::Handle handle;
 
 public:
     // engine.rs:129-167, argument for argument
@@ -346,7 +353,7 @@ public:
         cfg.log10_global_read_mismapping_rate = log10_global_read_mismapping_rate;
         cfg.read_disqualification_scale = read_disqualification_scale;
         cfg.expected_error_rate_per_base = expected_error_rate_per_base;
-        handle = detail::make_handle(0, 0);
+        (void)detail::shared_handle(0);  // fail here, like the reference's mode check, if there is no device
     }
 
     // engine.rs:195-242
@@ -384,11 +391,14 @@ public:
         std::vector<double> out(nr * nh);
         Bytes keep(nr, 1);
         int32_t ref = result.reference_allele_index ? (int32_t)*result.reference_allele_index : -1;
-        if (nr && nh)
-            detail::check(handle.get(),
-                          phmm_engine_compute(handle.get(), &cfg, 1, rro.data(), rho.data(), ro.data(), bases.data(),
-                                              quals.data(), tags ? ins.data() : nullptr, tags ? del.data() : nullptr,
-                                              mapq.data(), ho.data(), haps.data(), &ref, oo.data(), out.data(), keep.data()));
+        if (nr && nh) {
+            phmm_handle *h = detail::shared_handle(0);
+            uint64_t ticket = 0;
+            detail::check(h, phmm_engine_submit(h, &cfg, 1, rro.data(), rho.data(), ro.data(), bases.data(), quals.data(),
+                                                tags ? ins.data() : nullptr, tags ? del.data() : nullptr, mapq.data(),
+                                                ho.data(), haps.data(), &ref, oo.data(), out.data(), keep.data(), &ticket));
+            detail::check(h, phmm_wait(h, ticket));
+        }
         // scatter [read][hap] -> [allele, read] per sample, applying the keep mask the way
         // remove_evidence_by_index does (allele_likelihoods.rs:968-1018): compact, NaN tail
         size_t pos = 0;

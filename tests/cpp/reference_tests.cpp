@@ -7,10 +7,12 @@
 //   reference tests/pair_hmm_likelihood_calculation_engine_unit_tests.rs  test_compute_likelihoods
 //
 // usage: reference_tests <path to pairhmm-testdata.txt>     (run by tests/test_cpp_host_layer.py, -m gpu)
+#include <atomic>
 #include <cstdio>
 #include <fstream>
 #include <functional>
 #include <sstream>
+#include <thread>
 
 #include "../../lorikeet_amd/csrc/host/lorikeet_pair_hmm.hpp"
 
@@ -328,6 +330,118 @@ static void test_error_behaviour() {
     ASSERT(threw, "Unknown PCR Error Model");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The reference's threading (assembly_region_walker.rs:210-273): rayon workers, each with a clone of the engine per
+// task, one region per compute_read_likelihoods call, all at once.  Every worker must get what a lone caller gets.
+// ---------------------------------------------------------------------------------------------------------
+struct WorkerRegion {
+    std::vector<Haplotype> haps;
+    std::vector<HmmRead> reads;
+};
+
+static WorkerRegion random_region(uint64_t seed) {
+    uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return (uint32_t)(x >> 20);
+    };
+    const char acgt[] = "ACGT";
+    WorkerRegion g;
+    const size_t H = 80 + rnd() % 200, nh = 1 + rnd() % 5, nr = 1 + rnd() % 20;
+    Bytes root(H);
+    for (auto &b : root) b = acgt[rnd() & 3];
+    for (size_t a = 0; a < nh; ++a) {
+        Bytes h = root;
+        if (a) h[rnd() % H] = acgt[rnd() & 3], h[rnd() % H] = acgt[rnd() & 3];
+        Haplotype hap(h, a == 0);
+        bool dup = false;
+        for (const auto &o : g.haps) dup |= o.get_bases() == h;
+        if (!dup) g.haps.push_back(hap);
+    }
+    for (size_t r = 0; r < nr; ++r) {
+        const size_t n = 20 + rnd() % std::min<size_t>(100, H - 20), s = rnd() % (H - n + 1);
+        Bytes b(root.begin() + s, root.begin() + s + n), q(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (rnd() % 50 == 0) b[i] = acgt[rnd() & 3];
+            q[i] = (uint8_t)(10 + rnd() % 30);
+        }
+        HmmRead read(b, q);
+        read.mapq = (uint8_t)(rnd() % 3 ? 60 : 20);
+        g.reads.push_back(read);
+    }
+    return g;
+}
+
+static std::vector<double> region_values(const WorkerRegion &g, bool dynamic) {
+    PairHMMLikelihoodCalculationEngine lce(10, MathUtils::log_to_log10(QualityUtils::qual_to_error_prob_log10(45)),
+                                           PCRErrorModel::Conservative, 18, dynamic, 1.0, 0.02, true, false, true, AVXMode::Hip);
+    AssemblyResultSet ars(g.haps[0]);
+    for (const auto &h : g.haps) ars.add_haplotype(h);
+    std::map<size_t, std::vector<HmmRead>> per_sample{{0, g.reads}};
+    AlleleLikelihoods likes = lce.compute_read_likelihoods(ars, {0}, per_sample);
+    std::vector<double> v{(double)likes.evidence_count()};
+    const Matrix &m = likes.sample_matrix(0);
+    for (size_t a = 0; a < likes.alleles().size(); ++a)
+        for (size_t r = 0; r < likes.evidence_count(); ++r) v.push_back(m(a, r));
+    return v;
+}
+
+static void test_rayon_worker_pattern() {
+    const int T = 8, per_thread = 24;
+    std::vector<std::vector<WorkerRegion>> regions(T);
+    std::vector<std::vector<std::vector<double>>> want(T);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < per_thread; ++k) {
+            regions[t].push_back(random_region(1000 * t + k));
+            want[t].push_back(region_values(regions[t].back(), (t + k) % 2));  // lone caller
+        }
+    std::atomic<int> mismatches{0}, panics{0}, done{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            for (int rep = 0; rep < 3; ++rep)
+                for (int k = 0; k < per_thread; ++k) {
+                    try {
+                        const std::vector<double> got = region_values(regions[t][k], (t + k) % 2);
+                        bool same = got.size() == want[t][k].size();
+                        for (size_t i = 0; same && i < got.size(); ++i) same = std::fabs(got[i] - want[t][k][i]) <= 1e-12;
+                        if (!same) ++mismatches;
+                    } catch (const std::exception &) {
+                        ++panics;
+                    }
+                    ++done;
+                }
+        });
+    for (auto &x : th) x.join();
+    ASSERT(done == T * per_thread * 3, "all calls returned");
+    ASSERT(panics == 0, "%d calls panicked", panics.load());
+    ASSERT(mismatches == 0, "%d regions differ from the lone caller's results", mismatches.load());
+    // a worker whose region trips the reference's assert panics alone; its neighbours are served
+    std::atomic<int> bad_panics{0}, good_ok{0};
+    std::vector<std::thread> th2;
+    for (int t = 0; t < 6; ++t)
+        th2.emplace_back([&, t] {
+            for (int k = 0; k < 20; ++k) {
+                try {
+                    if (t == 0) {
+                        forward(Bytes(20, 'A'), Bytes(12, 'A'), Bytes(12, 60), Bytes(12, 0), Bytes(12, 0), Bytes(12, 60));
+                    } else {
+                        const double v = forward(bytes("ACGTACGTACGTACGTAAAC"), bytes("ACGTACGTACG"), Bytes(11, 30), Bytes(11, 40),
+                                                 Bytes(11, 40), Bytes(11, 10));
+                        if (v < 0.0 && v > -3.0) ++good_ok;
+                    }
+                } catch (const Panic &e) {
+                    if (t == 0 && std::string(e.what()) == "PairHmm Log Probability cannot be greater than 0.0") ++bad_panics;
+                }
+            }
+        });
+    for (auto &x : th2) x.join();
+    ASSERT(bad_panics == 20, "the faulty worker panicked %d of 20 times", bad_panics.load());
+    ASSERT(good_ok == 100, "%d of 100 neighbouring calls were served", good_ok.load());
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
@@ -350,6 +464,7 @@ int main(int argc, char **argv) {
         {"make_haplotype_indexing_provider", make_haplotype_indexing_provider},
         {"test_compute_likelihoods", test_compute_likelihoods},
         {"error_behaviour", test_error_behaviour},
+        {"rayon_worker_pattern (threads share one engine handle)", test_rayon_worker_pattern},
     };
     int failed = 0;
     for (const auto &t : tests) {

@@ -34,7 +34,7 @@ def test_reference_tests_in_cpp_pass_on_the_gpu():
     r = subprocess.run([EXE, os.path.join(GOLDEN, "pairhmm-testdata.txt")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "10 tests, 0 failed" in r.stdout
+    assert "11 tests, 0 failed" in r.stdout
     for name in ("test_likelihoods_avx", "make_basic_likelihood_tests", "test_compute_likelihoods",
-                 "make_haplotype_indexing_provider", "make_big_read_hmm_provider"):
+                 "make_haplotype_indexing_provider", "make_big_read_hmm_provider", "rayon_worker_pattern"):
         assert "PASS " + name in r.stdout
