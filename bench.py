@@ -271,6 +271,29 @@ def main():
         except Exception as exc:  # an optional row must never cost the bench line
             engine_row = {"error": repr(exc)}
 
+    calls_row = None
+    if rank == 0 and world == 1 and not a.main_only:
+        # The reference's call granularity (one region per compute_likelihoods call from every rayon worker), host buffers,
+        # PCIe included: tools/threads_bench (C++ threads on the C ABI, built with the library) in three configurations.
+        try:
+            import re
+            import subprocess
+            exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "threads_bench")
+
+            def point(mode, threads, per_call):
+                env = dict(os.environ, TB_MODE=mode, TB_THREADS=str(threads))
+                r = subprocess.run([exe, "1.0", "128", "8", "150", "300", str(per_call)], env=env, capture_output=True,
+                                   text=True, timeout=60)
+                m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS", r.stdout)
+                return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2))}
+            calls_row = {
+                "note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
+                "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
+                "one_region_per_call_32_threads_shared_handle_submit_wait": point("shared", 32, 1),
+                "eight_regions_per_call_4_threads_own_handles": point("own", 4, 8)}
+        except Exception as exc:  # an optional row must never cost the bench line
+            calls_row = {"error": repr(exc)}
+
     if rank == 0:
         res = out.cpu().numpy()
         assert (res <= 0).all(), "non-finite or positive likelihoods"
@@ -318,6 +341,8 @@ def main():
         line["single_region"] = single
         line["f32_first"] = f32_row
         line["engine_call"] = engine_row
+        if calls_row is not None:
+            line["host_calls"] = calls_row
         if world == 1 and not a.no_cpu_baseline and not a.main_only:
             line["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(line), flush=True)
