@@ -45,7 +45,14 @@ constexpr size_t kLdsBytesPerCU = 160 * 1024;
 constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
 constexpr uint32_t kNumSimd = 256 * 4;
 constexpr uint64_t kGenericScratchBytes = 1ull << 30;
-constexpr size_t kChunkBytes = 4u << 20;  // per-array bytes of one pipelined chunk; batches up to twice that go in one shot
+// Chunked host path: batches whose per-base arrays exceed kOneShotBytes are cut into chunks of regions whose arrays grow
+// from kFirstChunkBytes (the GPU starts early) to kChunkBytes (large launches are the efficient ones).  Measured on
+// config-2 batches, one shot vs chunked: 32 regions 548 -> 479 us, 256 regions 4.36 -> 3.13 ms, 4096 regions 43.2 ms with
+// 4 MB chunks vs 45.5 ms with 512 KB chunks throughout.  (PHMM_CHUNK_KB, PHMM_FIRST_CHUNK_KB, PHMM_ONESHOT_KB: tuning.)
+static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
+static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
+static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
+constexpr size_t kCombineBytes = 4u << 20;  // per-array bytes one combined flush of phmm_wait takes
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -109,6 +116,7 @@ struct phmm_handle {
     int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
     int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
     struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
+    bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
     std::once_flag comb_once;
 };
 
@@ -872,11 +880,24 @@ struct Parts {
     std::vector<uint64_t> n_out;
 };
 
+// When is the D2H copy of the results enqueued?  Right behind the kernels ("eager": one host wait per call, 15 us less
+// latency for a lone small call), or by finish_compute once the host has seen the kernels complete ("deferred").  A copy
+// that waits for a kernel sits at the head of its SDMA engine's queue and holds up every later copy that lands on that
+// engine -- the H2D of the next chunk, or of another lane (tools/ubench/overlap3.hip; seen as strict H2D / kernel / D2H
+// serialisation in the rocprofv3 timeline of the chunked path).  So: deferred wherever something else is in flight
+// (chunks of a pipelined call, combined flushes of phmm_wait), eager for a one-shot call.
+// PHMM_EAGER_D2H=1 / 0 forces one or the other (A/B measurements only).
+bool eager_d2h(const phmm_handle *h) {
+    static const int forced = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
+    return forced >= 0 ? forced != 0 : !h->defer_d2h;
+}
+
 struct PendingCompute {
     phmm_batch *b = nullptr;
     int slot = 0;
     double *out = nullptr;
     const Parts *parts = nullptr;  // non-null: results go to parts->out[s] instead of `out`
+    bool d2h_pending = false;      // the D2H copy of [status | out] is still to be issued (see eager_d2h)
 };
 
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
@@ -950,7 +971,8 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     }
     if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
     t_launch = now();
-    if (st == PHMM_OK &&
+    const bool eager = eager_d2h(h);  // otherwise finish_compute fetches the results
+    if (st == PHMM_OK && eager &&
         !hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
                                   hipMemcpyDeviceToHost, h->S()),
                 "D2H results"))
@@ -969,6 +991,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     pending->slot = h->slot;
     pending->out = out;
     pending->parts = parts;
+    pending->d2h_pending = !eager;
     return PHMM_OK;
 }
 
@@ -976,6 +999,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
 struct ChunkView {
     uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
     uint32_t index = 0;  // how many chunks came before this one
+    bool f32_first = false;  // the handle's precision mode (decides the chunk sizes)
     size_t read_byte0 = 0, hap_byte0 = 0;
     std::vector<uint32_t> rro, rho, ro, ho;
     std::vector<uint64_t> oo;
@@ -988,9 +1012,14 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     if (g0 >= n_regions) return false;
     uint32_t g1 = g0 + 1;
     const size_t base_r = read_off[region_read_off[g0]];
-    // the first chunks are short so that the GPU starts early; staging of the following ones hides behind its kernels
+    // the first chunks are short so that the GPU starts early (0.5, 0.5, 1, 2, 4, 4 ... MB per array); staging and the
+    // H2D copy of the following ones hide behind its kernels
     c.index = g0 == 0 ? 0 : c.index + 1;
-    const size_t limit = c.index == 0 ? kChunkBytes / 4 : c.index == 1 ? kChunkBytes / 2 : kChunkBytes;
+    // f64: 0.5 MB per array four times, then 1, 1, 2, 2, 4, 4 ... (mid-size batches want many small chunks, large ones
+    // large launches).  f32-first handles: 1, 2, 4, 4 ... -- the f32 sweep only exists as the chained kernel, which needs
+    // a few hundred regions per launch.
+    const uint32_t step = c.f32_first ? c.index + 1 : (c.index < 4 ? 0 : (c.index - 2) / 2);
+    const size_t limit = std::min(kChunkBytes, (c.f32_first ? (1u << 20) / 2 : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
     while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= limit) ++g1;
     c.g0 = g0;
     c.g1 = g1;
@@ -1021,7 +1050,13 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
     int st = PHMM_OK;
     phmm_batch *b = p->b;
     const Arena &A = h->arenas[p->slot];
-    if (!hip_ok(h, hipStreamSynchronize(h->streams[p->slot]), "sync")) {
+    hipStream_t S = h->streams[p->slot];
+    if (!hip_ok(h, hipStreamSynchronize(S), "sync") ||
+        (p->d2h_pending &&  // kernels are done: fetch [status | out] now
+         (!hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
+                                    hipMemcpyDeviceToHost, S),
+                  "D2H results") ||
+          !hip_ok(h, hipStreamSynchronize(S), "sync(D2H)")))) {
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + b->out_arena_off;
@@ -1062,7 +1097,8 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     }
     const uint32_t n_reads = region_read_off[n_regions];
     // ---- small / medium batch: one shot ------------------------------------------------------------
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kChunkBytes || getenv("PHMM_NO_PIPELINE")) {
+    const bool f32_first = (h->flags & PHMM_FLAG_F32_FIRST) != 0;
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= (f32_first ? (size_t)(8u << 20) : kOneShotBytes) || getenv("PHMM_NO_PIPELINE")) {
         h->slot = 0;
         PendingCompute p;
         int st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
@@ -1079,7 +1115,9 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     PendingCompute pend[kSlots];
     int st = PHMM_OK;
     ChunkView c;
+    c.f32_first = f32_first;
     int n_chunks = 0;
+    h->defer_d2h = true;
     while (st == PHMM_OK && next_chunk(c, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
         const int slot = n_chunks % kSlots;
         st = finish_compute(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
@@ -1096,6 +1134,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
         if (st == PHMM_OK) st = s2;
     }
     h->slot = 0;
+    h->defer_d2h = false;
     if (trace) fprintf(stderr, "phmm_compute: %d chunks pipelined over %d slots, total %.1f us\n", n_chunks, kSlots, now() - t0);
     return st;
 }
@@ -1192,6 +1231,11 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
         submission_alone(lane, subs[0]);
         return;
     }
+    struct Defer {  // combined flushes happen when other threads are busy too: keep the copy engines unblocked
+        phmm_handle *h;
+        explicit Defer(phmm_handle *hh) : h(hh) { h->defer_d2h = true; }
+        ~Defer() { h->defer_d2h = false; }
+    } defer(lane);
     // concatenate the offset arrays (every submission starts at 0, so each is shifted by what came before it)
     w.rro.assign(1, 0);
     w.rho.assign(1, 0);
@@ -1398,7 +1442,7 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
         size_t bytes = 0;
         while (!c->queue.empty() && subs.size() < Combiner::kMaxParts) {
             Submission *s = &c->live.find(c->queue.front())->second;
-            if (!subs.empty() && (bytes + s->read_bytes > kChunkBytes || !s->compatible(*subs[0]))) break;
+            if (!subs.empty() && (bytes + s->read_bytes > kCombineBytes || !s->compatible(*subs[0]))) break;
             bytes += s->read_bytes;
             s->state = Submission::RUNNING;
             subs.push_back(s);
@@ -1437,8 +1481,9 @@ struct PendingEngine {
     int slot = 0;
     double *out = nullptr;
     uint8_t *keep = nullptr;
-    size_t res_off = 0, keep_bytes = 0;
+    size_t res_off = 0, keep_bytes = 0, res_bytes = 0;
     uint32_t n_reads = 0;
+    bool d2h_pending = false;
 };
 
 // Stage one batch of the engine-level call in the current slot's arena and enqueue H2D, pre-step, PairHMM, post-step
@@ -1549,9 +1594,13 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         po.symmetric = cfg->symmetrically_normalize_alleles_to_reference;
         if (ok) ok = hip_ok(h, launch_post(po, h->S()), "phmm_post_reads");
         const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
-        if (ok) ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->S()),
-                            "D2H results");
+        const bool eager = eager_d2h(h);  // otherwise engine_finish fetches the results
+        if (ok && eager)
+            ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->S()),
+                        "D2H results");
         if (ok) {
+            pending->res_bytes = res_bytes;
+            pending->d2h_pending = !eager;
             pending->b = b;
             pending->slot = h->slot;
             pending->out = out;
@@ -1576,7 +1625,12 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
     int st = PHMM_OK;
     phmm_batch *b = p->b;
     const Arena &A = h->arenas[p->slot];
-    if (!hip_ok(h, hipStreamSynchronize(h->streams[p->slot]), "sync")) {
+    hipStream_t S = h->streams[p->slot];
+    if (!hip_ok(h, hipStreamSynchronize(S), "sync") ||
+        (p->d2h_pending &&
+         (!hip_ok(h, hipMemcpyAsync(A.host + p->res_off, A.dev + p->res_off, p->res_bytes, hipMemcpyDeviceToHost, S),
+                  "D2H results") ||
+          !hip_ok(h, hipStreamSynchronize(S), "sync(D2H)")))) {
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + p->res_off;
@@ -1612,7 +1666,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     }
     const uint32_t n_reads = region_read_off[n_regions];
     // ---- small / medium batch: one shot ------------------------------------------------------------
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= 2 * kChunkBytes || !region_hap_off || !hap_off || !out_off ||
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes || !region_hap_off || !hap_off || !out_off ||
         getenv("PHMM_NO_PIPELINE")) {
         h->slot = 0;
         PendingEngine p;
@@ -1626,6 +1680,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     int st = PHMM_OK;
     ChunkView c;
     int n_chunks = 0;
+    h->defer_d2h = true;
     while (st == PHMM_OK && next_chunk(c, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
         const int slot = n_chunks % kSlots;
         st = engine_finish(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
@@ -1645,6 +1700,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         if (st == PHMM_OK) st = s2;
     }
     h->slot = 0;
+    h->defer_d2h = false;
     return st;
 }
 
