@@ -52,6 +52,7 @@ constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
 static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
+static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
 constexpr size_t kCombineBytes = 4u << 20;  // per-array bytes one combined flush of phmm_wait takes
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -898,6 +899,7 @@ struct PendingCompute {
     double *out = nullptr;
     const Parts *parts = nullptr;  // non-null: results go to parts->out[s] instead of `out`
     bool d2h_pending = false;      // the D2H copy of [status | out] is still to be issued (see eager_d2h)
+    bool zero_copy = false;        // the kernels wrote `out` into the pinned mirror themselves; status is checked here
 };
 
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
@@ -909,6 +911,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
     double t_plan = 0, t_stage = 0, t_h2d = 0, t_launch = 0;
+    bool zero_copy = false;
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
     if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
@@ -960,6 +963,16 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         memset(A.host + in_bytes, 0, 256);  // status word
         b->d_status = (uint32_t *)(A.dev + in_bytes);
         double *d_out = (double *)(A.dev + in_bytes + 256);
+        // A small one-shot call gets no D2H copy at all: its kernels store the few results straight into the pinned
+        // mirror (8 bytes per pair over PCIe), and finish_compute applies the reference's `<= 0` check on the host.
+        zero_copy = eager_d2h(h) && b->tight_out && b->n_out * 8 <= kZeroCopyOutBytes && !parts;
+        if (zero_copy) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, A.host + in_bytes + 256, 0) == hipSuccess && dp)
+                d_out = (double *)dp;
+            else
+                zero_copy = false;
+        }
         if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch"))
             st = PHMM_ERR_HIP;
         // slots the kernels never write (gaps the caller left in out_off) come back as NaN
@@ -972,7 +985,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     if (st == PHMM_OK) st = phmm_batch_launch(b, nullptr);
     t_launch = now();
     const bool eager = eager_d2h(h);  // otherwise finish_compute fetches the results
-    if (st == PHMM_OK && eager &&
+    if (st == PHMM_OK && eager && !zero_copy &&
         !hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
                                   hipMemcpyDeviceToHost, h->S()),
                 "D2H results"))
@@ -992,6 +1005,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     pending->out = out;
     pending->parts = parts;
     pending->d2h_pending = !eager;
+    pending->zero_copy = zero_copy;
     return PHMM_OK;
 }
 
@@ -1069,7 +1083,12 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
         } else if (b->n_out) {
             memcpy(p->out, hs + 256, b->n_out * 8);
         }
-        if (*(const uint32_t *)hs) {
+        bool positive = *(const uint32_t *)hs != 0;
+        if (p->zero_copy) {  // the status word stayed on the device: every slot was written once, look at the values
+            const double *v = (const double *)(hs + 256);
+            for (uint64_t i = 0; i < b->n_out; ++i) positive |= !(v[i] <= 0.0);
+        }
+        if (positive) {
             h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
             st = PHMM_ERR_POSITIVE_RESULT;
         }
@@ -1145,7 +1164,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
 // only queued; the first thread that waits while a lane is free becomes the leader of one flush, takes everything queued
 // so far -- its own region and those of the threads that arrived meanwhile -- and computes it as ONE batch (one H2D copy,
 // one set of launches, one D2H copy), then hands every region's results to its owner.  Nobody waits on a timer: batches
-// grow exactly as large as the number of threads that were waiting anyway.  Two lanes (private engine handles) let the
+// grow exactly as large as the number of threads that were waiting anyway.  Four lanes (private engine handles) let the
 // next flush stage and copy while the previous one computes.
 struct Submission {
     uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
@@ -1175,14 +1194,14 @@ struct Submission {
 };
 
 struct Combiner {
-    static constexpr int kMaxLanes = 4;
+    static constexpr int kMaxLanes = 8;
     static constexpr size_t kMaxParts = 256;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<uint64_t> queue;  // tickets nobody has picked up yet, in submission order
     std::unordered_map<uint64_t, Submission> live;  // until phmm_wait returns them (element addresses are stable)
     uint64_t next_ticket = 1;
-    int n_lanes = 2;
+    int n_lanes = 4;  // PHMM_SUBMIT_LANES: 2 flushes in flight leave the GPU idle during their copies, 4 match private handles at 4 threads
     phmm_handle *lane[kMaxLanes] = {};
     bool lane_busy[kMaxLanes] = {};
     uint64_t n_flushes = 0, n_parts = 0;  // statistics (phmm_submit_stats)
