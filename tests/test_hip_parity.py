@@ -326,19 +326,22 @@ def test_config5_stress_shape(hip_engine):
 
 
 def test_host_path_size_classes(hip_engine):
-    """phmm_compute stages small batches in one shot and cuts large ones into pipelined chunks (per-array limit
-    4 MB, one shot up to 8 MB): every size class, and the one-shot path forced on a large batch, against the oracle
-    and against each other."""
-    b = synthetic.config2(600, seed=41)      # 11.5 MB per per-base array: three chunks
+    """phmm_compute stages small batches in one shot (the smallest without a D2H copy: the kernels write the pinned
+    mirror), and cuts everything above 0.5 MB per array into pipelined chunks of growing size (0.5 MB x 4, 1, 1, 2, 2,
+    4 ... MB) whose results are fetched after the kernels are seen to finish: every size class, and the one-shot path
+    forced on a large batch, against the oracle and against each other."""
+    b = synthetic.config2(600, seed=41)      # 11.5 MB per per-base array: ten chunks, all sizes up to 4 MB
     chunked = hip_engine.compute(b)
     os.environ["PHMM_NO_PIPELINE"] = "1"
     try:
-        one_shot = hip_engine.compute(b)     # the same batch in one shot (arrays above the chunk limit)
+        one_shot = hip_engine.compute(b)     # the same batch in one shot
     finally:
         os.environ.pop("PHMM_NO_PIPELINE", None)
-    _close(one_shot, chunked, tol=1e-12)     # chunks plan their own run lengths: last-row summation order only
+    _close(one_shot, chunked, tol=1e-12)     # chunks plan their own kernel shapes: last-row summation order only
     _close(chunked[:int(b.out_off[3])], oracle.compute_batch(b.region_slice(0, 3).as_dict(), n_threads=8))
-    for n in (40, 300):                      # 0.8 MB; 5.8 MB per array (one shot, above the chunk limit)
+    # 1 region (results written by the kernels into the mirror), 8 (64 KB of results: the last such size), 9 (first with
+    # a D2H copy), 26 / 28 (either side of the one-shot limit), 40 (two chunks), 300 (eight chunks)
+    for n in (1, 8, 9, 26, 28, 40, 300):
         sub = b.region_slice(100, 100 + n)
         got = hip_engine.compute(sub)
         _close(got, chunked[int(b.out_off[100]):int(b.out_off[100 + n])], tol=1e-12)
