@@ -1,0 +1,88 @@
+// Private to the host side of libphmm.so (phmm_api.cpp, phmm_submit.cpp): the engine handle, its staging arenas and the
+// two internal entry points the cross-thread queue builds on.  Nothing here is part of the ABI (include/phmm.h).
+#pragma once
+#include "../../include/phmm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// Grow-only device arena with a pinned host mirror at identical offsets.  phmm_compute() places the
+// whole batch (offset arrays, work lists, payload, status word, results) in it, so a call costs one
+// H2D copy, the kernel launches and one D2H copy -- no hipMalloc/hipFree once the arena is warm.
+struct Arena {
+    char *dev = nullptr, *host = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+constexpr int kSlots = 3;  // pipeline depth of the chunked host path
+
+
+struct phmm_handle {
+    // Each slot is an independent (arena, stream) pair; single calls use slot 0, the chunked large-batch
+    // path rotates through all of them so that staging / H2D of chunk i+1 overlaps the kernels of chunk i.
+    Arena arenas[kSlots];
+    hipStream_t streams[kSlots] = {nullptr, nullptr, nullptr};
+    int slot = 0;
+    Arena &A() { return arenas[slot]; }
+    hipStream_t S() { return streams[slot]; }
+    int device = 0;
+    unsigned flags = 0;
+    double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr, *d_ratio_mis = nullptr, *d_inv_om = nullptr;
+    uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
+    std::string err;
+    int err_code = PHMM_OK;  // status of the last failure (set together with err)
+    int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
+    int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
+    struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
+    bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
+    std::once_flag comb_once;
+};
+
+namespace phmm_host {
+
+// Inputs of several independent submissions that one launch computes together (phmm_submit): part s contributes
+// read_bytes[s] bytes to each of the five per-base read arrays, hap_bytes[s] to the haplotype bases, and receives
+// n_out[s] results.
+struct Parts {
+    std::vector<const uint8_t *> src[6];
+    std::vector<size_t> read_bytes, hap_bytes;
+    std::vector<double *> out;
+    std::vector<uint64_t> n_out;
+};
+
+struct PendingCompute {
+    phmm_batch *b = nullptr;
+    int slot = 0;
+    double *out = nullptr;
+    const Parts *parts = nullptr;  // non-null: results go to parts->out[s] instead of `out`
+    bool d2h_pending = false;      // the D2H copy of [status | out] is still to be issued (see eager_d2h)
+    bool zero_copy = false;        // the kernels wrote `out` into the pinned mirror themselves; status is checked here
+};
+
+constexpr size_t kCombineBytes = 4u << 20;  // per-array bytes one combined flush of phmm_wait takes
+
+// Stage one batch in the current slot's arena and enqueue H2D and kernels (and, for a one-shot call, the D2H) on its
+// stream; no sync.  finish_compute waits, fetches the results if that is still to do, and hands them to the caller.
+int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                    const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                    const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                    const uint64_t *out_off, double *out, PendingCompute *pending, const Parts *parts = nullptr);
+int finish_compute(phmm_handle *h, PendingCompute *p);
+
+// What every entry point checks before it touches the arrays; returns the message of the first violation or nullptr.
+const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                             const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool *tight_out);
+
+// phmm_submit / phmm_wait are the only entry points several threads may call on one handle, so their messages are kept
+// per calling thread (phmm_last_error returns them); every other entry point resets the pair.
+void set_thread_error(const phmm_handle *h, const std::string &msg);
+void clear_thread_error(const phmm_handle *h);
+
+void combiner_destroy(Combiner *c);  // phmm_submit.cpp; called by phmm_destroy
+
+}  // namespace phmm_host
