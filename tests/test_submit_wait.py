@@ -198,3 +198,27 @@ def test_engine_level_submissions_share_flushes():
     flushes, subs = shared.submit_stats()
     assert subs == T * 10 * 2 + 4 * 6 and flushes <= subs
     shared.close()
+
+
+def test_shared_handle_in_f32_first_mode():
+    """The lanes of a shared handle inherit its flags: submissions that together are large enough are swept in f32 first
+    (gate 1e-5, north_star), small ones are f64 as on a private f32-first handle."""
+    shared = HipPairHMMEngine(0, f32_first=True)
+    e64 = HipPairHMMEngine(0)
+    # 3 x 60 regions: none is large enough for the chained (f32) kernel on its own, the 182 regions of the flush are
+    big = [synthetic.config2(60, seed=70 + i) for i in range(3)]
+    small = synthetic.config2(2, seed=75)
+    tickets = [shared.submit(b) for b in big] + [shared.submit(small)]
+    for t, _ in tickets:
+        shared.wait(t)
+    assert shared.submit_stats() == (1, 4)
+    worst = 0.0
+    for b, (_, out) in zip(big + [small], tickets):
+        ref = e64.compute(b)
+        assert np.all(out <= 0.0) and not np.isnan(out).any()
+        worst = max(worst, float(np.max(np.abs(out - ref))))
+    assert 0.0 < worst <= 1e-5, worst   # f32 results: not the f64 numbers, inside the gate
+    want = oracle.compute_batch(small.as_dict(), n_threads=4)
+    assert np.max(np.abs(tickets[3][1] - want)) <= 1e-5
+    e64.close()
+    shared.close()
