@@ -492,7 +492,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             }
             // one wave per SIMD is enough to stop trading lanes for waves (measured on 1, 2, 4 regions of config 2:
             // <64,5> 41 us, <32,10> 54 us vs <64,5> 60 us, <16,19> 87 us vs <32,10> 88 us)
-            if (waves >= 1ull * kNumSimd || min_L == 64 || h->force_L) break;
+            if (waves * h->gpu_sharers >= 1ull * kNumSimd || min_L == 64 || h->force_L) break;
             min_L *= 2;
         }
     };

@@ -39,6 +39,8 @@ struct phmm_handle {
     int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
     int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
     struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
+    uint32_t gpu_sharers = 1;         // flows computing at the same time (phmm_wait, combined flushes): the planner stops
+                                      // trading lanes for waves once the batch fills its share of the chip
     bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
     std::once_flag comb_once;
 };

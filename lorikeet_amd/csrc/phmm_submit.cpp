@@ -326,6 +326,14 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
             c->queue.pop_front();
         }
         c->lane_busy[lane] = true;
+        {
+            // A combined flush means the handle is under load: plan it for the share of the chip it will get (the lanes
+            // computing right now, this one included) rather than for an empty chip -- 16 threads 53-60 k -> 59-68 k
+            // regions/s.  Single regions keep the wide latency shape: narrowing those costs 25 % at 2-4 threads.
+            uint32_t busy = 0;
+            for (int l = 0; l < c->n_lanes; ++l) busy += c->lane_busy[l] ? 1u : 0u;
+            c->lane[lane]->gpu_sharers = subs.size() >= 2 ? busy : 1u;
+        }
         c->n_flushes += 1;
         c->n_parts += subs.size();
         auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
