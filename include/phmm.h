@@ -126,6 +126,24 @@ int phmm_wait(phmm_handle *h, uint64_t ticket);
 void phmm_submit_stats(phmm_handle *h, uint64_t *n_flushes, uint64_t *n_submissions);
 
 /*
+ * Several devices, one process (regions shard, nothing is exchanged).  phmm_compute_multi is phmm_compute over
+ * `n_handles` engines, normally one per device: whole regions are assigned by greedy longest-processing-time on
+ * cells(region) = sum of read lengths x sum of haplotype lengths (heaviest region first onto the least loaded engine),
+ * every engine computes its share concurrently on a host thread of its own, and the results land in the caller's `out`
+ * exactly where phmm_compute would put them.  The handles must not be in use by other threads during the call; on
+ * failure the message is phmm_last_error(handles[0]).  phmm_assign_regions exposes the assignment alone (host only, no
+ * device needed): part_of_region[g] in [0, n_parts).
+ */
+int phmm_assign_regions(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                        const uint32_t *read_off, const uint32_t *hap_off, uint32_t n_parts,
+                        uint32_t *part_of_region);
+int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t n_regions,
+                       const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                       const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                       const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                       const uint64_t *out_off, double *out);
+
+/*
  * Split-phase interface for device-resident data and for overlapping transfers with compute.
  * A batch owns the launch plan (regions binned into kernel shape classes) and the device copy
  * of the offset arrays; the byte payload and the output live in device memory that is either

@@ -164,3 +164,29 @@ class HipPairHMMEngine:
             self.close()
         except Exception:
             pass
+
+
+def assign_regions(batch: RegionBatch, n_parts):
+    """phmm_assign_regions: greedy longest-processing-time assignment of whole regions to `n_parts` engines by
+    cells(region).  Host only -- works without a device.  Returns uint32[n_regions]."""
+    lib = _lib.load()
+    part = np.zeros(batch.n_regions, np.uint32)
+    code = lib.phmm_assign_regions(batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
+                                   _p(batch.read_off, _lib.u32p), _p(batch.hap_off, _lib.u32p), int(n_parts),
+                                   _p(part, _lib.u32p))
+    if code != _lib.PHMM_OK:
+        raise PhmmError(code, "phmm_assign_regions: invalid argument")
+    return part
+
+
+def compute_multi(engines, batch: RegionBatch):
+    """phmm_compute_multi: one batch over several engines (normally one per device) of this process; regions are
+    sharded by assign_regions, every engine computes its share concurrently, no exchange between devices."""
+    import ctypes as C
+    lib = engines[0].lib
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    out = np.empty(batch.n_out, dtype=np.float64)
+    code = lib.phmm_compute_multi(hs, len(engines), *HipPairHMMEngine._abi_args(batch), _p(out, _lib.f64p))
+    if code != _lib.PHMM_OK:
+        raise PhmmError(code, engines[0].last_error())
+    return out

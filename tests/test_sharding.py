@@ -92,3 +92,16 @@ def test_bench_shards_are_disjoint_per_rank():
     a = synthetic.config2(2, seed=1000)
     b = synthetic.config2(2, seed=1001)
     assert not np.array_equal(a.hap_bases, b.hap_bases)
+
+
+def test_c_abi_assignment_matches_the_python_sharding():
+    """phmm_assign_regions (what phmm_compute_multi shards by, one process over several devices) is the same greedy
+    longest-processing-time assignment as the multi-process path's: same cells, same tie-breaking.  Host only."""
+    from lorikeet_amd.engine import assign_regions
+    for batch in (_ragged_batch(), synthetic.config3(37, seed=3), synthetic.config2(5, seed=1)):
+        cells = sharding.region_cells(batch)
+        for parts in (1, 2, 3, 8, 64):
+            want = np.zeros(batch.n_regions, np.uint32)
+            for p, regions in enumerate(sharding.assign_regions(cells, parts)):
+                want[regions] = p
+            assert np.array_equal(assign_regions(batch, parts), want), parts
