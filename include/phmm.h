@@ -30,7 +30,10 @@
  * DESIGN.md section 4); the reference's own gate is 1e-5 abs.
  *
  * Threading: a handle may be used by one thread at a time; create one per host thread (the
- * reference clones its engine per rayon task, assembly_region_walker.rs:227) or serialise.
+ * reference clones its engine per rayon task, assembly_region_walker.rs:227) or serialise.  The exception is
+ * phmm_submit / phmm_engine_submit / phmm_wait: any number of threads may call them on ONE shared handle, and the
+ * library computes the regions of all waiting threads together.  phmm_compute_multi spreads one call over several
+ * handles (one per device).
  * There is NO CPU fallback: without a HIP device phmm_create() fails.
  */
 #ifndef PHMM_H
