@@ -22,12 +22,21 @@
  *     tristate correction ON unless PHMM_FLAG_NO_TRISTATE (pair_hmm.rs:189-191, :643-651);
  *   - base comparison is raw byte equality, uppercase 'N' on either side is a wildcard (:643);
  *   - qualities are full u8 (0..=255); reads longer than the haplotype are legal; an empty read
- *     gives -inf; an empty read list is a no-op (:224);
+ *     gives -inf; an empty read list is a no-op (:224); an EMPTY HAPLOTYPE is rejected with
+ *     PHMM_ERR_INVALID_ARG by every entry point (the reference would divide 2^1020 by zero and return
+ *     -inf for every read of the region, :515-517; Lorikeet's assembler never produces one);
  *   - every result satisfies <= 0.0; a violation (the reference asserts, :478-481) is reported
  *     as PHMM_ERR_POSITIVE_RESULT.
  * Results agree with the reference's scalar f64 path to ~1e-13 absolute in log10 (FMA contraction,
  * exact rescalings of the DP state and the order of the final row sum are the only differences,
- * DESIGN.md section 4); the reference's own gate is 1e-5 abs.
+ * DESIGN.md section 4); the reference's own gate is 1e-5 abs.  Pairs whose log10 likelihood is below -600 --
+ * where the reference's 2^1020-scaled sums approach the denormal range and every rounding shows -- are recomputed
+ * in the reference's own operation order, so the underflow band (down to and including the point where the result
+ * turns to -inf, ~1e-628) agrees with the scalar arm as well.
+ *
+ * Every entry point returns with the calling thread's current HIP device restored, and no C++ exception crosses
+ * the boundary (PHMM_ERR_NO_MEMORY / PHMM_ERR_INTERNAL).  Slots of `out` that out_off leaves between regions
+ * (gaps) are never written.
  *
  * Threading: a handle may be used by one thread at a time; create one per host thread (the
  * reference clones its engine per rayon task, assembly_region_walker.rs:227) or serialise.  The exception is
@@ -64,6 +73,8 @@ extern "C" {
 #define PHMM_ERR_HIP 3              /* a HIP runtime call failed; see phmm_last_error          */
 #define PHMM_ERR_POSITIVE_RESULT 4  /* some log10 likelihood > 0 (reference asserts, :478-481) */
 #define PHMM_ERR_NOT_BOUND 5        /* phmm_batch_launch before device buffers were bound      */
+#define PHMM_ERR_NO_MEMORY 6        /* a host allocation failed (std::bad_alloc never crosses the ABI)    */
+#define PHMM_ERR_INTERNAL 7         /* any other C++ exception inside the library; see phmm_last_error    */
 
 typedef struct phmm_handle phmm_handle;
 typedef struct phmm_batch phmm_batch;
@@ -247,6 +258,18 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
                        const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
                        const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
                        double *out, uint8_t *keep, uint64_t *ticket);
+
+/*
+ * Developer switches and counters (tests, A/B measurements; never needed in production).
+ * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
+ * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
+ * "no_pipeline", "no_rescue", "trace"; value -1 / 0 = back to the planner's choice as documented there).  Not to be
+ * called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
+ * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
+ * staging so far), "rescue_passes" (batches that needed the exact pass below -600); unknown names give 0.
+ */
+int phmm_set_switch(phmm_handle *h, const char *name, int value);
+uint64_t phmm_get_stat(phmm_handle *h, const char *name);
 
 /* Host copies of the device tables, for parity tests against the oracle:
  * eps[q] = 10^(-q/10) for q in 0..=255, mm = triangular match->match table incl. row 255. */

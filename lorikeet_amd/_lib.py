@@ -23,6 +23,8 @@ PHMM_ERR_NO_DEVICE = 2
 PHMM_ERR_HIP = 3
 PHMM_ERR_POSITIVE_RESULT = 4
 PHMM_ERR_NOT_BOUND = 5
+PHMM_ERR_NO_MEMORY = 6
+PHMM_ERR_INTERNAL = 7
 
 class EngineConfig(C.Structure):
     """phmm_engine_config (include/phmm.h)."""
@@ -63,6 +65,8 @@ SYMBOLS = [
                                       u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_engine_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                      u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p, C.POINTER(C.c_uint64)]),
+    ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),
     ("phmm_table_match_to_match", C.c_size_t, [C.POINTER(f64p)]),
 ]

@@ -54,8 +54,23 @@ static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv(
 static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
 static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
+static const int kForcedEagerD2H = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
+// (these five are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Entry points leave the calling thread's current HIP device as they found it.
+struct DeviceGuard {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
 
 struct ShapeClass {
     int L = 0, K = 0;  // L == 0 -> generic kernel
@@ -110,6 +125,11 @@ struct phmm_batch {
     std::vector<void *> mallocs;  // hipMalloc'ed pieces owned by this batch (persistent batches, generic scratch)
     size_t out_arena_off = 0;     // arena mode: offset of [status word | out]
     bool tight_out = true;        // out_off has no gaps (every slot is written by a kernel)
+    std::vector<std::pair<uint64_t, uint64_t>> out_extents;  // !tight_out: (first slot, Nr*Nh) per region -- gaps stay untouched
+    uint32_t max_h = 0;           // longest haplotype (sizes the scratch of phmm_rescue)
+    double *rescue_scratch = nullptr;  // non-null: the exact pass rides behind every launch (persistent batches: own
+                                       // scratch; engine-level call: the arena's, its results are consumed on the device)
+    uint32_t rescue_blocks = 0;
     bool bound = false;
     std::string dominant;
 };
@@ -134,6 +154,36 @@ bool hip_ok(phmm_handle *h, hipError_t e, const char *what) {
     do {                                       \
         if (!hip_ok((h), (call), #call)) return ret; \
     } while (0)
+
+// No C++ exception crosses the C ABI: every extern "C" body that can allocate runs inside PHMM_GUARD.
+int on_exception(phmm_handle *h, const char *where, const char *what, int code) {
+    std::string msg = std::string(where) + ": " + what;
+    if (h) {
+        h->err = msg;
+        h->err_code = code;
+    } else {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_err = msg;
+    }
+    return code;
+}
+#define PHMM_GUARD_BEGIN try {
+#define PHMM_GUARD_END(h, where, fail)                                                                    \
+    }                                                                                                     \
+    catch (const std::bad_alloc &) {                                                                      \
+        (void)on_exception((h), (where), "out of host memory", PHMM_ERR_NO_MEMORY);                       \
+        return fail(PHMM_ERR_NO_MEMORY);                                                                  \
+    }                                                                                                     \
+    catch (const std::exception &e) {                                                                     \
+        (void)on_exception((h), (where), e.what(), PHMM_ERR_INTERNAL);                                    \
+        return fail(PHMM_ERR_INTERNAL);                                                                   \
+    }                                                                                                     \
+    catch (...) {                                                                                         \
+        (void)on_exception((h), (where), "unknown exception", PHMM_ERR_INTERNAL);                         \
+        return fail(PHMM_ERR_INTERNAL);                                                                   \
+    }
+#define PHMM_FAIL_CODE(c) (c)
+#define PHMM_FAIL_NULL(c) nullptr
 
 int round_up_k(int k) {
     for (int i = 0; i < kNumInstantiatedK; ++i)
@@ -204,12 +254,28 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         g_create_err = "phmm_create: no HIP device with that id (this engine has no CPU fallback)";
         return nullptr;
     }
-    if (!hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice")) return nullptr;
+    DeviceGuard dg(device_id);
+    if (!dg.ok && !hip_ok(nullptr, hipErrorInvalidDevice, "hipSetDevice")) return nullptr;
+    PHMM_GUARD_BEGIN
     phmm_handle *h = new phmm_handle();
     h->device = device_id;
     h->flags = flags;
-    if (const char *e = getenv("PHMM_FORCE_L")) h->force_L = atoi(e);
-    if (const char *e = getenv("PHMM_FORCE_QUAD_SPLIT")) h->force_split = atoi(e);
+    {   // the one place the PHMM_* developer switches are read (phmm_set_switch changes them per handle afterwards)
+        Switches &w = h->sw;
+        auto env = [](const char *name, int &dst) {
+            if (const char *e = getenv(name)) dst = atoi(e);
+        };
+        env("PHMM_FORCE_L", w.force_L);
+        env("PHMM_FORCE_QUAD_SPLIT", w.force_split);
+        env("PHMM_FORCE_CHAIN", w.force_chain);
+        env("PHMM_FORCE_STREAMS", w.force_streams);
+        env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
+        env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
+        env("PHMM_SUBMIT_LANES", w.submit_lanes);
+        w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
+        w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
+        w.trace = getenv("PHMM_TRACE") != nullptr;
+    }
     const auto &eps = table_eps();
     const auto &eps3 = table_eps_third();
     const auto &mm = table_match_to_match();
@@ -252,12 +318,13 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         return nullptr;
     }
     return h;
+    PHMM_GUARD_END(nullptr, "phmm_create", PHMM_FAIL_NULL)
 }
 
 void phmm_destroy(phmm_handle *h) {
     if (!h) return;
     if (h->comb) phmm_host::combiner_destroy(h->comb);
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     for (int i = 0; i < kSlots; ++i)
         if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
     if (h->d_eps) (void)hipFree(h->d_eps);
@@ -269,6 +336,7 @@ void phmm_destroy(phmm_handle *h) {
     for (int i = 0; i < kSlots; ++i) {
         if (h->arenas[i].dev) (void)hipFree(h->arenas[i].dev);
         if (h->arenas[i].host) (void)hipHostFree(h->arenas[i].host);
+        if (h->arenas[i].rescue) (void)hipFree(h->arenas[i].rescue);
     }
     delete h;
 }
@@ -284,7 +352,7 @@ size_t phmm_table_match_to_match(const double **mm) {
 
 void phmm_batch_destroy(phmm_batch *b) {
     if (!b) return;
-    (void)hipSetDevice(b->h->device);
+    DeviceGuard dg(b->h->device);
     for (void *m : b->mallocs) (void)hipFree(m);
     delete b;
 }
@@ -319,8 +387,11 @@ const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off
     }
     for (uint32_t r = 0; r < n_reads; ++r)
         if (read_off[r + 1] < read_off[r]) return "phmm_batch_create: read_off not monotonic";
-    for (uint32_t a = 0; a < n_haps; ++a)
+    for (uint32_t a = 0; a < n_haps; ++a) {
         if (hap_off[a + 1] < hap_off[a]) return "phmm_batch_create: hap_off not monotonic";
+        // the reference would compute 2^1020 / 0 (pair_hmm.rs:515-517); SURVEY 8b asks for an explicit error
+        if (hap_off[a + 1] == hap_off[a]) return "phmm_batch_create: empty haplotype";
+    }
     if (tight_out) *tight_out = tight;
     return nullptr;
 }
@@ -343,8 +414,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         return nullptr;
     }
     const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
-    if (hipSetDevice(h->device) != hipSuccess) {
+    DeviceGuard dg(h->device);
+    if (!dg.ok) {
         h->err = "hipSetDevice failed";
+        h->err_code = PHMM_ERR_HIP;
         return nullptr;
     }
 
@@ -357,18 +430,202 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     b->read_bytes = read_off[n_reads];
     b->hap_bytes = hap_off[n_haps];
     b->tight_out = tight;
+    if (!tight)
+        for (uint32_t g = 0; g < n_regions; ++g)
+            b->out_extents.emplace_back(out_off[g], (uint64_t)(region_read_off[g + 1] - region_read_off[g]) *
+                                                        (uint64_t)(region_hap_off[g + 1] - region_hap_off[g]));
     b->home_stream = h->S();
 
-    // ---- device memory provider ---------------------------------------------------------------
+    bool ok = true;
+
+    // ---- per-region shape, totals -----------------------------------------------------------
+    struct RegionShape {
+        uint32_t nr, nh, max_r, max_h, mean_r, min_r = 0xffffffffu, min_h = 0xffffffffu;
+        uint64_t cells;
+    };
+    std::vector<RegionShape> shape(n_regions);
+    std::vector<uint32_t> read_region(n_reads);
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        RegionShape s{};
+        s.nr = region_read_off[g + 1] - region_read_off[g];
+        s.nh = region_hap_off[g + 1] - region_hap_off[g];
+        uint64_t sum_r = 0, sum_h = 0;
+        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) {
+            const uint32_t len = read_off[r + 1] - read_off[r];
+            s.max_r = std::max(s.max_r, len);
+            s.min_r = std::min(s.min_r, len);
+            sum_r += len;
+            read_region[r] = g;
+        }
+        for (uint32_t a = region_hap_off[g]; a < region_hap_off[g + 1]; ++a) {
+            const uint32_t len = hap_off[a + 1] - hap_off[a];
+            s.max_h = std::max(s.max_h, len);
+            s.min_h = std::min(s.min_h, len);
+            sum_h += len;
+        }
+        s.mean_r = s.nr ? (uint32_t)(sum_r / s.nr) : 0;
+        s.cells = sum_r * sum_h;
+        b->cells += s.cells;
+        b->alg_bytes += 5 * sum_r + sum_h + 8ull * s.nr * s.nh;
+        shape[g] = s;
+    }
+
+    // ---- choose <L,K> per region ------------------------------------------------------------
+    // Candidates L in {16,32,64}; K = ceil(max_h / L) rounded up to an instantiated value.
+    // Pick the most efficient one, then trade lanes-per-pair for more waves while the batch is
+    // too small to fill the chip.
+    // The chained kernel holds a 19 KB LDS ring per wave (two waves per SIMD): a win wherever the per-read kernel
+    // runs two waves per SIMD anyway, a loss against the three or four waves small K gets at 32 / 64 lanes per
+    // pair (measured: <32,10> 3150 per-read vs 2860 chained; <32,13> 3030 vs 3450; <32,19> 3220 vs 3470).
+    const Switches &sw = h->sw;
+    const bool chain_forced = sw.force_chain >= 0;  // tests: every chainable shape chains
+    auto chain_shape_ok = [&](int L, int k, const RegionShape &s) {
+        return k > 0 && k <= chain_max_k() && (L == 16 || k >= 13 || chain_forced) && s.min_r >= 1 && s.min_h >= 1;
+    };
+    bool assume_chain = false;  // second planning pass: the batch is large enough for the chained kernel
+    auto pick = [&](const RegionShape &s, int min_L, int &L_out, int &K_out) {
+        double best = -1.0;
+        L_out = 0;
+        K_out = 0;
+        for (int L : {16, 32, 64}) {
+            if (L < min_L) continue;
+            if (h->sw.force_L && L != h->sw.force_L) continue;
+            const int k = round_up_k((int)((std::max<uint32_t>(s.max_h, 1) + L - 1) / L));
+            if (!k) continue;
+            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h, assume_chain && chain_shape_ok(L, k, s));
+            if (e > best) {
+                best = e;
+                L_out = L;
+                K_out = k;
+            }
+        }
+    };
+    std::vector<int> reg_L(n_regions), reg_K(n_regions);
+    int min_L = 16;
+    auto plan_shapes = [&]() {
+        min_L = 16;
+        for (;;) {
+            uint64_t waves = 0;
+            for (uint32_t g = 0; g < n_regions; ++g) {
+                const RegionShape &s = shape[g];
+                if (!s.nr || !s.nh) {
+                    reg_L[g] = reg_K[g] = -1;  // nothing to do
+                    continue;
+                }
+                pick(s, min_L, reg_L[g], reg_K[g]);
+                if (reg_L[g]) waves += (uint64_t)s.nr * ((s.nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
+            }
+            // one wave per SIMD is enough to stop trading lanes for waves (measured on 1, 2, 4 regions of config 2:
+            // <64,5> 41 us, <32,10> 54 us vs <64,5> 60 us, <16,19> 87 us vs <32,10> 88 us)
+            if (waves * h->gpu_sharers >= 1ull * kNumSimd || min_L == 64 || h->sw.force_L) break;
+            min_L *= 2;
+        }
+    };
+    plan_shapes();
+
+    // Chained kernel (phmm_chain_kernels.hip): reads of a region stream back to back through the lane
+    // pipeline, which removes the per-read fill/drain steps.  Worth it (and balanced) only when there is
+    // enough work to give every wave a run of reads: decide per batch, qualify per region.
+    const int force_streams = sw.force_streams;  // tests: 1 | 2 | 4
+    auto streams_of = [&](uint32_t g) {
+        if (reg_L[g] != 16) return 1;
+        if (force_streams == 1 || force_streams == 2 || force_streams == 4) return force_streams;
+        return chain_streams(shape[g].nh, nullptr);
+    };
+    auto count_units = [&]() {  // wave-sweeps (one read against one wave-load of haplotypes) under the chosen shapes
+        uint64_t u = 0;
+        for (uint32_t g = 0; g < n_regions; ++g)
+            if (reg_L[g] > 0) {
+                const uint32_t S = (uint32_t)streams_of(g), gs = (uint32_t)(WAVE / reg_L[g]) / S;
+                u += (uint64_t)shape[g].nr * ((shape[g].nh + gs - 1) / gs) / S;
+            }
+        return u;
+    };
+    uint64_t units = count_units();
+    // run length: about eight runs per wave slot (balance), but never runs shorter than four reads (measured on 128
+    // regions of config 2: runs of 2 reads 3380, of 4 reads 3530, per-read kernel 3450 GCUPS); below two runs of two
+    // per slot the batch stays with the per-read kernel
+    auto runs_for = [&](uint64_t u) {
+        const uint32_t r = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, u / (8ull * 2 * kNumSimd));
+        return r >= 2 && r < 4 ? 4u : r;
+    };
+    uint32_t chain_reads = runs_for(units);
+    if (chain_forced) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, sw.force_chain);
+    if (chain_reads >= 2 && !h->sw.force_L) {
+        // chained sweeps pay no per-read fill/drain: choose the shapes again without that term (more lanes per pair
+        // become attractive for regions with few haplotypes), and keep the result if the batch still chains
+        std::vector<int> L0 = reg_L, K0 = reg_K;
+        assume_chain = true;
+        plan_shapes();
+        const uint32_t cr = chain_forced ? chain_reads : runs_for(count_units());
+        if (cr >= 2 && min_L == 16) {
+            chain_reads = cr;
+            units = count_units();
+        } else {
+            reg_L = L0;
+            reg_K = K0;
+        }
+        assume_chain = false;
+    }
+    auto chainable = [&](uint32_t g) {
+        const RegionShape &s = shape[g];
+        return chain_reads >= 2 && reg_L[g] > 0 && chain_shape_ok(reg_L[g], reg_K[g], s);
+    };
+
+    if (sw.trace)
+        fprintf(stderr, "phmm plan: %u regions, min_L %d, units %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
+                min_L, (unsigned long long)units, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
+                n_regions ? (int)chainable(0) : 0);
+    std::map<std::tuple<int, int, int>, ShapeClass> by_shape;  // (L, K, 0 = per-read kernel | streams of the chained kernel)
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if (reg_L[g] < 0) continue;
+        const RegionShape &s = shape[g];
+        int L = reg_L[g], K = reg_K[g];
+        // LDS staging must hold the longest read of the region, one wave per block at least
+        const size_t rows = align_up((size_t)s.max_r + 1, 8);
+        if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
+        const bool chain = L && chainable(g);
+        const int streams = chain ? streams_of(g) : 1;
+        ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? streams : 0)];
+        c.L = L;
+        c.K = K;
+        c.chain = chain;
+        c.streams = streams;
+        if (chain) c.regions.push_back(g);
+        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.reads.push_back(r);
+        c.max_r = std::max(c.max_r, s.max_r);
+        c.max_h = std::max(c.max_h, s.max_h);
+        if (L) c.max_quads = std::max(c.max_quads, (s.nh + WAVE / L - 1) / (WAVE / L));
+        c.cells += s.cells;
+        if (!L)
+            for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.pair_first.push_back(s.nh);
+    }
+
+    // bytes of per-class work lists the plan will place in device memory
+    size_t class_meta = 0;
+    for (const auto &kv : by_shape) {
+        const ShapeClass &c = kv.second;
+        b->max_h = std::max(b->max_h, c.max_h);
+        class_meta += align_up(c.reads.size() * 4, 256);
+        if (c.chain) {
+            const uint32_t run = std::min<uint32_t>(CHAIN_MAX_READS, chain_reads * (uint32_t)c.streams);
+            const uint32_t gs = (uint32_t)(WAVE / c.L) / (uint32_t)c.streams;
+            uint64_t items = 0;
+            for (uint32_t g : c.regions) items += (uint64_t)((shape[g].nh + gs - 1) / gs) * ((shape[g].nr + run - 1) / run);
+            class_meta += align_up(items * sizeof(ChainItem), 256);
+        }
+        if (!c.L) class_meta += align_up((c.pair_first.size() + 1) * 8, 256);
+    }
+    // ---- device memory provider (after planning: the arena is sized from the plan) -----------------
     // arena mode: bump-allocate from the handle's arena, "uploads" go to the pinned mirror and travel in
     // one copy later; otherwise hipMalloc per piece and async copies on the handle's stream.
-    bool ok = true;
     if (use_arena) {
-        const size_t need = align_up((size_t)n_reads * 4, 256) * 2 + align_up((size_t)(n_regions + 1) * 4, 256) * 2 +
+        // exact: every dalloc() below and the payload / result placement of enqueue_compute (each piece starts on a
+        // 256-byte boundary), so that nothing staged later can fail for lack of room
+        const size_t need = align_up((size_t)n_reads * 4, 256) + align_up((size_t)(n_regions + 1) * 4, 256) * 2 +
                             align_up((size_t)(n_reads + 1) * 4, 256) + align_up((size_t)(n_haps + 1) * 4, 256) +
-                            align_up((size_t)(n_regions + 1) * 8, 256) + 5 * align_up(b->read_bytes, 256) +
-                            align_up(b->hap_bytes, 256) + align_up(b->n_out * 8, 256) + 64 * 1024 + extra_arena_bytes +
-                            (size_t)n_reads * 64 /* chain items (16 B): up to four per read fit; more spill to hipMalloc (dalloc) */ +
+                            align_up((size_t)(n_regions + 1) * 8, 256) + class_meta + 5 * align_up(b->read_bytes, 256) +
+                            align_up(b->hap_bytes, 256) + 256 + align_up(b->n_out * 8, 256) + 4096 + extra_arena_bytes +
                             align_up((size_t)n_reads, 256) /* redo flags of the f32-first mode */;
         Arena &A = h->A();
         if (A.cap < need) {
@@ -414,169 +671,6 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         }
     };
 
-    // ---- per-region shape, totals -----------------------------------------------------------
-    struct RegionShape {
-        uint32_t nr, nh, max_r, max_h, mean_r, min_r = 0xffffffffu, min_h = 0xffffffffu;
-        uint64_t cells;
-    };
-    std::vector<RegionShape> shape(n_regions);
-    std::vector<uint32_t> read_region(n_reads);
-    for (uint32_t g = 0; g < n_regions; ++g) {
-        RegionShape s{};
-        s.nr = region_read_off[g + 1] - region_read_off[g];
-        s.nh = region_hap_off[g + 1] - region_hap_off[g];
-        uint64_t sum_r = 0, sum_h = 0;
-        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) {
-            const uint32_t len = read_off[r + 1] - read_off[r];
-            s.max_r = std::max(s.max_r, len);
-            s.min_r = std::min(s.min_r, len);
-            sum_r += len;
-            read_region[r] = g;
-        }
-        for (uint32_t a = region_hap_off[g]; a < region_hap_off[g + 1]; ++a) {
-            const uint32_t len = hap_off[a + 1] - hap_off[a];
-            s.max_h = std::max(s.max_h, len);
-            s.min_h = std::min(s.min_h, len);
-            sum_h += len;
-        }
-        s.mean_r = s.nr ? (uint32_t)(sum_r / s.nr) : 0;
-        s.cells = sum_r * sum_h;
-        b->cells += s.cells;
-        b->alg_bytes += 5 * sum_r + sum_h + 8ull * s.nr * s.nh;
-        shape[g] = s;
-    }
-
-    // ---- choose <L,K> per region ------------------------------------------------------------
-    // Candidates L in {16,32,64}; K = ceil(max_h / L) rounded up to an instantiated value.
-    // Pick the most efficient one, then trade lanes-per-pair for more waves while the batch is
-    // too small to fill the chip.
-    // The chained kernel holds a 19 KB LDS ring per wave (two waves per SIMD): a win wherever the per-read kernel
-    // runs two waves per SIMD anyway, a loss against the three or four waves small K gets at 32 / 64 lanes per
-    // pair (measured: <32,10> 3150 per-read vs 2860 chained; <32,13> 3030 vs 3450; <32,19> 3220 vs 3470).
-    const bool chain_forced = getenv("PHMM_FORCE_CHAIN") != nullptr;  // tests: every chainable shape chains
-    auto chain_shape_ok = [&](int L, int k, const RegionShape &s) {
-        return k > 0 && k <= chain_max_k() && (L == 16 || k >= 13 || chain_forced) && s.min_r >= 1 && s.min_h >= 1;
-    };
-    bool assume_chain = false;  // second planning pass: the batch is large enough for the chained kernel
-    auto pick = [&](const RegionShape &s, int min_L, int &L_out, int &K_out) {
-        double best = -1.0;
-        L_out = 0;
-        K_out = 0;
-        for (int L : {16, 32, 64}) {
-            if (L < min_L) continue;
-            if (h->force_L && L != h->force_L) continue;
-            const int k = round_up_k((int)((std::max<uint32_t>(s.max_h, 1) + L - 1) / L));
-            if (!k) continue;
-            const double e = shape_efficiency(L, k, s.nh, s.mean_r, s.max_h, assume_chain && chain_shape_ok(L, k, s));
-            if (e > best) {
-                best = e;
-                L_out = L;
-                K_out = k;
-            }
-        }
-    };
-    std::vector<int> reg_L(n_regions), reg_K(n_regions);
-    int min_L = 16;
-    auto plan_shapes = [&]() {
-        min_L = 16;
-        for (;;) {
-            uint64_t waves = 0;
-            for (uint32_t g = 0; g < n_regions; ++g) {
-                const RegionShape &s = shape[g];
-                if (!s.nr || !s.nh) {
-                    reg_L[g] = reg_K[g] = -1;  // nothing to do
-                    continue;
-                }
-                pick(s, min_L, reg_L[g], reg_K[g]);
-                if (reg_L[g]) waves += (uint64_t)s.nr * ((s.nh + WAVE / reg_L[g] - 1) / (WAVE / reg_L[g]));
-            }
-            // one wave per SIMD is enough to stop trading lanes for waves (measured on 1, 2, 4 regions of config 2:
-            // <64,5> 41 us, <32,10> 54 us vs <64,5> 60 us, <16,19> 87 us vs <32,10> 88 us)
-            if (waves * h->gpu_sharers >= 1ull * kNumSimd || min_L == 64 || h->force_L) break;
-            min_L *= 2;
-        }
-    };
-    plan_shapes();
-
-    // Chained kernel (phmm_chain_kernels.hip): reads of a region stream back to back through the lane
-    // pipeline, which removes the per-read fill/drain steps.  Worth it (and balanced) only when there is
-    // enough work to give every wave a run of reads: decide per batch, qualify per region.
-    int force_streams = 0;  // tests: PHMM_FORCE_STREAMS = 1 | 2 | 4
-    if (const char *e = getenv("PHMM_FORCE_STREAMS")) force_streams = atoi(e);
-    auto streams_of = [&](uint32_t g) {
-        if (reg_L[g] != 16) return 1;
-        if (force_streams == 1 || force_streams == 2 || force_streams == 4) return force_streams;
-        return chain_streams(shape[g].nh, nullptr);
-    };
-    auto count_units = [&]() {  // wave-sweeps (one read against one wave-load of haplotypes) under the chosen shapes
-        uint64_t u = 0;
-        for (uint32_t g = 0; g < n_regions; ++g)
-            if (reg_L[g] > 0) {
-                const uint32_t S = (uint32_t)streams_of(g), gs = (uint32_t)(WAVE / reg_L[g]) / S;
-                u += (uint64_t)shape[g].nr * ((shape[g].nh + gs - 1) / gs) / S;
-            }
-        return u;
-    };
-    uint64_t units = count_units();
-    // run length: about eight runs per wave slot (balance), but never runs shorter than four reads (measured on 128
-    // regions of config 2: runs of 2 reads 3380, of 4 reads 3530, per-read kernel 3450 GCUPS); below two runs of two
-    // per slot the batch stays with the per-read kernel
-    auto runs_for = [&](uint64_t u) {
-        const uint32_t r = (uint32_t)std::min<uint64_t>(CHAIN_MAX_READS, u / (8ull * 2 * kNumSimd));
-        return r >= 2 && r < 4 ? 4u : r;
-    };
-    uint32_t chain_reads = runs_for(units);
-    if (const char *e = getenv("PHMM_FORCE_CHAIN")) chain_reads = (uint32_t)std::min(CHAIN_MAX_READS, std::max(0, atoi(e)));
-    if (chain_reads >= 2 && !h->force_L) {
-        // chained sweeps pay no per-read fill/drain: choose the shapes again without that term (more lanes per pair
-        // become attractive for regions with few haplotypes), and keep the result if the batch still chains
-        std::vector<int> L0 = reg_L, K0 = reg_K;
-        assume_chain = true;
-        plan_shapes();
-        const uint32_t cr = getenv("PHMM_FORCE_CHAIN") ? chain_reads : runs_for(count_units());
-        if (cr >= 2 && min_L == 16) {
-            chain_reads = cr;
-            units = count_units();
-        } else {
-            reg_L = L0;
-            reg_K = K0;
-        }
-        assume_chain = false;
-    }
-    auto chainable = [&](uint32_t g) {
-        const RegionShape &s = shape[g];
-        return chain_reads >= 2 && reg_L[g] > 0 && chain_shape_ok(reg_L[g], reg_K[g], s);
-    };
-
-    if (getenv("PHMM_TRACE"))
-        fprintf(stderr, "phmm plan: %u regions, min_L %d, units %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
-                min_L, (unsigned long long)units, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
-                n_regions ? (int)chainable(0) : 0);
-    std::map<std::tuple<int, int, int>, ShapeClass> by_shape;  // (L, K, 0 = per-read kernel | streams of the chained kernel)
-    for (uint32_t g = 0; g < n_regions; ++g) {
-        if (reg_L[g] < 0) continue;
-        const RegionShape &s = shape[g];
-        int L = reg_L[g], K = reg_K[g];
-        // LDS staging must hold the longest read of the region, one wave per block at least
-        const size_t rows = align_up((size_t)s.max_r + 1, 8);
-        if (L && rows * kLdsRowBytes > kLdsBytesPerCU) L = K = 0;
-        const bool chain = L && chainable(g);
-        const int streams = chain ? streams_of(g) : 1;
-        ShapeClass &c = by_shape[std::make_tuple(L, K, chain ? streams : 0)];
-        c.L = L;
-        c.K = K;
-        c.chain = chain;
-        c.streams = streams;
-        if (chain) c.regions.push_back(g);
-        for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.reads.push_back(r);
-        c.max_r = std::max(c.max_r, s.max_r);
-        c.max_h = std::max(c.max_h, s.max_h);
-        if (L) c.max_quads = std::max(c.max_quads, (s.nh + WAVE / L - 1) / (WAVE / L));
-        c.cells += s.cells;
-        if (!L)
-            for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.pair_first.push_back(s.nh);
-    }
-
     // ---- device metadata --------------------------------------------------------------------
     void *m_rr, *m_rro, *m_rho, *m_ro, *m_ho, *m_oo;
     b->d_read_region = (uint32_t *)dalloc((size_t)n_reads * 4, &m_rr);
@@ -594,6 +688,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     if (!b->arena) {  // persistent batch: own status word (arena mode keeps it next to the results)
         b->d_status = (uint32_t *)dalloc(256, nullptr);
         if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->S()), "memset status");
+        // ... and own scratch for the exact pass, which rides behind the forward kernels of every launch (the caller
+        // owns the stream, so the library cannot look at the status word in between)
+        if (ok && n_reads && !sw.no_rescue) {
+            size_t bytes = 0;
+            rescue_geometry(b->max_h, &b->rescue_blocks, &bytes);
+            ok = hip_ok(h, hipMalloc((void **)&b->rescue_scratch, bytes), "hipMalloc(rescue scratch)");
+            if (ok) b->mallocs.push_back(b->rescue_scratch);
+        }
     }
 
     // ---- finalise classes -------------------------------------------------------------------
@@ -651,20 +753,20 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             // One wave per workgroup: waves are independent (no barrier, private LDS), and a multi-wave block
             // would hold its LDS until its longest read finishes -- with mixed read lengths that idles SIMDs.
             c.waves_per_block = 1;
-            if (const char *e = getenv("PHMM_WAVES_PER_BLOCK"))
-                c.waves_per_block = (int)std::min<size_t>(std::max(1, atoi(e)),
+            if (sw.waves_per_block > 0)
+                c.waves_per_block = (int)std::min<size_t>((size_t)sw.waves_per_block,
                                                           std::min<size_t>(MAX_WAVES_PER_BLOCK, kLdsBytesPerCU / per_wave));
             c.lds_bytes = per_wave * c.waves_per_block;
             // Enough reads to fill the chip -> one wave walks all haplotype groups of its read (row
             // constants staged once); otherwise spread the groups over gridDim.y.
             bool split = (uint64_t)n_items < 4ull * kNumSimd;
-            if (h->force_split >= 0) split = h->force_split != 0;
+            if (h->sw.force_split >= 0) split = h->sw.force_split != 0;
             c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
             // a wave alone on its SIMD is latency-bound: the v_cndmask select (one more VALU op, no EXEC round
             // trip) is ~8 % faster there; with two resident waves the EXEC-masked select wins
             const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
             c.cnd_select = waves < 2ull * kNumSimd ? 1u : 0u;
-            if (const char *e = getenv("PHMM_FORCE_CND_SELECT")) c.cnd_select = atoi(e) ? 1u : 0u;
+            if (sw.force_cnd_select >= 0) c.cnd_select = sw.force_cnd_select ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {
             // generic: exclusive prefix of pairs per read, scratch for a bounded grid
@@ -707,7 +809,9 @@ extern "C" {
 phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
                               const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off,
                               const uint64_t *out_off) {
+    PHMM_GUARD_BEGIN
     return batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, false);
+    PHMM_GUARD_END(h, "phmm_batch_create", PHMM_FAIL_NULL)
 }
 
 int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q, const uint8_t *d_ins_q,
@@ -737,7 +841,7 @@ int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *b
         h->err = "phmm_batch_upload: null host pointer";
         return PHMM_ERR_INVALID_ARG;
     }
-    HIP_TRY(h, hipSetDevice(h->device), PHMM_ERR_HIP);
+    DeviceGuard dg(h->device);
     const size_t rb = align_up(b->read_bytes, 256), hb = align_up(b->hap_bytes, 256), ob = align_up(b->n_out * 8, 256);
     if (!b->d_owned) {
         HIP_TRY(h, hipMalloc(&b->d_owned, 5 * rb + hb + ob + 256), PHMM_ERR_HIP);
@@ -756,6 +860,61 @@ int phmm_batch_upload(phmm_batch *b, const uint8_t *read_bases, const uint8_t *b
     return phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
 }
 
+// Everything of a launch that does not depend on the shape class.
+static ForwardParams base_params(const phmm_batch *b) {
+    const phmm_handle *h = b->h;
+    ForwardParams p{};
+    p.read_region = b->d_read_region;
+    p.region_read_off = b->d_region_read_off;
+    p.region_hap_off = b->d_region_hap_off;
+    p.read_off = b->d_read_off;
+    p.hap_off = b->d_hap_off;
+    p.out_off = b->d_out_off;
+    p.read_bases = b->d_read_bases;
+    p.base_q = b->d_base_q;
+    p.ins_q = b->d_ins_q;
+    p.del_q = b->d_del_q;
+    p.gcp = b->d_gcp;
+    p.hap_bases = b->d_hap_bases;
+    p.out = b->d_out;
+    p.eps = h->d_eps;
+    p.eps_mis = h->d_eps_mis;
+    p.mm = h->d_mm;
+    p.ratio_mis = h->d_ratio_mis;
+    p.inv_om = h->d_inv_om;
+    p.initial_condition = initial_condition();
+    p.initial_condition_log10 = initial_condition_log10();
+    p.status = b->d_status;
+    return p;
+}
+
+// The exact pass over the pairs below kRescueBelow (phmm_exact_kernels.hip).  force == 0: in-stream, the kernel looks
+// at the status word itself and returns at once when no forward kernel raised STATUS_RESCUE.
+static int launch_rescue_pass(phmm_batch *b, double *scratch, uint32_t n_blocks, bool force, hipStream_t stream) {
+    RescueParams rp{};
+    rp.f = base_params(b);
+    rp.n_reads = b->n_reads;
+    rp.scratch = scratch;
+    rp.max_h = b->max_h;
+    rp.n_blocks = n_blocks;
+    rp.force = force ? 1u : 0u;
+    return hip_ok(b->h, launch_rescue(rp, stream), "phmm_rescue") ? PHMM_OK : PHMM_ERR_HIP;
+}
+
+// Scratch of the exact pass for batches staged in arena `A` (grow-only; the caller has made sure nothing that could
+// use the old buffer is in flight on this slot).
+static bool ensure_arena_rescue(phmm_handle *h, Arena &A, uint32_t max_h, uint32_t *n_blocks) {
+    size_t bytes = 0;
+    rescue_geometry(max_h, n_blocks, &bytes);
+    if (A.rescue_cap >= bytes) return true;
+    if (A.rescue) (void)hipFree(A.rescue);
+    A.rescue = nullptr;
+    A.rescue_cap = 0;
+    if (!hip_ok(h, hipMalloc((void **)&A.rescue, bytes), "hipMalloc(rescue scratch)")) return false;
+    A.rescue_cap = bytes;
+    return true;
+}
+
 int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     if (!b) return PHMM_ERR_INVALID_ARG;
     phmm_handle *h = b->h;
@@ -763,35 +922,15 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         h->err = "phmm_batch_launch: no device buffers bound";
         return PHMM_ERR_NOT_BOUND;
     }
+    DeviceGuard dg(h->device);
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : b->home_stream;
     if (b->d_redo && !hip_ok(h, hipMemsetAsync(b->d_redo, 0, b->n_reads, stream), "memset redo")) return PHMM_ERR_HIP;
     for (auto &c : b->classes) {
-        ForwardParams p{};
+        ForwardParams p = base_params(b);
         p.class_reads = c.identity ? nullptr : c.d_reads;
         p.n_items = (uint32_t)c.reads.size();
-        p.read_region = b->d_read_region;
-        p.region_read_off = b->d_region_read_off;
-        p.region_hap_off = b->d_region_hap_off;
-        p.read_off = b->d_read_off;
-        p.hap_off = b->d_hap_off;
-        p.out_off = b->d_out_off;
-        p.read_bases = b->d_read_bases;
-        p.base_q = b->d_base_q;
-        p.ins_q = b->d_ins_q;
-        p.del_q = b->d_del_q;
-        p.gcp = b->d_gcp;
-        p.hap_bases = b->d_hap_bases;
-        p.out = b->d_out;
-        p.eps = h->d_eps;
-        p.eps_mis = h->d_eps_mis;
-        p.mm = h->d_mm;
-        p.ratio_mis = h->d_ratio_mis;
-        p.inv_om = h->d_inv_om;
-        p.initial_condition = initial_condition();
-        p.initial_condition_log10 = initial_condition_log10();
         p.lds_rows = c.lds_rows;
         p.cnd_select = c.cnd_select;
-        p.status = b->d_status;
         if (!p.n_items) continue;
         hipError_t e;
         if (c.chain) {
@@ -824,16 +963,22 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         }
         if (!hip_ok(h, e, c.name)) return PHMM_ERR_HIP;
     }
+    // Results below kRescueBelow are redone in the reference's operation order.  Persistent batches and the
+    // engine-level call carry the pass in-stream (it returns at once unless a forward kernel asked for it); the
+    // host-buffer path looks at the status word in finish_compute instead and pays nothing in the common case.
+    if (b->rescue_scratch && !h->sw.no_rescue && b->n_reads)
+        return launch_rescue_pass(b, b->rescue_scratch, b->rescue_blocks, false, stream);
     return PHMM_OK;
 }
 
 int phmm_batch_status(phmm_batch *b) {
     if (!b) return PHMM_ERR_INVALID_ARG;
     phmm_handle *h = b->h;
+    DeviceGuard dg(h->device);
     uint32_t st = 0;
     HIP_TRY(h, hipMemcpy(&st, b->d_status, 4, hipMemcpyDeviceToHost), PHMM_ERR_HIP);
-    if (st) {
-        HIP_TRY(h, hipMemset(b->d_status, 0, 4), PHMM_ERR_HIP);
+    if (st) HIP_TRY(h, hipMemset(b->d_status, 0, 4), PHMM_ERR_HIP);
+    if (st & STATUS_POSITIVE) {
         h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
         return PHMM_ERR_POSITIVE_RESULT;
     }
@@ -844,6 +989,7 @@ int phmm_batch_download(phmm_batch *b, double *out) {
     if (!b || (b->n_out && !out)) return PHMM_ERR_INVALID_ARG;
     phmm_handle *h = b->h;
     if (!b->bound) return PHMM_ERR_NOT_BOUND;
+    DeviceGuard dg(h->device);
     if (b->n_out)
         HIP_TRY(h, hipMemcpyAsync(out, b->d_out, b->n_out * 8, hipMemcpyDeviceToHost, b->home_stream), PHMM_ERR_HIP);
     HIP_TRY(h, hipStreamSynchronize(b->home_stream), PHMM_ERR_HIP);
@@ -862,8 +1008,7 @@ namespace phmm_host {
 // (chunks of a pipelined call, combined flushes of phmm_wait), eager for a one-shot call.
 // PHMM_EAGER_D2H=1 / 0 forces one or the other (A/B measurements only).
 bool eager_d2h(const phmm_handle *h) {
-    static const int forced = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
-    return forced >= 0 ? forced != 0 : !h->defer_d2h;
+    return kForcedEagerD2H >= 0 ? kForcedEagerD2H != 0 : !h->defer_d2h;
 }
 
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
@@ -871,7 +1016,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                     const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
                     const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
                     const uint64_t *out_off, double *out, PendingCompute *pending, const Parts *parts) {
-    static const bool trace = getenv("PHMM_TRACE") != nullptr;
+    const bool trace = h->sw.trace != 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
     double t_plan = 0, t_stage = 0, t_h2d = 0, t_launch = 0;
@@ -911,6 +1056,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             } else if (bytes) {
                 memcpy(A.host + off, src[i], bytes);
             }
+            h->stat_staged_bytes += bytes;
             d[i] = (const uint8_t *)(A.dev + off);
         }
         const size_t in_bytes = align_up(A.used, 256);
@@ -939,10 +1085,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         }
         if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch"))
             st = PHMM_ERR_HIP;
-        // slots the kernels never write (gaps the caller left in out_off) come back as NaN
-        if (st == PHMM_OK && !b->tight_out && b->n_out &&
-            !hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->S()), "memset out"))
-            st = PHMM_ERR_HIP;
+        // (slots the kernels never write -- gaps the caller left in out_off -- are never copied back either)
         if (st == PHMM_OK) st = phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
         t_h2d = now();
     }
@@ -1027,34 +1170,71 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
     if (!p->b) return PHMM_OK;
     int st = PHMM_OK;
     phmm_batch *b = p->b;
-    const Arena &A = h->arenas[p->slot];
+    Arena &A = h->arenas[p->slot];
     hipStream_t S = h->streams[p->slot];
-    if (!hip_ok(h, hipStreamSynchronize(S), "sync") ||
-        (p->d2h_pending &&  // kernels are done: fetch [status | out] now
-         (!hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, 256 + b->n_out * 8,
-                                    hipMemcpyDeviceToHost, S),
-                  "D2H results") ||
-          !hip_ok(h, hipStreamSynchronize(S), "sync(D2H)")))) {
+    const size_t res_bytes = 256 + b->n_out * 8;
+    auto fetch = [&]() {  // [status | out] -> pinned mirror
+        return hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, res_bytes, hipMemcpyDeviceToHost, S),
+                      "D2H results") &&
+               hip_ok(h, hipStreamSynchronize(S), "sync(D2H)");
+    };
+    if (!hip_ok(h, hipStreamSynchronize(S), "sync") || (p->d2h_pending && !fetch())) {  // kernels are done: fetch now
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + b->out_arena_off;
-        if (p->parts) {
-            const char *src = hs + 256;
-            for (size_t s = 0; s < p->parts->out.size(); ++s) {
-                if (p->parts->n_out[s]) memcpy(p->parts->out[s], src, p->parts->n_out[s] * 8);
-                src += p->parts->n_out[s] * 8;
-            }
-        } else if (b->n_out) {
-            memcpy(p->out, hs + 256, b->n_out * 8);
-        }
-        bool positive = *(const uint32_t *)hs != 0;
+        const double *v = (const double *)(hs + 256);
+        uint32_t bits = *(const uint32_t *)hs;
+        auto each_result = [&](auto &&f) {  // every slot a kernel wrote
+            if (b->tight_out)
+                for (uint64_t i = 0; i < b->n_out; ++i) f(v[i]);
+            else
+                for (const auto &e : b->out_extents)
+                    for (uint64_t i = 0; i < e.second; ++i) f(v[e.first + i]);
+        };
         if (p->zero_copy) {  // the status word stayed on the device: every slot was written once, look at the values
-            const double *v = (const double *)(hs + 256);
-            for (uint64_t i = 0; i < b->n_out; ++i) positive |= !(v[i] <= 0.0);
+            bits = 0;
+            each_result([&](double x) { bits |= status_bits(x); });
         }
-        if (positive) {
-            h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
-            st = PHMM_ERR_POSITIVE_RESULT;
+        if ((bits & STATUS_RESCUE) && !h->sw.no_rescue) {
+            // some pair came out below kRescueBelow: redo those in the reference's operation order, fetch again
+            uint32_t nb = 0;
+            h->stat_rescue_passes += 1;
+            if (!ensure_arena_rescue(h, A, b->max_h, &nb) || launch_rescue_pass(b, A.rescue, nb, true, S) != PHMM_OK ||
+                !hip_ok(h, hipStreamSynchronize(S), "sync(rescue)") || (!p->zero_copy && !fetch())) {
+                st = PHMM_ERR_HIP;
+            } else if (p->zero_copy) {
+                bits = 0;
+                each_result([&](double x) { bits |= status_bits(x); });
+            } else {
+                bits = *(const uint32_t *)hs;
+            }
+        }
+        if (st == PHMM_OK) {
+            const char *src = hs + 256;
+            if (p->parts) {
+                // part s owns the regions [first_region[s], first_region[s+1]) of the combined batch
+                for (size_t s = 0; s < p->parts->out.size(); ++s) {
+                    if (b->tight_out) {
+                        if (p->parts->n_out[s]) memcpy(p->parts->out[s], src, p->parts->n_out[s] * 8);
+                    } else {
+                        const uint32_t g0 = p->parts->first_region[s], g1 = p->parts->first_region[s + 1];
+                        for (uint32_t g = g0; g < g1; ++g) {  // the part's out_off starts at 0, like every offset array
+                            const auto &e = b->out_extents[g];
+                            if (e.second) memcpy(p->parts->out[s] + (e.first - b->out_extents[g0].first), v + e.first, e.second * 8);
+                        }
+                    }
+                    src += p->parts->n_out[s] * 8;
+                }
+            } else if (b->tight_out) {
+                if (b->n_out) memcpy(p->out, src, b->n_out * 8);
+            } else {
+                for (const auto &e : b->out_extents)
+                    if (e.second) memcpy(p->out + e.first, v + e.first, e.second * 8);
+            }
+            if (bits & STATUS_POSITIVE) {
+                h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
+                st = PHMM_ERR_POSITIVE_RESULT;
+            }
         }
     }
     std::string keep = h->err;
@@ -1073,17 +1253,27 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
                  const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
                  const uint64_t *out_off, double *out) {
     if (!h) return PHMM_ERR_INVALID_ARG;
-    static const bool trace = getenv("PHMM_TRACE") != nullptr;
+    PHMM_GUARD_BEGIN
+    const bool trace = h->sw.trace != 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    if (!region_read_off || !region_hap_off || !read_off || !hap_off || !out_off) {
-        h->err = "phmm_compute: null offset array";
-        return PHMM_ERR_INVALID_ARG;
+    // the whole batch is checked before anything is indexed: the chunked path below walks the caller's arrays
+    h->err_code = PHMM_OK;
+    if (tl_err_h == h) tl_err_h = nullptr;
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr)) {
+        h->err = bad;
+        return h->err_code = PHMM_ERR_INVALID_ARG;
     }
     const uint32_t n_reads = region_read_off[n_regions];
+    if ((read_off[n_reads] && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) ||
+        (hap_off[region_hap_off[n_regions]] && !hap_bases) || (out_off[n_regions] && !out)) {
+        h->err = "phmm_compute: null pointer";
+        return h->err_code = PHMM_ERR_INVALID_ARG;
+    }
+    DeviceGuard dg(h->device);
     // ---- small / medium batch: one shot ------------------------------------------------------------
     const bool f32_first = (h->flags & PHMM_FLAG_F32_FIRST) != 0;
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= (f32_first ? (size_t)(8u << 20) : kOneShotBytes) || getenv("PHMM_NO_PIPELINE")) {
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= (f32_first ? (size_t)(8u << 20) : kOneShotBytes) || h->sw.no_pipeline) {
         h->slot = 0;
         PendingCompute p;
         int st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
@@ -1098,6 +1288,20 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     //      and the H2D copy of chunk i+1 overlap the kernels of chunk i.  Results are identical: every
     //      region is independent, the chunk only rebases the offsets. -----------------------------------
     PendingCompute pend[kSlots];
+    struct Drain {  // an exception on the way (host allocation) must not leave chunks in flight
+        phmm_handle *h;
+        PendingCompute *pend;
+        ~Drain() {
+            for (int i = 0; i < kSlots; ++i)
+                if (pend[i].b) {
+                    (void)hipStreamSynchronize(h->streams[pend[i].slot]);
+                    phmm_batch_destroy(pend[i].b);
+                    pend[i].b = nullptr;
+                }
+            h->slot = 0;
+            h->defer_d2h = false;
+        }
+    } drain{h, pend};
     int st = PHMM_OK;
     ChunkView c;
     c.f32_first = f32_first;
@@ -1122,6 +1326,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     h->defer_d2h = false;
     if (trace) fprintf(stderr, "phmm_compute: %d chunks pipelined over %d slots, total %.1f us\n", n_chunks, kSlots, now() - t0);
     return st;
+    PHMM_GUARD_END(h, "phmm_compute", PHMM_FAIL_CODE)
 }
 
 namespace {
@@ -1197,7 +1402,12 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         double *d_out = (double *)(A.dev + res_off + 256 + keep_bytes);
         bool ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->S()), "H2D batch") &&
                   hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->S()), "memset status");
-        if (ok && !b->tight_out && b->n_out) ok = hip_ok(h, hipMemsetAsync(d_out, 0xff, b->n_out * 8, h->S()), "memset out");
+        // the post-step consumes the likelihoods on the device, so the exact pass below kRescueBelow rides in-stream
+        // between the forward kernels and the post-step (phmm_batch_launch); nothing of this slot is in flight now
+        if (ok && n_reads && !h->sw.no_rescue) {
+            ok = ensure_arena_rescue(h, A, b->max_h, &b->rescue_blocks);
+            if (ok) b->rescue_scratch = A.rescue;
+        }
         uint32_t max_r = 0;
         for (uint32_t r = 0; r < n_reads; ++r) max_r = std::max(max_r, read_off[r + 1] - read_off[r]);
         PrepParams pp{};
@@ -1285,8 +1495,14 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
     } else {
         const char *hs = A.host + p->res_off;
         if (p->n_reads) memcpy(p->keep, hs + 256, p->n_reads);
-        if (b->n_out) memcpy(p->out, hs + 256 + p->keep_bytes, b->n_out * 8);
-        if (*(const uint32_t *)hs) {
+        const double *v = (const double *)(hs + 256 + p->keep_bytes);
+        if (b->tight_out) {
+            if (b->n_out) memcpy(p->out, v, b->n_out * 8);
+        } else {  // gaps the caller left in out_off stay untouched
+            for (const auto &e : b->out_extents)
+                if (e.second) memcpy(p->out + e.first, v + e.first, e.second * 8);
+        }
+        if (*(const uint32_t *)hs & STATUS_POSITIVE) {
             h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
             st = PHMM_ERR_POSITIVE_RESULT;
         }
@@ -1306,18 +1522,27 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
                         const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases,
                         const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep) {
     if (!h || !cfg) return PHMM_ERR_INVALID_ARG;
+    PHMM_GUARD_BEGIN
+    h->err_code = PHMM_OK;
+    if (tl_err_h == h) tl_err_h = nullptr;
     if (cfg->pcr_error_model > 3) {
         h->err = "phmm_engine_compute: Unknown PCR Error Model";  // engine.rs:89
-        return PHMM_ERR_INVALID_ARG;
+        return h->err_code = PHMM_ERR_INVALID_ARG;
     }
-    if (!region_read_off || !read_off) {
-        h->err = "phmm_engine_compute: null offset array";
-        return PHMM_ERR_INVALID_ARG;
+    // the whole batch is checked before anything is indexed: the chunked path below walks the caller's arrays
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr)) {
+        h->err = bad;
+        return h->err_code = PHMM_ERR_INVALID_ARG;
     }
     const uint32_t n_reads = region_read_off[n_regions];
+    if ((read_off[n_reads] && (!read_bases || !base_q)) || (n_reads && (!mapq || !keep)) ||
+        (hap_off[region_hap_off[n_regions]] && !hap_bases) || (out_off[n_regions] && !out)) {
+        h->err = "phmm_engine_compute: null pointer";
+        return h->err_code = PHMM_ERR_INVALID_ARG;
+    }
+    DeviceGuard dg(h->device);
     // ---- small / medium batch: one shot ------------------------------------------------------------
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes || !region_hap_off || !hap_off || !out_off ||
-        getenv("PHMM_NO_PIPELINE")) {
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes || h->sw.no_pipeline) {
         h->slot = 0;
         PendingEngine p;
         int st = engine_enqueue(h, cfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q,
@@ -1327,6 +1552,20 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     }
     // ---- large batch: chunks of regions through the kSlots (arena, stream) pairs, like phmm_compute ----
     PendingEngine pend[kSlots];
+    struct Drain {  // an exception on the way (host allocation) must not leave chunks in flight
+        phmm_handle *h;
+        PendingEngine *pend;
+        ~Drain() {
+            for (int i = 0; i < kSlots; ++i)
+                if (pend[i].b) {
+                    (void)hipStreamSynchronize(h->streams[pend[i].slot]);
+                    phmm_batch_destroy(pend[i].b);
+                    pend[i].b = nullptr;
+                }
+            h->slot = 0;
+            h->defer_d2h = false;
+        }
+    } drain{h, pend};
     int st = PHMM_OK;
     ChunkView c;
     int n_chunks = 0;
@@ -1352,6 +1591,38 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
     h->slot = 0;
     h->defer_d2h = false;
     return st;
+    PHMM_GUARD_END(h, "phmm_engine_compute", PHMM_FAIL_CODE)
+}
+
+int phmm_set_switch(phmm_handle *h, const char *name, int value) {
+    if (!h || !name) return PHMM_ERR_INVALID_ARG;
+    Switches &w = h->sw;
+    const std::string n(name);
+    if (n == "force_L") w.force_L = value > 0 ? value : 0;
+    else if (n == "force_quad_split") w.force_split = value;
+    else if (n == "force_chain") w.force_chain = value;
+    else if (n == "force_streams") w.force_streams = value > 0 ? value : 0;
+    else if (n == "waves_per_block") w.waves_per_block = value > 0 ? value : 0;
+    else if (n == "force_cnd_select") w.force_cnd_select = value;
+    else if (n == "no_pipeline") w.no_pipeline = value != 0;
+    else if (n == "no_rescue") w.no_rescue = value != 0;
+    else if (n == "trace") w.trace = value != 0;
+    else {
+        h->err = "phmm_set_switch: unknown switch";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    if (h->comb) phmm_host::combiner_set_switches(h->comb, w);
+    return PHMM_OK;
+}
+
+uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
+    if (!h || !name) return 0;
+    const std::string n(name);
+    uint64_t own = 0;
+    if (n == "staged_bytes") own = h->stat_staged_bytes;
+    else if (n == "rescue_passes") own = h->stat_rescue_passes;
+    else return 0;
+    return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }
 
 uint64_t phmm_batch_cells(const phmm_batch *b) { return b ? b->cells : 0; }

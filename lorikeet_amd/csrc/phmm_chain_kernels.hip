@@ -89,7 +89,7 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
         if (l == 0 && hv) {
             const double v = log10(s) - p.initial_condition_log10;
             p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
-            if (!(v <= 0.0)) atomicOr(p.status, 1u);
+            if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);
         }
     }
     (void)grp;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void chain_fallback_streams(const ForwardParams &p, u
         if (l == 0 && hv && valid) {
             const double v = log10(s) - p.initial_condition_log10;
             p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
-            if (!(v <= 0.0)) atomicOr(p.status, 1u);
+            if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);
         }
     }
 }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
                     if (k == ek) sum = (Dp[k] + Mp[k]) + Ip[k];
                 const double v = log10(sum) - log10_scale;
                 p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
-                if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
+                if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
             }
         }
     };

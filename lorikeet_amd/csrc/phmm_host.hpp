@@ -17,6 +17,23 @@
 struct Arena {
     char *dev = nullptr, *host = nullptr;
     size_t cap = 0, used = 0;
+    double *rescue = nullptr;  // scratch of phmm_rescue for batches staged in this arena (grown on demand)
+    size_t rescue_cap = 0;
+};
+
+// Developer switches: read from the PHMM_* environment variables ONCE, in phmm_create, and
+// changed afterwards only through phmm_set_switch -- nothing on the host path calls getenv.
+struct Switches {
+    int force_L = 0;            // PHMM_FORCE_L: 16 / 32 / 64 lanes per pair, 0 = planner's choice
+    int force_split = -1;       // PHMM_FORCE_QUAD_SPLIT: 1 = one wave per (read, hap group), 0 = loop in wave
+    int force_chain = -1;       // PHMM_FORCE_CHAIN: reads per run of the chained kernel, 0 = per-read kernel only, -1 = planner
+    int force_streams = 0;      // PHMM_FORCE_STREAMS: 1 / 2 / 4 streams of the chained kernel
+    int waves_per_block = 0;    // PHMM_WAVES_PER_BLOCK
+    int force_cnd_select = -1;  // PHMM_FORCE_CND_SELECT
+    int no_pipeline = 0;        // PHMM_NO_PIPELINE: host path in one shot whatever the size
+    int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
+    int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
+    int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
@@ -36,8 +53,9 @@ struct phmm_handle {
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
     int err_code = PHMM_OK;  // status of the last failure (set together with err)
-    int force_L = 0;      // PHMM_FORCE_L env (tuning / tests)
-    int force_split = -1; // PHMM_FORCE_QUAD_SPLIT env: 1 = one wave per (read, hap group), 0 = loop in wave
+    Switches sw;
+    uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
+    uint64_t stat_rescue_passes = 0;  // how many batches needed the exact pass (phmm_get_stat)
     struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
     uint32_t gpu_sharers = 1;         // flows computing at the same time (phmm_wait, combined flushes): the planner stops
                                       // trading lanes for waves once the batch fills its share of the chip
@@ -55,6 +73,7 @@ struct Parts {
     std::vector<size_t> read_bytes, hap_bytes;
     std::vector<double *> out;
     std::vector<uint64_t> n_out;
+    std::vector<uint32_t> first_region;  // [parts + 1] regions of the combined batch each part owns
 };
 
 struct PendingCompute {
@@ -86,5 +105,7 @@ void set_thread_error(const phmm_handle *h, const std::string &msg);
 void clear_thread_error(const phmm_handle *h);
 
 void combiner_destroy(Combiner *c);  // phmm_submit.cpp; called by phmm_destroy
+void combiner_set_switches(Combiner *c, const Switches &sw);  // phmm_set_switch on a shared handle reaches its lanes
+uint64_t combiner_stat(Combiner *c, const char *name);        // sum of phmm_get_stat over the lanes
 
 }  // namespace phmm_host

@@ -37,8 +37,22 @@ struct ForwardParams {
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
     const uint8_t *redo;             // not null: only reads with redo[r] != 0 are computed (f64 pass of the f32-first mode)
     uint32_t cnd_select;             // 1: v_cndmask prior select (launches with < 2 waves per SIMD, K <= PHMM_CND_MAX_K)
-    uint32_t *status;                // device status word (bit0: positive result)
+    uint32_t *status;                // device status word (STATUS_POSITIVE | STATUS_RESCUE)
 };
+
+// Status word bits the forward kernels raise.
+constexpr uint32_t STATUS_POSITIVE = 1u;  // some log10 likelihood came out > 0 (or NaN): pair_hmm.rs:478-481 asserts
+constexpr uint32_t STATUS_RESCUE = 2u;    // some result lies below kRescueBelow: phmm_rescue recomputes those pairs
+// Below this log10 likelihood the scaled row sum of the reference (2^1020 / H scale, pair_hmm.rs:515-529,598-614) gets
+// close to the denormal range, where every rounding counts: the fast kernels (folded row constants, FMA contraction,
+// the chained kernel's common 2^1010 start) are no longer within 1e-9 of the reference there, and they reach -inf at a
+// different point.  Every pair whose result comes out below it (or -inf / NaN) is recomputed by phmm_rescue in the
+// reference's own operation order, so that the underflow band agrees with the scalar arm including where it turns to
+// -inf.  The fast kernels keep 1e-13 down to about -617 (scaled sum >= 2^-1040); -600 leaves 17 decades of margin.
+constexpr double kRescueBelow = -600.0;
+__host__ __device__ inline uint32_t status_bits(double v) {
+    return (!(v <= 0.0) ? STATUS_POSITIVE : 0u) | (!(v >= kRescueBelow) ? STATUS_RESCUE : 0u);
+}
 
 // Launch the <L,K> instantiation.  Returns hipErrorInvalidValue if (L,K) is not instantiated.
 hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int waves_per_block, size_t lds_bytes,
@@ -53,6 +67,26 @@ struct GenericParams {
     uint32_t n_blocks;      // grid the scratch was sized for (256 threads per block)
 };
 hipError_t launch_generic(const GenericParams &p, hipStream_t stream);
+
+// Exact recomputation of the pairs below kRescueBelow (phmm_exact_kernels.hip): one thread per read scans its row of
+// results and redoes what it finds, two rolling rows of M/I/D per thread in `scratch`.
+struct RescueParams {
+    ForwardParams f;
+    uint32_t n_reads;    // reads of the batch (f.read_region etc. cover all of them)
+    double *scratch;     // [n_threads * 6 * (max_h + 1)]
+    uint32_t max_h;      // longest haplotype of the batch
+    uint32_t n_blocks;   // grid the scratch was sized for (64 threads per block)
+    uint32_t force;      // 0: return at once unless the status word carries STATUS_RESCUE (in-stream use)
+};
+hipError_t launch_rescue(const RescueParams &p, hipStream_t stream);
+// threads (a multiple of 64) and bytes of scratch for a batch whose longest haplotype has max_h columns
+inline void rescue_geometry(uint32_t max_h, uint32_t *n_blocks, size_t *scratch_bytes) {
+    const size_t per_thread = 6ull * ((size_t)max_h + 1) * sizeof(double);
+    size_t threads = (64ull << 20) / per_thread / 64 * 64;  // <= 64 MB of scratch
+    threads = threads < 64 ? 64 : threads > 4096 ? 4096 : threads;
+    *n_blocks = (uint32_t)(threads / 64);
+    *scratch_bytes = threads * per_thread;
+}
 
 // ---- chained forward kernel (phmm_chain_kernels.hip) ------------------------------------------------
 constexpr int CHAIN_MAX_READS = 64;  // reads per chain (one lane per read when the stream offsets are scanned)

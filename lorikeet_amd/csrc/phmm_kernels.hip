@@ -94,90 +94,10 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
         if (l == 0 && hv) {
             const double v = log10(s) - p.initial_condition_log10;
             out_row[a] = v;
-            if (!(v <= 0.0)) atomicOr(p.status, 1u);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
+            if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
         }
     }
 }
-
-#ifdef PHMM_WITH_GENERIC
-// ---- generic any-shape fallback -----------------------------------------------------------------
-// One thread per (read, haplotype) pair, two rolling rows of M/I/D in global scratch, interleaved by
-// thread so that neighbouring threads touch neighbouring addresses.  Only used for shapes outside
-// the register-resident kernel (haplotype > 64*KMAX columns or read too long for the LDS staging).
-__global__ __launch_bounds__(256) void phmm_forward_generic(const GenericParams gp) {
-    const ForwardParams &p = gp.f;
-    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t W = (uint64_t)gp.max_h + 1;
-    double *S = gp.scratch;
-    auto at = [&](int arr, uint64_t j) -> double & { return S[((uint64_t)arr * W + j) * nthreads + tid]; };
-    for (uint64_t pair = tid; pair < gp.n_pairs; pair += nthreads) {
-        // item = last i with pair_first[i] <= pair
-        uint32_t lo = 0, hi = p.n_items;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (gp.pair_first[mid] <= pair) lo = mid; else hi = mid;
-        }
-        const uint32_t r = p.class_reads ? p.class_reads[lo] : lo;
-        const uint32_t a = (uint32_t)(pair - gp.pair_first[lo]);
-        const uint32_t reg = p.read_region[r];
-        const uint32_t ro = p.read_off[r];
-        const int R = (int)(p.read_off[r + 1] - ro);
-        const uint32_t h0 = p.region_hap_off[reg];
-        const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
-        const uint32_t ho = p.hap_off[h0 + a];
-        const int H = (int)(p.hap_off[h0 + a + 1] - ho);
-        const double c = p.initial_condition / (double)H;
-        int prv = 0, cur = 3;
-        for (int j = 0; j <= H; ++j) {
-            at(prv + 0, j) = 0.0;
-            at(prv + 1, j) = 0.0;
-            at(prv + 2, j) = c;
-        }
-        for (int i = 0; i < R; ++i) {
-            const uint32_t x = p.read_bases[ro + i], q = p.base_q[ro + i], iq = p.ins_q[ro + i], dq = p.del_q[ro + i],
-                           g = p.gcp[ro + i];
-            const uint32_t mx = max(iq, dq), mn = min(iq, dq);
-            const double mm = p.mm[((mx * (mx + 1)) >> 1) + mn], mi = p.eps[iq], md = p.eps[dq], ii = p.eps[g];
-            const double im = 1.0 - ii, eq = p.eps[q], pm = 1.0 - eq;
-            const double px = (x == 'N') ? pm : p.eps_mis[q];
-            double dM = at(prv + 0, 0), dI = at(prv + 1, 0), dD = at(prv + 2, 0);
-            double leftM = 0.0, leftD = 0.0;
-            at(cur + 0, 0) = 0.0;
-            at(cur + 1, 0) = 0.0;
-            at(cur + 2, 0) = 0.0;
-            for (int j = 1; j <= H; ++j) {
-                const uint32_t y = p.hap_bases[ho + j - 1];
-                const double uM = at(prv + 0, j), uI = at(prv + 1, j), uD = at(prv + 2, j);
-                const double prior = (x == y || y == 'N') ? pm : px;
-                double t = dM * mm;
-                t = fma(dI, im, t);
-                t = fma(dD, im, t);
-                const double Mn = prior * t;
-                const double In = fma(uI, ii, uM * mi);
-                const double Dn = fma(leftD, ii, leftM * md);
-                at(cur + 0, j) = Mn;
-                at(cur + 1, j) = In;
-                at(cur + 2, j) = Dn;
-                dM = uM;
-                dI = uI;
-                dD = uD;
-                leftM = Mn;
-                leftD = Dn;
-            }
-            const int tmp = prv;
-            prv = cur;
-            cur = tmp;
-        }
-        double s = 0.0;
-        for (int j = 1; j <= H; ++j) s += at(prv + 0, j) + at(prv + 1, j);
-        const double v = log10(s) - p.initial_condition_log10;
-        p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = v;
-        if (!(v <= 0.0)) atomicOr(p.status, 1u);
-    }
-}
-
-#endif  // PHMM_WITH_GENERIC
 
 // ---- launch tables -------------------------------------------------------------------------------
 #define PHMM_K_LIST(X, L)                                                                              \
@@ -185,7 +105,8 @@ __global__ __launch_bounds__(256) void phmm_forward_generic(const GenericParams 
     X(L, 15) X(L, 16) X(L, 17) X(L, 18) X(L, 19) X(L, 20) X(L, 21) X(L, 22) X(L, 23) X(L, 24) X(L, 25) X(L, 26) \
     X(L, 27) X(L, 28) X(L, 29) X(L, 30) X(L, 31) X(L, 32)
 // This file is compiled once per lanes-per-pair value (-DPHMM_L=16|32|64) so the three sets of 31
-// instantiations build in parallel; the L=16 object also carries the generic kernel and the dispatcher.
+// instantiations build in parallel; the L=16 object also carries the dispatcher
+// (the generic any-shape kernel lives in phmm_exact_kernels.hip).
 #ifndef PHMM_L
 #error "compile with -DPHMM_L=16|32|64"
 #endif
@@ -220,12 +141,6 @@ hipError_t launch_forward(int L, int K, const ForwardParams &p, dim3 grid, int w
     if (L == 32) return launch_forward_L32(K, p, grid, waves_per_block, lds_bytes, stream);
     if (L == 64) return launch_forward_L64(K, p, grid, waves_per_block, lds_bytes, stream);
     return hipErrorInvalidValue;
-}
-
-hipError_t launch_generic(const GenericParams &gp, hipStream_t stream) {
-    // scratch was sized for exactly this grid by the planner
-    hipLaunchKernelGGL(phmm_forward_generic, dim3(gp.n_blocks), dim3(256), 0, stream, gp);
-    return hipGetLastError();
 }
 
 const int kInstantiatedK[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,

@@ -61,6 +61,7 @@ struct Combiner {
     bool lane_busy[kMaxLanes] = {};
     uint64_t n_flushes = 0, n_parts = 0;  // statistics (phmm_submit_stats)
     double flush_us = 0;  // time spent inside flushes (PHMM_TRACE prints the mean when the handle is destroyed)
+    bool trace = false;
     struct Scratch {  // per lane, reused between flushes
         std::vector<uint32_t> rro, rho, ro, ho;
         std::vector<uint64_t> oo;
@@ -75,12 +76,26 @@ struct Combiner {
 namespace phmm_host {
 
 void combiner_destroy(Combiner *c) {
-    if (getenv("PHMM_TRACE") && c->n_flushes)
+    if (c->trace && c->n_flushes)
         fprintf(stderr, "phmm_submit: %llu flushes carried %llu submissions, mean flush %.1f us\n",
                 (unsigned long long)c->n_flushes, (unsigned long long)c->n_parts, c->flush_us / c->n_flushes);
     for (int l = 0; l < Combiner::kMaxLanes; ++l)
         if (c->lane[l]) phmm_destroy(c->lane[l]);
     delete c;
+}
+
+void combiner_set_switches(Combiner *c, const Switches &sw) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int l = 0; l < Combiner::kMaxLanes; ++l)
+        if (c->lane[l]) c->lane[l]->sw = sw;
+}
+
+uint64_t combiner_stat(Combiner *c, const char *name) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    uint64_t n = 0;
+    for (int l = 0; l < Combiner::kMaxLanes; ++l)
+        if (c->lane[l]) n += phmm_get_stat(c->lane[l], name);
+    return n;
 }
 
 }  // namespace phmm_host
@@ -122,6 +137,7 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
     parts.hap_bytes.clear();
     parts.out.clear();
     parts.n_out.clear();
+    parts.first_region.assign(1, 0);
     for (const Submission *s : subs) {
         const uint32_t r0 = w.rro.back(), h0 = w.rho.back(), rb0 = w.ro.back(), hb0 = w.ho.back();
         const uint64_t o0 = w.oo.back();
@@ -137,6 +153,7 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
         parts.hap_bytes.push_back(s->hap_bytes);
         parts.out.push_back(s->out);
         parts.n_out.push_back(s->n_out);
+        parts.first_region.push_back(parts.first_region.back() + s->n_regions);
     }
     if (subs[0]->engine) {
         const Submission &f = *subs[0];
@@ -201,7 +218,8 @@ namespace {
 int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
     std::call_once(h->comb_once, [h] {
         Combiner *c = new Combiner();
-        if (const char *e = getenv("PHMM_SUBMIT_LANES")) c->n_lanes = std::min(std::max(atoi(e), 1), (int)Combiner::kMaxLanes);
+        c->n_lanes = std::min(std::max(h->sw.submit_lanes, 1), (int)Combiner::kMaxLanes);
+        c->trace = h->sw.trace != 0;
         h->comb = c;
     });
     Combiner *c = h->comb;
@@ -210,6 +228,7 @@ int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
         if (!c->lane[l]) {  // first submission: the lanes are engines of their own on the same device
             c->lane[l] = phmm_create(h->device, h->flags);
             if (!c->lane[l]) return submit_fail(h, PHMM_ERR_HIP, phmm_last_error(nullptr));
+            c->lane[l]->sw = h->sw;  // the lanes follow the shared handle's developer switches
         }
     const uint64_t t = c->next_ticket++;
     c->live.emplace(t, std::move(s));

@@ -154,6 +154,32 @@ class HipPairHMMEngine:
     def plan(self, batch: RegionBatch):
         return DevicePlan(self, batch)
 
+    def set_switch(self, name, value):
+        """phmm_set_switch: one developer switch of this handle (tests / A-B measurements; include/phmm.h)."""
+        self._check(self.lib.phmm_set_switch(self._h, name.encode(), int(value)))
+
+    def switches(self, **kw):
+        """Context manager: set developer switches for the duration of a `with` block, then back to the planner's
+        choice (force_L=0, force_chain=-1, force_streams=0, no_pipeline=0, ...)."""
+        import contextlib
+        defaults = {"force_L": 0, "force_quad_split": -1, "force_chain": -1, "force_streams": 0, "waves_per_block": 0,
+                    "force_cnd_select": -1, "no_pipeline": 0, "no_rescue": 0, "trace": 0}
+
+        @contextlib.contextmanager
+        def cm():
+            for k, v in kw.items():
+                self.set_switch(k, v)
+            try:
+                yield self
+            finally:
+                for k in kw:
+                    self.set_switch(k, defaults[k])
+        return cm()
+
+    def stat(self, name):
+        """phmm_get_stat: "staged_bytes", "rescue_passes"."""
+        return int(self.lib.phmm_get_stat(self._h, name.encode()))
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.phmm_destroy(self._h)

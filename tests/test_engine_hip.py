@@ -169,11 +169,8 @@ def test_large_engine_call_is_pipelined_transparently():
         return out, keep
 
     out_p, keep_p = run()
-    os.environ["PHMM_NO_PIPELINE"] = "1"
-    try:
+    with eng.switches(no_pipeline=1):
         out_1, keep_1 = run()
-    finally:
-        os.environ.pop("PHMM_NO_PIPELINE", None)
     # chunks plan their own shapes (run lengths differ with the batch size): same numbers up to the last-row
     # summation order, identical keep decisions
     assert np.max(np.abs(out_p - out_1)) <= 1e-12

@@ -60,17 +60,13 @@ def test_f32_first_known_answer_vectors(engines, kat_rows):
     kb = RegionBatch.from_regions(regs)
     exp = np.array([r["expected"] for rows in by_hap.values() for r in rows])
     for lanes, streams in (("16", "1"), ("16", "2"), ("16", "4"), ("32", "1")):
-        os.environ.update({"PHMM_FORCE_CHAIN": "5", "PHMM_FORCE_L": lanes, "PHMM_FORCE_STREAMS": streams})
-        try:
-            eng = HipPairHMMEngine(0, f32_first=True)
+        eng = HipPairHMMEngine(0, f32_first=True)
+        with eng.switches(force_chain=5, force_L=int(lanes), force_streams=int(streams)):
             plan = eng.plan(kb)
             assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<%s," % lanes), plan.dominant_kernel
             plan.close()
             got = eng.compute(kb)
-            eng.close()
-        finally:
-            for k in ("PHMM_FORCE_CHAIN", "PHMM_FORCE_L", "PHMM_FORCE_STREAMS"):
-                os.environ.pop(k, None)
+        eng.close()
         assert np.max(np.abs(got - exp)) < TOL_F32
 
 
@@ -106,11 +102,8 @@ def test_what_f32_cannot_be_trusted_with_is_redone_in_f64(engines):
     assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<16,"), plan.dominant_kernel
     plan.close()
     r64, r32 = e64.compute(b), e32.compute(b)
-    os.environ["PHMM_FORCE_CHAIN"] = "0"                # the f64 per-read kernel: what the redo pass runs
-    try:
+    with e64.switches(force_chain=0):                   # the f64 per-read kernel: what the redo pass runs
         per_read = e64.compute(b).reshape(-1, 4)
-    finally:
-        os.environ.pop("PHMM_FORCE_CHAIN", None)
     m = r64.reshape(-1, 4)
     m32 = r32.reshape(-1, 4)
     redone = (m.min(axis=1) < F32_TRUST - 25)          # reads with a pair far below the trust range are redone entirely

@@ -37,19 +37,12 @@ def test_hip_equals_oracle_on_drawn_batches(regions, force_l, chain, streams):
     from lorikeet_amd import HipPairHMMEngine
     b = RegionBatch.from_regions(regions)
     want = oracle.compute_batch(b.as_dict())
-    for k, v in (("PHMM_FORCE_L", force_l), ("PHMM_FORCE_CHAIN", chain), ("PHMM_FORCE_STREAMS", streams)):
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
-    try:
-        eng = HipPairHMMEngine(0)
-        got = eng.compute(b)
-        eng.close()
-    finally:
-        os.environ.pop("PHMM_FORCE_L", None)
-        os.environ.pop("PHMM_FORCE_CHAIN", None)
-        os.environ.pop("PHMM_FORCE_STREAMS", None)
+    eng = HipPairHMMEngine(0)
+    for k, v in (("force_L", force_l), ("force_chain", chain), ("force_streams", streams)):
+        if v is not None:
+            eng.set_switch(k, int(v))
+    got = eng.compute(b)
+    eng.close()
     assert got.shape == want.shape
     inf = np.isinf(want)
     assert np.array_equal(np.isinf(got), inf)

@@ -30,11 +30,9 @@ def _close(got, want, tol=TOL_VS_ORACLE):
 
 
 def _forced_engine(L, **kw):
-    os.environ["PHMM_FORCE_L"] = str(L)
-    try:
-        return HipPairHMMEngine(0, **kw)
-    finally:
-        os.environ.pop("PHMM_FORCE_L", None)
+    e = HipPairHMMEngine(0, **kw)
+    e.set_switch("force_L", L)  # for the life of the engine
+    return e
 
 
 @pytest.fixture(scope="module")
@@ -60,7 +58,7 @@ def engine_no_tristate():
 def test_known_answer_vectors_raw_forward(kat_rows):
     """tests/vector_pair_hmm_unit_tests.rs:51-63: the raw forward() closure."""
     from lorikeet_amd.pair_hmm import forward
-    for r in kat_rows[::4]:
+    for r in kat_rows:  # all 104
         got = forward(r["hap"], r["read"], r["qual"], r["ins"], r["dele"], r["gcp"])
         assert abs(got - r["expected"]) < TOL_REFERENCE
 
@@ -80,7 +78,7 @@ def test_known_answer_vectors_through_pairhmm_and_allele_likelihoods(kat_rows):
     """tests/vector_pair_hmm_unit_tests.rs:66-90: PairHMM::initialize -> compute_log10_likelihoods ->
     get_log_likelihood_array()[0], and the [allele, read] scatter."""
     from lorikeet_amd.pair_hmm import AlleleLikelihoods, Haplotype, HmmRead, PairHMM, PairHMMInputScoreImputator
-    for r in kat_rows[::8]:
+    for r in kat_rows:  # all 104
         hap = Haplotype(r["hap"], True)
         read = HmmRead(r["read"], r["qual"], r["ins"], r["dele"])
         read_map = {0: [read]}
@@ -332,11 +330,8 @@ def test_host_path_size_classes(hip_engine):
     forced on a large batch, against the oracle and against each other."""
     b = synthetic.config2(600, seed=41)      # 11.5 MB per per-base array: ten chunks, all sizes up to 4 MB
     chunked = hip_engine.compute(b)
-    os.environ["PHMM_NO_PIPELINE"] = "1"
-    try:
+    with hip_engine.switches(no_pipeline=1):
         one_shot = hip_engine.compute(b)     # the same batch in one shot
-    finally:
-        os.environ.pop("PHMM_NO_PIPELINE", None)
     _close(one_shot, chunked, tol=1e-12)     # chunks plan their own kernel shapes: last-row summation order only
     _close(chunked[:int(b.out_off[3])], oracle.compute_batch(b.region_slice(0, 3).as_dict(), n_threads=8))
     # 1 region (results written by the kernels into the mirror), 8 (64 KB of results: the last such size), 9 (first with
@@ -407,10 +402,12 @@ def test_concurrent_host_threads_one_handle_each():
 # chained kernel (phmm_forward_chain<L,K>): reads of a region stream back to back through the lanes
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture()
-def force_chain():
-    os.environ["PHMM_FORCE_CHAIN"] = "5"  # runs of 5 reads per wave regardless of batch size
+def force_chain(engines):
+    for e in engines.values():
+        e.set_switch("force_chain", 5)  # runs of 5 reads per wave regardless of batch size
     yield
-    os.environ.pop("PHMM_FORCE_CHAIN", None)
+    for e in engines.values():
+        e.set_switch("force_chain", -1)
 
 
 @pytest.mark.parametrize("lanes", [16, 32, 64])
@@ -476,7 +473,7 @@ def test_chained_kernel_streams(engines, force_chain, streams, kat_rows):
     """16 lanes per pair: the run of reads is split into 2 or 4 streams swept side by side on 2 or 1 haplotype slots
     each (what the planner does for regions whose haplotype count is not a multiple of four)."""
     hip_engine = engines[16]
-    os.environ["PHMM_FORCE_STREAMS"] = str(streams)
+    hip_engine.set_switch("force_streams", streams)
     try:
         rng = np.random.default_rng(80 + streams)
         # 1..9 haplotypes, 1..14 reads (fewer reads than streams, uneven sub-runs), reads beyond the per-stream ring
@@ -501,7 +498,7 @@ def test_chained_kernel_streams(engines, force_chain, streams, kat_rows):
         exp = np.array([r["expected"] for rows in by_hap.values() for r in rows])
         assert np.max(np.abs(got - exp)) < TOL_REFERENCE
     finally:
-        os.environ.pop("PHMM_FORCE_STREAMS", None)
+        hip_engine.set_switch("force_streams", 0)
 
 
 def test_planner_fills_the_wave_for_any_haplotype_count(hip_engine):
@@ -521,14 +518,8 @@ def test_chained_and_plain_kernels_agree(engines):
     hip_engine = engines[16]
     b = synthetic.config2(24, seed=9)
     plain = hip_engine.compute(b)
-    os.environ["PHMM_FORCE_CHAIN"] = "16"
-    try:
+    with hip_engine.switches(force_chain=16):
         chained = hip_engine.compute(b)
-    finally:
-        os.environ.pop("PHMM_FORCE_CHAIN", None)
     _close(chained, plain, tol=1e-12)
-    os.environ["PHMM_FORCE_CHAIN"] = "0"
-    try:
+    with hip_engine.switches(force_chain=0):
         assert np.array_equal(hip_engine.compute(b), plain)
-    finally:
-        os.environ.pop("PHMM_FORCE_CHAIN", None)

@@ -24,12 +24,11 @@ for n in [int(a) for a in sys.argv[1:]] or [256, 1024]:
             pp(b.hap_off, _lib.u32p), pp(b.hap_bases, _lib.u8p), pp(ref, C.POINTER(C.c_int32)), pp(b.out_off, _lib.u64p),
             pp(out, _lib.f64p), pp(keep, _lib.u8p))
     for mode in ("pipelined", "one shot"):
-        if mode == "one shot": os.environ["PHMM_NO_PIPELINE"] = "1"
-        else: os.environ.pop("PHMM_NO_PIPELINE", None)
+        eng.set_switch("no_pipeline", 1 if mode == "one shot" else 0)
         assert eng.lib.phmm_engine_compute(*args) == 0, eng.last_error()
         t = time.perf_counter()
         for _ in range(5):
             assert eng.lib.phmm_engine_compute(*args) == 0
         dt = (time.perf_counter() - t) / 5
         print("%5d regions  %-9s %8.2f ms  %7.1f GCUPS incl. PCIe, kept %.3f" % (n, mode, dt * 1e3, b.cells() / dt / 1e9, keep.mean()), flush=True)
-    os.environ.pop("PHMM_NO_PIPELINE", None)
+    eng.set_switch("no_pipeline", 0)

@@ -1,0 +1,3 @@
+set -x
+cd /root/repo
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15

@@ -69,15 +69,11 @@ while time.time() < t_end:
     batch = RegionBatch.from_regions(regions)
     want = oracle.compute_batch(batch.as_dict(), n_threads=cores)
     # the planner's choice; the chained kernel forced at 16 lanes per pair, with 1 and with 2 or 4 streams; and at 32
-    for env in ({}, {"PHMM_FORCE_CHAIN": "6", "PHMM_FORCE_L": "16", "PHMM_FORCE_STREAMS": "1"},
-                {"PHMM_FORCE_CHAIN": "5", "PHMM_FORCE_L": "16", "PHMM_FORCE_STREAMS": str(rng.choice([2, 4]))},
-                {"PHMM_FORCE_CHAIN": "7", "PHMM_FORCE_L": "32"}):
-        os.environ.update(env)
-        try:
+    for sw in ({}, {"force_chain": 6, "force_L": 16, "force_streams": 1},
+               {"force_chain": 5, "force_L": 16, "force_streams": int(rng.choice([2, 4]))},
+               {"force_chain": 7, "force_L": 32}):
+        with eng.switches(**sw):
             got = eng.compute(batch)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
         inf = np.isinf(want)
         assert np.array_equal(np.isinf(got), inf), kind
         assert not np.isnan(got).any(), kind
@@ -86,12 +82,8 @@ while time.time() < t_end:
             worst = max(worst, d)
             assert d <= 1e-9, (kind, d)
     # f32-first mode, chained kernel forced so that the f32 sweep (and its f64 redo) really runs on these small batches
-    os.environ.update({"PHMM_FORCE_CHAIN": "4", "PHMM_FORCE_L": str(rng.choice([16, 16, 32]))})
-    try:
+    with eng32.switches(force_chain=4, force_L=int(rng.choice([16, 16, 32]))):
         got = eng32.compute(batch)
-    finally:
-        os.environ.pop("PHMM_FORCE_CHAIN", None)
-        os.environ.pop("PHMM_FORCE_L", None)
     inf = np.isinf(want)
     assert np.array_equal(np.isinf(got), inf), (kind, "f32 first")
     assert not np.isnan(got).any(), (kind, "f32 first")
