@@ -4,23 +4,37 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (phmm_batch_launch: the forward kernels, nothing else) over
-one batch of synthetic assembly regions already resident in HBM.  Workload at every N: per GPU
-`--regions` (default 1024) regions of the BASELINE.json configs[1] shape -- 128 reads x 8
-haplotypes, 150 bp reads, 300 bp haplotypes -- i.e. SURVEY.md 8(d)'s batched form of config 2;
-rank r draws its own regions (seed base+r): regions shard across GPUs with no collective ("weak"
-scaling).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (phmm_batch_launch: the forward kernels, nothing else) over one batch of
+synthetic assembly regions already resident in HBM.
 
-Extra objects on the line:
-  roofline     algorithmic HBM bytes (5*sum R + sum H + 8*Nr*Nh per region) per launch
-               / the dominant kernel's mean launch duration (HIP events on the launch stream), vs
-               8 TB/s.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes, read from
-               profiles/ (null if no summary for this workload is committed).  The path is NOT
-               HBM-bound: `valu_f64` carries the binding roofline next to it.
-  cpu_baseline the CPU oracle (C port of the reference's scalar path, oracle/) on the host cores of
-               this box, rank 0 at N=1 only, on a bounded sample of the same regions.
+`value` (every N): per GPU `--regions` (default 1024) regions of the BASELINE.json configs[1] shape -- 128 reads x 8
+haplotypes, 150 bp reads, 300 bp haplotypes -- i.e. SURVEY.md 8(d)'s batched form of config 2; rank r draws its own
+regions (seed base+r): regions shard across GPUs with no collective, "weak" scaling.  Rank 0 prints ONE JSON line.
+
+Rows next to it on the same line (BASELINE.json configs[2..4]; all ranks take part, rank 0 reports):
+  config3_10k   the SAME 10 000-region set (seed 20250928, read lengths mixed {100,150,250}) at every N, sharded over the
+                N ranks in contiguous ranges balanced by cells (no collective): strong scaling -- regions/s, GCUPS,
+                per-rank cells, imbalance, dominant kernel and its launch time, oracle sample check
+  config5_256   the same for the 256 stress regions (512 reads x 64 haplotypes, H = 400; seed 7000)
+  ragged        a long-tailed mix of regions (3 ... 5 000 reads, 1 ... 128 haplotypes, H 60 ... 500, R 30 ... 250), rank 0
+  f32_first     the opt-in PHMM_FLAG_F32_FIRST mode on the `value` batch (never `value`)
+  single_region / engine_call / host_calls   one region per launch; the engine-level call; the reference's call
+                granularity from host threads (PCIe included)
+
+Objects:
+  roofline      algorithmic HBM bytes (5*sum R + sum H + 8*Nr*Nh per region) per launch / the dominant
+                kernel's mean launch duration (HIP events on the launch stream), vs 8 TB/s.  `traffic`, `l2_hit_rate`
+                and `valu_issue` come from rocprofv3 PMC passes of this very command committed in
+                profiles/pmc_traffic.json, and ONLY if that entry was measured on the same kernel built from the same
+                sources (kernel name + hash of lorikeet_amd/csrc/*.hip,*.hpp); otherwise null and a note.
+                The path is NOT HBM-bound: `valu_f64` carries the binding roofline next to it.
+  cpu_baseline  the CPU oracle -- C port of the reference's scalar path -- on the host cores of this box, rank 0 at
+                N=1 only, bounded sample.  `cpu_baseline_simd`: the stand-in for the reference's vector arm (gkl), our
+                restatement: f32 first with f64 redo, one SIMD lane per pair (oracle/pairhmm_simd.c).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -31,10 +45,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_F64_PEAK_TFLOPS = 78.6  # vector FP64 peak (256 CU * 2.4 GHz * 128 flop/clk)
+VALU_F32_PEAK_TFLOPS = 157.3
 NUM_SIMD = 1024              # 256 CUs x 4
 VALU_ISSUE_PEAK = 0.6        # G wave64 VALU instructions / s / SIMD at 2.4 GHz, one per 4 clk
-VALU_ISSUE_UBENCH = 0.595    # what the kernel's own cell body sustains alone (tools/ubench/issue.hip, 2 waves/SIMD)
+VALU_ISSUE_UBENCH = 0.595    # what the f64 kernel's own cell body sustains alone (tools/ubench/issue.hip, 2 waves/SIMD)
 FLOP_PER_CELL = 12           # M 4 mul + 2 add, I 2+1, D 2+1
+PAYLOAD = ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")
 
 
 def parse():
@@ -42,25 +58,28 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--regions", type=int, default=1024, help="regions per GPU per step")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--regions", type=int, default=None, help="regions per GPU per step of the main workload")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "ragged"])
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--f32-first", action="store_true", help="PMC passes only: the main loop on a PHMM_FLAG_F32_FIRST engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flush-caches", action="store_true",
                     help="PMC calibration only: overwrite a 1 GiB buffer before every launch so that no input byte "
                          "survives in L2 / Infinity Cache from the previous launch (the timing then includes the fill)")
     ap.add_argument("--main-only", action="store_true",
-                    help="only the timed loop (no single_region / engine_call / cpu_baseline rows): for PMC passes")
+                    help="only the timed loop (no extra rows, no cpu_baseline): for PMC passes")
     return ap.parse_args()
 
 
 def make_workload(name, n_regions, seed):
     from lorikeet_amd import synthetic
     if name == "config2":
-        return synthetic.config2(n_regions, seed=seed), "128 reads x 8 haps, R=150, H=300"
+        return synthetic.config2(n_regions or 1024, seed=seed), "128 reads x 8 haps, R=150, H=300"
     if name == "config3":
-        return synthetic.config3(n_regions, seed=seed), "128 reads x 8 haps, H=300, R in {100,150,250}"
-    return synthetic.config5(n_regions, seed=seed), "512 reads x 64 haps, R=150, H=400"
+        return synthetic.config3(n_regions or 10000), "128 reads x 8 haps, H=300, R in {100,150,250}"
+    if name == "config5":
+        return synthetic.config5(n_regions or 256), "512 reads x 64 haps, R=150, H=400"
+    return synthetic.ragged(n_regions or 1536), "long-tailed mix: 3..5000 reads x 1..128 haps, H 60..500, R 30..250"
 
 
 def usable_cores():
@@ -82,8 +101,8 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(batch, budget_s=20.0):
-    """Oracle ("port" of the reference's scalar path) on all usable host cores, bounded sample."""
+def cpu_baselines(batch, budget_s=12.0):
+    """(scalar port, SIMD stand-in) on all usable host cores, each on a bounded sample of rank 0's batch."""
     from oracle import oracle
     cores = usable_cores()
     try:
@@ -91,215 +110,439 @@ def cpu_baseline(batch, budget_s=20.0):
         native = True
     except Exception:
         native = False
-    # calibrate on one region per core, then size the sample to ~budget_s
-    n0 = min(batch.n_regions, cores)
-    sub = batch.region_slice(0, n0)
-    t = time.perf_counter()
-    oracle.compute_batch(sub.as_dict(), n_threads=cores, native=native)
-    dt0 = time.perf_counter() - t
-    rounds = max(1, min(int(budget_s / max(dt0, 1e-3)), batch.n_regions // n0))
-    n1 = n0 * rounds
-    sub = batch.region_slice(0, n1)
-    t = time.perf_counter()
-    oracle.compute_batch(sub.as_dict(), n_threads=cores, native=native)
-    dt = time.perf_counter() - t
-    return {"value": round(sub.cells() / dt / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": "first %d regions of rank 0's batch (%.3g cells, %.1f s); oracle/pairhmm_oracle.c, f64 scalar, "
-                      "one region per pthread task%s; cores = min(affinity, cgroup cpu quota) of %d logical CPUs"
-                      % (n1, sub.cells(), dt, ", -march=native" if native else "", os.cpu_count() or 1)}
-
-
-def pmc_traffic(workload, regions):
-    """(HBM bytes per launch, L2 hit rate, wave64 VALU instructions per launch) measured with rocprofv3 PMC
-    passes of this very command (profiles/pmc_traffic.json; tools/profile.sh + tools/rocpd_summary.py)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    cpu = ""
     try:
-        for e in json.load(open(path)):
-            if e["workload"] == workload and e["regions"] == regions:
-                return e["hbm_bytes_per_launch"], e.get("l2_hit_rate"), e.get("valu_insts_per_launch")
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
     except Exception:
         pass
-    return None, None, None
+
+    def timed(fn, n0):
+        sub = batch.region_slice(0, n0)
+        t = time.perf_counter()
+        fn(sub)
+        dt0 = time.perf_counter() - t
+        rounds = max(1, min(int(budget_s / max(dt0, 1e-3)), batch.n_regions // n0))
+        sub = batch.region_slice(0, n0 * rounds)
+        t = time.perf_counter()
+        res = fn(sub)
+        return sub, time.perf_counter() - t, res
+
+    n0 = min(batch.n_regions, cores)
+    sub, dt, want = timed(lambda s: oracle.compute_batch(s.as_dict(), n_threads=cores, native=native), n0)
+    scalar = {"value": round(sub.cells() / dt / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+              "sample": "first %d regions of rank 0's batch (%.3g cells, %.1f s); oracle/pairhmm_oracle.c, the reference's "
+                        "SCALAR arm (f64), one region per pthread task%s; cores = min(affinity, cgroup cpu quota) of %d "
+                        "logical CPUs; %s" % (sub.n_regions, sub.cells(), dt, ", -march=native" if native else "",
+                                              os.cpu_count() or 1, cpu)}
+    simd = None
+    try:
+        sub2, dt2, (got, redone) = timed(lambda s: oracle.compute_batch_simd(s.as_dict(), n_threads=cores, native=native),
+                                         min(batch.n_regions, 4 * cores))
+        n = min(sub.n_out, sub2.n_out)
+        simd = {"value": round(sub2.cells() / dt2 / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+                "stand_in_for": "gkl::pairhmm::forward (the reference's default AVX arm, pair_hmm.rs:348-366) -- OUR "
+                                "restatement, not gkl: the crate is not vendored and cannot be built here",
+                "sample": "first %d regions (%.3g cells, %.1f s); oracle/pairhmm_simd.c: f32 under 2^120 with f64 redo "
+                          "below 1e-28, one SIMD lane per (read, haplotype) pair, %d lanes (gcc vector extensions%s), one "
+                          "region per pthread task" % (sub2.n_regions, sub2.cells(), dt2, oracle.lib().oracle_simd_lanes(),
+                                                       ", -march=native" if native else ""),
+                "pairs_redone_in_f64": redone, "max_abs_diff_vs_scalar_port": float(abs(got[:n] - want[:n]).max()),
+                "tolerance": 1e-5}
+    except Exception as exc:  # an optional row must never cost the bench line
+        simd = {"error": repr(exc)}
+    return scalar, simd
+
+
+def source_hash():
+    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(workload, regions, kernel, precision="f64"):
+    """The rocprofv3 PMC measurement of this command (profiles/pmc_traffic.json; tools/profile.sh +
+    tools/pmc_update.py), or (None, why) when there is none for this workload, kernel and source hash."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        entries = json.load(open(path))
+    except Exception:
+        return None, "profiles/pmc_traffic.json missing"
+    src = source_hash()
+    why = "no PMC entry for workload %s x %s (%s)" % (workload, regions, precision)
+    for e in entries:
+        if e.get("workload") != workload or e.get("regions") != regions or e.get("precision", "f64") != precision:
+            continue
+        if e.get("kernel_short") != kernel:
+            why = "PMC entry is for kernel %s, this run's dominant kernel is %s" % (e.get("kernel_short"), kernel)
+            continue
+        if e.get("src_hash") != src:
+            why = "PMC entry was measured on kernel sources %s, this tree is %s: stale, not reported" % (e.get("src_hash"), src)
+            continue
+        return e, None
+    return None, why
+
+
+class Dist:
+    """barrier + max-over-ranks + tiny gathers only; no data-path collective."""
+
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, self.world))
+        # one process per GPU; BENCH_DIST_BACKEND=gloo (ranks may then share a device) exists only to exercise the
+        # N>1 code path on a single-GPU box
+        self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        self.dev_index = self.local_rank if self.backend == "nccl" else self.local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier(device_ids=[self.dev_index]) if self.backend == "nccl" else self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank (one float64 each)."""
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        t[self.rank] = x
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        if self.world > 1:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+class Resident:
+    """A batch resident in HBM, bound to a launch plan."""
+
+    def __init__(self, eng, batch, dev):
+        import torch
+        self.batch = batch
+        self.plan = eng.plan(batch)
+        self.tens = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in PAYLOAD}
+        self.out = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
+        self.plan.bind_torch(self.tens, self.out)
+
+    def close(self):
+        self.plan.close()
+
+
+def timed_launches(D, res, stream, steps, warmup, flush=None):
+    """`steps` launches bracketed by barrier + synchronize on both sides; returns (max-over-ranks seconds, per-launch ms
+    from HIP events on the launch stream)."""
+    torch = D.torch
+    sh = stream.cuda_stream
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            res.plan.launch(sh)
+        D.barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        for i in range(steps):
+            if flush is not None:
+                flush.fill_(float(i))
+            res.plan.launch(sh)
+            ev[i + 1].record(stream)
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+    res.plan.status()  # raises if any likelihood came out > 0
+    return D.max(elapsed), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def oracle_sample_diff(batch, got, max_regions, max_cells):
+    """max |hip - oracle| over the first regions of `batch` that fit the CPU budget (bench rows are checked, not only
+    `<= 0`)."""
+    import numpy as np
+    from lorikeet_amd import sharding
+    from oracle import oracle
+    cells = sharding.region_cells(batch)
+    picked, used = [], 0
+    for g in range(batch.n_regions):
+        if len(picked) >= max_regions:
+            break
+        if used + int(cells[g]) <= max_cells:
+            picked.append(g)
+            used += int(cells[g])
+    worst = 0.0
+    for g in picked:
+        sub = batch.region_slice(g, g + 1)
+        want = oracle.compute_batch(sub.as_dict(), n_threads=usable_cores())
+        have = got[int(batch.out_off[g]):int(batch.out_off[g + 1])]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(have), fin), "bench: -inf / NaN pattern differs from the oracle in region %d" % g
+        if fin.any():
+            worst = max(worst, float(np.max(np.abs(have[fin] - want[fin]))))
+    return {"regions_checked": len(picked), "cells_checked": used, "max_abs_diff": worst, "tolerance": 1e-9}
+
+
+def strong_row(D, eng, stream, name, steps, sample):
+    """One fixed set at every N, sharded over the ranks in contiguous cell-balanced ranges (BASELINE.json configs[3],[4])."""
+    import numpy as np
+    from lorikeet_amd import sharding, synthetic
+    n_regions, seed = synthetic.CONFIGS[name][4], synthetic.CONFIGS[name][5]
+    cells = synthetic.config_cells(name)  # cheap: read lengths only
+    bounds = sharding.split_contiguous(cells, D.world)
+    lo, hi = bounds[D.rank], bounds[D.rank + 1]
+    batch = synthetic.config(name, only=(lo, hi))  # every rank makes only its own regions (chunk-seeded generator)
+    res = Resident(eng, batch, D.dev)
+    elapsed, kern_ms = timed_launches(D, res, stream, steps, 1)
+    mine = int(cells[lo:hi].sum())
+    assert mine == res.plan.cells
+    per_rank = D.gather(mine)
+    row = None
+    if D.rank == 0:
+        got = res.out.cpu().numpy()
+        assert (got <= 0).all(), "non-finite or positive likelihoods"
+        total = float(cells.sum())
+        kms = sum(kern_ms) / len(kern_ms) / max(res.plan.num_launches, 1)
+        row = {"workload": "%s: the same %d regions (seed %d) at every N" % (name, n_regions, seed), "scaling": "strong",
+               "regions": n_regions, "cells": int(total), "steps": steps,
+               "gcups": round(total * steps / elapsed / 1e9, 1), "regions_per_s": round(n_regions * steps / elapsed, 1),
+               "ms_per_step": round(elapsed / steps * 1e3, 4),
+               "sharding": "contiguous ranges of regions balanced by cells (sharding.split_contiguous == "
+                           "phmm_split_regions), one process per GPU, no collective",
+               "per_rank_cells": [int(c) for c in per_rank],
+               "imbalance": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 5),
+               "rank0": {"regions": hi - lo, "kernel": res.plan.dominant_kernel, "launches": res.plan.num_launches,
+                         "kernel_ms": round(kms, 4), "gcups": round(mine / (sum(kern_ms) / len(kern_ms)) / 1e6, 1),
+                         "algorithmic_bytes_per_launch": res.plan.algorithmic_bytes,
+                         "hbm_achieved_gbs": round(res.plan.algorithmic_bytes / kms / 1e6, 3)},
+               "oracle_sample": oracle_sample_diff(batch, got, *sample)}
+        e, why = pmc_entry(name, n_regions, res.plan.dominant_kernel) if D.world == 1 else (None, "PMC entries are for N=1")
+        row["rocprof"] = ({"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "l2_hit_rate": e.get("l2_hit_rate"),
+                           "hbm_gbs_from_counters": round(e["hbm_bytes_per_launch"] / kms / 1e6, 2),
+                           "traffic_over_algorithmic": round(e["hbm_bytes_per_launch"] / res.plan.algorithmic_bytes, 3),
+                           "valu_per_cell": round(e["valu_insts_per_launch"] * 64 / mine, 3) if e.get("valu_insts_per_launch") else None,
+                           "source": e.get("source")} if e else {"hbm_bytes_per_launch": None, "note": why})
+    res.close()
+    return row
 
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world))
-    # one process per GPU; BENCH_DIST_BACKEND=gloo (ranks may then share a device) exists only to exercise the
-    # N>1 code path on a single-GPU box
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:  # barrier + max-over-ranks only; no data-path collective
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    D = Dist(a)
+    torch, dev, rank, world = D.torch, D.dev, D.rank, D.world
+    extras = not a.main_only
 
     from lorikeet_amd import HipPairHMMEngine
     batch, shape = make_workload(a.workload, a.regions, a.seed + rank)
-    eng = HipPairHMMEngine(dev_index)
-    plan = eng.plan(batch)
-    tens = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in
-            ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
-    out = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
-    plan.bind_torch(tens, out)
+    regions = batch.n_regions
+    eng = HipPairHMMEngine(D.dev_index, f32_first=a.f32_first)
+    res = Resident(eng, batch, dev)
+    plan, out, tens = res.plan, res.out, res.tens
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize(dev)
-
     flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if a.flush_caches else None
-    with torch.cuda.stream(stream):
-        for _ in range(a.warmup):
-            plan.launch(sh)
-        barrier()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-        t0 = time.perf_counter()
-        ev[0].record(stream)
-        for i in range(a.steps):
-            if flush is not None:
-                flush.fill_(float(i))
-            plan.launch(sh)
-            ev[i + 1].record(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    plan.status()  # raises if any likelihood came out > 0
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, kern_ms = timed_launches(D, res, stream, a.steps, a.warmup, flush)
     cells_total = plan.cells * world  # identical shapes on every rank
-    regions_total = batch.n_regions * world
+    regions_total = regions * world
 
-    single = None
-    if rank == 0 and not a.main_only:  # configs[1] literally: ONE region per launch (latency mode: the planner spreads it over all SIMDs)
+    def optional(fn):
         try:
-            one, _ = make_workload(a.workload, 1, a.seed + 7919)
-            p1 = eng.plan(one)
-            t1 = {k: torch.from_numpy(getattr(one, k)).to(dev) for k in
-                  ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")}
-            o1 = torch.empty(one.n_out, dtype=torch.float64, device=dev)
-            p1.bind_torch(t1, o1)
-            with torch.cuda.stream(stream):
-                for _ in range(10):
-                    p1.launch(sh)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(100):
-                    p1.launch(sh)
-                e1.record(stream)
-                stream.synchronize()
-            us = e0.elapsed_time(e1) * 10.0
-            single = {"regions": 1, "us_per_region": round(us, 2), "gcups": round(p1.cells / us / 1e3, 1),
-                      "kernel": p1.dominant_kernel, "note": "one region per launch, back-to-back launches on one stream"}
-            p1.close()
+            return fn()
         except Exception as exc:  # an optional row must never cost the bench line
-            single = {"error": repr(exc)}
+            return {"error": repr(exc)}
 
-    f32_row = None
-    if rank == 0 and not a.main_only:  # the opt-in PHMM_FLAG_F32_FIRST mode on the same resident batch (never `value`)
+    # ---- rows every rank takes part in: the fixed sets of BASELINE.json configs[2..4], strong scaling -------------
+    config3_row = config5_row = None
+    if extras and a.workload == "config2":
         try:
-            e32 = HipPairHMMEngine(dev_index, f32_first=True)
-            p32 = e32.plan(batch)
-            out32 = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
-            p32.bind_torch(tens, out32)
-            with torch.cuda.stream(stream):
-                for _ in range(2):
-                    p32.launch(sh)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(a.steps):
-                    p32.launch(sh)
-                e1.record(stream)
-                stream.synchronize()
-            p32.status()
-            ms32 = e0.elapsed_time(e1) / a.steps
-            f32_row = {"value": round(p32.cells / ms32 / 1e6, 2), "unit": "GCUPS", "ms_per_step": round(ms32, 4),
-                       "kernel": p32.dominant_kernel, "dtype": "f32 first, f64 redo of what f32 cannot be trusted with",
-                       "max_abs_diff_vs_f64": float((out32 - out).abs().max().item()), "tolerance": 1e-5,
-                       "note": "opt-in flag of phmm_create, what the reference's vector arm (gkl) does; default and `value` are f64"}
-            p32.close()
-            e32.close()
-        except Exception as exc:  # an optional row must never cost the bench line
-            f32_row = {"error": repr(exc)}
-
-    engine_row = None
-    if rank == 0 and not a.main_only:  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
+            config3_row = strong_row(D, eng, stream, "config3", 5, (2, int(2e8)))
+        except Exception as exc:
+            config3_row = {"error": repr(exc)}
         try:
-            import ctypes as C
-            import math
-            import numpy as np
-            from lorikeet_amd import _lib
-            nreg = min(256, batch.n_regions)
-            sub = batch.region_slice(0, nreg)
-            cfg = _lib.EngineConfig()
-            cfg.constant_gcp, cfg.pcr_error_model, cfg.base_quality_score_threshold = 10, 3, 18
-            cfg.dynamic_read_disqualification, cfg.symmetrically_normalize_alleles_to_reference = 1, 1
-            cfg.log10_global_read_mismapping_rate = -4.5 * math.log10(math.e)
-            cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = 1.0, 0.02
-            mapq = np.full(sub.n_reads, 60, np.uint8)
-            ref = np.zeros(nreg, np.int32)
-            eout = np.empty(sub.n_out, np.float64)
-            keep = np.zeros(sub.n_reads, np.uint8)
-            pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
-            args = (eng._h, C.byref(cfg), nreg, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p),
-                    pp(sub.read_off, _lib.u32p), pp(sub.read_bases, _lib.u8p), pp(sub.base_q, _lib.u8p), None, None,
-                    pp(mapq, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p),
-                    pp(ref, C.POINTER(C.c_int32)), pp(sub.out_off, _lib.u64p), pp(eout, _lib.f64p), pp(keep, _lib.u8p))
-            assert eng.lib.phmm_engine_compute(*args) == 0, eng.last_error()
-            te = time.perf_counter()
-            for _ in range(5):
-                assert eng.lib.phmm_engine_compute(*args) == 0
-            te = (time.perf_counter() - te) / 5
-            engine_row = {"call": "phmm_engine_compute (PCR model conservative, dynamic disqualification), host buffers, "
-                                  "PCIe included", "regions": nreg, "ms_per_call": round(te * 1e3, 3),
-                          "gcups_incl_pcie": round(sub.cells() / te / 1e9, 1), "reads_kept_fraction": round(float(keep.mean()), 4)}
-        except Exception as exc:  # an optional row must never cost the bench line
-            engine_row = {"error": repr(exc)}
+            config5_row = strong_row(D, eng, stream, "config5", 5, (1, int(2.1e9)))
+        except Exception as exc:
+            config5_row = {"error": repr(exc)}
 
-    calls_row = None
-    if rank == 0 and world == 1 and not a.main_only:
+    def single_region():  # configs[1] literally: ONE region per launch (latency mode: the planner spreads it over all SIMDs)
+        one, _ = make_workload("config2", 1, a.seed + 7919)
+        r1 = Resident(eng, one, dev)
+        with torch.cuda.stream(stream):
+            for _ in range(10):
+                r1.plan.launch(sh)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(100):
+                r1.plan.launch(sh)
+            e1.record(stream)
+            stream.synchronize()
+        us = e0.elapsed_time(e1) * 10.0
+        row = {"regions": 1, "us_per_region": round(us, 2), "gcups": round(r1.plan.cells / us / 1e3, 1),
+               "kernel": r1.plan.dominant_kernel, "note": "one region per launch, back-to-back launches on one stream"}
+        r1.close()
+        return row
+
+    def f32_first():  # the opt-in PHMM_FLAG_F32_FIRST mode on the same resident batch (never `value`)
+        e32 = HipPairHMMEngine(D.dev_index, f32_first=True)
+        p32 = e32.plan(batch)
+        out32 = torch.empty(batch.n_out, dtype=torch.float64, device=dev)
+        p32.bind_torch(tens, out32)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                p32.launch(sh)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(a.steps):
+                p32.launch(sh)
+            e1.record(stream)
+            stream.synchronize()
+        p32.status()
+        ms32 = e0.elapsed_time(e1) / a.steps
+        row = {"value": round(p32.cells / ms32 / 1e6, 2), "unit": "GCUPS", "ms_per_step": round(ms32, 4),
+               "kernel": p32.dominant_kernel, "dtype": "f32 first, f64 redo of what f32 cannot be trusted with",
+               "max_abs_diff_vs_f64": float((out32 - out).abs().max().item()), "tolerance": 1e-5,
+               "valu_f32": {"achieved": round(FLOP_PER_CELL * p32.cells / ms32 / 1e9, 3), "peak": VALU_F32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * p32.cells / ms32 / 1e9 / VALU_F32_PEAK_TFLOPS, 4)},
+               "note": "opt-in flag of phmm_create, what the reference's vector arm (gkl) does; default and `value` are f64"}
+        e, why = pmc_entry(a.workload, regions, p32.dominant_kernel, "f32_first")
+        if e and e.get("valu_insts_per_launch"):
+            rate = e["valu_insts_per_launch"] / (ms32 / 1e3) / NUM_SIMD / 1e9
+            row["valu_issue"] = {"achieved": round(rate, 4), "peak": VALU_ISSUE_PEAK, "unit": "G wave64-instr/s per SIMD",
+                                 "frac": round(rate / VALU_ISSUE_PEAK, 4),
+                                 "valu_per_cell": round(e["valu_insts_per_launch"] * 64 / p32.cells, 3),
+                                 "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "l2_hit_rate": e.get("l2_hit_rate"),
+                                 "source": e.get("source")}
+        else:
+            row["valu_issue"] = {"achieved": None, "note": why}
+        p32.close()
+        e32.close()
+        return row
+
+    def engine_call():  # SURVEY 8(f1/f2): the engine-level call (pre-step + PairHMM + normalise/disqualify), host buffers
+        import ctypes as C
+        import math
+        import numpy as np
+        from lorikeet_amd import _lib
+        nreg = min(256, batch.n_regions)
+        sub = batch.region_slice(0, nreg)
+        cfg = _lib.EngineConfig()
+        cfg.constant_gcp, cfg.pcr_error_model, cfg.base_quality_score_threshold = 10, 3, 18
+        cfg.dynamic_read_disqualification, cfg.symmetrically_normalize_alleles_to_reference = 1, 1
+        cfg.log10_global_read_mismapping_rate = -4.5 * math.log10(math.e)
+        cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = 1.0, 0.02
+        mapq = np.full(sub.n_reads, 60, np.uint8)
+        ref = np.zeros(nreg, np.int32)
+        eout = np.empty(sub.n_out, np.float64)
+        keep = np.zeros(sub.n_reads, np.uint8)
+        pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+        args = (eng._h, C.byref(cfg), nreg, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p),
+                pp(sub.read_off, _lib.u32p), pp(sub.read_bases, _lib.u8p), pp(sub.base_q, _lib.u8p), None, None,
+                pp(mapq, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p),
+                pp(ref, C.POINTER(C.c_int32)), pp(sub.out_off, _lib.u64p), pp(eout, _lib.f64p), pp(keep, _lib.u8p))
+        assert eng.lib.phmm_engine_compute(*args) == 0, eng.last_error()
+        te = time.perf_counter()
+        for _ in range(5):
+            assert eng.lib.phmm_engine_compute(*args) == 0
+        te = (time.perf_counter() - te) / 5
+        return {"call": "phmm_engine_compute (PCR model conservative, dynamic disqualification), host buffers, "
+                        "PCIe included", "regions": nreg, "ms_per_call": round(te * 1e3, 3),
+                "gcups_incl_pcie": round(sub.cells() / te / 1e9, 1), "reads_kept_fraction": round(float(keep.mean()), 4)}
+
+    def host_calls():
         # The reference's call granularity (one region per compute_likelihoods call from every rayon worker), host buffers,
         # PCIe included: tools/threads_bench (C++ threads on the C ABI, built with the library) in three configurations.
-        try:
-            import re
-            import subprocess
-            exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "threads_bench")
+        import re
+        import subprocess
+        exe = os.path.join(ROOT, "tools", "threads_bench")
 
-            def point(mode, threads, per_call):
-                env = dict(os.environ, TB_MODE=mode, TB_THREADS=str(threads))
-                r = subprocess.run([exe, "1.0", "128", "8", "150", "300", str(per_call)], env=env, capture_output=True,
-                                   text=True, timeout=60)
-                m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS", r.stdout)
-                return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2))}
-            calls_row = {
-                "note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
+        def point(mode, threads, per_call):
+            env = dict(os.environ, TB_MODE=mode, TB_THREADS=str(threads))
+            r = subprocess.run([exe, "1.0", "128", "8", "150", "300", str(per_call)], env=env, capture_output=True,
+                               text=True, timeout=60)
+            m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS", r.stdout)
+            return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2))}
+        return {"note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
                 "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
                 "one_region_per_call_32_threads_shared_handle_submit_wait": point("shared", 32, 1),
                 "eight_regions_per_call_4_threads_own_handles": point("own", 4, 8)}
-        except Exception as exc:  # an optional row must never cost the bench line
-            calls_row = {"error": repr(exc)}
+
+    def ragged():
+        """Real regions span 3 x 2 ... 5 000 x 128: the planner on a long-tailed mix, resident and through host buffers."""
+        from lorikeet_amd import sharding
+        rb, rshape = make_workload("ragged", None, 0)
+        r = Resident(eng, rb, dev)
+        el, kms = timed_launches(Dist1(D), r, stream, 5, 1)
+        got = r.out.cpu().numpy()
+        t = time.perf_counter()
+        host = eng.compute(rb)
+        t_host = time.perf_counter() - t
+        t = time.perf_counter()
+        host = eng.compute(rb)
+        t_host = min(t_host, time.perf_counter() - t)
+        import numpy as np
+        assert np.allclose(host, got, rtol=0, atol=1e-9)
+        cells = sharding.region_cells(rb)
+        row = {"workload": rshape, "regions": rb.n_regions, "reads": rb.n_reads, "pairs": rb.n_out, "cells": int(rb.cells()),
+               "cells_per_region_min_median_max": [int(cells.min()), int(np.median(cells)), int(cells.max())],
+               "gcups": round(r.plan.cells * 5 / el / 1e9, 1), "regions_per_s": round(rb.n_regions * 5 / el, 1),
+               "ms_per_step": round(el / 5 * 1e3, 4), "launches_per_step": r.plan.num_launches,
+               "dominant_kernel": r.plan.dominant_kernel,
+               "host_buffers_incl_pcie": {"ms_per_call": round(t_host * 1e3, 3), "gcups": round(rb.cells() / t_host / 1e9, 1),
+                                          "regions_per_s": round(rb.n_regions / t_host, 1)},
+               "oracle_sample": oracle_sample_diff(rb, got, 64, int(1.5e9))}
+        r.close()
+        return row
+
+    class Dist1:  # rank-0-only rows: same timing code, no cross-rank barrier
+        def __init__(self, d):
+            self.torch, self.dev = d.torch, d.dev
+
+        def barrier(self):
+            self.torch.cuda.synchronize(self.dev)
+
+        def max(self, x):
+            return float(x)
+
+    single = f32_row = engine_row = calls_row = ragged_row = None
+    if rank == 0 and extras:
+        single = optional(single_region)
+        if not a.f32_first:
+            f32_row = optional(f32_first)
+        engine_row = optional(engine_call)
+        if world == 1:
+            calls_row = optional(host_calls)
+        if a.workload == "config2":
+            ragged_row = optional(ragged)
 
     if rank == 0:
-        res = out.cpu().numpy()
-        assert (res <= 0).all(), "non-finite or positive likelihoods"
+        got = out.cpu().numpy()
+        assert (got <= 0).all(), "non-finite or positive likelihoods"
         mean_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3 / max(plan.num_launches, 1)
         alg_bytes = plan.algorithmic_bytes
         achieved_gbs = alg_bytes / mean_kernel_s / 1e9
+        e, why = pmc_entry(a.workload, regions, plan.dominant_kernel, "f32_first" if a.f32_first else "f64")
         line = {
             "metric": "PairHMM cell-updates/s (GCUPS)",
             "value": round(cells_total * a.steps / elapsed / 1e9, 2),
@@ -307,48 +550,56 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32 first, f64 redo (PMC pass only)" if a.f32_first else "f64", "data": "synthetic",
             "config": {"workload": "%s x %d regions per GPU: %s (BASELINE.json configs[1] shape, batched per "
-                                   "SURVEY 8d)" % (a.workload, a.regions, shape)
-                       if a.workload == "config2" else "%s x %d regions per GPU: %s" % (a.workload, a.regions, shape),
-                       "regions_per_gpu": a.regions, "pairs_per_gpu": int(batch.n_out),
+                                   "SURVEY 8d)" % (a.workload, regions, shape)
+                       if a.workload == "config2" else "%s x %d regions per GPU: %s" % (a.workload, regions, shape),
+                       "regions_per_gpu": regions, "pairs_per_gpu": int(batch.n_out),
                        "cells_per_gpu_per_step": int(plan.cells), "seed": a.seed,
                        "sharding": "regions, one process per GPU, no collective"},
             "regions_per_s": round(regions_total * a.steps / elapsed, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(a.workload, a.regions)[0],
-                         "l2_hit_rate": pmc_traffic(a.workload, a.regions)[1],
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
+                         "traffic": e["hbm_bytes_per_launch"] if e else None, "l2_hit_rate": e.get("l2_hit_rate") if e else None,
                          "kernel": plan.dominant_kernel, "kernel_ms": round(mean_kernel_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "compulsory traffic is 2.3e-3 B/cell: the path is FP64-VALU bound, see valu_f64"},
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "src_hash": source_hash(),
+                         "note": "compulsory traffic is 2.3e-3 B/cell: the path is FP64-VALU bound, see valu_f64"
+                                 + ("" if e else "; traffic: " + why)},
             "valu_f64": {"achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
                          "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
                          "flop_per_cell": FLOP_PER_CELL,
                          "note": "flop_per_cell counts the reference recurrence (pair_hmm.rs:561-587); the kernel "
                                  "executes 10 (4 FMA + 2 MUL) after folding three factors into the row constants"},
+            "oracle_sample": optional(lambda: oracle_sample_diff(batch, got, 2, int(2e8))) if extras else None,
         }
-        valu_insts = pmc_traffic(a.workload, a.regions)[2]
-        if valu_insts:  # the bound that actually binds: wave64 VALU issue slots (every VALU op costs one, FP64 or not)
+        if e and e.get("valu_insts_per_launch"):  # the bound that actually binds: wave64 VALU issue slots (every VALU op costs one, FP64 or not)
+            valu_insts = e["valu_insts_per_launch"]
             rate = valu_insts / mean_kernel_s / NUM_SIMD / 1e9
             line["valu_issue"] = {
                 "achieved": round(rate, 4), "peak": VALU_ISSUE_PEAK, "unit": "G wave64-instr/s per SIMD",
                 "frac": round(rate / VALU_ISSUE_PEAK, 4), "valu_per_cell": round(valu_insts * 64 / plan.cells, 3),
-                "same_mix_ubench": VALU_ISSUE_UBENCH,
+                "same_mix_ubench": VALU_ISSUE_UBENCH, "source": e.get("source"),
                 "note": "peak = 2.4 GHz / 4 clk; same_mix_ubench = the 7-instruction cell body alone (hoisted v_cmp -> SGPR "
                         "mask form) at 2 waves/SIMD on the whole chip (tools/ubench/issue.hip: 3.9 clk per instruction at "
                         "the 2.3 GHz the chip sustains)"}
+        else:
+            line["valu_issue"] = {"achieved": None, "note": why}
+        line["config3_10k"] = config3_row
+        line["config5_256"] = config5_row
+        line["ragged"] = ragged_row
         line["single_region"] = single
         line["f32_first"] = f32_row
         line["engine_call"] = engine_row
         if calls_row is not None:
             line["host_calls"] = calls_row
-        if world == 1 and not a.no_cpu_baseline and not a.main_only:
-            line["cpu_baseline"] = cpu_baseline(batch)
+        if world == 1 and not a.no_cpu_baseline and extras:
+            scalar, simd = cpu_baselines(batch)
+            line["cpu_baseline"] = scalar
+            line["cpu_baseline_simd"] = simd
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
-        dist.destroy_process_group()
+    res.close()
+    D.close()
 
 
 if __name__ == "__main__":

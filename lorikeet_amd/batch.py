@@ -68,6 +68,28 @@ class RegionBatch:
             read_off=np.asarray(ro, np.uint32), hap_off=np.asarray(ho, np.uint32), out_off=np.asarray(oo, np.uint64),
             read_bases=cat(rb), base_q=cat(bq), ins_q=cat(iq), del_q=cat(dq), gcp=cat(gc), hap_bases=cat(hb))
 
+    @staticmethod
+    def concat(batches):
+        """Regions of several batches, in order, as one batch (offsets shifted; out_off gaps are preserved)."""
+        batches = list(batches)
+        if not batches:
+            return RegionBatch.from_regions([])
+
+        def offs(name, dtype):
+            parts, base = [np.zeros(1, np.int64)], 0
+            for b in batches:
+                a = getattr(b, name).astype(np.int64)
+                parts.append(a[1:] + base)
+                base += int(a[-1])
+            return np.concatenate(parts).astype(dtype)
+
+        def cat(name):
+            return np.ascontiguousarray(np.concatenate([getattr(b, name) for b in batches]), dtype=np.uint8)
+        return RegionBatch(region_read_off=offs("region_read_off", np.uint32), region_hap_off=offs("region_hap_off", np.uint32),
+                           read_off=offs("read_off", np.uint32), hap_off=offs("hap_off", np.uint32),
+                           out_off=offs("out_off", np.uint64), read_bases=cat("read_bases"), base_q=cat("base_q"),
+                           ins_q=cat("ins_q"), del_q=cat("del_q"), gcp=cat("gcp"), hap_bases=cat("hap_bases"))
+
     # ---- shape queries ----
     @property
     def n_regions(self):

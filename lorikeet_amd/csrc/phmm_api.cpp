@@ -110,6 +110,14 @@ struct phmm_batch {
     uint64_t n_out = 0, read_bytes = 0, hap_bytes = 0;
     uint64_t cells = 0, alg_bytes = 0;
     std::vector<ShapeClass> classes;
+    // every chained f64 class of one lanes-per-pair value goes out in ONE launch (phmm_chain_kernels.hip)
+    struct ChainGroup {
+        int L = 0;
+        int single_k = 0;  // the K all items share (per-K kernel), 0 = mixed (any-K kernel)
+        std::vector<ChainItem> items;
+        ChainItem *d_items = nullptr;
+    };
+    std::vector<ChainGroup> chain_groups;
     // device metadata (one allocation)
     uint32_t *d_read_region = nullptr, *d_region_read_off = nullptr, *d_region_hap_off = nullptr, *d_read_off = nullptr,
              *d_hap_off = nullptr, *d_status = nullptr;
@@ -480,7 +488,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     const Switches &sw = h->sw;
     const bool chain_forced = sw.force_chain >= 0;  // tests: every chainable shape chains
     auto chain_shape_ok = [&](int L, int k, const RegionShape &s) {
-        return k > 0 && k <= chain_max_k() && (L == 16 || k >= 13 || chain_forced) && s.min_r >= 1 && s.min_h >= 1;
+        return k > 0 && k <= chain_max_k() && (L == 16 || k >= 13 || chain_forced) && s.min_r >= 1 && s.min_h >= 1 &&
+               s.nh <= 0xffffu /* ChainItem::quad */;
     };
     bool assume_chain = false;  // second planning pass: the batch is large enough for the chained kernel
     auto pick = [&](const RegionShape &s, int min_L, int &L_out, int &K_out) {
@@ -718,17 +727,29 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 const uint32_t run = std::min<uint32_t>(CHAIN_MAX_READS, chain_reads * (uint32_t)c.streams);
                 for (uint32_t q = 0; q < nq; ++q)
                     for (uint32_t r = r0; r < r1; r += run)
-                        c.chain_items.push_back(ChainItem{g, q, r, std::min(r1, r + run)});
+                        c.chain_items.push_back(ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)c.streams, r, std::min(r1, r + run)});
             }
             // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
             // be filled by the short ones (stable, so equal-length batches keep their order)
             std::stable_sort(c.chain_items.begin(), c.chain_items.end(), [&](const ChainItem &x, const ChainItem &y) {
                 return read_off[x.read_end] - read_off[x.read_begin] > read_off[y.read_end] - read_off[y.read_begin];
             });
-            void *mirror;
-            c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
-            up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
             c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && (c.L == 16 || c.L == 32);
+            if (c.f32_first) {  // the f32 sweep is launched per class ...
+                void *mirror;
+                c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
+                up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
+            } else {            // ... the f64 classes of one lanes-per-pair value share a launch
+                phmm_batch::ChainGroup *grp = nullptr;
+                for (auto &gq : b->chain_groups)
+                    if (gq.L == c.L) grp = &gq;
+                if (!grp) {
+                    b->chain_groups.emplace_back();
+                    grp = &b->chain_groups.back();
+                    grp->L = c.L;
+                }
+                grp->items.insert(grp->items.end(), c.chain_items.begin(), c.chain_items.end());
+            }
             if (c.f32_first) {  // the f64 per-read kernel runs behind the f32 sweep over the reads it flags
                 if (!c.identity) {
                     void *mr;
@@ -794,6 +815,24 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             b->dominant = c.name;
         }
         b->classes.push_back(std::move(c));
+    }
+    for (auto &grp : b->chain_groups) {
+        // longest item first across all classes of the launch: (rows of the run + its SUM / RESET rows) x the cost of a
+        // step at the item's K (7 VALU per column + ~11 per step)
+        auto cost = [&](const ChainItem &x) {
+            return (uint64_t)(read_off[x.read_end] - read_off[x.read_begin] + 2 * (x.read_end - x.read_begin) + grp.L) *
+                   (uint64_t)(7 * x.k + 11);
+        };
+        std::stable_sort(grp.items.begin(), grp.items.end(), [&](const ChainItem &x, const ChainItem &y) { return cost(x) > cost(y); });
+        grp.single_k = grp.items.empty() ? 0 : grp.items[0].k;
+        for (const ChainItem &it : grp.items)
+            if (it.k != grp.single_k) {
+                grp.single_k = 0;
+                break;
+            }
+        void *mirror;
+        grp.d_items = (ChainItem *)dalloc(grp.items.size() * sizeof(ChainItem), &mirror);
+        up(grp.d_items, mirror, grp.items.data(), grp.items.size() * sizeof(ChainItem));
     }
     // host staging vectors die at return: finish the async copies first (arena mode copied into the mirror)
     if (ok && async_pending) ok = hip_ok(h, hipStreamSynchronize(h->S()), "sync(meta)");
@@ -933,21 +972,18 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.cnd_select = c.cnd_select;
         if (!p.n_items) continue;
         hipError_t e;
-        if (c.chain) {
+        if (c.chain && !c.f32_first) continue;  // launched with its group below
+        if (c.chain) {  // f32 sweep, then the f64 per-read kernel over exactly the reads it flagged
             ChainParams cp{};
             cp.f = p;
             cp.items = c.d_chain_items;
             cp.n_items = (uint32_t)c.chain_items.size();
             cp.streams = (uint32_t)c.streams;
-            if (c.f32_first) {  // f32 sweep, then the f64 per-read kernel over exactly the reads it flagged
-                cp.redo = b->d_redo;
-                e = launch_chain_f32(c.L, c.K, cp, stream);
-                if (e == hipSuccess) {
-                    p.redo = b->d_redo;
-                    e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
-                }
-            } else {
-                e = launch_chain(c.L, c.K, cp, stream);
+            cp.redo = b->d_redo;
+            e = launch_chain_f32(c.L, c.K, cp, stream);
+            if (e == hipSuccess) {
+                p.redo = b->d_redo;
+                e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
             }
         } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
@@ -962,6 +998,13 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             e = gp.n_pairs ? launch_generic(gp, stream) : hipSuccess;
         }
         if (!hip_ok(h, e, c.name)) return PHMM_ERR_HIP;
+    }
+    for (auto &grp : b->chain_groups) {
+        ChainParams cp{};
+        cp.f = base_params(b);
+        cp.items = grp.d_items;
+        cp.n_items = (uint32_t)grp.items.size();
+        if (!hip_ok(h, launch_chain(grp.L, grp.single_k, cp, stream), "phmm_forward_chain")) return PHMM_ERR_HIP;
     }
     // Results below kRescueBelow are redone in the reference's operation order.  Persistent batches and the
     // engine-level call carry the pass in-stream (it returns at once unless a forward kernel asked for it); the
@@ -1627,7 +1670,13 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
 
 uint64_t phmm_batch_cells(const phmm_batch *b) { return b ? b->cells : 0; }
 uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b) { return b ? b->alg_bytes : 0; }
-uint32_t phmm_batch_num_launches(const phmm_batch *b) { return b ? (uint32_t)b->classes.size() : 0; }
+uint32_t phmm_batch_num_launches(const phmm_batch *b) {
+    if (!b) return 0;
+    uint32_t n = (uint32_t)b->chain_groups.size();
+    for (const auto &c : b->classes)
+        if (!c.chain || c.f32_first) n += c.f32_first ? 2u : 1u;
+    return n;
+}
 const char *phmm_batch_dominant_kernel(const phmm_batch *b) { return b ? b->dominant.c_str() : ""; }
 
 }  // extern "C"

@@ -126,21 +126,20 @@ __device__ __forceinline__ void chain_fallback_streams(const ForwardParams &p, u
 
 }  // namespace
 
+// One work item = one wave: a run of reads of one region against one group of its haplotypes, K columns per lane.
 template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the three units' kernel symbols apart)
-__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams cp) {
+__device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainItem it, unsigned char *smem) {
     static_assert(CLT == CL, "one lanes-per-pair value per compilation unit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ForwardParams &p = cp.f;
     const int lane = threadIdx.x;
     const int grp = lane / CL, l = lane % CL;
     const bool group_head = (CL == 32) && (lane == 32);
-    const ChainItem it = cp.items[blockIdx.x];
     const uint32_t reg = it.region;
     const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
     // streams (see the header): S sub-runs of reads side by side, each on G/S haplotype slots
-    const int S = (CL == 16) ? (int)cp.streams : 1;
+    const int S = (CL == 16) ? (int)it.streams : 1;
     const int GS = (WAVE / CL) / S;             // haplotype slots per stream
     const int sid = grp / GS;                   // stream of this lane's group
     const int a = (int)it.quad * GS + grp % GS;
@@ -354,35 +353,68 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     }
 }
 
-// ---- launch ----------------------------------------------------------------------------------------
+// ---- the kernel: every item carries its own K (and stream count), so ONE launch per lanes-per-pair value covers
+// every shape class of a batch.  A long-tailed mix of regions (3 x 2 ... 5 000 x 128, haplotypes of 60 ... 500 bases)
+// falls into dozens of <K, streams> classes; launched one after the other, each left most of the chip idle and had a
+// tail of its own (1 536 mixed regions: 72 launches, 145 ms for 12.6 ms of work).  The wave reads its item, branches
+// once (scalar) to the body compiled for that K, and never meets another K again; the launch is sorted longest item
+// first across all classes.  Registers are those of the largest body, which costs nothing: the 19 KB LDS ring
+// already limits the kernel to two waves per SIMD.
 #define PHMM_CHAIN_K_LIST(X) \
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
     X(23) X(24) X(25)
+
+template <int CLT>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ChainItem it = cp.items[blockIdx.x];
+    switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
+#define PHMM_CASE(KK)                        \
+    case KK:                                 \
+        chain_body<CLT, KK>(cp, it, smem);   \
+        break;
+        PHMM_CHAIN_K_LIST(PHMM_CASE)
+#undef PHMM_CASE
+        default:
+            break;
+    }
+}
+
+// The same body as a kernel of its own: what a launch whose items all share one K uses (the uniform batches of
+// BASELINE.json).  Compiled alone a body keeps its own register allocation -- the any-K kernel above carries the
+// scalar-register pressure of 24 bodies and runs the very same items 1.5-2 % slower (config 2: 10.69 vs 10.50 ms).
+template <int CLT, int K>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_k(const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    chain_body<CLT, K>(cp, cp.items[blockIdx.x], smem);
+}
 
 #define PHMM_CHAIN_CAT2(a, b) a##b
 #define PHMM_CHAIN_CAT(a, b) PHMM_CHAIN_CAT2(a, b)
 #define PHMM_CHAIN_LAUNCH PHMM_CHAIN_CAT(launch_chain_L, PHMM_CHAIN_L)
 
-hipError_t PHMM_CHAIN_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
+// single_k: the K every item of the launch has, or 0 for a mixed launch
+hipError_t PHMM_CHAIN_LAUNCH(int single_k, const ChainParams &cp, hipStream_t stream) {
     const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
-#define PHMM_CASE(KK)                                                                                  \
-    if (K == KK) {                                                                                     \
-        hipLaunchKernelGGL((phmm_forward_chain<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \
-        return hipGetLastError();                                                                      \
+#define PHMM_CASE(KK)                                                                                     \
+    if (single_k == KK) {                                                                                 \
+        hipLaunchKernelGGL((phmm_forward_chain_k<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \
+        return hipGetLastError();                                                                         \
     }
     PHMM_CHAIN_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
-    return hipErrorInvalidValue;
+    hipLaunchKernelGGL((phmm_forward_chain<CL>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);
+    return hipGetLastError();
 }
 
 #if PHMM_CHAIN_L == 16
-hipError_t launch_chain_L32(int K, const ChainParams &cp, hipStream_t stream);
-hipError_t launch_chain_L64(int K, const ChainParams &cp, hipStream_t stream);
+hipError_t launch_chain_L32(int single_k, const ChainParams &cp, hipStream_t stream);
+hipError_t launch_chain_L64(int single_k, const ChainParams &cp, hipStream_t stream);
 int chain_max_k() { return 25; }
-hipError_t launch_chain(int L, int K, const ChainParams &cp, hipStream_t stream) {
+hipError_t launch_chain(int L, int single_k, const ChainParams &cp, hipStream_t stream) {
     if (!cp.n_items) return hipSuccess;
-    return L == 16 ? launch_chain_L16(K, cp, stream) : L == 32 ? launch_chain_L32(K, cp, stream)
-         : L == 64 ? launch_chain_L64(K, cp, stream) : hipErrorInvalidValue;
+    return L == 16 ? launch_chain_L16(single_k, cp, stream) : L == 32 ? launch_chain_L32(single_k, cp, stream)
+         : L == 64 ? launch_chain_L64(single_k, cp, stream) : hipErrorInvalidValue;
 }
 #endif
 

@@ -91,18 +91,22 @@ inline void rescue_geometry(uint32_t max_h, uint32_t *n_blocks, size_t *scratch_
 // ---- chained forward kernel (phmm_chain_kernels.hip) ------------------------------------------------
 constexpr int CHAIN_MAX_READS = 64;  // reads per chain (one lane per read when the stream offsets are scanned)
 struct ChainItem {
-    uint32_t region, quad;          // region index, haplotype group (64/L haplotypes) inside it
+    uint32_t region;                // region index
+    uint16_t quad;                  // haplotype group ((64/L)/streams haplotypes) inside the region
+    uint8_t k, streams;             // columns per lane of this item's body; 1 | 2 | 4 sub-runs swept side by side (L = 16)
     uint32_t read_begin, read_end;  // global read indices [begin, end), all of that region
 };
+static_assert(sizeof(ChainItem) == 16, "work item record");
 struct ChainParams {
     ForwardParams f;
     const ChainItem *items;
     uint32_t n_items;
     uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
-    uint32_t streams;  // 16 lanes per pair only: the run of reads is split into 1, 2 or 4 sub-runs swept side by side,
-                       // each on 4/streams haplotype slots (ChainItem::quad then counts groups of 4/streams haplotypes)
+    uint32_t streams;  // f32-first kernel only (one class per launch): sub-runs swept side by side, see ChainItem::streams
 };
-hipError_t launch_chain(int L, int K, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
+// all chained classes of one lanes-per-pair value in ONE launch (every item carries its K and stream count);
+// single_k = the K all items share (the per-K kernel is used), 0 = mixed (the any-K kernel)
+hipError_t launch_chain(int L, int single_k, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
 hipError_t launch_chain_f32(int L, int K, const ChainParams &p, hipStream_t stream);  // phmm_chain32_kernels.hip, L = 16 | 32
 int chain_max_k();  // largest instantiated K
 

@@ -36,6 +36,42 @@ def assign_regions(cells, world_size):
     return [sorted(o) for o in owned]
 
 
+def split_contiguous(cells, n_parts):
+    """Boundaries b[0..n_parts] of contiguous, cell-balanced ranges of regions: part k owns [b[k], b[k+1]).  Boundary k
+    is the prefix position closest to k/n_parts of the total (ties to the left), kept monotone.  The same rule as
+    phmm_split_regions (libphmm.so); no gather is needed to hand a contiguous range to an engine, so this is what
+    phmm_compute_multi and bench.py's strong-scaling rows use unless the set is too heavy-tailed for it."""
+    cells = [int(c) for c in cells]
+    n = len(cells)
+    prefix = [0]
+    for c in cells:
+        prefix.append(prefix[-1] + c)
+    total = prefix[-1]
+    bounds = [0]
+    g = 0
+    for k in range(1, n_parts):
+        # first g with prefix[g] * n_parts >= total * k
+        while g < n and prefix[g] * n_parts < total * k:
+            g += 1
+        if g > bounds[-1] and g > 0 and (total * k - prefix[g - 1] * n_parts) <= (prefix[g] * n_parts - total * k):
+            g -= 1
+        g = max(g, bounds[-1])
+        bounds.append(g)
+    bounds.append(n)
+    return bounds
+
+
+def imbalance(cells, bounds=None, owned=None):
+    """Heaviest part / mean part load (1.0 = perfectly balanced) for contiguous `bounds` or LPT `owned` lists."""
+    cells = [int(c) for c in cells]
+    if bounds is not None:
+        loads = [sum(cells[bounds[k]:bounds[k + 1]]) for k in range(len(bounds) - 1)]
+    else:
+        loads = [sum(cells[g] for g in o) for o in owned]
+    mean = sum(loads) / max(len(loads), 1)
+    return (max(loads) / mean) if mean > 0 else 1.0
+
+
 def take_regions(batch: RegionBatch, regions):
     """Sub-batch made of the listed regions (any order), offsets rebased."""
     from .batch import Read

@@ -51,6 +51,10 @@ def _load(path):
     lib.oracle_compute.restype = C.c_int
     lib.oracle_compute.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u32p, _u8p,
                                    _u64p, _f64p, C.c_int, C.c_int]
+    lib.oracle_simd_compute.restype = C.c_int
+    lib.oracle_simd_compute.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u32p, _u8p,
+                                        _u64p, _f64p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.oracle_simd_lanes.restype = C.c_int
     lib.oracle_mm_table_len.restype = C.c_size_t
     lib.oracle_mm_prob_table.restype = _f64p
     # engine_oracle.c
@@ -153,6 +157,26 @@ def compute_batch(batch, disable_tristate=False, n_threads=1, native=False):
     if st:
         raise AssertionError("oracle status %d" % st)
     return out
+
+
+def compute_batch_simd(batch, disable_tristate=False, n_threads=1, native=False):
+    """The stand-in for the reference's VECTOR arm (oracle/pairhmm_simd.c: f32 first, f64 redo, one SIMD lane per
+    haplotype).  Returns (out float64, number of pairs redone in f64)."""
+    L = lib(native=native)
+    rro = np.ascontiguousarray(batch["region_read_off"], dtype=np.uint32)
+    rho = np.ascontiguousarray(batch["region_hap_off"], dtype=np.uint32)
+    ro = np.ascontiguousarray(batch["read_off"], dtype=np.uint32)
+    ho = np.ascontiguousarray(batch["hap_off"], dtype=np.uint32)
+    oo = np.ascontiguousarray(batch["out_off"], dtype=np.uint64)
+    arrs = [np.ascontiguousarray(batch[k], dtype=np.uint8) for k in
+            ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")]
+    out = np.zeros(int(oo[-1]), dtype=np.float64)
+    p8 = [a.ctypes.data_as(_u8p) for a in arrs]
+    redone = C.c_uint64(0)
+    L.oracle_simd_compute(len(rro) - 1, rro.ctypes.data_as(_u32p), rho.ctypes.data_as(_u32p), ro.ctypes.data_as(_u32p),
+                          p8[0], p8[1], p8[2], p8[3], p8[4], ho.ctypes.data_as(_u32p), p8[5], oo.ctypes.data_as(_u64p),
+                          out.ctypes.data_as(_f64p), int(disable_tristate), int(n_threads), C.byref(redone))
+    return out, int(redone.value)
 
 
 def load_kat(path):
