@@ -141,16 +141,23 @@ void phmm_submit_stats(phmm_handle *h, uint64_t *n_flushes, uint64_t *n_submissi
 
 /*
  * Several devices, one process (regions shard, nothing is exchanged).  phmm_compute_multi is phmm_compute over
- * `n_handles` engines, normally one per device: whole regions are assigned by greedy longest-processing-time on
- * cells(region) = sum of read lengths x sum of haplotype lengths (heaviest region first onto the least loaded engine),
- * every engine computes its share concurrently on a host thread of its own, and the results land in the caller's `out`
- * exactly where phmm_compute would put them.  The handles must not be in use by other threads during the call; on
- * failure the message is phmm_last_error(handles[0]).  phmm_assign_regions exposes the assignment alone (host only, no
- * device needed): part_of_region[g] in [0, n_parts).
+ * `n_handles` engines, normally one per device.  Whole regions go to engines in CONTIGUOUS ranges balanced by
+ * cells(region) = sum of read lengths x sum of haplotype lengths (phmm_split_regions); only when such ranges come out
+ * more than 5 % uneven -- a heavy-tailed set -- are regions dealt out one by one by greedy longest-processing-time
+ * (phmm_assign_regions: heaviest region first onto the least loaded engine).  Either way every engine stages its share
+ * straight from the caller's arrays (no gather: each payload byte is copied once, into that engine's pinned staging),
+ * computes it concurrently on a host thread of its own pinned to the CPUs local to its GPU, and the results land in the
+ * caller's `out` exactly where phmm_compute would put them.  The handles must not be in use by other threads during the
+ * call; on failure the message is phmm_last_error(handles[0]).  phmm_assign_regions / phmm_split_regions expose the two
+ * assignments alone (host only, no device needed): part_of_region[g] in [0, n_parts); first_region[0..n_parts], part k
+ * owning the regions [first_region[k], first_region[k+1]).
  */
 int phmm_assign_regions(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                         const uint32_t *read_off, const uint32_t *hap_off, uint32_t n_parts,
                         uint32_t *part_of_region);
+int phmm_split_regions(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                       const uint32_t *read_off, const uint32_t *hap_off, uint32_t n_parts,
+                       uint32_t *first_region);
 int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t n_regions,
                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,

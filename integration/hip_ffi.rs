@@ -1,0 +1,215 @@
+//! `extern "C"` bindings of libphmm.so -- the MI355X-native PairHMM engine -- for Lorikeet.
+//!
+//! One declaration per export of `include/phmm.h`, same order, same argument order; nothing elided.
+//! `tests/test_integration_artifacts.py` parses both files and fails when a name, an arity or a scalar width
+//! differs.  This file is added to Lorikeet as `src/pair_hmm/hip_ffi.rs` by `integration/lorikeet-hip.patch`
+//! (behind the cargo feature `hip`); the safe wrapper the PairHMM arm calls is `src/pair_hmm/hip_backend.rs`
+//! of the same patch.
+#![allow(non_camel_case_types, dead_code)]
+
+use std::os::raw::{c_char, c_int, c_uint, c_void};
+
+/// Opaque engine handle (`phmm_handle`).
+#[repr(C)]
+pub struct phmm_handle {
+    _private: [u8; 0],
+}
+/// Opaque launch plan (`phmm_batch`).
+#[repr(C)]
+pub struct phmm_batch {
+    _private: [u8; 0],
+}
+
+pub const PHMM_VERSION: c_int = 1;
+
+pub const PHMM_FLAG_NO_TRISTATE: c_uint = 1;
+pub const PHMM_FLAG_F32_FIRST: c_uint = 2;
+
+pub const PHMM_OK: c_int = 0;
+pub const PHMM_ERR_INVALID_ARG: c_int = 1;
+pub const PHMM_ERR_NO_DEVICE: c_int = 2;
+pub const PHMM_ERR_HIP: c_int = 3;
+pub const PHMM_ERR_POSITIVE_RESULT: c_int = 4;
+pub const PHMM_ERR_NOT_BOUND: c_int = 5;
+pub const PHMM_ERR_NO_MEMORY: c_int = 6;
+pub const PHMM_ERR_INTERNAL: c_int = 7;
+
+/// `phmm_engine_config`: the arguments of `PairHMMLikelihoodCalculationEngine::new`
+/// (src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs:129-141) the device needs.
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct phmm_engine_config {
+    pub constant_gcp: u8,
+    pub pcr_error_model: u8,
+    pub base_quality_score_threshold: u8,
+    pub dynamic_read_disqualification: u8,
+    pub symmetrically_normalize_alleles_to_reference: u8,
+    pub disable_cap_read_qualities_to_mapq: u8,
+    pub reserved: [u8; 2],
+    pub log10_global_read_mismapping_rate: f64,
+    pub read_disqualification_scale: f64,
+    pub expected_error_rate_per_base: f64,
+}
+
+extern "C" {
+    pub fn phmm_device_count() -> c_int;
+    pub fn phmm_create(device_id: c_int, flags: c_uint) -> *mut phmm_handle;
+    pub fn phmm_destroy(h: *mut phmm_handle);
+    pub fn phmm_last_error(h: *mut phmm_handle) -> *const c_char;
+
+    pub fn phmm_compute(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        gcp: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        out_off: *const u64,
+        out: *mut f64,
+    ) -> c_int;
+
+    pub fn phmm_submit(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        gcp: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        out_off: *const u64,
+        out: *mut f64,
+        ticket: *mut u64,
+    ) -> c_int;
+    pub fn phmm_wait(h: *mut phmm_handle, ticket: u64) -> c_int;
+    pub fn phmm_submit_stats(h: *mut phmm_handle, n_flushes: *mut u64, n_submissions: *mut u64);
+
+    pub fn phmm_assign_regions(
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        hap_off: *const u32,
+        n_parts: u32,
+        part_of_region: *mut u32,
+    ) -> c_int;
+    pub fn phmm_split_regions(
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        hap_off: *const u32,
+        n_parts: u32,
+        first_region: *mut u32,
+    ) -> c_int;
+    pub fn phmm_compute_multi(
+        handles: *const *mut phmm_handle,
+        n_handles: u32,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        gcp: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        out_off: *const u64,
+        out: *mut f64,
+    ) -> c_int;
+
+    pub fn phmm_batch_create(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        hap_off: *const u32,
+        out_off: *const u64,
+    ) -> *mut phmm_batch;
+    pub fn phmm_batch_destroy(b: *mut phmm_batch);
+    pub fn phmm_batch_bind_device(
+        b: *mut phmm_batch,
+        d_read_bases: *const u8,
+        d_base_q: *const u8,
+        d_ins_q: *const u8,
+        d_del_q: *const u8,
+        d_gcp: *const u8,
+        d_hap_bases: *const u8,
+        d_out: *mut f64,
+    ) -> c_int;
+    pub fn phmm_batch_upload(
+        b: *mut phmm_batch,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        gcp: *const u8,
+        hap_bases: *const u8,
+    ) -> c_int;
+    pub fn phmm_batch_launch(b: *mut phmm_batch, stream: *mut c_void) -> c_int;
+    pub fn phmm_batch_download(b: *mut phmm_batch, out: *mut f64) -> c_int;
+    pub fn phmm_batch_status(b: *mut phmm_batch) -> c_int;
+    pub fn phmm_batch_cells(b: *const phmm_batch) -> u64;
+    pub fn phmm_batch_algorithmic_bytes(b: *const phmm_batch) -> u64;
+    pub fn phmm_batch_num_launches(b: *const phmm_batch) -> u32;
+    pub fn phmm_batch_dominant_kernel(b: *const phmm_batch) -> *const c_char;
+
+    pub fn phmm_engine_compute(
+        h: *mut phmm_handle,
+        cfg: *const phmm_engine_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+    ) -> c_int;
+    pub fn phmm_engine_submit(
+        h: *mut phmm_handle,
+        cfg: *const phmm_engine_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+        ticket: *mut u64,
+    ) -> c_int;
+
+    pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;
+    pub fn phmm_get_stat(h: *mut phmm_handle, name: *const c_char) -> u64;
+
+    pub fn phmm_table_eps(eps: *mut *const f64) -> usize;
+    pub fn phmm_table_match_to_match(mm: *mut *const f64) -> usize;
+}

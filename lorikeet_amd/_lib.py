@@ -48,6 +48,7 @@ SYMBOLS = [
     ("phmm_wait", C.c_int, [C.c_void_p, C.c_uint64]),
     ("phmm_submit_stats", None, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("phmm_assign_regions", C.c_int, [C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, u32p]),
+    ("phmm_split_regions", C.c_int, [C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, u32p]),
     ("phmm_compute_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                      u32p, u8p, u64p, f64p]),
     ("phmm_batch_create", C.c_void_p, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u32p, u64p]),

@@ -1163,28 +1163,34 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
 struct ChunkView {
     uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
     uint32_t index = 0;  // how many chunks came before this one
+    bool started = false;
     bool f32_first = false;  // the handle's precision mode (decides the chunk sizes)
     size_t read_byte0 = 0, hap_byte0 = 0;
     std::vector<uint32_t> rro, rho, ro, ho;
     std::vector<uint64_t> oo;
 };
 
-// Next chunk after `c` (start with c.g1 == 0): grows while every per-base array stays below the direct-copy limit.
+// Next chunk after `c` of the regions [.., n_regions) (start with c.g1 == first region, c.started == false): grows while
+// every per-base array stays below the direct-copy limit; `whole` takes everything that is left in one chunk.
 bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
-                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off) {
+                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool whole = false) {
     const uint32_t g0 = c.g1;
     if (g0 >= n_regions) return false;
     uint32_t g1 = g0 + 1;
     const size_t base_r = read_off[region_read_off[g0]];
     // the first chunks are short so that the GPU starts early (0.5, 0.5, 1, 2, 4, 4 ... MB per array); staging and the
     // H2D copy of the following ones hide behind its kernels
-    c.index = g0 == 0 ? 0 : c.index + 1;
+    c.index = c.started ? c.index + 1 : 0;
+    c.started = true;
     // f64: 0.5 MB per array four times, then 1, 1, 2, 2, 4, 4 ... (mid-size batches want many small chunks, large ones
     // large launches).  f32-first handles: 1, 2, 4, 4 ... -- the f32 sweep only exists as the chained kernel, which needs
     // a few hundred regions per launch.
     const uint32_t step = c.f32_first ? c.index + 1 : (c.index < 4 ? 0 : (c.index - 2) / 2);
     const size_t limit = std::min(kChunkBytes, (c.f32_first ? (1u << 20) / 2 : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
-    while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= limit) ++g1;
+    if (whole)
+        g1 = n_regions;
+    else
+        while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= limit) ++g1;
     c.g0 = g0;
     c.g1 = g1;
     c.r0 = region_read_off[g0];
@@ -1291,36 +1297,40 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
 
 extern "C" {
 
-int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
-                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
-                 const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
-                 const uint64_t *out_off, double *out) {
-    if (!h) return PHMM_ERR_INVALID_ARG;
-    PHMM_GUARD_BEGIN
+}  // extern "C"
+
+namespace phmm_host {
+
+// phmm_compute on the regions [g_begin, g_end) of the caller's (already validated) arrays; results go where
+// phmm_compute on the whole batch would put them.  phmm_compute is the range [0, n_regions); phmm_compute_multi hands
+// every engine a contiguous range -- no gather, every payload byte is copied once, into the pinned mirror.
+int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32_t *region_read_off,
+                  const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                  const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
+                  const uint8_t *hap_bases, const uint64_t *out_off, double *out) {
     const bool trace = h->sw.trace != 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    // the whole batch is checked before anything is indexed: the chunked path below walks the caller's arrays
-    h->err_code = PHMM_OK;
-    if (tl_err_h == h) tl_err_h = nullptr;
-    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr)) {
-        h->err = bad;
-        return h->err_code = PHMM_ERR_INVALID_ARG;
-    }
-    const uint32_t n_reads = region_read_off[n_regions];
-    if ((read_off[n_reads] && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) ||
-        (hap_off[region_hap_off[n_regions]] && !hap_bases) || (out_off[n_regions] && !out)) {
-        h->err = "phmm_compute: null pointer";
-        return h->err_code = PHMM_ERR_INVALID_ARG;
-    }
     DeviceGuard dg(h->device);
+    const uint32_t n_regions = g_end - g_begin;
+    const size_t range_bytes = (size_t)read_off[region_read_off[g_end]] - read_off[region_read_off[g_begin]];
     // ---- small / medium batch: one shot ------------------------------------------------------------
     const bool f32_first = (h->flags & PHMM_FLAG_F32_FIRST) != 0;
-    if (n_regions < 8 || (size_t)read_off[n_reads] <= (f32_first ? (size_t)(8u << 20) : kOneShotBytes) || h->sw.no_pipeline) {
+    if (n_regions < 8 || range_bytes <= (f32_first ? (size_t)(8u << 20) : kOneShotBytes) || h->sw.no_pipeline) {
         h->slot = 0;
         PendingCompute p;
-        int st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
+        int st;
+        if (g_begin == 0) {  // offsets already start at 0
+            st = enqueue_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
                                  hap_off, hap_bases, out_off, out, &p);
+        } else {
+            ChunkView c;
+            c.g1 = g_begin;
+            (void)next_chunk(c, g_end, region_read_off, region_hap_off, read_off, hap_off, out_off, true);
+            const size_t bo = c.read_byte0, co = c.hap_byte0;
+            st = enqueue_compute(h, n_regions, c.rro.data(), c.rho.data(), c.ro.data(), read_bases + bo, base_q + bo, ins_q + bo,
+                                 del_q + bo, gcp + bo, c.ho.data(), hap_bases + co, c.oo.data(), out + out_off[g_begin], &p);
+        }
         const double t1 = now();
         if (st == PHMM_OK) st = finish_compute(h, &p);
         if (trace)
@@ -1348,9 +1358,10 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     int st = PHMM_OK;
     ChunkView c;
     c.f32_first = f32_first;
+    c.g1 = g_begin;
     int n_chunks = 0;
     h->defer_d2h = true;
-    while (st == PHMM_OK && next_chunk(c, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
+    while (st == PHMM_OK && next_chunk(c, g_end, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
         const int slot = n_chunks % kSlots;
         st = finish_compute(h, &pend[slot]);  // the slot's previous chunk must be out of its arena
         if (st != PHMM_OK) break;
@@ -1369,6 +1380,118 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
     h->defer_d2h = false;
     if (trace) fprintf(stderr, "phmm_compute: %d chunks pipelined over %d slots, total %.1f us\n", n_chunks, kSlots, now() - t0);
     return st;
+}
+
+// The regions `list` (any order, any subset) of the caller's arrays on one engine: chunks of the list are staged
+// straight from the caller's arrays (a scatter-gather `Parts` entry per region) and rotate through the engine's slots
+// like the chunks of compute_range.  What phmm_compute_multi uses when a heavy-tailed set makes contiguous ranges
+// unbalanced and regions are dealt out one by one.
+int compute_list(phmm_handle *h, const uint32_t *list, uint32_t n_list, const uint32_t *region_read_off,
+                 const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                 const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
+                 const uint8_t *hap_bases, const uint64_t *out_off, double *out) {
+    DeviceGuard dg(h->device);
+    struct Slot {
+        PendingCompute pend;
+        Parts parts;
+        std::vector<uint32_t> rro, rho, ro, ho;
+        std::vector<uint64_t> oo;
+    } slots[kSlots];
+    struct Drain {
+        phmm_handle *h;
+        Slot *s;
+        ~Drain() {
+            for (int i = 0; i < kSlots; ++i)
+                if (s[i].pend.b) {
+                    (void)hipStreamSynchronize(h->streams[s[i].pend.slot]);
+                    phmm_batch_destroy(s[i].pend.b);
+                    s[i].pend.b = nullptr;
+                }
+            h->slot = 0;
+            h->defer_d2h = false;
+        }
+    } drain{h, slots};
+    const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
+    int st = PHMM_OK, n_chunks = 0;
+    h->defer_d2h = true;
+    for (uint32_t i0 = 0; i0 < n_list && st == PHMM_OK;) {
+        Slot &S = slots[n_chunks % kSlots];
+        st = finish_compute(h, &S.pend);  // the slot's previous chunk must be out of its arena (and of S.parts)
+        if (st != PHMM_OK) break;
+        const size_t limit = std::min(kChunkBytes, kFirstChunkBytes << std::min(n_chunks / 2, 16));
+        S.rro.assign(1, 0);
+        S.rho.assign(1, 0);
+        S.ro.assign(1, 0);
+        S.ho.assign(1, 0);
+        S.oo.assign(1, 0);
+        for (int k = 0; k < 6; ++k) S.parts.src[k].clear();
+        S.parts.read_bytes.clear();
+        S.parts.hap_bytes.clear();
+        S.parts.out.clear();
+        S.parts.n_out.clear();
+        S.parts.first_region.assign(1, 0);
+        uint32_t i1 = i0;
+        size_t bytes = 0;
+        while (i1 < n_list && S.parts.out.size() < 4096) {
+            const uint32_t g = list[i1];
+            const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1], a0 = region_hap_off[g], a1 = region_hap_off[g + 1];
+            const size_t rb = (size_t)read_off[r1] - read_off[r0], hb = (size_t)hap_off[a1] - hap_off[a0];
+            if (i1 > i0 && bytes + rb > limit) break;
+            bytes += rb;
+            for (uint32_t r = r0; r < r1; ++r) S.ro.push_back(S.ro.back() + (read_off[r + 1] - read_off[r]));
+            for (uint32_t a = a0; a < a1; ++a) S.ho.push_back(S.ho.back() + (hap_off[a + 1] - hap_off[a]));
+            S.rro.push_back(S.rro.back() + (r1 - r0));
+            S.rho.push_back(S.rho.back() + (a1 - a0));
+            S.oo.push_back(S.oo.back() + (out_off[g + 1] - out_off[g]));
+            for (int k = 0; k < 5; ++k) S.parts.src[k].push_back(src[k] + read_off[r0]);
+            S.parts.src[5].push_back(hap_bases + hap_off[a0]);
+            S.parts.read_bytes.push_back(rb);
+            S.parts.hap_bytes.push_back(hb);
+            S.parts.out.push_back(out + out_off[g]);
+            S.parts.n_out.push_back(out_off[g + 1] - out_off[g]);
+            S.parts.first_region.push_back(S.parts.first_region.back() + 1);
+            ++i1;
+        }
+        h->slot = n_chunks % kSlots;
+        st = enqueue_compute(h, i1 - i0, S.rro.data(), S.rho.data(), S.ro.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                             S.ho.data(), nullptr, S.oo.data(), nullptr, &S.pend, &S.parts);
+        ++n_chunks;
+        i0 = i1;
+    }
+    for (int i = 0; i < kSlots; ++i) {
+        const int s2 = finish_compute(h, &slots[(n_chunks + i) % kSlots].pend);
+        if (st == PHMM_OK) st = s2;
+    }
+    h->slot = 0;
+    h->defer_d2h = false;
+    return st;
+}
+
+}  // namespace phmm_host
+
+extern "C" {
+
+int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                 const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
+                 const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off, const uint8_t *hap_bases,
+                 const uint64_t *out_off, double *out) {
+    if (!h) return PHMM_ERR_INVALID_ARG;
+    PHMM_GUARD_BEGIN
+    // the whole batch is checked before anything is indexed: the chunked path walks the caller's arrays
+    h->err_code = PHMM_OK;
+    if (tl_err_h == h) tl_err_h = nullptr;
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr)) {
+        h->err = bad;
+        return h->err_code = PHMM_ERR_INVALID_ARG;
+    }
+    const uint32_t n_reads = region_read_off[n_regions];
+    if ((read_off[n_reads] && (!read_bases || !base_q || !ins_q || !del_q || !gcp)) ||
+        (hap_off[region_hap_off[n_regions]] && !hap_bases) || (out_off[n_regions] && !out)) {
+        h->err = "phmm_compute: null pointer";
+        return h->err_code = PHMM_ERR_INVALID_ARG;
+    }
+    return compute_range(h, 0, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
+                         hap_off, hap_bases, out_off, out);
     PHMM_GUARD_END(h, "phmm_compute", PHMM_FAIL_CODE)
 }
 

@@ -95,6 +95,17 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                     const uint64_t *out_off, double *out, PendingCompute *pending, const Parts *parts = nullptr);
 int finish_compute(phmm_handle *h, PendingCompute *p);
 
+// phmm_compute restricted to the regions [g_begin, g_end) / to the listed regions of the caller's validated arrays
+// (phmm_compute_multi: one range or one list per engine, nothing is gathered first).
+int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32_t *region_read_off,
+                  const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                  const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
+                  const uint8_t *hap_bases, const uint64_t *out_off, double *out);
+int compute_list(phmm_handle *h, const uint32_t *list, uint32_t n_list, const uint32_t *region_read_off,
+                 const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                 const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
+                 const uint8_t *hap_bases, const uint64_t *out_off, double *out);
+
 // What every entry point checks before it touches the arrays; returns the message of the first violation or nullptr.
 const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                              const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool *tight_out);

@@ -1,8 +1,15 @@
-// phmm_assign_regions / phmm_compute_multi (include/phmm.h): one call over several engines, one per device, from one
-// process -- what a single Lorikeet process on a multi-GPU node needs.  Whole regions are assigned by greedy
-// longest-processing-time on cells(region); every engine computes its share concurrently, on a host thread of its own,
-// into disjoint slices of `out`.  There is no exchange between devices and no CPU fallback.
+// phmm_assign_regions / phmm_split_regions / phmm_compute_multi (include/phmm.h): one call over several engines, one per
+// device, from one process -- what a single Lorikeet process on a multi-GPU node needs.  Whole regions go to
+// engines in contiguous cell-balanced ranges (or, for heavy-tailed sets, one by one by greedy longest-processing-time on
+// cells(region)); every engine computes its share concurrently, on a host thread of its own pinned next to its GPU,
+// staging straight from the caller's arrays into its pinned mirror and writing into disjoint slices of `out`.  Nothing
+// is gathered first ("expected limiter is host-side marshalling"), there is no exchange between devices and
+// no CPU fallback.
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <cstring>
 #include <queue>
 #include <string>
@@ -44,14 +51,55 @@ void assign_lpt(const std::vector<uint64_t> &cells, uint32_t n_parts, uint32_t *
     }
 }
 
-struct Share {  // the regions of one engine, gathered into arrays of their own (ascending region order)
-    std::vector<uint32_t> regions, rro{0}, rho{0}, ro{0}, ho{0};
-    std::vector<uint64_t> oo{0};
-    std::vector<uint8_t> bytes[6];
-    std::vector<double> out;
-    int status = PHMM_OK;
-    std::string err;
-};
+// Boundaries of n_parts contiguous, cell-balanced ranges: boundary k is the prefix position closest to k/n_parts of the
+// total (ties to the left), kept monotone -- the rule of lorikeet_amd/sharding.py:split_contiguous.
+void split_contiguous(const std::vector<uint64_t> &cells, uint32_t n_parts, uint32_t *first_region) {
+    const uint32_t n = (uint32_t)cells.size();
+    std::vector<unsigned __int128> prefix(n + 1, 0);
+    for (uint32_t g = 0; g < n; ++g) prefix[g + 1] = prefix[g] + cells[g];
+    const unsigned __int128 total = prefix[n];
+    first_region[0] = 0;
+    uint32_t g = 0;
+    for (uint32_t k = 1; k < n_parts; ++k) {
+        while (g < n && prefix[g] * n_parts < total * k) ++g;
+        if (g > first_region[k - 1] && g > 0 && (total * k - prefix[g - 1] * n_parts) <= (prefix[g] * n_parts - total * k)) --g;
+        g = std::max(g, first_region[k - 1]);
+        first_region[k] = g;
+    }
+    first_region[n_parts] = n;
+}
+
+// The calling thread moves next to its engine's GPU: the CPUs the device's PCI function lists as local
+// (/sys/bus/pci/devices/<bdf>/local_cpulist), intersected with what the thread may use.  Staging copies then run out
+// of the memory of the GPU's own NUMA node.  Best effort: any failure leaves the affinity alone.
+void pin_near_device(int device) {
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return;
+    for (char *p = bdf; *p; ++p) *p = (char)tolower(*p);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    CPU_ZERO(&want);
+    int n_want = 0;
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int lo = 0, hi = 0;
+        const int k = sscanf(tok, "%d-%d", &lo, &hi);
+        if (k < 1) continue;
+        if (k == 1) hi = lo;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, &want);
+                ++n_want;
+            }
+    }
+    if (n_want > 0) (void)sched_setaffinity(0, sizeof want, &want);
+}
 
 }  // namespace
 
@@ -61,7 +109,23 @@ int phmm_assign_regions(uint32_t n_regions, const uint32_t *region_read_off, con
                         const uint32_t *read_off, const uint32_t *hap_off, uint32_t n_parts, uint32_t *part_of_region) {
     if (!n_parts || (n_regions && (!region_read_off || !region_hap_off || !read_off || !hap_off || !part_of_region)))
         return PHMM_ERR_INVALID_ARG;
-    assign_lpt(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_parts, part_of_region);
+    try {
+        assign_lpt(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_parts, part_of_region);
+    } catch (...) {
+        return PHMM_ERR_NO_MEMORY;
+    }
+    return PHMM_OK;
+}
+
+int phmm_split_regions(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                       const uint32_t *read_off, const uint32_t *hap_off, uint32_t n_parts, uint32_t *first_region) {
+    if (!n_parts || !first_region || (n_regions && (!region_read_off || !region_hap_off || !read_off || !hap_off)))
+        return PHMM_ERR_INVALID_ARG;
+    try {
+        split_contiguous(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_parts, first_region);
+    } catch (...) {
+        return PHMM_ERR_NO_MEMORY;
+    }
     return PHMM_OK;
 }
 
@@ -90,51 +154,69 @@ int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t
         h0->err = "phmm_compute_multi: null pointer";
         return PHMM_ERR_INVALID_ARG;
     }
-    std::vector<uint32_t> part(n_regions);
-    assign_lpt(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_handles, part.data());
-    std::vector<Share> shares(n_handles);
-    const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
-    for (uint32_t g = 0; g < n_regions; ++g) {
-        Share &s = shares[part[g]];
-        s.regions.push_back(g);
-        const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1], a0 = region_hap_off[g], a1 = region_hap_off[g + 1];
-        for (uint32_t r = r0; r < r1; ++r) s.ro.push_back(s.ro.back() + (read_off[r + 1] - read_off[r]));
-        for (uint32_t a = a0; a < a1; ++a) s.ho.push_back(s.ho.back() + (hap_off[a + 1] - hap_off[a]));
-        for (int i = 0; i < 5; ++i) s.bytes[i].insert(s.bytes[i].end(), src[i] + read_off[r0], src[i] + read_off[r1]);
-        s.bytes[5].insert(s.bytes[5].end(), hap_bases + hap_off[a0], hap_bases + hap_off[a1]);
-        s.rro.push_back(s.rro.back() + (r1 - r0));
-        s.rho.push_back(s.rho.back() + (a1 - a0));
-        s.oo.push_back(s.oo.back() + (out_off[g + 1] - out_off[g]));
-    }
-    std::vector<std::thread> workers;
-    for (uint32_t k = 0; k < n_handles; ++k) {
-        Share &s = shares[k];
-        if (s.regions.empty()) continue;
-        s.out.resize(s.oo.back());
-        workers.emplace_back([&s, h = handles[k]] {
-            s.status = phmm_compute(h, (uint32_t)s.regions.size(), s.rro.data(), s.rho.data(), s.ro.data(), s.bytes[0].data(),
-                                    s.bytes[1].data(), s.bytes[2].data(), s.bytes[3].data(), s.bytes[4].data(), s.ho.data(),
-                                    s.bytes[5].data(), s.oo.data(), s.out.data());
-            if (s.status != PHMM_OK) s.err = phmm_last_error(h);
-        });
-    }
-    for (auto &w : workers) w.join();
-    int st = PHMM_OK;
-    for (uint32_t k = 0; k < n_handles; ++k) {
-        Share &s = shares[k];
-        // a share's results are valid numbers even when one of them tripped the `<= 0` check: hand everything over
-        if (s.status == PHMM_OK || s.status == PHMM_ERR_POSITIVE_RESULT)
-            for (size_t i = 0; i < s.regions.size(); ++i) {
-                const uint32_t g = s.regions[i];
-                const uint64_t n = s.oo[i + 1] - s.oo[i];
-                if (n) memcpy(out + out_off[g], s.out.data() + s.oo[i], n * 8);
-            }
-        if (s.status != PHMM_OK && st == PHMM_OK) {
-            st = s.status;
-            h0->err = s.err;
+    try {
+        // Contiguous, cell-balanced ranges need no gather at all: every engine stages its range straight from the
+        // caller's arrays.  Only when one heavy region makes such ranges uneven (a part more than 5 % above the mean)
+        // are regions dealt out one by one (greedy LPT) -- still without a gather: every engine walks its own list
+        // and stages region by region from the caller's arrays.
+        const std::vector<uint64_t> cells = region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off);
+        std::vector<uint32_t> first(n_handles + 1);
+        split_contiguous(cells, n_handles, first.data());
+        unsigned __int128 total = 0;
+        uint64_t heaviest = 0;
+        for (uint32_t k = 0; k < n_handles; ++k) {
+            uint64_t load = 0;
+            for (uint32_t g = first[k]; g < first[k + 1]; ++g) load += cells[g];
+            heaviest = std::max(heaviest, load);
+            total += load;
         }
+        const bool contiguous = (unsigned __int128)heaviest * n_handles * 100 <= total * 105;
+        std::vector<std::vector<uint32_t>> lists;
+        if (!contiguous) {
+            std::vector<uint32_t> part(n_regions);
+            assign_lpt(cells, n_handles, part.data());
+            lists.resize(n_handles);
+            for (uint32_t g = 0; g < n_regions; ++g) lists[part[g]].push_back(g);
+        }
+        std::vector<int> status(n_handles, PHMM_OK);
+        std::vector<std::string> errs(n_handles);
+        std::vector<std::thread> workers;
+        for (uint32_t k = 0; k < n_handles; ++k) {
+            if (contiguous ? first[k] == first[k + 1] : lists[k].empty()) continue;
+            workers.emplace_back([&, k] {
+                phmm_handle *h = handles[k];
+                try {
+                    pin_near_device(h->device);
+                    h->err_code = PHMM_OK;
+                    status[k] = contiguous
+                                    ? compute_range(h, first[k], first[k + 1], region_read_off, region_hap_off, read_off, read_bases,
+                                                    base_q, ins_q, del_q, gcp, hap_off, hap_bases, out_off, out)
+                                    : compute_list(h, lists[k].data(), (uint32_t)lists[k].size(), region_read_off, region_hap_off,
+                                                   read_off, read_bases, base_q, ins_q, del_q, gcp, hap_off, hap_bases, out_off, out);
+                    if (status[k] != PHMM_OK) errs[k] = h->err;
+                } catch (const std::bad_alloc &) {
+                    status[k] = PHMM_ERR_NO_MEMORY;
+                    errs[k] = "phmm_compute_multi: out of host memory";
+                } catch (const std::exception &e) {
+                    status[k] = PHMM_ERR_INTERNAL;
+                    errs[k] = std::string("phmm_compute_multi: ") + e.what();
+                }
+            });
+        }
+        for (auto &w : workers) w.join();
+        for (uint32_t k = 0; k < n_handles; ++k)
+            if (status[k] != PHMM_OK) {
+                h0->err = errs[k];
+                return status[k];
+            }
+        return PHMM_OK;
+    } catch (const std::bad_alloc &) {
+        h0->err = "phmm_compute_multi: out of host memory";
+        return PHMM_ERR_NO_MEMORY;
+    } catch (const std::exception &e) {
+        h0->err = std::string("phmm_compute_multi: ") + e.what();
+        return PHMM_ERR_INTERNAL;
     }
-    return st;
 }
 
 }  // extern "C"

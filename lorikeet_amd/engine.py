@@ -205,6 +205,19 @@ def assign_regions(batch: RegionBatch, n_parts):
     return part
 
 
+def split_regions(batch: RegionBatch, n_parts):
+    """phmm_split_regions: boundaries of `n_parts` contiguous, cell-balanced ranges of regions (host only).
+    Returns uint32[n_parts + 1]; identical to sharding.split_contiguous."""
+    lib = _lib.load()
+    first = np.zeros(int(n_parts) + 1, np.uint32)
+    code = lib.phmm_split_regions(batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p),
+                                  _p(batch.read_off, _lib.u32p), _p(batch.hap_off, _lib.u32p), int(n_parts),
+                                  _p(first, _lib.u32p))
+    if code != _lib.PHMM_OK:
+        raise PhmmError(code, "phmm_split_regions: invalid argument")
+    return first
+
+
 def compute_multi(engines, batch: RegionBatch):
     """phmm_compute_multi: one batch over several engines (normally one per device) of this process; regions are
     sharded by assign_regions, every engine computes its share concurrently, no exchange between devices."""

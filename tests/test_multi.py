@@ -6,7 +6,7 @@ import pytest
 from lorikeet_amd import HipPairHMMEngine, PhmmError, synthetic
 from lorikeet_amd import _lib
 from lorikeet_amd.batch import Read, RegionBatch
-from lorikeet_amd.engine import assign_regions, compute_multi
+from lorikeet_amd.engine import assign_regions, compute_multi, split_regions
 from oracle import oracle
 from test_sharding import _ragged_batch
 
@@ -49,3 +49,43 @@ def test_errors_of_a_share_reach_the_caller():
     assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "monotonic" in str(e.value)
     for x in engines:
         x.close()
+
+
+def test_no_payload_byte_is_copied_more_than_once():
+    """phmm_compute_multi used to gather every engine's share on the calling thread and then copy it again
+    into the pinned mirror.  Now every engine stages straight from the caller's arrays: the engines' staging counters add
+    up to exactly the payload (5 bytes per read base + 1 per haplotype base), in both assignment modes."""
+    engines = [HipPairHMMEngine(0) for _ in range(3)]
+    uniform = synthetic.config3(90, seed=12)                    # contiguous cell-balanced ranges, chunked per engine
+    heavy = RegionBatch.concat([synthetic.make_regions(1, 1200, 8, 300, 150, seed=5), synthetic.config2(6, seed=6),
+                                synthetic.make_regions(12, 10, 2, 80, 40, seed=7)])   # one region dominates: LPT lists
+    cells = lambda b: [int(c) for c in __import__("lorikeet_amd").sharding.region_cells(b)]  # noqa: E731
+    from lorikeet_amd import sharding
+    assert sharding.imbalance(cells(uniform), bounds=split_regions(uniform, 3).tolist()) <= 1.05
+    assert sharding.imbalance(cells(heavy), bounds=split_regions(heavy, 3).tolist()) > 1.05
+    for b in (uniform, heavy):
+        before = sum(e.stat("staged_bytes") for e in engines)
+        got = compute_multi(engines, b)
+        staged = sum(e.stat("staged_bytes") for e in engines) - before
+        assert staged == 5 * int(b.read_off[-1]) + int(b.hap_off[-1]), (staged, b.algorithmic_bytes())
+        assert np.max(np.abs(got - engines[0].compute(b))) <= 1e-12
+        sub = b.region_slice(0, 2)
+        assert np.max(np.abs(got[:sub.n_out] - oracle.compute_batch(sub.as_dict(), n_threads=8))) <= 1e-9
+    # gaps in out_off survive both modes
+    need = np.diff(heavy.out_off.astype(np.int64))
+    off = np.concatenate([[0], np.cumsum(need + 2)]).astype(np.uint64)
+    d = heavy.as_dict()
+    d["out_off"] = off
+    gapped = RegionBatch(**d)
+    import ctypes as C
+    out = np.full(int(off[-1]), -7.5)
+    hs = (C.c_void_p * 3)(*[e._h for e in engines])
+    st = engines[0].lib.phmm_compute_multi(hs, 3, *HipPairHMMEngine._abi_args(gapped), out.ctypes.data_as(_lib.f64p))
+    assert st == 0, engines[0].last_error()
+    want = engines[0].compute(heavy)
+    for g in range(heavy.n_regions):
+        o, n = int(off[g]), int(need[g])
+        assert np.max(np.abs(out[o:o + n] - want[int(heavy.out_off[g]):int(heavy.out_off[g + 1])])) <= 1e-12
+        assert np.all(out[o + n:int(off[g + 1])] == -7.5)
+    for e in engines:
+        e.close()

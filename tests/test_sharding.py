@@ -105,3 +105,37 @@ def test_c_abi_assignment_matches_the_python_sharding():
             for p, regions in enumerate(sharding.assign_regions(cells, parts)):
                 want[regions] = p
             assert np.array_equal(assign_regions(batch, parts), want), parts
+
+
+def test_contiguous_split_c_abi_matches_python_and_is_balanced():
+    """phmm_split_regions == sharding.split_contiguous (what phmm_compute_multi and bench.py's strong-scaling rows shard
+    by): same boundaries, every region in exactly one part, and on the uniform sets of BASELINE.json the heaviest part
+    is within a region of the mean.  Host only."""
+    from lorikeet_amd.engine import split_regions
+    for batch in (_ragged_batch(), synthetic.config3(37, seed=3), synthetic.config2(5, seed=1), synthetic.ragged(40, seed=2)):
+        cells = sharding.region_cells(batch)
+        for parts in (1, 2, 3, 8, 64):
+            want = sharding.split_contiguous(cells, parts)
+            got = split_regions(batch, parts)
+            assert got.tolist() == want, (parts, got, want)
+            assert want[0] == 0 and want[-1] == batch.n_regions and all(a <= b for a, b in zip(want, want[1:]))
+    cells = synthetic.config_cells("config3")
+    for parts in (2, 4, 8):
+        b = sharding.split_contiguous(cells, parts)
+        assert sharding.imbalance(cells, bounds=b) < 1.001
+    c5 = synthetic.config_cells("config5")
+    assert sharding.imbalance(c5, bounds=sharding.split_contiguous(c5, 8)) == 1.0
+
+
+def test_strong_scaling_shards_cover_the_fixed_set_exactly_once():
+    """bench.py's config3_10k / config5_256 rows: rank r generates only regions [b[r], b[r+1]) of the shared set; together the
+    ranks hold the whole set, bit-identical to generating it in one piece."""
+    full = synthetic.config3(300)
+    cells = synthetic.config_cells("config3", 300)
+    assert np.array_equal(cells, sharding.region_cells(full))
+    for world in (2, 3):
+        b = sharding.split_contiguous(cells, world)
+        parts = [synthetic.config3(300, only=(b[r], b[r + 1])) for r in range(world)]
+        whole = RegionBatch.concat(parts)
+        for f in RegionBatch.FIELDS:
+            assert np.array_equal(getattr(whole, f), getattr(full, f)), f
