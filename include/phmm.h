@@ -75,6 +75,7 @@ extern "C" {
 #define PHMM_ERR_NOT_BOUND 5        /* phmm_batch_launch before device buffers were bound      */
 #define PHMM_ERR_NO_MEMORY 6        /* a host allocation failed (std::bad_alloc never crosses the ABI)    */
 #define PHMM_ERR_INTERNAL 7         /* any other C++ exception inside the library; see phmm_last_error    */
+#define PHMM_ERR_CIGAR_CAPACITY 8   /* phmm_sw_align: a CIGAR did not fit its slot; n_cigar has the sizes */
 
 typedef struct phmm_handle phmm_handle;
 typedef struct phmm_batch phmm_batch;
@@ -265,6 +266,39 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
                        const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
                        const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
                        double *out, uint8_t *keep, uint64_t *ticket);
+
+/*
+ * Smith-Waterman alignment: SmithWatermanAligner::align of the reference
+ * (src/smith_waterman/smith_waterman_aligner.rs:47-107 dispatch and exact-substring shortcut, :124-271 calculate_matrix,
+ * :273-443 calculate_cigar) for a batch of (reference, alternate) pairs under one parameter set and one overhang
+ * strategy -- what each of its call sites has in hand (read -> best haplotype: src/reads/alignment_utils.rs:40-70 via
+ * src/assembly/assembly_based_caller_utils.rs:208-246; haplotype -> reference: src/reads/cigar_utils.rs:358-405).
+ * Matrix, backtrack and CIGAR assembly all run on the device; the arithmetic is i32 and every tie rule is the
+ * reference's, so CIGAR and offset EQUAL the reference's scalar arm (which its own tests assert equal to the vector
+ * arm, tests/smith_waterman_aligner_unit_tests.rs:999-1103).
+ *
+ *   ref_off / alt_off [n+1]   byte offsets of each pair's reference / alternate sequence; both must be non-empty
+ *                             (the reference asserts, :65-68) and at most 32 000 bases
+ *   params                    gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)
+ *   overhang_strategy         PHMM_SW_* below == gkl::smithwaterman::OverhangStrategy
+ *   cigar_off [n+1]           element offsets into `cigar`: alignment a may use cigar_off[a+1] - cigar_off[a] elements
+ *                             (ref_len + alt_len + 3 always suffices; real CIGARs have a handful)
+ *   cigar                     elements in BAM encoding, (length << 4) | op with M = 0, I = 1, D = 2, S = 4
+ *   n_cigar [n]               elements of each CIGAR; if one exceeds its slot the call returns
+ *                             PHMM_ERR_CIGAR_CAPACITY, every other alignment is valid and n_cigar tells the size to retry with
+ *   alignment_offset [n]      SmithWatermanAlignmentResult::alignment_offset
+ */
+#define PHMM_SW_SOFTCLIP 0
+#define PHMM_SW_INDEL 1
+#define PHMM_SW_LEADING_INDEL 2
+#define PHMM_SW_IGNORE 3
+typedef struct phmm_sw_parameters {
+    int32_t match_value, mismatch_penalty, gap_open_penalty, gap_extend_penalty;
+} phmm_sw_parameters;
+int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32_t *ref_off, const uint8_t *ref_bases,
+                  const uint32_t *alt_off, const uint8_t *alt_bases, const phmm_sw_parameters *params,
+                  int overhang_strategy, const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar,
+                  int32_t *alignment_offset);
 
 /*
  * Developer switches and counters (tests, A/B measurements; never needed in production).

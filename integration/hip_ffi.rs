@@ -33,6 +33,23 @@ pub const PHMM_ERR_POSITIVE_RESULT: c_int = 4;
 pub const PHMM_ERR_NOT_BOUND: c_int = 5;
 pub const PHMM_ERR_NO_MEMORY: c_int = 6;
 pub const PHMM_ERR_INTERNAL: c_int = 7;
+pub const PHMM_ERR_CIGAR_CAPACITY: c_int = 8;
+
+/// `overhang_strategy` of `phmm_sw_align` == gkl::smithwaterman::OverhangStrategy
+pub const PHMM_SW_SOFTCLIP: c_int = 0;
+pub const PHMM_SW_INDEL: c_int = 1;
+pub const PHMM_SW_LEADING_INDEL: c_int = 2;
+pub const PHMM_SW_IGNORE: c_int = 3;
+
+/// `phmm_sw_parameters` == gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct phmm_sw_parameters {
+    pub match_value: i32,
+    pub mismatch_penalty: i32,
+    pub gap_open_penalty: i32,
+    pub gap_extend_penalty: i32,
+}
 
 /// `phmm_engine_config`: the arguments of `PairHMMLikelihoodCalculationEngine::new`
 /// (src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs:129-141) the device needs.
@@ -205,6 +222,21 @@ extern "C" {
         out: *mut f64,
         keep: *mut u8,
         ticket: *mut u64,
+    ) -> c_int;
+
+    pub fn phmm_sw_align(
+        h: *mut phmm_handle,
+        n_alignments: u32,
+        ref_off: *const u32,
+        ref_bases: *const u8,
+        alt_off: *const u32,
+        alt_bases: *const u8,
+        params: *const phmm_sw_parameters,
+        overhang_strategy: c_int,
+        cigar_off: *const u64,
+        cigar: *mut u32,
+        n_cigar: *mut u32,
+        alignment_offset: *mut i32,
     ) -> c_int;
 
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;

@@ -25,6 +25,8 @@ PHMM_ERR_POSITIVE_RESULT = 4
 PHMM_ERR_NOT_BOUND = 5
 PHMM_ERR_NO_MEMORY = 6
 PHMM_ERR_INTERNAL = 7
+PHMM_ERR_CIGAR_CAPACITY = 8
+PHMM_SW_SOFTCLIP, PHMM_SW_INDEL, PHMM_SW_LEADING_INDEL, PHMM_SW_IGNORE = 0, 1, 2, 3
 
 class EngineConfig(C.Structure):
     """phmm_engine_config (include/phmm.h)."""
@@ -34,6 +36,12 @@ class EngineConfig(C.Structure):
                 ("disable_cap_read_qualities_to_mapq", C.c_uint8), ("reserved", C.c_uint8 * 2),
                 ("log10_global_read_mismapping_rate", C.c_double), ("read_disqualification_scale", C.c_double),
                 ("expected_error_rate_per_base", C.c_double)]
+
+
+class SwParameters(C.Structure):
+    """phmm_sw_parameters == gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)."""
+    _fields_ = [("match_value", C.c_int32), ("mismatch_penalty", C.c_int32), ("gap_open_penalty", C.c_int32),
+                ("gap_extend_penalty", C.c_int32)]
 
 
 # every symbol include/phmm.h declares: (name, restype, argtypes)
@@ -66,6 +74,8 @@ SYMBOLS = [
                                       u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_engine_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                      u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p, C.POINTER(C.c_uint64)]),
+    ("phmm_sw_align", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p,
+                                C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),

@@ -346,6 +346,9 @@ void phmm_destroy(phmm_handle *h) {
         if (h->arenas[i].host) (void)hipHostFree(h->arenas[i].host);
         if (h->arenas[i].rescue) (void)hipFree(h->arenas[i].rescue);
     }
+    if (h->swork.dev) (void)hipFree(h->swork.dev);
+    if (h->swork.host) (void)hipHostFree(h->swork.host);
+    if (h->swork.slab) (void)hipFree(h->swork.slab);
     delete h;
 }
 

@@ -54,6 +54,12 @@ struct phmm_handle {
     std::string err;
     int err_code = PHMM_OK;  // status of the last failure (set together with err)
     Switches sw;
+    struct SwWork {  // phmm_sw_align (phmm_sw.cpp): grow-only staging and backtrack slabs
+        char *dev = nullptr, *host = nullptr;
+        size_t cap = 0;
+        int16_t *slab = nullptr;
+        size_t slab_bytes = 0;
+    } swork;
     uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
     uint64_t stat_rescue_passes = 0;  // how many batches needed the exact pass (phmm_get_stat)
     struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit

@@ -138,6 +138,29 @@ struct PostParams {
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 hipError_t launch_post(const PostParams &p, hipStream_t stream);
 
+// ---- Smith-Waterman (phmm_sw_kernels.hip) -------------------------------------------------------------------------
+constexpr int PHMM_SW_STRATEGY_SOFTCLIP = 0, PHMM_SW_STRATEGY_INDEL = 1, PHMM_SW_STRATEGY_LEADING_INDEL = 2,
+              PHMM_SW_STRATEGY_IGNORE = 3;  // == PHMM_SW_* of include/phmm.h
+constexpr uint32_t SW_STATUS_EMPTY = 1u;     // an empty reference or alternate sequence
+constexpr uint32_t SW_STATUS_CAPACITY = 2u;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
+struct SwParams {
+    uint32_t n_alignments;
+    const uint32_t *ref_off, *alt_off;     // [n_alignments + 1]
+    const uint8_t *ref_bases, *alt_bases;
+    int32_t w_match, w_mismatch, w_open, w_extend;
+    int strategy;
+    const uint64_t *cigar_off;             // [n_alignments + 1]
+    uint32_t *cigar, *n_cigar;
+    int32_t *alignment_offset;
+    int16_t *slab;                         // backtrack storage, one slab per worker
+    size_t slab_stride;                    // int16 elements per worker: strips(max_alt) * (max_ref + 64) * 64
+    uint32_t *counter;                     // next alignment to hand out
+    uint32_t *status;
+    uint32_t max_ref, max_alt;             // longest sequences of the batch
+    uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
+};
+hipError_t launch_sw(const SwParams &p, uint32_t n_workers, size_t lds_bytes, hipStream_t stream);
+
 // The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
 extern const int kInstantiatedK[];
 extern const int kNumInstantiatedK;

@@ -55,6 +55,9 @@ def _load(path):
     lib.oracle_simd_compute.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u8p, _u8p, _u8p, _u8p, _u8p, _u32p, _u8p,
                                         _u64p, _f64p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.oracle_simd_lanes.restype = C.c_int
+    lib.oracle_sw_align.restype = C.c_int
+    lib.oracle_sw_align.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
+                                    _u32p, C.POINTER(C.c_int32)]
     lib.oracle_mm_table_len.restype = C.c_size_t
     lib.oracle_mm_prob_table.restype = _f64p
     # engine_oracle.c
@@ -239,3 +242,31 @@ def filter_poorly_modeled_evidence(values, thresholds):
     n = lib().oracle_filter_poorly_modeled_evidence(v.ctypes.data_as(_f64p), v.shape[0], v.shape[1],
                                                     t.ctypes.data_as(_f64p), keep.ctypes.data_as(_u8p))
     return v, keep.astype(bool), int(n)
+
+
+# ---- Smith-Waterman (oracle/sw_oracle.c) -----------------------------------------------------------------------------
+SW_STRATEGIES = {"SoftClip": 0, "InDel": 1, "LeadingInDel": 2, "Ignore": 3}   # the numbering of include/phmm.h
+_CIGAR_OPS = "MIDNSHP=X"
+
+
+def cigar_to_string(elements):
+    """[(len << 4) | BAM op, ...] -> '5M3S'."""
+    return "".join("%d%s" % (int(e) >> 4, _CIGAR_OPS[int(e) & 15]) for e in elements)
+
+
+def sw_align(reference, alternate, params, strategy):
+    """The reference's scalar SmithWatermanAligner::align (smith_waterman_aligner.rs:47-107).  params = (match,
+    mismatch, gap open, gap extend); strategy = name or number.  Returns (cigar elements uint32[], alignment offset)."""
+    L = lib()
+    r = np.frombuffer(bytes(reference), np.uint8) if isinstance(reference, (bytes, bytearray, str)) and not isinstance(reference, str) \
+        else np.ascontiguousarray(np.frombuffer(reference.encode(), np.uint8) if isinstance(reference, str) else reference, dtype=np.uint8)
+    a = np.frombuffer(bytes(alternate), np.uint8) if isinstance(alternate, (bytes, bytearray)) \
+        else np.ascontiguousarray(np.frombuffer(alternate.encode(), np.uint8) if isinstance(alternate, str) else alternate, dtype=np.uint8)
+    st = SW_STRATEGIES[strategy] if isinstance(strategy, str) else int(strategy)
+    cig = np.zeros(len(r) + len(a) + 3, np.uint32)
+    off = C.c_int32(0)
+    n = L.oracle_sw_align(r.ctypes.data_as(_u8p), len(r), a.ctypes.data_as(_u8p), len(a), int(params[0]), int(params[1]),
+                          int(params[2]), int(params[3]), st, cig.ctypes.data_as(_u32p), C.byref(off))
+    if n < 0:
+        raise AssertionError("non-empty sequences are required for the Smith-Waterman calculation")
+    return cig[:n].copy(), int(off.value)

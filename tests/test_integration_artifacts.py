@@ -25,10 +25,11 @@ REFERENCE = "/root/reference"
 
 C_SCALARS = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64",
              "int32_t": "i32", "double": "f64", "size_t": "usize", "char": "c_char", "void": "void",
-             "phmm_handle": "phmm_handle", "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config"}
+             "phmm_handle": "phmm_handle", "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config", "phmm_sw_parameters": "phmm_sw_parameters"}
 RS_SCALARS = {"c_int": "i32", "c_uint": "u32", "u8": "u8", "u32": "u32", "u64": "u64", "i32": "i32", "f64": "f64",
               "usize": "usize", "c_char": "c_char", "c_void": "void", "phmm_handle": "phmm_handle",
-              "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config"}
+              "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config",
+              "phmm_sw_parameters": "phmm_sw_parameters"}
 
 
 def _strip_c(text):
@@ -114,7 +115,7 @@ def test_rust_declarations_mirror_the_header_one_to_one():
 
 def test_rust_constants_and_struct_mirror_the_header():
     h, r = open(HEADER).read(), open(FFI).read()
-    for name, val in re.findall(r"#define (PHMM_[A-Z0-9_]+) (\d+)u?", h):
+    for name, val in re.findall(r"#define (PHMM_[A-Z0-9_]+) (\d+)u?\b", h):
         m = re.search(r"pub const %s: c_(?:int|uint) = (\d+);" % name, r)
         assert m and m.group(1) == val, name
     fields_c = re.findall(r"^\s+(uint8_t|double)\s+(\w+)(\[\d+\])?;", re.search(r"typedef struct phmm_engine_config \{(.*?)\}", h, re.S).group(1), re.M)

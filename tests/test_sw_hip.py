@@ -1,0 +1,139 @@
+"""Smith-Waterman on the MI355X (phmm_sw_align) against the oracle (the reference's scalar arm in C)
+and the reference's own asserted cases: integer work, so CIGAR and offset must be EQUAL."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lorikeet_amd import HipPairHMMEngine, PhmmError, _lib
+from lorikeet_amd.smith_waterman import (ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, NEW_SW_PARAMETERS, ORIGINAL_DEFAULT,
+                                         STANDARD_NGS, OverhangStrategy, Parameters, SmithWatermanAligner)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smith_waterman_cases.json")))
+STRATEGIES = ("SoftClip", "InDel", "LeadingInDel", "Ignore")
+
+
+@pytest.fixture(scope="module")
+def aligner(hip_engine):
+    return SmithWatermanAligner(hip_engine)
+
+
+def _same(got, ref, alt, params, strategy, ctx=None):
+    cig, off = oracle.sw_align(ref, alt, [params.match_value, params.mismatch_penalty, params.gap_open_penalty,
+                                          params.gap_extend_penalty], strategy)
+    assert got.alignment_offset == off and np.array_equal(got.elements, cig), \
+        (ctx, strategy, got, oracle.cigar_to_string(cig), off)
+
+
+def test_asserted_cases_of_the_reference(aligner):
+    for c in GOLD["asserted"]:
+        r = aligner.align(c["reference"], c["read"], Parameters(*c["params"]), c["strategy"])
+        assert (r.get_alignment_offset(), r.cigar_string()) == (c["expected_offset"], c["expected_cigar"]), c["source"]
+
+
+def test_long_pairs_of_the_reference_equal_the_scalar_arm(aligner):
+    """tests/smith_waterman_aligner_unit_tests.rs:999-1103: three parameter sets x the overhang strategies on the three
+    long pairs (reads of 1 010 - 1 295 bases: twenty strips of 64 columns), plus the flank-length pairs (:320-378)."""
+    f = GOLD["flank_pairs"]
+    pad = "N" * 10
+    pairs = [(p["reference"], p["read"]) for p in GOLD["avx_equals_scalar_pairs"]]
+    pairs += [(pad + f["padded_ref"] + pad, pad + f["padded_hap"] + pad), (pad + f["not_padded_ref"] + pad, pad + f["not_padded_hap"] + pad)]
+    pairs += [(b, a) for a, b in pairs[:2]]   # and the other way round: a long reference, 5 strips
+    for params in (NEW_SW_PARAMETERS, STANDARD_NGS, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS):
+        for strategy in STRATEGIES:
+            for k, (got, (ref, alt)) in enumerate(zip(aligner.align_batch(pairs, params, strategy, capacity=400), pairs)):
+                _same(got, ref, alt, params, strategy, k)
+
+
+def _mutate(rng, seq, p_sub, p_indel):
+    out = []
+    alpha = b"ACGT"
+    i = 0
+    while i < len(seq):
+        u = rng.random()
+        if u < p_indel / 2:
+            i += int(rng.integers(1, 8))           # deletion
+        elif u < p_indel:
+            out.extend(alpha[int(k)] for k in rng.integers(0, 4, int(rng.integers(1, 8))))  # insertion
+        elif u < p_indel + p_sub:
+            out.append(alpha[int(rng.integers(0, 4))])
+            i += 1
+        else:
+            out.append(seq[i])
+            i += 1
+    return bytes(out) or b"A"
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_random_batches_equal_the_oracle(aligner, strategy):
+    """Ragged batches: 1 ... 700 bases on either side (strip boundaries at 64, 128, ...), related and unrelated sequences,
+    parameter sets where ties are frequent (small integers), read -> haplotype and haplotype -> reference shapes."""
+    rng = np.random.default_rng({"SoftClip": 1, "InDel": 2, "LeadingInDel": 3, "Ignore": 4}[strategy])
+    alpha = b"ACGT"
+    pairs = []
+    for k in range(260):
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 127, 128, 129, 200, 333, 512, 700])) if k % 3 == 0 else int(rng.integers(1, 420))
+        ref = bytes(alpha[int(x)] for x in rng.integers(0, 4 if k % 5 else 2, n))
+        kind = k % 4
+        if kind == 0:   # unrelated
+            alt = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 300))))
+        elif kind == 1:  # a read out of the reference, with errors
+            s = int(rng.integers(0, n))
+            alt = _mutate(rng, ref[s:s + int(rng.integers(1, 160))], 0.03, 0.02)
+        elif kind == 2:  # a haplotype: the whole reference with variants
+            alt = _mutate(rng, ref, 0.01, 0.01)
+        else:            # overhanging on both sides
+            alt = bytes(alpha[int(x)] for x in rng.integers(0, 4, 7)) + _mutate(rng, ref[: max(1, n // 2)], 0.02, 0.02) + b"GGGTT"
+        pairs.append((ref, alt))
+    for params in (ORIGINAL_DEFAULT, NEW_SW_PARAMETERS, Parameters(1, -1, -1, -1), Parameters(2, -3, -5, -2)):
+        got = aligner.align_batch(pairs, params, strategy)
+        for k, (g, (ref, alt)) in enumerate(zip(got, pairs)):
+            _same(g, ref, alt, params, strategy, k)
+
+
+def test_capacity_is_reported_not_overrun(hip_engine):
+    """A CIGAR that needs more elements than its slot: PHMM_ERR_CIGAR_CAPACITY, n_cigar holds the size, the guard word
+    behind the slot is untouched and the other alignments of the call are valid."""
+    import ctypes as C
+    p = GOLD["avx_equals_scalar_pairs"][0]
+    refs = [np.frombuffer(p["reference"].encode(), np.uint8), np.frombuffer(b"AAACCCCC", np.uint8)]
+    alts = [np.frombuffer(p["read"].encode(), np.uint8), np.frombuffer(b"CCCCC", np.uint8)]
+    ref_off = np.array([0, len(refs[0]), len(refs[0]) + 8], np.uint32)
+    alt_off = np.array([0, len(alts[0]), len(alts[0]) + 5], np.uint32)
+    cig_off = np.array([0, 4, 8], np.uint64)
+    cigar = np.full(9, 0xdeadbeef, np.uint32)
+    n_cig = np.zeros(2, np.uint32)
+    off = np.zeros(2, np.int32)
+    prm = NEW_SW_PARAMETERS.as_struct()
+    rb, ab = np.concatenate(refs), np.concatenate(alts)
+    code = hip_engine.lib.phmm_sw_align(hip_engine._h, 2, ref_off.ctypes.data_as(_lib.u32p), rb.ctypes.data_as(_lib.u8p),
+                                        alt_off.ctypes.data_as(_lib.u32p), ab.ctypes.data_as(_lib.u8p), C.byref(prm),
+                                        OverhangStrategy.InDel, cig_off.ctypes.data_as(_lib.u64p), cigar.ctypes.data_as(_lib.u32p),
+                                        n_cig.ctypes.data_as(_lib.u32p), off.ctypes.data_as(C.POINTER(C.c_int32)))
+    want, _ = oracle.sw_align(p["reference"], p["read"], [200, -150, -260, -11], "InDel")
+    assert code == _lib.PHMM_ERR_CIGAR_CAPACITY and n_cig[0] == len(want) > 4
+    assert n_cig[1] == 2 and oracle.cigar_to_string(cigar[4:6]) == "3D5M" and cigar[8] == 0xdeadbeef
+    # the Python mirror retries with the reported sizes
+    r = SmithWatermanAligner(hip_engine).align(p["reference"], p["read"], NEW_SW_PARAMETERS, "InDel")
+    assert np.array_equal(r.elements, want)
+
+
+def test_argument_errors(hip_engine, aligner):
+    with pytest.raises(AssertionError, match="non-empty"):
+        aligner.align(b"", b"ACGT", ORIGINAL_DEFAULT, "SoftClip")
+    import ctypes as C
+    z = np.zeros(2, np.uint32)
+    one = np.array([0, 1], np.uint32)
+    seq = np.frombuffer(b"A", np.uint8)
+    prm = ORIGINAL_DEFAULT.as_struct()
+    args = lambda ro, ao, st: (hip_engine._h, 1, ro.ctypes.data_as(_lib.u32p), seq.ctypes.data_as(_lib.u8p),  # noqa: E731
+                               ao.ctypes.data_as(_lib.u32p), seq.ctypes.data_as(_lib.u8p), C.byref(prm), st,
+                               np.array([0, 4], np.uint64).ctypes.data_as(_lib.u64p), np.zeros(4, np.uint32).ctypes.data_as(_lib.u32p),
+                               np.zeros(1, np.uint32).ctypes.data_as(_lib.u32p), np.zeros(1, np.int32).ctypes.data_as(C.POINTER(C.c_int32)))
+    assert hip_engine.lib.phmm_sw_align(*args(z, one, 0)) == _lib.PHMM_ERR_INVALID_ARG and "non-empty" in hip_engine.last_error()
+    assert hip_engine.lib.phmm_sw_align(*args(one, one, 7)) == _lib.PHMM_ERR_INVALID_ARG
+    assert hip_engine.lib.phmm_sw_align(*args(one, one, 1)) == _lib.PHMM_OK

@@ -1,0 +1,2 @@
+cd /root/repo
+timeout 300 python -m pytest tests/test_sw_hip.py -x -q --timeout 100 2>&1 | tail -15
