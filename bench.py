@@ -515,6 +515,69 @@ def main():
         r.close()
         return row
 
+    def smith_waterman():
+        """every read of the first 256 regions of the batch realigned to the first haplotype of its
+        region (the shape of realign_reads_to_their_best_haplotype, src/assembly/assembly_based_caller_utils.rs:208-246:
+        SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), host buffers, PCIe included."""
+        import ctypes as C
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        from lorikeet_amd import _lib
+        from oracle import oracle
+        sub = batch.region_slice(0, min(256, batch.n_regions))
+        n = sub.n_reads
+        alt_off, alt = sub.read_off, sub.read_bases
+        reg_of_read = np.repeat(np.arange(sub.n_regions), np.diff(sub.region_read_off.astype(np.int64)))
+        first_hap = sub.region_hap_off[:-1].astype(np.int64)[reg_of_read]
+        h0, h1 = sub.hap_off.astype(np.int64)[first_hap], sub.hap_off.astype(np.int64)[first_hap + 1]
+        ref_off = np.concatenate([[0], np.cumsum(h1 - h0)]).astype(np.uint32)
+        ref = np.concatenate([sub.hap_bases[a:b] for a, b in zip(h0, h1)])
+        cells = int(np.sum((h1 - h0) * np.diff(alt_off.astype(np.int64))))
+        cap = 16
+        cig_off = (np.arange(n + 1, dtype=np.uint64) * cap)
+        cigar = np.zeros(n * cap, np.uint32)
+        n_cig = np.zeros(n, np.uint32)
+        off = np.zeros(n, np.int32)
+        prm = _lib.SwParameters(10, -15, -30, -5)
+        pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+        args = (eng._h, n, pp(ref_off, _lib.u32p), pp(ref, _lib.u8p), pp(alt_off, _lib.u32p), pp(alt, _lib.u8p), C.byref(prm),
+                _lib.PHMM_SW_SOFTCLIP, pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p), pp(off, C.POINTER(C.c_int32)))
+        assert eng.lib.phmm_sw_align(*args) == 0, eng.last_error()
+        t = time.perf_counter()
+        for _ in range(3):
+            assert eng.lib.phmm_sw_align(*args) == 0
+        dt = (time.perf_counter() - t) / 3
+        # oracle (the reference's scalar arm in C) on a sample: equality, and the CPU rate beside it
+        k = min(n, 4096)
+        L = oracle.lib()
+        cores = usable_cores()
+        o_cig, o_n, o_off = np.zeros(k * cap, np.uint32), np.zeros(k, np.uint32), np.zeros(k, np.int32)
+
+        def chunk(lo, hi):
+            for a in range(lo, hi):
+                tmp = np.zeros(int(ref_off[a + 1] - ref_off[a]) + int(alt_off[a + 1] - alt_off[a]) + 3, np.uint32)
+                o = C.c_int32(0)
+                m = L.oracle_sw_align(pp(ref[int(ref_off[a]):], _lib.u8p), int(ref_off[a + 1] - ref_off[a]),
+                                      pp(alt[int(alt_off[a]):], _lib.u8p), int(alt_off[a + 1] - alt_off[a]), 10, -15, -30, -5, 0,
+                                      pp(tmp, _lib.u32p), C.byref(o))
+                o_n[a], o_off[a] = m, o.value
+                o_cig[a * cap:a * cap + min(m, cap)] = tmp[:min(m, cap)]
+        tc = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda r: chunk(*r), [(i, min(k, i + 64)) for i in range(0, k, 64)]))
+        tc = time.perf_counter() - tc
+        same = bool(np.array_equal(o_n, n_cig[:k]) and np.array_equal(o_off, off[:k]) and
+                    all(np.array_equal(o_cig[a * cap:a * cap + min(int(o_n[a]), cap)], cigar[a * cap:a * cap + min(int(o_n[a]), cap)]) for a in range(k)))
+        cells_k = int(np.sum((h1 - h0)[:k] * np.diff(alt_off.astype(np.int64))[:k]))
+        return {"call": "phmm_sw_align: reads -> first haplotype of their region, SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS "
+                        "(10,-15,-30,-5); host buffers, PCIe and CIGAR assembly included",
+                "alignments": int(n), "cells": cells, "ms_per_call": round(dt * 1e3, 3),
+                "alignments_per_s": round(n / dt, 1), "gcups_i32": round(cells / dt / 1e9, 1),
+                "exact_substring_shortcuts": int(np.sum((n_cig == 1) & (cigar[::cap] >> 4 == np.diff(alt_off.astype(np.int64))))),
+                "equal_to_oracle_on_sample": same, "sample": int(k),
+                "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
+                               "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
+
     class Dist1:  # rank-0-only rows: same timing code, no cross-rank barrier
         def __init__(self, d):
             self.torch, self.dev = d.torch, d.dev
@@ -525,7 +588,7 @@ def main():
         def max(self, x):
             return float(x)
 
-    single = f32_row = engine_row = calls_row = ragged_row = None
+    single = f32_row = engine_row = calls_row = ragged_row = sw_row = None
     if rank == 0 and extras:
         single = optional(single_region)
         if not a.f32_first:
@@ -535,6 +598,7 @@ def main():
             calls_row = optional(host_calls)
         if a.workload == "config2":
             ragged_row = optional(ragged)
+            sw_row = optional(smith_waterman)
 
     if rank == 0:
         got = out.cpu().numpy()
@@ -591,6 +655,7 @@ def main():
         line["single_region"] = single
         line["f32_first"] = f32_row
         line["engine_call"] = engine_row
+        line["smith_waterman"] = sw_row
         if calls_row is not None:
             line["host_calls"] = calls_row
         if world == 1 and not a.no_cpu_baseline and extras:

@@ -177,3 +177,105 @@ def test_large_engine_call_is_pipelined_transparently():
     assert np.array_equal(keep_p, keep_1)
     assert 0.9 < keep_p.mean() <= 1.0
     eng.close()
+
+
+def _engine_call(eng, batch, mapq, cap, symmetric=True, ref=None, dynamic=False, pcr=0, gcp=10, bq_threshold=18):
+    import ctypes as C
+    from lorikeet_amd import _lib
+    cfg = _lib.EngineConfig()
+    cfg.constant_gcp, cfg.pcr_error_model, cfg.base_quality_score_threshold = gcp, pcr, bq_threshold
+    cfg.dynamic_read_disqualification, cfg.symmetrically_normalize_alleles_to_reference = int(dynamic), int(symmetric)
+    cfg.log10_global_read_mismapping_rate = cap
+    cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = 1.0, 0.02
+    out = np.empty(batch.n_out, np.float64)
+    keep = np.zeros(batch.n_reads, np.uint8)
+    mq = np.full(batch.n_reads, mapq, np.uint8)
+    pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+    st = eng.lib.phmm_engine_compute(
+        eng._h, C.byref(cfg), batch.n_regions, pp(batch.region_read_off, _lib.u32p), pp(batch.region_hap_off, _lib.u32p),
+        pp(batch.read_off, _lib.u32p), pp(batch.read_bases, _lib.u8p), pp(batch.base_q, _lib.u8p), pp(batch.ins_q, _lib.u8p),
+        pp(batch.del_q, _lib.u8p), pp(mq, _lib.u8p), pp(batch.hap_off, _lib.u32p), pp(batch.hap_bases, _lib.u8p),
+        pp(ref, C.POINTER(C.c_int32)) if ref is not None else None, pp(batch.out_off, _lib.u64p), pp(out, _lib.f64p), pp(keep, _lib.u8p))
+    assert st == 0, eng.last_error()
+    return out, keep
+
+
+def test_filter_and_normalise_properties_of_the_reference_on_the_device(hip_engine):
+    """The reference's container properties (tests/allele_likelihoods_unit_tests.rs:399-442, :725-770) through the HIP
+    engine call: with every odd read unrelated to the haplotypes, exactly the even reads are kept, in order; and with
+    a cap of -0.001 every value is max(best - 0.001, raw) of the PairHMM results."""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    regions = []
+    for g in range(6):
+        root = acgt[rng.integers(0, 4, 200)]
+        haps = [root.copy() for _ in range(4)]
+        for h in haps[1:]:
+            h[rng.integers(0, 200, 2)] = acgt[rng.integers(0, 4, 2)]
+        reads = []
+        for r in range(24):
+            n = int(rng.choice([80, 120]))
+            if r & 1:                                      # odd reads: random sequence, likelihood ~ 1e-100 and worse
+                bases = acgt[rng.integers(0, 4, n)]
+            else:                                          # even reads: a piece of a haplotype with at most one error
+                s0 = int(rng.integers(0, 200 - n))
+                bases = haps[int(rng.integers(0, 4))][s0:s0 + n].copy()
+                if r % 4 == 0:
+                    bases[n // 2] = acgt[(int(np.where(acgt == bases[n // 2])[0][0]) + 1) % 4]
+            # PCR model off, quals above the cap threshold, MAPQ 60: the pre-step leaves the qualities alone
+            reads.append(Read(bases, np.full(n, 35), np.full(n, 40), np.full(n, 40), np.full(n, 10)))
+        regions.append((reads, haps))
+    bad = RegionBatch.from_regions(regions)
+    raw = hip_engine.compute(bad)                          # plain PairHMM on the same (unmodified) qualities
+    out, keep = _engine_call(hip_engine, bad, 60, -0.001)
+    assert keep.tolist() == [1 - (r & 1) for r in range(bad.n_reads)]     # threshold min(2, ceil(R * 0.02)) * -4 = -8
+    for g in range(bad.n_regions):
+        r0, r1 = int(bad.region_read_off[g]), int(bad.region_read_off[g + 1])
+        nh = int(bad.region_hap_off[g + 1] - bad.region_hap_off[g])
+        m_raw = raw[int(bad.out_off[g]):int(bad.out_off[g + 1])].reshape(r1 - r0, nh)
+        m_out = out[int(bad.out_off[g]):int(bad.out_off[g + 1])].reshape(r1 - r0, nh)
+        want = np.maximum(m_raw.max(axis=1, keepdims=True) - 0.001, m_raw)
+        assert np.max(np.abs(m_out - want)) <= 1e-12
+        # scatter like the caller does: kept reads in order == the even reads, values equal
+        kept = m_out[keep[r0:r1] == 1]
+        assert np.array_equal(kept, m_out[0::2])
+    # the oracle pipeline agrees on both (normalised values and keep flags)
+    for g in range(2):
+        sub = bad.region_slice(g, g + 1)
+        raw_o = oracle.compute_batch(sub.as_dict(), n_threads=4).reshape(sub.n_reads, -1)
+        norm = oracle.normalize_likelihoods(raw_o.T.copy(), -0.001, True, 0)
+        thr = [oracle.read_disqualification_threshold(sub.base_q[int(sub.read_off[r]):int(sub.read_off[r + 1])], False, 1.0, 0.02)
+               for r in range(sub.n_reads)]
+        _, k_o, _ = oracle.filter_poorly_modeled_evidence(norm.copy(), thr)
+        r0 = int(bad.region_read_off[g])
+        assert k_o.tolist() == [bool(x) for x in keep[r0:r0 + sub.n_reads]]
+        assert np.max(np.abs(norm.T.reshape(-1) - out[int(bad.out_off[g]):int(bad.out_off[g + 1])])) <= 1e-9
+
+
+def test_ragged_mix_matches_the_oracle(hip_engine):
+    """regions drawn from a long-tailed distribution (3 ... 5 000 reads, 1 ... 128 haplotypes, H 60 ... 500,
+    R 30 ... 250 mixed, some haplotypes with 'N'): 70 regions of the bench's ragged set against the oracle, resident and
+    through host buffers, plus the whole 1 536-region set resident vs host buffers (one launch per lanes-per-pair value vs
+    chunks with plans of their own)."""
+    from lorikeet_amd import sharding, synthetic
+    full = synthetic.ragged()
+    cells = sharding.region_cells(full)
+    assert cells.max() > 1e9 and cells.min() < 1e5 and (full.hap_bases == ord("N")).sum() > 50
+    small = [g for g in range(full.n_regions) if cells[g] < 6e7][:68] + [int(np.argsort(cells)[-40])]   # + one heavy region
+    sub = sharding.take_regions(full, small)
+    want = oracle.compute_batch(sub.as_dict(), n_threads=16)
+    got = hip_engine.compute(sub)
+    assert np.max(np.abs(got - want)) <= 1e-9
+    plan = hip_engine.plan(sub)
+    plan.upload()
+    plan.launch()
+    assert np.max(np.abs(plan.download() - want)) <= 1e-9
+    plan.close()
+    plan = hip_engine.plan(full)
+    assert plan.num_launches <= 6, plan.num_launches      # one per lanes-per-pair value (+ per-read classes), not one per <K, streams>
+    plan.upload()
+    plan.launch()
+    resident = plan.download()
+    plan.close()
+    host = hip_engine.compute(full)
+    assert np.max(np.abs(resident - host)) <= 1e-9 and (resident <= 0).all()

@@ -87,3 +87,48 @@ def test_normalize_and_filter_semantics():
     assert keep.tolist() == [False, True, False] and n == 1
     assert np.array_equal(v[:, 0], m[:, 1]) and np.isnan(v[:, 1:]).all()
     del nan
+
+
+# ---- the reference's own property tests of the container, restated against the engine oracle ----------------------
+def _shapes():
+    """(alleles, reads per sample) like data_for_test_*: a few sample / allele / read-count combinations."""
+    rng = np.random.default_rng(13)
+    return [(int(rng.integers(1, 7)), [int(rng.integers(0, 40)) for _ in range(int(rng.integers(1, 4)))]) for _ in range(25)]
+
+
+def test_filter_poorly_modeled_reads_property():
+    """tests/allele_likelihoods_unit_tests.rs:399-442 (+ make_good_and_bad_likelihoods :560-581): every odd read gets
+    -10000 for all alleles, threshold -100 for everybody -> exactly the even reads survive, in order, with their values;
+    the removed ones are all accounted for."""
+    rng = np.random.default_rng(7)
+    for n_alleles, per_sample in _shapes():
+        for n_reads in per_sample:
+            original = rng.uniform(-50.0, 0.0, (n_alleles, n_reads))   # "good" reads: anything above the threshold
+            original[:, 1::2] = -10000.0
+            v, keep, n_kept = oracle.filter_poorly_modeled_evidence(original.copy(), [-100.0] * n_reads)
+            assert n_kept == (n_reads + 1) // 2
+            assert keep.tolist() == [(r & 1) == 0 for r in range(n_reads)]
+            for r in range(n_kept):
+                assert np.array_equal(v[:, r], original[:, 2 * r])      # compacted, in order, values untouched
+            assert np.isnan(v[:, n_kept:]).all()                        # the slots of the removed reads
+
+
+def test_normalize_cap_worst_likelihood_property():
+    """tests/allele_likelihoods_unit_tests.rs:725-770: normalize_likelihoods(-0.001, symmetric) == max(best - 0.001, v)
+    per read, and a read whose best is -inf is left alone."""
+    rng = np.random.default_rng(8)
+    for n_alleles, per_sample in _shapes():
+        for n_reads in per_sample:
+            if n_reads == 0:
+                continue
+            original = -np.abs(rng.normal(0.0, 3.0, (n_alleles, n_reads)))
+            if n_reads > 2:
+                original[:, 1] = -np.inf
+            got = oracle.normalize_likelihoods(original.copy(), -0.001, True, 0)
+            want = original.copy()
+            if n_alleles > 1:   # a single allele is a no-op in the reference (allele_likelihoods.rs:386-389)
+                for r in range(n_reads):
+                    best = original[:, r].max()
+                    if best != -np.inf:
+                        want[:, r] = np.maximum(best - 0.001, original[:, r])
+            assert np.array_equal(got, want)
