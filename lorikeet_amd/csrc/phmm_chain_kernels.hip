@@ -40,7 +40,10 @@ namespace {
 #define PHMM_CHAIN_L 16
 #endif
 constexpr int CL = PHMM_CHAIN_L;     // lanes per pair
-constexpr int RING = 256;            // ring rows (power of two), shared by the streams; slot RING holds the neutral row
+#ifndef PHMM_RING
+#define PHMM_RING 256
+#endif
+constexpr int RING = PHMM_RING;      // ring rows (power of two), shared by the streams; slot RING holds the neutral row
 constexpr int CHAIN_META = CHAIN_MAX_READS + 8;  // per-read offsets of all streams: n_chain + S entries
 constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
@@ -145,7 +148,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     const int a = (int)it.quad * GS + grp % GS;
     const bool hv = a < Nh;
     const int n_sub = (n_chain + S - 1) / S;    // reads per stream (the last streams may get fewer, or none)
-    const int TPS = WAVE / S;                   // rows produced per stream and tick == steps per tick
+    const int TPS = (RING / 4) / S;             // rows produced per stream and tick == steps per tick (a quarter of the stream's ring)
     const int NM = RING / S - 1;                // ring rows per stream - 1 (mask)
     auto n_of = [&](int s) { return max(0, min(n_sub, n_chain - s * n_sub)); };
     const int n_mine = n_of(sid);
@@ -218,7 +221,8 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
     // producer side of this lane: row (lane % TPS) of stream (lane / TPS) of each tick.  Its position in that stream,
     // (p_lo = read of the stream, p_row = row of that read, counting SUM and RESET), moves on by TPS rows per tick.
-    const int ps = lane / TPS, pj = lane % TPS;
+    const bool producer = lane < S * TPS;       // RING / 4 lanes build a row per tick (all 64 with the 256-row ring)
+    const int ps = producer ? lane / TPS : 0, pj = lane % TPS;
     const int pcb = ps * (n_sub + 1), pn = n_of(ps);
     int p_lo = 0, p_row = pj - LEAD - TPS;  // before the first advance(); rows < 0 are the neutral lead-in
     uint32_t p_ro = pn > 0 ? roff[pcb] : 0u;
@@ -238,7 +242,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
         advance();
         const int row = p_row, R = p_R;
         const uint32_t ro = p_ro;
-        if (p_lo < pn && row >= 0 && row <= R) {
+        if (producer && p_lo < pn && row >= 0 && row <= R) {
             pb_qp = row > 0 ? (uint32_t)p.base_q[ro + row - 1] : 0u;  // row == R: the SUM row needs pm(R)
             if (row < R) {
                 pb_x = p.read_bases[ro + row];
@@ -269,7 +273,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
         } else {
             n = neutral_row();
         }
-        ring[ps * (NM + 1) + (Q & NM)] = n;
+        if (producer) ring[ps * (NM + 1) + (Q & NM)] = n;
     };
     issue();
     finish(0);
