@@ -324,7 +324,7 @@ def strong_row(D, eng, stream, name, steps, sample):
         got = res.out.cpu().numpy()
         assert (got <= 0).all(), "non-finite or positive likelihoods"
         total = float(cells.sum())
-        kms = sum(kern_ms) / len(kern_ms) / max(res.plan.num_launches, 1)
+        kms = sum(kern_ms) / len(kern_ms)
         row = {"workload": "%s: the same %d regions (seed %d) at every N" % (name, n_regions, seed), "scaling": "strong",
                "regions": n_regions, "cells": int(total), "steps": steps,
                "gcups": round(total * steps / elapsed / 1e9, 1), "regions_per_s": round(n_regions * steps / elapsed, 1),
@@ -547,6 +547,8 @@ def main():
         for _ in range(3):
             assert eng.lib.phmm_sw_align(*args) == 0
         dt = (time.perf_counter() - t) / 3
+        kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernel of the last call
+        bt_bytes = eng.stat("sw_backtrack_bytes")
         # oracle (the reference's scalar arm in C) on a sample: equality, and the CPU rate beside it
         k = min(n, 4096)
         L = oracle.lib()
@@ -573,8 +575,16 @@ def main():
                         "(10,-15,-30,-5); host buffers, PCIe and CIGAR assembly included",
                 "alignments": int(n), "cells": cells, "ms_per_call": round(dt * 1e3, 3),
                 "alignments_per_s": round(n / dt, 1), "gcups_i32": round(cells / dt / 1e9, 1),
-                "exact_substring_shortcuts": int(np.sum((n_cig == 1) & (cigar[::cap] >> 4 == np.diff(alt_off.astype(np.int64))))),
+                "single_element_cigars": int(np.sum(n_cig == 1)),
                 "equal_to_oracle_on_sample": same, "sample": int(k),
+                "kernel": {"ms": round(kern_s * 1e3, 3), "gcups_i32": round(cells / max(kern_s, 1e-9) / 1e9, 1),
+                           "note": "phmm_sw_align_kernel<K> alone (HIP events in the library, phmm_get_stat)"},
+                "roofline": {"bound": "hbm", "achieved": round(bt_bytes / max(kern_s, 1e-9) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(bt_bytes / max(kern_s, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes_per_launch": int(bt_bytes),
+                             "note": "the backtrack matrix (int16 per cell slot) is the traffic that scales with the cells; "
+                                     "the other bound is INT32 VALU: 33 lane-ops per cell measured (SQ_INSTS_VALU, "
+                                     "profiles/r02_sw_bench_summary.txt) against 39.3 T lane-ops/s = 1.19 TCUPS"},
                 "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
                                "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
 
@@ -603,7 +613,8 @@ def main():
     if rank == 0:
         got = out.cpu().numpy()
         assert (got <= 0).all(), "non-finite or positive likelihoods"
-        mean_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3 / max(plan.num_launches, 1)
+        # one phmm_batch_launch = every kernel of the plan (one for a uniform batch); the roofline is taken over all of it
+        mean_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
         alg_bytes = plan.algorithmic_bytes
         achieved_gbs = alg_bytes / mean_kernel_s / 1e9
         e, why = pmc_entry(a.workload, regions, plan.dominant_kernel, "f32_first" if a.f32_first else "f64")
@@ -626,6 +637,7 @@ def main():
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
                          "traffic": e["hbm_bytes_per_launch"] if e else None, "l2_hit_rate": e.get("l2_hit_rate") if e else None,
                          "kernel": plan.dominant_kernel, "kernel_ms": round(mean_kernel_s * 1e3, 4),
+                         "kernels_per_launch": plan.num_launches,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "src_hash": source_hash(),
                          "note": "compulsory traffic is 2.3e-3 B/cell: the path is FP64-VALU bound, see valu_f64"
                                  + ("" if e else "; traffic: " + why)},

@@ -307,7 +307,8 @@ int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32_t *ref_off
  * "no_pipeline", "no_rescue", "trace"; value -1 / 0 = back to the planner's choice as documented there).  Not to be
  * called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
- * staging so far), "rescue_passes" (batches that needed the exact pass below -600); unknown names give 0.
+ * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes"
+ * (device time of the last phmm_sw_align's kernel by HIP events, and the backtrack bytes it stored); unknown names give 0.
  */
 int phmm_set_switch(phmm_handle *h, const char *name, int value);
 uint64_t phmm_get_stat(phmm_handle *h, const char *name);

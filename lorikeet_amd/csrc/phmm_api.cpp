@@ -349,6 +349,8 @@ void phmm_destroy(phmm_handle *h) {
     if (h->swork.dev) (void)hipFree(h->swork.dev);
     if (h->swork.host) (void)hipHostFree(h->swork.host);
     if (h->swork.slab) (void)hipFree(h->swork.slab);
+    if (h->swork.ev0) (void)hipEventDestroy(h->swork.ev0);
+    if (h->swork.ev1) (void)hipEventDestroy(h->swork.ev1);
     delete h;
 }
 
@@ -613,6 +615,33 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.pair_first.push_back(s.nh);
     }
 
+    // Reads per run, region by region.  `chain_reads` is right for the batch's AVERAGE read (about eight runs per wave
+    // slot); a long-tailed mix has regions whose reads are several times longer or whose K is several times larger,
+    // and with equal read counts their runs would be the stragglers of the launch.  So the count is scaled by the
+    // region's cost per read -- (rows + SUM + RESET) x (7 VALU per column + ~11 per step) -- relative to the batch's
+    // mean: every work item then costs about the same.  Uniform batches get exactly `chain_reads`; a forced value
+    // (tests) is taken as is.
+    std::vector<uint32_t> reg_run(n_regions, 0);
+    {
+        auto read_cost = [&](uint32_t g, int K) { return (double)(shape[g].mean_r + 2) * (7.0 * K + 11.0); };
+        double cost_sum = 0.0, unit_sum = 0.0;
+        for (const auto &kv : by_shape)
+            if (kv.second.chain)
+                for (uint32_t g : kv.second.regions) {
+                    const uint32_t gs = (uint32_t)(WAVE / kv.second.L) / (uint32_t)kv.second.streams;
+                    const double u = (double)shape[g].nr * ((shape[g].nh + gs - 1) / gs) / kv.second.streams;
+                    cost_sum += u * read_cost(g, kv.second.K);
+                    unit_sum += u;
+                }
+        const double mean_cost = unit_sum > 0 ? cost_sum / unit_sum : 1.0;
+        for (const auto &kv : by_shape)
+            if (kv.second.chain)
+                for (uint32_t g : kv.second.regions) {
+                    double r = chain_reads;
+                    if (!chain_forced) r = std::min<double>(CHAIN_MAX_READS, std::max(4.0, r * mean_cost / read_cost(g, kv.second.K) + 0.5));
+                    reg_run[g] = std::min<uint32_t>(CHAIN_MAX_READS, (uint32_t)r * (uint32_t)kv.second.streams);
+                }
+    }
     // bytes of per-class work lists the plan will place in device memory
     size_t class_meta = 0;
     for (const auto &kv : by_shape) {
@@ -620,10 +649,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         b->max_h = std::max(b->max_h, c.max_h);
         class_meta += align_up(c.reads.size() * 4, 256);
         if (c.chain) {
-            const uint32_t run = std::min<uint32_t>(CHAIN_MAX_READS, chain_reads * (uint32_t)c.streams);
             const uint32_t gs = (uint32_t)(WAVE / c.L) / (uint32_t)c.streams;
             uint64_t items = 0;
-            for (uint32_t g : c.regions) items += (uint64_t)((shape[g].nh + gs - 1) / gs) * ((shape[g].nr + run - 1) / run);
+            for (uint32_t g : c.regions)
+                items += (uint64_t)((shape[g].nh + gs - 1) / gs) * ((shape[g].nr + reg_run[g] - 1) / reg_run[g]);
             class_meta += align_up(items * sizeof(ChainItem), 256);
         }
         if (!c.L) class_meta += align_up((c.pair_first.size() + 1) * 8, 256);
@@ -727,9 +756,12 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 const uint32_t r0 = region_read_off[g], r1 = region_read_off[g + 1];
                 const uint32_t gs = (uint32_t)(WAVE / c.L) / (uint32_t)c.streams;  // haplotypes per work item
                 const uint32_t nq = (shape[g].nh + gs - 1) / gs;
-                const uint32_t run = std::min<uint32_t>(CHAIN_MAX_READS, chain_reads * (uint32_t)c.streams);
-                for (uint32_t q = 0; q < nq; ++q)
-                    for (uint32_t r = r0; r < r1; r += run)
+                const uint32_t run = reg_run[g];
+                // the haplotype groups of one run next to each other: they sweep the same read bytes, and items that are
+                // launched together find them in L2 (config 3, 10 000 regions: HBM traffic 2.7 x the algorithmic bytes
+                // with the groups a whole pass apart)
+                for (uint32_t r = r0; r < r1; r += run)
+                    for (uint32_t q = 0; q < nq; ++q)
                         c.chain_items.push_back(ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)c.streams, r, std::min(r1, r + run)});
             }
             // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
@@ -817,6 +849,9 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             best_cells = c.cells;
             b->dominant = c.name;
         }
+        if (sw.trace)
+            fprintf(stderr, "  class %-40s regions %6zu reads %8zu items %8zu cells %.3e max_h %u\n", c.name, c.regions.size(),
+                    c.reads.size(), c.chain_items.size(), (double)c.cells, c.max_h);
         b->classes.push_back(std::move(c));
     }
     for (auto &grp : b->chain_groups) {
@@ -1790,6 +1825,8 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     uint64_t own = 0;
     if (n == "staged_bytes") own = h->stat_staged_bytes;
     else if (n == "rescue_passes") own = h->stat_rescue_passes;
+    else if (n == "sw_kernel_us") return h->swork.last_kernel_us;
+    else if (n == "sw_backtrack_bytes") return h->swork.last_backtrack_bytes;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }

@@ -59,6 +59,8 @@ struct phmm_handle {
         size_t cap = 0;
         int16_t *slab = nullptr;
         size_t slab_bytes = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the kernel of the last call (phmm_get_stat "sw_kernel_us")
+        uint64_t last_kernel_us = 0, last_backtrack_bytes = 0;
     } swork;
     uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
     uint64_t stat_rescue_passes = 0;  // how many batches needed the exact pass (phmm_get_stat)

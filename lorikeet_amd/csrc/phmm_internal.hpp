@@ -152,14 +152,17 @@ struct SwParams {
     const uint64_t *cigar_off;             // [n_alignments + 1]
     uint32_t *cigar, *n_cigar;
     int32_t *alignment_offset;
-    int16_t *slab;                         // backtrack storage, one slab per worker
-    size_t slab_stride;                    // int16 elements per worker: strips(max_alt) * (max_ref + 64) * 64
-    uint32_t *counter;                     // next alignment to hand out
+    int16_t *slab;                         // backtrack storage, one slab per alignment in flight (4 per block)
+    size_t slab_stride;                    // int16 elements per slab: strips * (max_ref + 16) * 16 * K
     uint32_t *status;
     uint32_t max_ref, max_alt;             // longest sequences of the batch
     uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
+    uint32_t lds_group_bytes;              // LDS of one alignment (a block holds four)
 };
-hipError_t launch_sw(const SwParams &p, uint32_t n_workers, size_t lds_bytes, hipStream_t stream);
+// K columns per lane (one of kSwK), 16 lanes per alignment, 4 alignments per block
+hipError_t launch_sw(int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
+extern const int kSwK[];
+extern const int kNumSwK;
 
 // The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
 extern const int kInstantiatedK[];

@@ -70,16 +70,25 @@ extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32
 
         DevGuard dg(h->device);
         // ---- geometry ---------------------------------------------------------------------------------------------
+        // K columns per lane so that one strip of 16 x K columns covers the longest alternate sequence (up to 512
+        // columns; longer ones take several strips of 512)
+        int K = kSwK[kNumSwK - 1];
+        for (int i = kNumSwK - 1; i >= 0; --i)
+            if ((size_t)kSwK[i] * 16 >= max_alt) K = kSwK[i];
+        const size_t strips = (max_alt + 16ull * K - 1) / (16ull * K);
         const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
-        const size_t lds = lds_ref + lds_alt + 4ull * (4ull * (max_ref + 1) + (max_alt + 1));
+        // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, three i32 per row
+        const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 12ull * (max_ref + 1) : 0) + 15) / 16 * 16;
+        const size_t lds = 4 * lds_group;
         if (lds > 160 * 1024) return fail("phmm_sw_align: sequences too long for the LDS staging");
-        const size_t strips = (max_alt + WAVE - 1) / WAVE;
-        const size_t slab_stride = strips * (size_t)(max_ref + WAVE) * WAVE;  // int16 elements per worker
-        // workers: what the LDS lets a CU hold (at most 8 waves), capped by the work and by 6 GB of backtrack storage
-        size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-        size_t workers = std::min<size_t>(256 * per_cu, n_alignments);
-        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (slab_stride * 2)));
-        const size_t slab_bytes = workers * slab_stride * 2;
+        const size_t slab_stride = strips * (size_t)(max_ref + 16) * 16 * K;  // int16 elements per alignment in flight
+        // blocks (one wave, four alignments each): what LDS and registers let a CU hold (at most 24 waves: the kernel is
+        // latency-bound), capped by the work and by 6 GB of backtrack storage
+        static const size_t max_per_cu = getenv("PHMM_SW_WAVES_PER_CU") ? (size_t)atoi(getenv("PHMM_SW_WAVES_PER_CU")) : 24;
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(max_per_cu, (160 * 1024) / lds));
+        size_t workers = std::min<size_t>(256 * per_cu, ((size_t)n_alignments + 3) / 4);
+        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (4 * slab_stride * 2)));
+        const size_t slab_bytes = workers * 4 * slab_stride * 2;
         phmm_handle::SwWork &W = h->swork;
         hipStream_t S = h->streams[0];
         if (W.slab_bytes < slab_bytes) {
@@ -132,16 +141,27 @@ extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32
         p.alignment_offset = (int32_t *)(W.dev + o_of);
         p.slab = W.slab;
         p.slab_stride = slab_stride;
-        p.counter = (uint32_t *)(W.dev + o_st);
         p.status = (uint32_t *)(W.dev + o_st + 64);
         p.max_ref = max_ref;
         p.max_alt = max_alt;
         p.lds_ref_bytes = (uint32_t)lds_ref;
         p.lds_alt_bytes = (uint32_t)lds_alt;
-        if (!ok(h, launch_sw(p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel") ||
+        p.lds_group_bytes = (uint32_t)lds_group;
+        if (!W.ev0 && (!ok(h, hipEventCreate(&W.ev0), "hipEventCreate") || !ok(h, hipEventCreate(&W.ev1), "hipEventCreate")))
+            return PHMM_ERR_HIP;
+        (void)hipEventRecord(W.ev0, S);
+        const bool launched = ok(h, launch_sw(K, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        (void)hipEventRecord(W.ev1, S);
+        if (!launched ||
             !ok(h, hipMemcpyAsync(W.host + o_st, W.dev + o_st, total - o_st, hipMemcpyDeviceToHost, S), "D2H sw") ||
             !ok(h, hipStreamSynchronize(S), "sync(sw)"))
             return PHMM_ERR_HIP;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, W.ev0, W.ev1) == hipSuccess) W.last_kernel_us = (uint64_t)(ms * 1e3f);
+        W.last_backtrack_bytes = 0;
+        for (uint32_t a = 0; a < n_alignments; ++a)  // what the kernel stores per alignment: (rows + 15) steps x 16 K columns x 2 B per strip
+            W.last_backtrack_bytes += (uint64_t)((alt_off[a + 1] - alt_off[a] + 16ull * K - 1) / (16ull * K)) *
+                                      (ref_off[a + 1] - ref_off[a] + 15ull) * 16ull * K * 2ull;
         memcpy(n_cigar, W.host + o_nc, 4ull * n_alignments);
         memcpy(alignment_offset, W.host + o_of, 4ull * n_alignments);
         if (n_cig) memcpy(cigar, W.host + o_cg, 4ull * n_cig);

@@ -1,0 +1,40 @@
+"""Developer tool: phmm_sw_align on the read -> haplotype realignment shape (reads of config-2 regions against the first
+haplotype of their region; SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), host buffers.  usage:
+python tools/sw_bench.py [regions] [strategy]   (run under rocprofv3 --kernel-trace for the kernel's own time)"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lorikeet_amd import HipPairHMMEngine, _lib, synthetic  # noqa: E402
+
+nreg = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+strategy = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+sub = synthetic.config2(nreg, seed=1000)
+n = sub.n_reads
+alt_off, alt = sub.read_off, sub.read_bases
+reg = np.repeat(np.arange(sub.n_regions), np.diff(sub.region_read_off.astype(np.int64)))
+fh = sub.region_hap_off[:-1].astype(np.int64)[reg]
+hb = sub.hap_off.astype(np.int64)
+ref_off = np.concatenate([[0], np.cumsum(hb[fh + 1] - hb[fh])]).astype(np.uint32)
+idx = (hb[fh][:, None] + np.arange(300)[None, :]).reshape(-1)   # config 2: every haplotype has 300 bases
+ref = np.ascontiguousarray(sub.hap_bases[idx])
+cells = int(np.sum((hb[fh + 1] - hb[fh]) * np.diff(alt_off.astype(np.int64))))
+cap = 16
+cig_off = np.arange(n + 1, dtype=np.uint64) * cap
+cigar, n_cig, off = np.zeros(n * cap, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+prm = _lib.SwParameters(10, -15, -30, -5)
+eng = HipPairHMMEngine(0)
+pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+args = (eng._h, n, pp(ref_off, _lib.u32p), pp(ref, _lib.u8p), pp(alt_off, _lib.u32p), pp(alt, _lib.u8p), C.byref(prm), strategy,
+        pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p), pp(off, C.POINTER(C.c_int32)))
+assert eng.lib.phmm_sw_align(*args) == 0, eng.last_error()
+t = time.perf_counter()
+for _ in range(5):
+    assert eng.lib.phmm_sw_align(*args) == 0
+dt = (time.perf_counter() - t) / 5
+print("%d alignments, %.3g cells: %.3f ms per call, %.1f GCUPS-i32, %.2f M alignments/s (host buffers, PCIe included); "
+      "CIGAR element counts: %s" % (n, cells, dt * 1e3, cells / dt / 1e9, n / dt / 1e6, np.bincount(n_cig)[:8].tolist()))
