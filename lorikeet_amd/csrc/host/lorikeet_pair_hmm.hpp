@@ -27,6 +27,7 @@
 #include <memory>
 #include <optional>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -421,6 +422,90 @@ public:
             reads = kept;
         }
         return result;
+    }
+};
+
+}  // namespace lorikeet
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Smith-Waterman (reference src/smith_waterman/smith_waterman_aligner.rs): same names, argument order and results;
+// every alignment runs on the device through phmm_sw_align (there is no CPU path).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace lorikeet {
+
+struct Parameters {  // gkl::smithwaterman::Parameters::new(match_value, mismatch_penalty, gap_open_penalty, gap_extend_penalty)
+    int32_t match_value, mismatch_penalty, gap_open_penalty, gap_extend_penalty;
+};
+enum class OverhangStrategy { SoftClip = PHMM_SW_SOFTCLIP, InDel = PHMM_SW_INDEL, LeadingInDel = PHMM_SW_LEADING_INDEL, Ignore = PHMM_SW_IGNORE };
+
+// smith_waterman_aligner.rs:11-26
+static const Parameters ORIGINAL_DEFAULT{3, -1, -4, -3};
+static const Parameters STANDARD_NGS{25, -50, -110, -6};
+static const Parameters NEW_SW_PARAMETERS{200, -150, -260, -11};
+static const Parameters ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS{10, -15, -30, -5};
+
+struct SmithWatermanAlignmentResult {  // :454-476
+    std::vector<uint32_t> cigar;  // BAM encoding: (length << 4) | op, M = 0, I = 1, D = 2, S = 4
+    int32_t alignment_offset = 0;
+    int32_t get_alignment_offset() const { return alignment_offset; }
+    std::string get_cigar() const {  // CigarString::to_string()
+        static const char ops[] = "MIDNSHP=X";
+        std::string out;
+        for (uint32_t e : cigar) out += std::to_string(e >> 4) + ops[e & 15];
+        return out;
+    }
+};
+
+class SmithWatermanAligner {
+public:
+    // align(reference, alternate, parameters, overhang_strategy, avx_mode) (:47-107); AVXMode is accepted for source
+    // compatibility, the device is the only arm here
+    static SmithWatermanAlignmentResult align(const Bytes &reference, const Bytes &alternate, const Parameters &parameters,
+                                              OverhangStrategy overhang_strategy, AVXMode = AVXMode::Hip) {
+        return align_batch({{reference, alternate}}, parameters, overhang_strategy)[0];
+    }
+
+    // Many pairs under one parameter set and strategy: what each call site of the reference has in hand (reads ->
+    // best haplotype, src/reads/alignment_utils.rs:40-70; haplotypes -> reference, src/reads/cigar_utils.rs:358-405).
+    static std::vector<SmithWatermanAlignmentResult> align_batch(const std::vector<std::pair<Bytes, Bytes>> &pairs,
+                                                                 const Parameters &parameters, OverhangStrategy strategy) {
+        static std::mutex mu;  // phmm_sw_align is one-thread-per-handle like every entry point but submit / wait
+        static detail::Handle handle = detail::make_handle(0, 0);
+        std::vector<uint32_t> ref_off{0}, alt_off{0};
+        Bytes ref, alt;
+        for (const auto &pr : pairs) {
+            if (pr.first.empty() || pr.second.empty())  // :65-68
+                throw Panic("non-empty sequences are required for the Smith-Waterman calculation");
+            ref.insert(ref.end(), pr.first.begin(), pr.first.end());
+            alt.insert(alt.end(), pr.second.begin(), pr.second.end());
+            ref_off.push_back((uint32_t)ref.size());
+            alt_off.push_back((uint32_t)alt.size());
+        }
+        const uint32_t n = (uint32_t)pairs.size();
+        std::vector<uint64_t> cap(n, 24), cig_off(n + 1, 0);
+        std::vector<uint32_t> cigar, n_cig(n);
+        std::vector<int32_t> off(n);
+        const phmm_sw_parameters prm{parameters.match_value, parameters.mismatch_penalty, parameters.gap_open_penalty,
+                                     parameters.gap_extend_penalty};
+        std::lock_guard<std::mutex> lock(mu);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (uint32_t a = 0; a < n; ++a) cig_off[a + 1] = cig_off[a] + cap[a];
+            cigar.assign(cig_off[n], 0);
+            const int rc = phmm_sw_align(handle.get(), n, ref_off.data(), ref.data(), alt_off.data(), alt.data(), &prm,
+                                         (int)strategy, cig_off.data(), cigar.data(), n_cig.data(), off.data());
+            if (rc == PHMM_ERR_CIGAR_CAPACITY && attempt == 0) {  // the library reports the sizes: once more with those
+                for (uint32_t a = 0; a < n; ++a) cap[a] = std::max<uint64_t>(cap[a], n_cig[a]);
+                continue;
+            }
+            detail::check(handle.get(), rc);
+            break;
+        }
+        std::vector<SmithWatermanAlignmentResult> out(n);
+        for (uint32_t a = 0; a < n; ++a) {
+            out[a].cigar.assign(cigar.begin() + cig_off[a], cigar.begin() + cig_off[a] + n_cig[a]);
+            out[a].alignment_offset = off[a];
+        }
+        return out;
     }
 };
 

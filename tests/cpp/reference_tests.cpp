@@ -7,6 +7,7 @@
 //   reference tests/pair_hmm_likelihood_calculation_engine_unit_tests.rs  test_compute_likelihoods
 //
 // usage: reference_tests <path to pairhmm-testdata.txt>     (run by tests/test_cpp_host_layer.py, -m gpu)
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <fstream>
@@ -442,6 +443,61 @@ static void test_rayon_worker_pattern() {
     ASSERT(good_ok == 100, "%d of 100 neighbouring calls were served", good_ok.load());
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// tests/smith_waterman_aligner_unit_tests.rs: the asserted cases (:228-318, :380-400) and the flank-length
+// property (:320-378), through the mirrored SmithWatermanAligner
+// ---------------------------------------------------------------------------------------------------------
+static void assert_alignment_matches_expected(const std::string &reference, const std::string &read, int expected_start,
+                                              const std::string &expected_cigar, const Parameters &weights,
+                                              OverhangStrategy strategy) {  // :200-226
+    const auto alignment = SmithWatermanAligner::align(bytes(reference), bytes(read), weights, strategy, detect_mode());
+    ASSERT(alignment.get_alignment_offset() == expected_start, "offset %d, expected %d (%s)", alignment.get_alignment_offset(),
+           expected_start, expected_cigar.c_str());
+    ASSERT(alignment.get_cigar() == expected_cigar, "cigar %s, expected %s", alignment.get_cigar().c_str(), expected_cigar.c_str());
+}
+
+static void test_smith_waterman_asserted_cases() {
+    assert_alignment_matches_expected("AAAGGACTGACTG", "ACTGACTGACTG", 1, "12M", ORIGINAL_DEFAULT, OverhangStrategy::SoftClip);   // :229-231
+    assert_alignment_matches_expected("AAAGACTACTG", "AACGGACACTG", 1, "2M2I3M1D4M", Parameters{50, -100, -220, -12}, OverhangStrategy::SoftClip);  // :254-260
+    assert_alignment_matches_expected("AAAGACTACTG", "AACGGACACTG", 0, "11M", Parameters{200, -50, -300, -22}, OverhangStrategy::SoftClip);        // :261-267
+    const std::string matc = "CCCCC";
+    assert_alignment_matches_expected("AAA" + matc, matc + "GGG", 3, "5M3S", ORIGINAL_DEFAULT, OverhangStrategy::SoftClip);         // :288-302
+    assert_alignment_matches_expected("TGTGTGTGTGTGTGACAGAGAGAGAGAGAGAGAGAGAGAGAGAGA", "ACAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGA",
+                                      14, "31M20S", STANDARD_NGS, OverhangStrategy::SoftClip);                                    // :305-318
+    assert_alignment_matches_expected("AAA" + matc, matc, 3, "5M", ORIGINAL_DEFAULT, OverhangStrategy::SoftClip);                   // :381-386
+    assert_alignment_matches_expected("AAA" + matc, matc, 0, "3D5M", ORIGINAL_DEFAULT, OverhangStrategy::InDel);
+    assert_alignment_matches_expected("AAA" + matc, matc, 0, "3D5M", ORIGINAL_DEFAULT, OverhangStrategy::LeadingInDel);
+    assert_alignment_matches_expected("AAA" + matc, matc, 3, "5M", ORIGINAL_DEFAULT, OverhangStrategy::Ignore);
+    bool panicked = false;
+    try {
+        SmithWatermanAligner::align(bytes(""), bytes("ACGT"), ORIGINAL_DEFAULT, OverhangStrategy::SoftClip);
+    } catch (const Panic &) {
+        panicked = true;
+    }
+    ASSERT(panicked, "empty sequences must panic like the reference asserts");
+}
+
+static void test_for_identical_alignments_with_differing_flank_lengths() {  // :320-378
+    auto strip = [](std::string s) {
+        s.erase(std::remove(s.begin(), s.end(), '-'), s.end());
+        return s;
+    };
+    const std::string core_ref = "CTTTAAGCCTGAGCCCCGCCCCCTGGCTCCCCGCCCCCTCTTCTCCCCTCCCCCAAGCCAGCACCTGGTGCCCCGGCGGGTCGTGCGGCGCGGCGCTCCGCGGTGAGCGCCTGACCCCGAGGGGGCCCGGGGCCGCGTCCCTGGGCCCTCCCCACCCTTGCGGTGGCCTCGCGGGTCCCAGGGGCGGGGCTGGAGCGGCAGCAGGGCCGGGGAGATGGGCGGTGGGGAGCGCGGGAGGGA";
+    const std::string core_hap = strip("CTTTAAGCCTGAGCCCCGCCCCCTGGCTCCCCGCCCCCTCTTCTCCCCTCCCCCAAGCCAGCACCTGGTGCCCCGGCGGGTCGTGCGGCGCGGCGCTCCGCGGTGAGCGCCTGACCCCGA---------GGGCC--------GGGCCCTCCCCACCCTTGCGGTGGCCTCGCGGGTCCCAGGGGCGGGGCTGGAGCGGCAGCAGGGCCGGGGAGATGGGCGGTGGGGAGCGCGGGAGGGA");
+    const std::string left = "GCGTCGCAGTCTTAAGGCCCCGCCTTTTCAGACAGCTTCCGCTGGGCCTGGGCCGCTGCGGGGCGGTCACGGCCC", right = "CCGGGCCGAGCCGGGGGAAGGGCTCCGGTGACT";
+    const std::string pad = "NNNNNNNNNN";
+    const auto flanked = SmithWatermanAligner::align(bytes(pad + left + core_ref + right + pad), bytes(pad + left + core_hap + right + pad),
+                                                     NEW_SW_PARAMETERS, OverhangStrategy::SoftClip);
+    const auto bare = SmithWatermanAligner::align(bytes(pad + core_ref + pad), bytes(pad + core_hap + pad), NEW_SW_PARAMETERS,
+                                                  OverhangStrategy::SoftClip);
+    // the indel elements of the two alignments are the same (type and length), only the flanking M differ
+    std::vector<uint32_t> a, b;
+    for (uint32_t e : flanked.cigar) if ((e & 15) != 0) a.push_back(e);
+    for (uint32_t e : bare.cigar) if ((e & 15) != 0) b.push_back(e);
+    ASSERT(flanked.cigar.size() == bare.cigar.size() && a == b && a.size() >= 2, "%s vs %s", flanked.get_cigar().c_str(),
+           bare.get_cigar().c_str());
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
@@ -465,6 +521,8 @@ int main(int argc, char **argv) {
         {"test_compute_likelihoods", test_compute_likelihoods},
         {"error_behaviour", test_error_behaviour},
         {"rayon_worker_pattern (threads share one engine handle)", test_rayon_worker_pattern},
+        {"smith_waterman_asserted_cases", test_smith_waterman_asserted_cases},
+        {"test_for_identical_alignments_with_differing_flank_lengths", test_for_identical_alignments_with_differing_flank_lengths},
     };
     int failed = 0;
     for (const auto &t : tests) {
