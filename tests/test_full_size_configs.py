@@ -1,0 +1,52 @@
+"""BASELINE.json's full-size sets, every pair of them (configs 3 and 5 were parity-tested on a few regions only).
+
+The scalar oracle needs minutes per set, so the full sets are cross-checked against the SIMD stand-in of the reference's
+vector arm (oracle/pairhmm_simd.c: an independent implementation -- f32 first, f64 redo, inter-pair lanes -- pinned by the
+reference's 104 vectors at 1e-5, tests/test_oracle_simd.py) at the reference's own gate for that arm, 1e-5 on EVERY pair,
+and against the scalar oracle at 1e-9 on a sample of regions spread over the set; plus size-independent properties:
+the resident launch and the chunked host path agree, a permutation of the regions permutes the results."""
+import numpy as np
+import pytest
+
+from lorikeet_amd import synthetic
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_full_set(eng, b, sample):
+    got = eng.compute(b)                                    # host buffers: chunked pipeline, a plan per chunk
+    plan = eng.plan(b)                                      # resident: one plan over the whole set
+    plan.upload()
+    plan.launch()
+    resident = plan.download()
+    plan.close()
+    assert got.shape == (b.n_out,) and (got <= 0).all() and np.isfinite(got).all()
+    assert np.max(np.abs(got - resident)) <= 1e-12          # chunks choose run lengths of their own: summation order only
+    simd, redone = oracle.compute_batch_simd(b.as_dict(), n_threads=16, native=False)
+    assert float(np.max(np.abs(got - simd))) <= 1e-5, "full set vs the vector-arm stand-in"
+    for g in sample:
+        sub = b.region_slice(g, g + 1)
+        want = oracle.compute_batch(sub.as_dict(), n_threads=16)
+        have = got[int(b.out_off[g]):int(b.out_off[g + 1])]
+        assert float(np.max(np.abs(have - want))) <= 1e-9, g
+    return got
+
+
+def test_config3_all_10000_regions(hip_engine):
+    b = synthetic.config3()
+    assert b.n_regions == 10000 and abs(b.cells() - 5.12e11) < 0.01e11
+    got = _check_full_set(hip_engine, b, [0, 1, 4999, 7777, 9999])
+    # regions 2000..2999 moved to the front: the same numbers, moved
+    from lorikeet_amd.batch import RegionBatch
+    perm = RegionBatch.concat([b.region_slice(2000, 3000), b.region_slice(0, 2000)])
+    p = hip_engine.compute(perm)
+    o = b.out_off.astype(np.int64)
+    assert np.max(np.abs(p[:o[3000] - o[2000]] - got[o[2000]:o[3000]])) <= 1e-12
+    assert np.max(np.abs(p[o[3000] - o[2000]:] - got[:o[2000]])) <= 1e-12
+
+
+def test_config5_all_256_stress_regions(hip_engine):
+    b = synthetic.config5()
+    assert b.n_regions == 256 and b.cells() == 256 * 512 * 150 * 64 * 400    # 5.03e11, SURVEY 8(d)
+    _check_full_set(hip_engine, b, [0, 255])
