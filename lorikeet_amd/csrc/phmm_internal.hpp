@@ -157,7 +157,8 @@ struct SwParams {
     uint32_t *status;
     uint32_t max_ref, max_alt;             // longest sequences of the batch
     uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
-    uint32_t lds_group_bytes;              // LDS of one alignment (a block holds four)
+    uint32_t lds_group_bytes;              // LDS of one alignment
+    uint32_t groups_per_block;             // alignments a block works on side by side: 4, or 1 for very long sequences
 };
 // K columns per lane (one of kSwK), 16 lanes per alignment, 4 alignments per block
 hipError_t launch_sw(int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);

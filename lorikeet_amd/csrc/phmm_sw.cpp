@@ -79,16 +79,18 @@ extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32
         const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
         // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, three i32 per row
         const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 12ull * (max_ref + 1) : 0) + 15) / 16 * 16;
-        const size_t lds = 4 * lds_group;
-        if (lds > 160 * 1024) return fail("phmm_sw_align: sequences too long for the LDS staging");
+        // four alignments share a wave; sequences so long that four do not fit a block's LDS get the wave to themselves
+        const size_t gpb = 4 * lds_group <= 160 * 1024 ? 4 : 1;
+        const size_t lds = gpb * lds_group;
+        if (lds > 160 * 1024) return fail("phmm_sw_align: sequences too long for the LDS staging (about 8 000 bases each)");
         const size_t slab_stride = strips * (size_t)(max_ref + 16) * 16 * K;  // int16 elements per alignment in flight
         // blocks (one wave, four alignments each): what LDS and registers let a CU hold (at most 24 waves: the kernel is
         // latency-bound), capped by the work and by 6 GB of backtrack storage
         static const size_t max_per_cu = getenv("PHMM_SW_WAVES_PER_CU") ? (size_t)atoi(getenv("PHMM_SW_WAVES_PER_CU")) : 24;
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(max_per_cu, (160 * 1024) / lds));
-        size_t workers = std::min<size_t>(256 * per_cu, ((size_t)n_alignments + 3) / 4);
-        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (4 * slab_stride * 2)));
-        const size_t slab_bytes = workers * 4 * slab_stride * 2;
+        size_t workers = std::min<size_t>(256 * per_cu, ((size_t)n_alignments + gpb - 1) / gpb);
+        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (gpb * slab_stride * 2)));
+        const size_t slab_bytes = workers * gpb * slab_stride * 2;
         phmm_handle::SwWork &W = h->swork;
         hipStream_t S = h->streams[0];
         if (W.slab_bytes < slab_bytes) {
@@ -147,6 +149,7 @@ extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32
         p.lds_ref_bytes = (uint32_t)lds_ref;
         p.lds_alt_bytes = (uint32_t)lds_alt;
         p.lds_group_bytes = (uint32_t)lds_group;
+        p.groups_per_block = (uint32_t)gpb;
         if (!W.ev0 && (!ok(h, hipEventCreate(&W.ev0), "hipEventCreate") || !ok(h, hipEventCreate(&W.ev1), "hipEventCreate")))
             return PHMM_ERR_HIP;
         (void)hipEventRecord(W.ev0, S);

@@ -77,23 +77,24 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
     // LDS of this group: reference | alternate | bottom row | (several strips only) strip edge: sw, best_gap_h, -gap_size_h
-    unsigned char *gbase = smem + (size_t)g * p.lds_group_bytes;
+    const uint32_t gpb = p.groups_per_block;  // 4, or 1 when the sequences are so long that a block's LDS holds one alignment
+    unsigned char *gbase = smem + (size_t)(g < (int)gpb ? g : 0) * p.lds_group_bytes;
     uint8_t *s_ref = gbase;
     uint8_t *s_alt = s_ref + p.lds_ref_bytes;
     int32_t *bottom = reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     int32_t *e_ngsh = e_bgh + (p.max_ref + 1);
-    int16_t *slab = p.slab + ((size_t)blockIdx.x * 4 + g) * p.slab_stride;
+    int16_t *slab = p.slab + ((size_t)blockIdx.x * gpb + (g < (int)gpb ? g : 0)) * p.slab_stride;
     const int32_t w_match = p.w_match, w_mismatch = p.w_mismatch, w_open = p.w_open, w_extend = p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
     const size_t strip_stride = (size_t)(p.max_ref + SW_L) * SW_L * K;  // backtrack entries of one strip
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? w_open + (jj - 1) * w_extend : 0; };  // :150-158
 
-    for (uint32_t base = blockIdx.x * 4u; base < p.n_alignments; base += gridDim.x * 4u) {
+    for (uint32_t base = blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
         const uint32_t a = base + (uint32_t)g;
-        const bool valid = a < p.n_alignments;
+        const bool valid = (uint32_t)g < gpb && a < p.n_alignments;
         uint32_t ro = 0, ao = 0;
         int n = 0, m = 0;
         if (valid) {

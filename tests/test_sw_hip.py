@@ -95,6 +95,20 @@ def test_random_batches_equal_the_oracle(aligner, strategy):
             _same(g, ref, alt, params, strategy, k)
 
 
+def test_long_sequences_one_alignment_per_wave(aligner):
+    """Sequences of a few thousand bases: the four-alignments-per-wave layout no longer fits a block's LDS, every wave
+    takes one alignment (several strips of 512 columns, strip edges through LDS); beyond ~8 000 bases the call is refused."""
+    rng = np.random.default_rng(9)
+    alpha = b"ACGT"
+    ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, 3100))
+    pairs = [(ref, _mutate(rng, ref[200:2900], 0.01, 0.004)), (ref[:2500], _mutate(rng, ref[:2500], 0.02, 0.01)), (b"ACGT" * 30, b"ACGTTACG")]
+    for strategy in ("SoftClip", "InDel"):
+        for g, (r, a) in zip(aligner.align_batch(pairs, NEW_SW_PARAMETERS, strategy, capacity=64), pairs):
+            _same(g, r, a, NEW_SW_PARAMETERS, strategy)
+    with pytest.raises(PhmmError, match="too long"):
+        aligner.align(b"A" * 20000, b"C" * 20000, NEW_SW_PARAMETERS, "InDel")
+
+
 def test_capacity_is_reported_not_overrun(hip_engine):
     """A CIGAR that needs more elements than its slot: PHMM_ERR_CIGAR_CAPACITY, n_cigar holds the size, the guard word
     behind the slot is untouched and the other alignments of the call are valid."""
