@@ -282,6 +282,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_SUBMIT_LANES", w.submit_lanes);
         w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
         w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
+        w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
         w.trace = getenv("PHMM_TRACE") != nullptr;
     }
     const auto &eps = table_eps();
@@ -862,6 +863,40 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                    (uint64_t)(7 * x.k + 11);
         };
         std::stable_sort(grp.items.begin(), grp.items.end(), [&](const ChainItem &x, const ChainItem &y) { return cost(x) > cost(y); });
+        // XCD-aware placement.  The haplotype groups of one run (same region, same reads: equal cost, so the stable sort
+        // left them next to each other) sweep the same read bytes.  Workgroups are dealt to the eight XCDs round robin,
+        // each XCD with an L2 of its own, so neighbours in the launch never share one: take eight runs at a time and
+        // emit their first groups, then their second groups, ... -- the groups of a run are then 8 blocks apart, on
+        // the same XCD, started together.
+        if (!sw.no_xcd_interleave) {
+            std::vector<ChainItem> out;
+            out.reserve(grp.items.size());
+            auto same_run = [](const ChainItem &x, const ChainItem &y) {
+                return x.region == y.region && x.read_begin == y.read_begin && x.read_end == y.read_end;
+            };
+            size_t i = 0;
+            const size_t n = grp.items.size();
+            while (i < n) {
+                size_t start[9], len[8];  // up to eight consecutive runs
+                int nr = 0;
+                size_t j = i;
+                while (nr < 8 && j < n) {
+                    size_t e = j + 1;
+                    while (e < n && same_run(grp.items[j], grp.items[e])) ++e;
+                    start[nr] = j;
+                    len[nr] = e - j;
+                    ++nr;
+                    j = e;
+                }
+                size_t longest = 0;
+                for (int r = 0; r < nr; ++r) longest = std::max(longest, len[r]);
+                for (size_t q = 0; q < longest; ++q)
+                    for (int r = 0; r < nr; ++r)
+                        if (q < len[r]) out.push_back(grp.items[start[r] + q]);
+                i = j;
+            }
+            grp.items.swap(out);
+        }
         grp.single_k = grp.items.empty() ? 0 : grp.items[0].k;
         for (const ChainItem &it : grp.items)
             if (it.k != grp.single_k) {
@@ -1810,6 +1845,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "force_cnd_select") w.force_cnd_select = value;
     else if (n == "no_pipeline") w.no_pipeline = value != 0;
     else if (n == "no_rescue") w.no_rescue = value != 0;
+    else if (n == "no_xcd_interleave") w.no_xcd_interleave = value != 0;
     else if (n == "trace") w.trace = value != 0;
     else {
         h->err = "phmm_set_switch: unknown switch";

@@ -31,6 +31,7 @@ struct Switches {
     int waves_per_block = 0;    // PHMM_WAVES_PER_BLOCK
     int force_cnd_select = -1;  // PHMM_FORCE_CND_SELECT
     int no_pipeline = 0;        // PHMM_NO_PIPELINE: host path in one shot whatever the size
+    int no_xcd_interleave = 0;  // PHMM_NO_XCD_INTERLEAVE: haplotype groups of a run adjacent in the launch instead of 8 blocks apart
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
