@@ -113,6 +113,7 @@ struct phmm_batch {
     // every chained f64 class of one lanes-per-pair value goes out in ONE launch (phmm_chain_kernels.hip)
     struct ChainGroup {
         int L = 0;
+        bool f32 = false;  // the f32 sweep of a PHMM_FLAG_F32_FIRST handle (the f64 per-read redo follows per class)
         int single_k = 0;  // the K all items share (per-K kernel), 0 = mixed (any-K kernel)
         std::vector<ChainItem> items;
         ChainItem *d_items = nullptr;
@@ -771,18 +772,15 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 return read_off[x.read_end] - read_off[x.read_begin] > read_off[y.read_end] - read_off[y.read_begin];
             });
             c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && (c.L == 16 || c.L == 32);
-            if (c.f32_first) {  // the f32 sweep is launched per class ...
-                void *mirror;
-                c.d_chain_items = (ChainItem *)dalloc(c.chain_items.size() * sizeof(ChainItem), &mirror);
-                up(c.d_chain_items, mirror, c.chain_items.data(), c.chain_items.size() * sizeof(ChainItem));
-            } else {            // ... the f64 classes of one lanes-per-pair value share a launch
+            {   // the chained classes of one lanes-per-pair value (and one precision) share a launch
                 phmm_batch::ChainGroup *grp = nullptr;
                 for (auto &gq : b->chain_groups)
-                    if (gq.L == c.L) grp = &gq;
+                    if (gq.L == c.L && gq.f32 == c.f32_first) grp = &gq;
                 if (!grp) {
                     b->chain_groups.emplace_back();
                     grp = &b->chain_groups.back();
                     grp->L = c.L;
+                    grp->f32 = c.f32_first;
                 }
                 grp->items.insert(grp->items.end(), c.chain_items.begin(), c.chain_items.end());
             }
@@ -1037,6 +1035,15 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     DeviceGuard dg(h->device);
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : b->home_stream;
     if (b->d_redo && !hip_ok(h, hipMemsetAsync(b->d_redo, 0, b->n_reads, stream), "memset redo")) return PHMM_ERR_HIP;
+    for (auto &grp : b->chain_groups) {  // the chained sweeps: one launch per lanes-per-pair value and precision
+        ChainParams cp{};
+        cp.f = base_params(b);
+        cp.items = grp.d_items;
+        cp.n_items = (uint32_t)grp.items.size();
+        cp.redo = grp.f32 ? b->d_redo : nullptr;
+        const hipError_t e = grp.f32 ? launch_chain_f32(grp.L, grp.single_k, cp, stream) : launch_chain(grp.L, grp.single_k, cp, stream);
+        if (!hip_ok(h, e, grp.f32 ? "phmm_forward_chain_f32" : "phmm_forward_chain")) return PHMM_ERR_HIP;
+    }
     for (auto &c : b->classes) {
         ForwardParams p = base_params(b);
         p.class_reads = c.identity ? nullptr : c.d_reads;
@@ -1045,19 +1052,10 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.cnd_select = c.cnd_select;
         if (!p.n_items) continue;
         hipError_t e;
-        if (c.chain && !c.f32_first) continue;  // launched with its group below
-        if (c.chain) {  // f32 sweep, then the f64 per-read kernel over exactly the reads it flagged
-            ChainParams cp{};
-            cp.f = p;
-            cp.items = c.d_chain_items;
-            cp.n_items = (uint32_t)c.chain_items.size();
-            cp.streams = (uint32_t)c.streams;
-            cp.redo = b->d_redo;
-            e = launch_chain_f32(c.L, c.K, cp, stream);
-            if (e == hipSuccess) {
-                p.redo = b->d_redo;
-                e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
-            }
+        if (c.chain && !c.f32_first) continue;  // done with its group above
+        if (c.chain) {  // behind the f32 sweep: the f64 per-read kernel over exactly the reads it flagged
+            p.redo = b->d_redo;
+            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
         } else if (c.L) {
             e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
         } else {
@@ -1071,13 +1069,6 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
             e = gp.n_pairs ? launch_generic(gp, stream) : hipSuccess;
         }
         if (!hip_ok(h, e, c.name)) return PHMM_ERR_HIP;
-    }
-    for (auto &grp : b->chain_groups) {
-        ChainParams cp{};
-        cp.f = base_params(b);
-        cp.items = grp.d_items;
-        cp.n_items = (uint32_t)grp.items.size();
-        if (!hip_ok(h, launch_chain(grp.L, grp.single_k, cp, stream), "phmm_forward_chain")) return PHMM_ERR_HIP;
     }
     // Results below kRescueBelow are redone in the reference's operation order.  Persistent batches and the
     // engine-level call carry the pass in-stream (it returns at once unless a forward kernel asked for it); the
@@ -1873,7 +1864,7 @@ uint32_t phmm_batch_num_launches(const phmm_batch *b) {
     if (!b) return 0;
     uint32_t n = (uint32_t)b->chain_groups.size();
     for (const auto &c : b->classes)
-        if (!c.chain || c.f32_first) n += c.f32_first ? 2u : 1u;
+        if (!c.chain || c.f32_first) n += 1u;  // per-read classes, and the f64 redo behind an f32 sweep
     return n;
 }
 const char *phmm_batch_dominant_kernel(const phmm_batch *b) { return b ? b->dominant.c_str() : ""; }

@@ -119,20 +119,19 @@ __device__ __forceinline__ Row32 neutral_row32() {
 
 }  // namespace
 
+// One work item = one wave (see phmm_chain_kernels.hip: every item carries its K and stream count).
 template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the units' kernel symbols apart)
-__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainParams cp) {
+__device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const ChainItem it, unsigned char *smem) {
     static_assert(CLT == CL, "one lanes-per-pair value per compilation unit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ForwardParams &p = cp.f;
     const int lane = threadIdx.x;
     const int grp = lane / CL, l = lane % CL;
     const bool group_head = (CL == 32) && (lane == 32);
-    const ChainItem it = cp.items[blockIdx.x];
     const uint32_t reg = it.region;
     const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
-    const int S = (CL == 16) ? (int)cp.streams : 1;
+    const int S = (CL == 16) ? (int)it.streams : 1;
     const int GS = (WAVE / CL) / S;
     const int sid = grp / GS;
     const int a = (int)it.quad * GS + grp % GS;
@@ -323,32 +322,57 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainPar
     }
 }
 
-// ---- launch ----------------------------------------------------------------------------------------
+// ---- kernels: one launch per lanes-per-pair value for a mixed batch, the body alone for a uniform one ---------------
 #define PHMM_CHAIN32_K_LIST(X) \
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
     X(23) X(24) X(25)
+
+template <int CLT>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32_any(const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ChainItem it = cp.items[blockIdx.x];
+    switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
+#define PHMM_CASE(KK)                            \
+    case KK:                                     \
+        chain_body_f32<CLT, KK>(cp, it, smem);   \
+        break;
+        PHMM_CHAIN32_K_LIST(PHMM_CASE)
+#undef PHMM_CASE
+        default:
+            break;
+    }
+}
+
+template <int CLT, int K>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    chain_body_f32<CLT, K>(cp, cp.items[blockIdx.x], smem);
+}
 
 #define PHMM_C32_CAT2(a, b) a##b
 #define PHMM_C32_CAT(a, b) PHMM_C32_CAT2(a, b)
 #define PHMM_C32_LAUNCH PHMM_C32_CAT(launch_chain_f32_L, PHMM_CHAIN32_L)
 
-hipError_t PHMM_C32_LAUNCH(int K, const ChainParams &cp, hipStream_t stream) {
+// single_k: the K every item of the launch has, or 0 for a mixed launch
+hipError_t PHMM_C32_LAUNCH(int single_k, const ChainParams &cp, hipStream_t stream) {
     const size_t lds = (size_t)(RING + 1) * sizeof(Row32) + (CHAIN_META + 4) * sizeof(uint32_t);
 #define PHMM_CASE(KK)                                                                                         \
-    if (K == KK) {                                                                                            \
+    if (single_k == KK) {                                                                                     \
         hipLaunchKernelGGL((phmm_forward_chain_f32<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);   \
         return hipGetLastError();                                                                             \
     }
     PHMM_CHAIN32_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
-    return hipErrorInvalidValue;
+    hipLaunchKernelGGL((phmm_forward_chain_f32_any<CL>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);
+    return hipGetLastError();
 }
 
 #if PHMM_CHAIN32_L == 16
-hipError_t launch_chain_f32_L32(int K, const ChainParams &cp, hipStream_t stream);
-hipError_t launch_chain_f32(int L, int K, const ChainParams &cp, hipStream_t stream) {
+hipError_t launch_chain_f32_L32(int single_k, const ChainParams &cp, hipStream_t stream);
+hipError_t launch_chain_f32(int L, int single_k, const ChainParams &cp, hipStream_t stream) {
     if (!cp.n_items) return hipSuccess;
-    return L == 16 ? launch_chain_f32_L16(K, cp, stream) : L == 32 ? launch_chain_f32_L32(K, cp, stream) : hipErrorInvalidValue;
+    return L == 16 ? launch_chain_f32_L16(single_k, cp, stream) : L == 32 ? launch_chain_f32_L32(single_k, cp, stream)
+                                                                           : hipErrorInvalidValue;
 }
 #endif
 

@@ -102,12 +102,11 @@ struct ChainParams {
     const ChainItem *items;
     uint32_t n_items;
     uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
-    uint32_t streams;  // f32-first kernel only (one class per launch): sub-runs swept side by side, see ChainItem::streams
 };
 // all chained classes of one lanes-per-pair value in ONE launch (every item carries its K and stream count);
 // single_k = the K all items share (the per-K kernel is used), 0 = mixed (the any-K kernel)
 hipError_t launch_chain(int L, int single_k, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
-hipError_t launch_chain_f32(int L, int K, const ChainParams &p, hipStream_t stream);  // phmm_chain32_kernels.hip, L = 16 | 32
+hipError_t launch_chain_f32(int L, int single_k, const ChainParams &p, hipStream_t stream);  // phmm_chain32_kernels.hip, L = 16 | 32
 int chain_max_k();  // largest instantiated K
 
 // ---- engine-level steps (phmm_engine_kernels.hip) -------------------------------------------------
