@@ -21,8 +21,8 @@ kern = max(pmc, key=lambda k: max(v["avg_duration_ns"] * v["dispatches"] for v i
 launches = max(v["dispatches"] for v in pmc[kern].values())
 c = {}
 for k in pmc:
-    for name, v in pmc[k].items():
-        c[name] = c.get(name, 0.0) + v["avg_per_dispatch"] * v["dispatches"] / launches
+    for cname, v in pmc[k].items():
+        c[cname] = c.get(cname, 0.0) + v["avg_per_dispatch"] * v["dispatches"] / launches
 entry = {
     "workload": bench["config"]["workload"].split(" ")[0], "regions": bench["config"]["regions_per_gpu"],
     "precision": "f32_first" if bench["dtype"].startswith("f32") else "f64",
