@@ -86,8 +86,7 @@ struct ShapeClass {
     // chained class: items are (region, haplotype group, run of reads) instead of single reads
     bool chain = false;
     std::vector<uint32_t> regions;  // member regions (chain classes)
-    std::vector<ChainItem> chain_items;
-    ChainItem *d_chain_items = nullptr;
+    std::vector<ChainItem> chain_items;  // host side; launched as part of its ChainGroup
     uint32_t cnd_select = 0;
     int streams = 1;  // chained classes: sub-runs swept side by side (phmm_chain_kernels.hip)
     bool f32_first = false;  // chained class at 16 lanes per pair of a PHMM_FLAG_F32_FIRST handle: f32 sweep, then the
