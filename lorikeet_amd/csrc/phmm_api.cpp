@@ -1235,6 +1235,7 @@ struct ChunkView {
     uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
     uint32_t index = 0;  // how many chunks came before this one
     bool started = false;
+    bool mixed = false;  // regions of different shapes: a chunk also has to be large enough for the chained kernel
     bool f32_first = false;  // the handle's precision mode (decides the chunk sizes)
     size_t read_byte0 = 0, hap_byte0 = 0;
     std::vector<uint32_t> rro, rho, ro, ho;
@@ -1258,10 +1259,26 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     // a few hundred regions per launch.
     const uint32_t step = c.f32_first ? c.index + 1 : (c.index < 4 ? 0 : (c.index - 2) / 2);
     const size_t limit = std::min(kChunkBytes, (c.f32_first ? (1u << 20) / 2 : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
-    if (whole)
+    if (whole) {
         g1 = n_regions;
-    else
+    } else if (!c.mixed) {
         while (g1 < n_regions && (size_t)read_off[region_read_off[g1 + 1]] - base_r <= limit) ++g1;
+    } else {
+        // A mixed batch falls into many shape classes, and a chunk of a few dozen regions is too small for the chained
+        // kernel: every class then gets a small per-read launch of its own (1 536 mixed regions: the first six chunks
+        // were 10-20 launches of ~5 us each for 184 regions).  Such a chunk keeps growing until it has enough wave-sweeps
+        // to chain (or reaches the largest chunk size).
+        auto units = [&](uint32_t g) {
+            return (uint64_t)(region_read_off[g + 1] - region_read_off[g]) * ((region_hap_off[g + 1] - region_hap_off[g] + 3) / 4);
+        };
+        uint64_t u = units(g0);
+        while (g1 < n_regions) {
+            const size_t bytes = (size_t)read_off[region_read_off[g1 + 1]] - base_r;
+            if (bytes > kChunkBytes || (bytes > limit && u >= 8ull * 2 * kNumSimd * 4)) break;
+            u += units(g1);
+            ++g1;
+        }
+    }
     c.g0 = g0;
     c.g1 = g1;
     c.r0 = region_read_off[g0];
@@ -1430,6 +1447,14 @@ int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32
     ChunkView c;
     c.f32_first = f32_first;
     c.g1 = g_begin;
+    {   // same read and haplotype counts and the same first haplotype length everywhere?
+        const uint32_t nr0 = region_read_off[g_begin + 1] - region_read_off[g_begin];
+        const uint32_t nh0 = region_hap_off[g_begin + 1] - region_hap_off[g_begin];
+        const uint32_t hl0 = nh0 ? hap_off[region_hap_off[g_begin] + 1] - hap_off[region_hap_off[g_begin]] : 0;
+        for (uint32_t g = g_begin + 1; g < g_end && !c.mixed; ++g)
+            c.mixed = region_read_off[g + 1] - region_read_off[g] != nr0 || region_hap_off[g + 1] - region_hap_off[g] != nh0 ||
+                      (nh0 && hap_off[region_hap_off[g] + 1] - hap_off[region_hap_off[g]] != hl0);
+    }
     int n_chunks = 0;
     h->defer_d2h = true;
     while (st == PHMM_OK && next_chunk(c, g_end, region_read_off, region_hap_off, read_off, hap_off, out_off)) {
