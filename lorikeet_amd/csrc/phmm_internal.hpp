@@ -151,8 +151,8 @@ struct SwParams {
     const uint64_t *cigar_off;             // [n_alignments + 1]
     uint32_t *cigar, *n_cigar;
     int32_t *alignment_offset;
-    int16_t *slab;                         // backtrack storage, one slab per alignment in flight (4 per block)
-    size_t slab_stride;                    // int16 elements per slab: strips * (max_ref + 16) * 16 * K
+    int16_t *slab;                         // backtrack storage, one slab per block
+    size_t slab_stride;                    // int16 entries per slab: strips * (max_ref + 16) * 64 * K
     uint32_t *status;
     uint32_t max_ref, max_alt;             // longest sequences of the batch
     uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)

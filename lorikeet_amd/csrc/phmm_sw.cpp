@@ -83,14 +83,15 @@ extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32
         const size_t gpb = 4 * lds_group <= 160 * 1024 ? 4 : 1;
         const size_t lds = gpb * lds_group;
         if (lds > 160 * 1024) return fail("phmm_sw_align: sequences too long for the LDS staging (about 8 000 bases each)");
-        const size_t slab_stride = strips * (size_t)(max_ref + 16) * 16 * K;  // int16 elements per alignment in flight
+        // int16 entries per block: strips x (rows + 15) steps x 64 lanes x K columns, whether a block holds four alignments or one
         // blocks (one wave, four alignments each): what LDS and registers let a CU hold (at most 24 waves: the kernel is
         // latency-bound), capped by the work and by 6 GB of backtrack storage
         static const size_t max_per_cu = getenv("PHMM_SW_WAVES_PER_CU") ? (size_t)atoi(getenv("PHMM_SW_WAVES_PER_CU")) : 24;
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(max_per_cu, (160 * 1024) / lds));
         size_t workers = std::min<size_t>(256 * per_cu, ((size_t)n_alignments + gpb - 1) / gpb);
-        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (gpb * slab_stride * 2)));
-        const size_t slab_bytes = workers * gpb * slab_stride * 2;
+        const size_t slab_stride = strips * (size_t)(max_ref + 16) * 64 * K;
+        workers = std::max<size_t>(1, std::min<size_t>(workers, (6ull << 30) / (slab_stride * 2)));
+        const size_t slab_bytes = workers * slab_stride * 2;
         phmm_handle::SwWork &W = h->swork;
         hipStream_t S = h->streams[0];
         if (W.slab_bytes < slab_bytes) {

@@ -15,9 +15,9 @@
 // columns; beyond that strips follow each other and what leaves one on its right edge -- three i32 per row -- waits
 // in LDS for the next).  Nothing of the score matrix is stored: the best cell of the last column (:303-309) is tracked
 // by the lane that owns it, the bottom row (:316-330) is kept in LDS.  The backtrack matrix goes to HBM as int16
-// (0 = diagonal, +k = k rows up, -k = k columns left: the reference's own encoding, :257-266), slot
-// [strip][step][lane][column], K contiguous entries per lane and step.  Backtracking is a pointer chase of ~n+m
-// entries: one lane per alignment, four at a time per wave, writes the CIGAR.
+// (0 = diagonal, +k = k rows up, -k = k columns left: the reference's own encoding, :257-266), two entries per dword,
+// slot [strip][step][column pair][lane]: every store of a wave covers 256 contiguous bytes.  Backtracking is a pointer
+// chase of ~n+m entries: one lane per alignment, four at a time per wave, writes the CIGAR.
 #include "phmm_internal.hpp"
 
 namespace phmm {
@@ -85,11 +85,13 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     int32_t *e_ngsh = e_bgh + (p.max_ref + 1);
-    int16_t *slab = p.slab + ((size_t)blockIdx.x * gpb + (g < (int)gpb ? g : 0)) * p.slab_stride;
+    // backtrack storage of this block: dwords of two entries, laid out [strip][step][column pair][lane], so that every
+    // store instruction of the wave writes 256 contiguous bytes
+    uint32_t *slab = reinterpret_cast<uint32_t *>(p.slab) + (size_t)blockIdx.x * (p.slab_stride / 2);
     const int32_t w_match = p.w_match, w_mismatch = p.w_mismatch, w_open = p.w_open, w_extend = p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
-    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * SW_L * K;  // backtrack entries of one strip
+    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * (K / 2) * WAVE;  // backtrack dwords of one strip
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? w_open + (jj - 1) * w_extend : 0; };  // :150-158
 
     for (uint32_t base = blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0, o_ngsh = 0;     // what this lane hands to its right neighbour (row of the previous step)
-            int16_t *bt = slab + (size_t)s * strip_stride + (size_t)l * K;
+            uint32_t *bt = slab + (size_t)s * strip_stride + lane;
             const int steps = n_max + SW_L - 1;
             for (int t = 0; t < steps; ++t) {
                 const int i = t - l + 1;                 // this lane's row at this step
@@ -191,11 +193,10 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                         up[k] = cur;
                         left = cur;
                     }
-                    int16_t *row_bt = bt + (size_t)t * SW_L * K;
+                    uint32_t *row_bt = bt + (size_t)t * (K / 2) * WAVE;
 #pragma unroll
                     for (int k = 0; k + 1 < K; k += 2)
-                        *reinterpret_cast<uint32_t *>(row_bt + k) = (uint32_t)(uint16_t)btr[k] | ((uint32_t)(uint16_t)btr[k + 1] << 16);
-                    if (K & 1) row_bt[K - 1] = (int16_t)btr[K - 1];
+                        row_bt[(k / 2) * WAVE] = (uint32_t)(uint16_t)btr[k] | ((uint32_t)(uint16_t)btr[k + 1] << 16);
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
             } else {
                 auto BT = [&](int i, int jj) -> int32_t {
                     const int ss = (jj - 1) / strip_cols, cc = (jj - 1) % strip_cols, ll = cc / K, kk = cc % K;
-                    return (int32_t)slab[(size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * SW_L + ll) * K + kk];
+                    const uint32_t w = slab[(size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * (K / 2) + kk / 2) * WAVE + (lane & 48) + ll];
+                    return (int32_t)(int16_t)((kk & 1) ? (w >> 16) : (w & 0xffffu));
                 };
                 int p1 = best.p1, p2 = best.p2;
                 if (segment_length > 0 && p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
