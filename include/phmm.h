@@ -278,8 +278,10 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
  * arm, tests/smith_waterman_aligner_unit_tests.rs:999-1103).
  *
  *   ref_off / alt_off [n+1]   byte offsets of each pair's reference / alternate sequence; both must be non-empty
- *                             (the reference asserts, :65-68) and at most 32 000 bases
- *   params                    gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)
+ *                             (the reference asserts, :65-68); about 8 000 bases each fit the LDS staging
+ *   params                    gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend);
+ *                             max |weight| x (longest ref + longest alt + 2) must stay below 1e8 (the range in which
+ *                             the reference's clamp at -1e8, :31, cannot act), otherwise PHMM_ERR_INVALID_ARG
  *   overhang_strategy         PHMM_SW_* below == gkl::smithwaterman::OverhangStrategy
  *   cigar_off [n+1]           element offsets into `cigar`: alignment a may use cigar_off[a+1] - cigar_off[a] elements
  *                             (ref_len + alt_len + 3 always suffices; real CIGARs have a handful)
@@ -304,11 +306,12 @@ int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32_t *ref_off
  * Developer switches and counters (tests, A/B measurements; never needed in production).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
- * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace"; value -1 / 0 = back to the planner's choice as documented there).  Not to be
- * called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
+ * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes"; value -1 / 0 = back to the
+ * planner's choice as documented there).  Not to be called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
- * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes"
- * (device time of the last phmm_sw_align's kernel by HIP events, and the backtrack bytes it stored); unknown names give 0.
+ * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes" /
+ * "sw_clock_mhz" (device time of the last phmm_sw_align's kernels by HIP events, the backtrack bytes they stored, the shader
+ * clock one of their blocks saw); unknown names give 0.
  */
 int phmm_set_switch(phmm_handle *h, const char *name, int value);
 uint64_t phmm_get_stat(phmm_handle *h, const char *name);

@@ -280,6 +280,9 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
         env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
         env("PHMM_SUBMIT_LANES", w.submit_lanes);
+        env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
+        env("PHMM_SW_CHUNKS", w.sw_chunks);
+        env("PHMM_SW_LANES", w.sw_lanes);
         w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
         w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
         w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
@@ -350,8 +353,9 @@ void phmm_destroy(phmm_handle *h) {
     if (h->swork.dev) (void)hipFree(h->swork.dev);
     if (h->swork.host) (void)hipHostFree(h->swork.host);
     if (h->swork.slab) (void)hipFree(h->swork.slab);
-    if (h->swork.ev0) (void)hipEventDestroy(h->swork.ev0);
-    if (h->swork.ev1) (void)hipEventDestroy(h->swork.ev1);
+    for (int c = 0; c < phmm_handle::SwWork::kMaxChunks; ++c)
+        for (hipEvent_t e : {h->swork.ev_in[c], h->swork.ev_out[c], h->swork.ev_k0[c], h->swork.ev_k1[c]})
+            if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1870,6 +1874,9 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "no_rescue") w.no_rescue = value != 0;
     else if (n == "no_xcd_interleave") w.no_xcd_interleave = value != 0;
     else if (n == "trace") w.trace = value != 0;
+    else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
+    else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
+    else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";
         return PHMM_ERR_INVALID_ARG;
@@ -1886,6 +1893,7 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "rescue_passes") own = h->stat_rescue_passes;
     else if (n == "sw_kernel_us") return h->swork.last_kernel_us;
     else if (n == "sw_backtrack_bytes") return h->swork.last_backtrack_bytes;
+    else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }

@@ -35,6 +35,9 @@ struct Switches {
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
+    int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
+    int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 lanes per Smith-Waterman alignment (0 = by the longest alternate sequence)
+    int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
@@ -58,10 +61,12 @@ struct phmm_handle {
     struct SwWork {  // phmm_sw_align (phmm_sw.cpp): grow-only staging and backtrack slabs
         char *dev = nullptr, *host = nullptr;
         size_t cap = 0;
-        int16_t *slab = nullptr;
+        uint32_t *slab = nullptr;
         size_t slab_bytes = 0;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the kernel of the last call (phmm_get_stat "sw_kernel_us")
-        uint64_t last_kernel_us = 0, last_backtrack_bytes = 0;
+        static constexpr int kMaxChunks = 8;      // pieces of one call: piece c+1 is staged and copied while piece c computes
+        hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
+                                                   // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
+        uint64_t last_kernel_us = 0, last_backtrack_bytes = 0, last_clock_mhz = 0;
     } swork;
     uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
     uint64_t stat_rescue_passes = 0;  // how many batches needed the exact pass (phmm_get_stat)

@@ -14,18 +14,28 @@
 // 16 x K columns make a strip (K is chosen so that one strip covers the batch's longest alternate sequence, up to 512
 // columns; beyond that strips follow each other and what leaves one on its right edge -- three i32 per row -- waits
 // in LDS for the next).  Nothing of the score matrix is stored: the best cell of the last column (:303-309) is tracked
-// by the lane that owns it, the bottom row (:316-330) is kept in LDS.  The backtrack matrix goes to HBM as int16
-// (0 = diagonal, +k = k rows up, -k = k columns left: the reference's own encoding, :257-266), two entries per dword,
-// slot [strip][step][column pair][lane]: every store of a wave covers 256 contiguous bytes.  Backtracking is a pointer
-// chase of ~n+m entries: one lane per alignment, four at a time per wave, writes the CIGAR.
+// by the lane that owns it, the bottom row (:316-330) is kept in LDS.
+// Backtrack: the reference stores 0 / +k / -k per cell (diagonal, k rows up, k columns left, :257-266), k being the
+// length of the best gap ending there (gap_size_v / gap_size_h, :207-240).  Here a cell leaves FOUR BITS: which of the
+// three candidates won (2 bits) and, for each direction, whether its best gap OPENS at this cell (1 = the `prev_gap >
+// best_gap` branch).  The gap length is recovered while backtracking -- k(i,j) = 1 if the gap opens at (i,j), else
+// 1 + k of the previous cell of that column / row -- so the kernel keeps no gap sizes at all, and the matrix in HBM is
+// 2 dwords per lane and step (4 when K > 16) laid out [strip][step][dword][lane]: every store of a wave covers 256
+// contiguous bytes.
+// Scores are carried times four, the low two bits naming the candidate (diagonal 2 > right 1 > down 0): one v_max3
+// both picks the value and resolves ties in the reference's priority order (:250-266), and v_alignbit shifts the two
+// bits into the lane's flag word.  (The host side bounds the parameters so that nothing overflows and the reference's
+// MATRIX_MIN_CUTOFF clamp, :31, can never be active.)
+// Backtracking: the sixteen lanes of an alignment fetch sixteen cells down the diagonal at once and take the run of
+// diagonal steps among them in one go (every step is a dependent read from HBM otherwise); lane 0 writes the CIGAR.
 #include "phmm_internal.hpp"
 
 namespace phmm {
 
 namespace {
 
-constexpr int32_t SW_LOW_INIT = INT32_MIN / 2;        // :137
-constexpr int32_t SW_MATRIX_MIN_CUTOFF = -100000000;  // :31
+constexpr int32_t SW_LOW_INIT = INT32_MIN / 2;        // :137 (below every scaled score; its low two bits are clear)
+enum : int32_t { TAG_DOWN = 0, TAG_RIGHT = 1, TAG_DIAG = 2 };
 enum : uint32_t { OP_M = 0, OP_I = 1, OP_D = 2, OP_S = 4 };
 enum : int { ST_MATCH = 0, ST_INSERTION = 1, ST_DELETION = 2, ST_CLIP = 3 };
 
@@ -38,9 +48,10 @@ __device__ __forceinline__ uint32_t make_element(int state, uint32_t length) {  
 struct CigarOut {
     uint32_t *slot;
     uint64_t cap;
+    bool writer;  // the lanes of an alignment all keep count, one of them writes
     uint32_t n = 0;
     __device__ void push(uint32_t e) {
-        if (n < cap) slot[n] = e;
+        if (writer && n < cap) slot[n] = e;
         ++n;
     }
     __device__ void finish() {  // lce.reverse() (:441)
@@ -55,7 +66,6 @@ struct CigarOut {
 
 }  // namespace
 
-constexpr int SW_L = 16;  // lanes per alignment
 
 __device__ __forceinline__ int32_t row_shr1(int32_t v) {  // lane l <- lane l-1 inside each group of 16 (first lane: 0)
     return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
@@ -72,29 +82,38 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
     return a.order < b.order;
 }
 
-template <int K>
-__global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
+#ifndef PHMM_SW_EU
+#define PHMM_SW_EU 5
+#endif
+// SW_L lanes per alignment (16 or 8: 4 or 8 alignments per wave), K columns per lane
+template <int SW_L, int K>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : 1)))
+void phmm_sw_align_kernel(const SwParams p) {
+    constexpr int GMASK = WAVE - SW_L;  // lane & GMASK = first lane of the lane's group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+    const int lane = threadIdx.x, g = lane / SW_L, l = lane % SW_L;
     // LDS of this group: reference | alternate | bottom row | (several strips only) strip edge: sw, best_gap_h, -gap_size_h
-    const uint32_t gpb = p.groups_per_block;  // 4, or 1 when the sequences are so long that a block's LDS holds one alignment
+    const uint32_t gpb = p.groups_per_block;  // 64 / SW_L, or 1 when the sequences are so long that a block's LDS holds one alignment
     unsigned char *gbase = smem + (size_t)(g < (int)gpb ? g : 0) * p.lds_group_bytes;
     uint8_t *s_ref = gbase;
     uint8_t *s_alt = s_ref + p.lds_ref_bytes;
     int32_t *bottom = reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
-    int32_t *e_ngsh = e_bgh + (p.max_ref + 1);
-    // backtrack storage of this block: dwords of two entries, laid out [strip][step][column pair][lane], so that every
-    // store instruction of the wave writes 256 contiguous bytes
-    uint32_t *slab = reinterpret_cast<uint32_t *>(p.slab) + (size_t)blockIdx.x * (p.slab_stride / 2);
-    const int32_t w_match = p.w_match, w_mismatch = p.w_mismatch, w_open = p.w_open, w_extend = p.w_extend;
+    // backtrack flags of this block, [strip][step][dword][lane]
+    constexpr int NH = (K + 15) / 16;  // flag-word pairs per lane and step
+    uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
+    // scores times four; the low two bits name the candidate
+    int32_t x_match = 4 * p.w_match + TAG_DIAG, x_mismatch = 4 * p.w_mismatch + TAG_DIAG;
+    asm volatile("" : "+s"(x_match), "+s"(x_mismatch));  // opaque: or the compiler selects between the raw weights and scales per cell
+    const int32_t x_open = 4 * p.w_open, x_open_r = 4 * p.w_open + TAG_RIGHT, x_extend = 4 * p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
-    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * (K / 2) * WAVE;  // backtrack dwords of one strip
-    auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? w_open + (jj - 1) * w_extend : 0; };  // :150-158
+    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * (2 * NH) * WAVE;  // flag dwords of one strip
+    auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
-    for (uint32_t base = blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
+    const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
+    for (uint32_t base = p.a_begin + blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
         const uint32_t a = base + (uint32_t)g;
         const bool valid = (uint32_t)g < gpb && a < p.n_alignments;
         uint32_t ro = 0, ao = 0;
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                 const int r = r0 - l;
                 bool ok = found < 0 && r0 >= 0 && r >= 0;
                 for (int q = 0; ok && q < m; ++q) ok = s_ref[r + q] == s_alt[q];
-                const uint32_t hit = (uint32_t)(__ballot(ok) >> (lane & 48)) & 0xffffu;
+                const uint32_t hit = (uint32_t)(__ballot(ok) >> (lane & GMASK)) & ((1u << SW_L) - 1);
                 if (hit && found < 0) found = r0 - (__ffs((int)hit) - 1);
                 r0 -= SW_L;
             }
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
         const int my_strips = dp ? (m + strip_cols - 1) / strip_cols : 0;
         int n_strips = my_strips, n_max = dp ? n : 0;
 #pragma unroll
-        for (int o = 32; o >= 16; o >>= 1) {  // over the four groups
+        for (int o = 32; o >= SW_L; o >>= 1) {  // over the groups
             n_strips = max(n_strips, __shfl_xor(n_strips, o, WAVE));
             n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
         }
@@ -141,75 +160,69 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
         for (int s = 0; s < n_strips; ++s) {
             const bool strip_on = dp && s < my_strips;
             const int j0 = s * strip_cols + l * K;  // columns j0+1 .. j0+K
-            int32_t up[K], bgv[K], gsv[K], bb[K];
+            // the row above lives in one of two register sets that swap roles every step (no copies at the loop's back edge)
+            int32_t up_a[K], up_b[K], bgv[K], bb[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = j0 + k + 1;
                 bb[k] = (strip_on && j <= m) ? (int32_t)s_alt[j - 1] : 0x1000;
-                up[k] = row0(j);
+                up_a[k] = up_b[k] = row0(j);             // (a lane's first row may fall on either set)
                 bgv[k] = SW_LOW_INIT;
-                gsv[k] = 0;
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
-            int32_t o_sw = 0, o_bgh = 0, o_ngsh = 0;     // what this lane hands to its right neighbour (row of the previous step)
+            int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
+            uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
             uint32_t *bt = slab + (size_t)s * strip_stride + lane;
-            const int steps = n_max + SW_L - 1;
-            for (int t = 0; t < steps; ++t) {
+            auto step = [&](const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
                 const int i = t - l + 1;                 // this lane's row at this step
-                int32_t left = row_shr1(o_sw), h_bg = row_shr1(o_bgh), h_ngs = row_shr1(o_ngsh);
+                int32_t left = row_shr1(o_sw), h_bg = row_shr1(o_bgh);
                 const bool active = strip_on && i >= 1 && i <= n;
                 if (active) {
                     if (l == 0) {
                         if (s == 0) {                    // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
-                            left = edge_gaps ? w_open + (i - 1) * w_extend : 0;
-                            h_bg = SW_LOW_INIT;
-                            h_ngs = 0;
+                            left = edge_gaps ? x_open + (i - 1) * x_extend : 0;
+                            h_bg = SW_LOW_INIT | TAG_RIGHT;
                         } else {                         // the right edge of the previous strip
                             left = e_sw[i];
                             h_bg = e_bgh[i];
-                            h_ngs = e_ngsh[i];
                         }
                     }
                     const int32_t a_base = (int32_t)s_ref[i - 1];
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
-                    int32_t d = diag;
-                    int32_t btr[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const int32_t step_diag = d + (a_base == bb[k] ? w_match : w_mismatch);   // :194-199
-                        const int32_t pv = up[k] + w_open;                                         // :207-218
-                        const int32_t ev = bgv[k] + w_extend;
-                        gsv[k] = pv > ev ? 1 : gsv[k] + 1;
+                        const int32_t d = k ? up[k - 1] : diag;
+                        const int32_t step_diag = d + (a_base == bb[k] ? x_match : x_mismatch);   // :194-199 (tag: diagonal)
+                        const int32_t pv = up[k] + x_open;                                         // :207-218
+                        const int32_t ev = bgv[k] + x_extend;
+                        acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(ev - pv), 31);  // 1: pv > ev, the gap opens here
                         bgv[k] = max(pv, ev);
-                        const int32_t ph = left + w_open;                                          // :229-240
-                        const int32_t eh = h_bg + w_extend;
-                        h_ngs = ph > eh ? -1 : h_ngs - 1;                                          // minus the gap length
+                        const int32_t ph = left + x_open_r;                                        // :229-240 (tag: right)
+                        const int32_t eh = h_bg + x_extend;
+                        acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(eh - ph), 31);
                         h_bg = max(ph, eh);
-                        const int32_t gap = max(h_bg, bgv[k]);
-                        // priority: diagonal, then right (horizontal), then down (:250-266)
-                        btr[k] = step_diag >= gap ? 0 : (h_bg >= bgv[k] ? h_ngs : gsv[k]);
-                        const int32_t cur = max(SW_MATRIX_MIN_CUTOFF, max(step_diag, gap));
-                        d = up[k];
-                        up[k] = cur;
-                        left = cur;
+                        // priority: diagonal, then right (horizontal), then down (:250-266) -- the tags break the ties
+                        const int32_t cx = max(step_diag, max(h_bg, bgv[k]));
+                        acc_c[k / 16] = __builtin_amdgcn_alignbit((uint32_t)cx, acc_c[k / 16], 2);
+                        left = out[k] = cx & ~3;
                     }
-                    uint32_t *row_bt = bt + (size_t)t * (K / 2) * WAVE;
+                    uint32_t *row_bt = bt + (size_t)t * (2 * NH) * WAVE;
 #pragma unroll
-                    for (int k = 0; k + 1 < K; k += 2)
-                        row_bt[(k / 2) * WAVE] = (uint32_t)(uint16_t)btr[k] | ((uint32_t)(uint16_t)btr[k + 1] << 16);
+                    for (int hh = 0; hh < NH; ++hh) {
+                        row_bt[(2 * hh) * WAVE] = acc_c[hh];
+                        row_bt[(2 * hh + 1) * WAVE] = acc_e[hh];
+                    }
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
-                    o_ngsh = h_ngs;
                     if (l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
                         e_sw[i] = left;
                         e_bgh[i] = h_bg;
-                        e_ngsh[i] = h_ngs;
                     }
                     if (s == sm && l == lm) {
-                        int32_t v = up[0];
+                        int32_t v = out[0];
 #pragma unroll
-                        for (int k = 1; k < K; ++k) v = (k == km) ? up[k] : v;
+                        for (int k = 1; k < K; ++k) v = (k == km) ? out[k] : v;
                         if (v >= lc_score) {
                             lc_score = v;
                             lc_row = i;
@@ -218,9 +231,14 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                     if (i == n) {
 #pragma unroll
                         for (int k = 0; k < K; ++k)
-                            if (j0 + k + 1 <= m) bottom[j0 + k + 1] = up[k];
+                            if (j0 + k + 1 <= m) bottom[j0 + k + 1] = out[k];
                     }
                 }
+            };
+            const int steps = (n_max + SW_L) & ~1;      // rounded up to even; nobody is active in the extra step
+            for (int t = 0; t < steps; t += 2) {
+                step(t, up_a, up_b);
+                step(t + 1, up_b, up_a);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                 best = Start{0, 0, 0, n, m};
             } else {
                 // the owner of the last column holds its best cell; everybody gets it
-                const int src = (lane & 48) | lm;
+                const int src = (lane & GMASK) | lm;
                 const int32_t sc = __shfl(lc_score, src, WAVE), rw = __shfl(lc_row, src, WAVE);
                 best = Start{sc, abs(rw - m), 0, rw, m};
                 if (p.strategy != PHMM_SW_STRATEGY_LEADING_INDEL) {
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
         }
         if (p.strategy != PHMM_SW_STRATEGY_INDEL && p.strategy != PHMM_SW_STRATEGY_LEADING_INDEL) {
 #pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) {  // best of the group
+            for (int o = SW_L / 2; o >= 1; o >>= 1) {  // best of the group
                 Start c;
                 c.score = __shfl_xor(best.score, o, WAVE);
                 c.dist = __shfl_xor(best.dist, o, WAVE);
@@ -261,20 +279,25 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
         if (dp && best.order > 0) segment_length = m - best.p2;  // a bottom-row cell: the end of the alternate overhangs (:327)
         __threadfence();  // every lane's backtrack entries are visible to the lane that walks them
 
-        // ---- calculate_cigar (:332-443): one lane per alignment ------------------------------------------------------
-        if (valid && l == 0) {
-            CigarOut cig{p.cigar + p.cigar_off[a], p.cigar_off[a + 1] - p.cigar_off[a]};
+        // ---- calculate_cigar (:332-443): the sixteen lanes of the alignment walk together ------------------------------
+        // Every backtrack step is a dependent read from HBM; sixteen cells down the diagonal are fetched at once, one
+        // per lane, and the run of diagonal steps among them is taken in one go -- a read of 150 bases is traced in a
+        // dozen round trips instead of 150.  Gap cells (rare) are handled one at a time, every lane doing the same.
+        if (valid) {
+            CigarOut cig{p.cigar + p.cigar_off[a], p.cigar_off[a + 1] - p.cigar_off[a], l == 0};
             int32_t alignment_offset = 0;
             if (n == 0 || m == 0) {  // the reference asserts (:65-68, :132-134); the host refuses such input beforehand
-                atomicOr(p.status, SW_STATUS_EMPTY);
+                if (l == 0) atomicOr(p.status, SW_STATUS_EMPTY);
             } else if (found >= 0) {
                 cig.push(make_element(ST_MATCH, (uint32_t)m));
                 alignment_offset = found;
             } else {
-                auto BT = [&](int i, int jj) -> int32_t {
+                // flag words of cell (i, jj): [0] candidate tags, [WAVE] gap-open bits; `sh` = 2 x (cells after it in the word)
+                auto cell_words = [&](int i, int jj, int &sh) -> const uint32_t * {
                     const int ss = (jj - 1) / strip_cols, cc = (jj - 1) % strip_cols, ll = cc / K, kk = cc % K;
-                    const uint32_t w = slab[(size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * (K / 2) + kk / 2) * WAVE + (lane & 48) + ll];
-                    return (int32_t)(int16_t)((kk & 1) ? (w >> 16) : (w & 0xffffu));
+                    const int hh = kk >> 4, nq = min(K - 16 * hh, 16);
+                    sh = 2 * (nq - 1 - (kk & 15));
+                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * (2 * NH) + 2 * hh) * WAVE + (lane & GMASK) + ll;
                 };
                 int p1 = best.p1, p2 = best.p2;
                 if (segment_length > 0 && p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
@@ -283,31 +306,54 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                 }
                 int state = ST_MATCH;
                 for (;;) {
-                    const int32_t btr = BT(p1, p2);
-                    int new_state;
-                    int32_t step_length = 1;
-                    if (btr > 0) {
-                        new_state = ST_DELETION;
-                        step_length = btr;
-                    } else if (btr < 0) {
-                        new_state = ST_INSERTION;
-                        step_length = -btr;
-                    } else {
-                        new_state = ST_MATCH;
+                    // lane l looks at cell (p1 - l, p2 - l); `run` = diagonal steps from (p1, p2) before anything else
+                    int sh;
+                    const bool inside = p1 - l >= 1 && p2 - l >= 1;
+                    const uint32_t *w = cell_words(inside ? p1 - l : 1, inside ? p2 - l : 1, sh);
+                    const uint32_t tag = inside ? (w[0] >> (30 - sh)) & 3u : 3u;
+                    const uint32_t diagonal = (uint32_t)(__ballot(tag == TAG_DIAG) >> (lane & GMASK)) & ((1u << SW_L) - 1);
+                    const int run = __ffs((int)(~diagonal & ((2u << SW_L) - 1))) - 1;  // 0 ... SW_L
+                    if (run > 0) {  // `run` times the reference's loop body with btrack == 0 (:372-417)
+                        if (state != ST_MATCH) {
+                            if (segment_length > 0) cig.push(make_element(state, (uint32_t)segment_length));
+                            segment_length = 0;
+                            state = ST_MATCH;
+                        }
+                        segment_length += run;
+                        p1 -= run;
+                        p2 -= run;
+                        if (p1 <= 0 || p2 <= 0) break;
+                        if (run == SW_L) continue;
                     }
-                    if (new_state == ST_MATCH) {
-                        p1 -= 1;
-                        p2 -= 1;
-                    } else if (new_state == ST_INSERTION) {
-                        p2 -= step_length;
+                    // a gap ends at (p1, p2).  The reference's btrack entry (:257-266) is +k (k rows up) or -k (k columns
+                    // left), k = the length the best gap ending here has: 1 where it opens, else one more than at the
+                    // previous cell of the column / row
+                    const int src = (lane & GMASK) | run;  // the lane that fetched this cell
+                    const uint32_t gtag = (uint32_t)__shfl((int)tag, src, WAVE);
+                    w = cell_words(p1, p2, sh);
+                    uint32_t e = w[WAVE];
+                    int32_t k = 1;
+                    if (gtag == TAG_RIGHT) {
+                        for (int j2 = p2; !((e >> sh) & 1u) && j2 > 1;) {
+                            ++k;
+                            --j2;
+                            e = cell_words(p1, j2, sh)[WAVE];
+                        }
+                        p2 -= k;
                     } else {
-                        p1 -= step_length;
+                        for (int i2 = p1; !((e >> (sh + 1)) & 1u) && i2 > 1;) {
+                            ++k;
+                            --i2;
+                            e = cell_words(i2, p2, sh)[WAVE];
+                        }
+                        p1 -= k;
                     }
+                    const int new_state = gtag == TAG_RIGHT ? ST_INSERTION : ST_DELETION;
                     if (new_state == state) {
-                        segment_length += step_length;
+                        segment_length += k;
                     } else {
                         if (segment_length > 0) cig.push(make_element(state, (uint32_t)segment_length));
-                        segment_length = step_length;
+                        segment_length = k;
                         state = new_state;
                     }
                     if (p1 <= 0 || p2 <= 0) break;
@@ -328,24 +374,53 @@ __global__ __launch_bounds__(WAVE) void phmm_sw_align_kernel(const SwParams p) {
                     alignment_offset = 0;
                 }
             }
-            cig.finish();
-            p.n_cigar[a] = cig.n;
-            p.alignment_offset[a] = alignment_offset;
-            if (cig.n > cig.cap) atomicOr(p.status, SW_STATUS_CAPACITY);
+            if (l == 0) {
+                cig.finish();
+                p.n_cigar[a] = cig.n;
+                p.alignment_offset[a] = alignment_offset;
+                if (cig.n > cig.cap) atomicOr(p.status, SW_STATUS_CAPACITY);
+            }
         }
         __builtin_amdgcn_s_barrier();  // (one wave per block: a scheduling point between rounds)
     }
+    if (blockIdx.x == 0 && lane == 0) {
+        p.status[2] = (uint32_t)(clock64() - clk0);        // shader clocks
+        p.status[3] = (uint32_t)(wall_clock64() - wall0);  // 100 MHz ticks
+    }
 }
 
-#define PHMM_SW_K_LIST(X) X(2) X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
-const int kSwK[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
-const int kNumSwK = sizeof(kSwK) / sizeof(int);
+// instantiated <lanes per alignment, columns per lane>; the host side picks the pair (phmm_sw.cpp)
+#define PHMM_SW_LIST(X)                                                                                                \
+    X(16, 2) X(16, 4) X(16, 6) X(16, 8) X(16, 10) X(16, 12) X(16, 14) X(16, 16) X(16, 20) X(16, 24) X(16, 28) X(16, 32) \
+    X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(8, 19) X(8, 22) X(8, 26) X(8, 32)
+const int kSwK16[] = {2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+const int kNumSwK16 = sizeof(kSwK16) / sizeof(int);
+const int kSwK8[] = {4, 8, 12, 16, 19, 22, 26, 32};
+const int kNumSwK8 = sizeof(kSwK8) / sizeof(int);
 
-hipError_t launch_sw(int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
-    if (!p.n_alignments) return hipSuccess;
-#define PHMM_CASE(KK)                                                                                              \
-    if (K == KK) {                                                                                                 \
-        auto kern = phmm_sw_align_kernel<KK>;                                                                      \
+// blocks (of one wave) of this instance a CU holds at once, by registers and LDS
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes) {
+#define PHMM_CASE(LL, KK)                                                                                          \
+    if (L == LL && K == KK) {                                                                                      \
+        auto kern = phmm_sw_align_kernel<LL, KK>;                                                                  \
+        if (lds_bytes > 64 * 1024 &&                                                                               \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds_bytes) != hipSuccess)                                                     \
+            return 0;                                                                                              \
+        int nb = 0;                                                                                                \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;        \
+        return nb;                                                                                                 \
+    }
+    PHMM_SW_LIST(PHMM_CASE)
+#undef PHMM_CASE
+    return 0;
+}
+
+hipError_t launch_sw(int L, int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
+    if (p.n_alignments <= p.a_begin) return hipSuccess;
+#define PHMM_CASE(LL, KK)                                                                                          \
+    if (L == LL && K == KK) {                                                                                      \
+        auto kern = phmm_sw_align_kernel<LL, KK>;                                                                  \
         if (lds_bytes > 64 * 1024) {                                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
@@ -354,7 +429,7 @@ hipError_t launch_sw(int K, const SwParams &p, uint32_t n_blocks, size_t lds_byt
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);                                \
         return hipGetLastError();                                                                                  \
     }
-    PHMM_SW_K_LIST(PHMM_CASE)
+    PHMM_SW_LIST(PHMM_CASE)
 #undef PHMM_CASE
     return hipErrorInvalidValue;
 }

@@ -151,3 +151,61 @@ def test_argument_errors(hip_engine, aligner):
     assert hip_engine.lib.phmm_sw_align(*args(z, one, 0)) == _lib.PHMM_ERR_INVALID_ARG and "non-empty" in hip_engine.last_error()
     assert hip_engine.lib.phmm_sw_align(*args(one, one, 7)) == _lib.PHMM_ERR_INVALID_ARG
     assert hip_engine.lib.phmm_sw_align(*args(one, one, 1)) == _lib.PHMM_OK
+
+
+def test_long_gaps_are_recovered_from_the_open_flags(aligner):
+    """The kernel stores which candidate won and where gaps open, not gap lengths: a backtrack step over a long gap walks
+    the flags back to the cell the gap opened at -- across the K columns of a lane, across lanes and across strips of
+    512 columns (an insertion of 700 bases), and up a column for deletions of hundreds of rows."""
+    rng = np.random.default_rng(77)
+    alpha = b"ACGT"
+    rnd = lambda n: bytes(alpha[int(x)] for x in rng.integers(0, 4, n))  # noqa: E731
+    core = rnd(900)
+    pairs = [
+        (core[:300] + core[420:], core),                                   # 120 bases missing from the reference: insertion
+        (core, core[:250] + core[610:]),                                   # 360 rows skipped: deletion
+        (core[:200] + core[200:260] * 1 + core[260:], core[:200] + rnd(700) + core[200:]),   # insertion longer than a strip
+        (core[:100] + rnd(333) + core[100:500], core[:500]),               # deletion of 333
+        (rnd(40) + core[:150], core[:150] + rnd(35)),                      # overhangs on both sides
+        (b"A" * 300, b"A" * 120 + b"C" * 90 + b"A" * 100),                 # low complexity: ties everywhere
+    ]
+    for params in (NEW_SW_PARAMETERS, Parameters(3, -2, -4, -1), Parameters(1, -3, -2, 0), Parameters(20000, -15000, -26000, -1100)):
+        for strategy in STRATEGIES:
+            for k, (g, (r, a)) in enumerate(zip(aligner.align_batch(pairs, params, strategy, capacity=256), pairs)):
+                _same(g, r, a, params, strategy, k)
+
+
+def test_pipelined_pieces_equal_one_piece(hip_engine, aligner):
+    """Large calls are cut into pieces whose staging overlaps the previous piece's kernel (switch `sw_chunks`; by size
+    otherwise): same results whatever the cut, ragged pieces and pieces of a single alignment included."""
+    rng = np.random.default_rng(5)
+    alpha = b"ACGT"
+    pairs = []
+    for k in range(203):
+        ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(20, 400))))
+        alt = _mutate(rng, ref[int(rng.integers(0, 10)):], 0.03, 0.02) if k % 3 else bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 200))))
+        pairs.append((ref, alt))
+    base = None
+    try:
+        for lanes in (8, 16):   # lanes per alignment: 8 while 160 columns suffice, 16 beyond -- forced either way here
+            hip_engine.set_switch("sw_lanes", lanes)
+            for chunks in (1, 2, 3, 7):
+                hip_engine.set_switch("sw_chunks", chunks)
+                for n in (len(pairs), 3):
+                    got = aligner.align_batch(pairs[:n], STANDARD_NGS, "SoftClip")
+                    if base is None:
+                        base = got
+                        for g, (r, a) in zip(got, pairs):
+                            _same(g, r, a, STANDARD_NGS, "SoftClip")
+                    for g, b in zip(got, base):
+                        assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements), (lanes, chunks)
+    finally:
+        hip_engine.set_switch("sw_chunks", 0)
+        hip_engine.set_switch("sw_lanes", 0)
+
+
+def test_parameters_beyond_the_exact_range_are_refused(aligner):
+    """Scores travel times four with a tag in the low bits and without the reference's clamp at -1e8: exact while
+    |weight| x (ref + alt) < 1e8, refused beyond (nobody aligns with weights of a million)."""
+    with pytest.raises(PhmmError, match="parameters too large"):
+        aligner.align(b"ACGT" * 50, b"ACGT" * 40, Parameters(1000000, -1000000, -2000000, -500000), "SoftClip")

@@ -38,3 +38,6 @@ for _ in range(5):
 dt = (time.perf_counter() - t) / 5
 print("%d alignments, %.3g cells: %.3f ms per call, %.1f GCUPS-i32, %.2f M alignments/s (host buffers, PCIe included); "
       "CIGAR element counts: %s" % (n, cells, dt * 1e3, cells / dt / 1e9, n / dt / 1e6, np.bincount(n_cig)[:8].tolist()))
+kus = eng.stat("sw_kernel_us")
+print("kernel (HIP events around the launch): %.3f ms = %.1f GCUPS-i32; backtrack flags written: %.2f GB; shader clock %d MHz" %
+      (kus / 1e3, cells / kus / 1e3, eng.stat("sw_backtrack_bytes") / 1e9, eng.stat("sw_clock_mhz")))
