@@ -82,12 +82,15 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
     return a.order < b.order;
 }
 
+#ifndef PHMM_SW_K4
+#define PHMM_SW_K4 19
+#endif
 #ifndef PHMM_SW_EU
 #define PHMM_SW_EU 5
 #endif
 // SW_L lanes per alignment (16 or 8: 4 or 8 alignments per wave), K columns per lane
 template <int SW_L, int K>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : 1)))
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : K <= PHMM_SW_K4 ? 4 : K <= 26 ? 3 : 2)))
 void phmm_sw_align_kernel(const SwParams p) {
     constexpr int GMASK = WAVE - SW_L;  // lane & GMASK = first lane of the lane's group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -173,21 +176,23 @@ void phmm_sw_align_kernel(const SwParams p) {
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
             uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
             uint32_t *bt = slab + (size_t)s * strip_stride + lane;
+            // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
+            int32_t a_next = (int32_t)s_ref[max(-l, 0)];
+            const bool first_strip = s == 0;
             auto step = [&](const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1(o_sw), h_bg = row_shr1(o_bgh);
                 const bool active = strip_on && i >= 1 && i <= n;
+                const int32_t a_base = a_next;
+                a_next = (int32_t)s_ref[max(i, 0)];      // row i + 1 (the LDS area is padded: one byte beyond the sequence is harmless)
                 if (active) {
-                    if (l == 0) {
-                        if (s == 0) {                    // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
-                            left = edge_gaps ? x_open + (i - 1) * x_extend : 0;
-                            h_bg = SW_LOW_INIT | TAG_RIGHT;
-                        } else {                         // the right edge of the previous strip
-                            left = e_sw[i];
-                            h_bg = e_bgh[i];
-                        }
+                    if (first_strip) {                   // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
+                        left = l == 0 ? (edge_gaps ? x_open + (i - 1) * x_extend : 0) : left;
+                        h_bg = l == 0 ? (SW_LOW_INIT | TAG_RIGHT) : h_bg;
+                    } else if (l == 0) {                 // the right edge of the previous strip
+                        left = e_sw[i];
+                        h_bg = e_bgh[i];
                     }
-                    const int32_t a_base = (int32_t)s_ref[i - 1];
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
