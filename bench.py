@@ -518,7 +518,7 @@ def main():
         return row
 
     def smith_waterman():
-        """every read of the first 256 regions of the batch realigned to the first haplotype of its
+        """every read of the batch's regions (up to 1 024) realigned to the first haplotype of its
         region (the shape of realign_reads_to_their_best_haplotype, src/assembly/assembly_based_caller_utils.rs:208-246:
         SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), host buffers, PCIe included."""
         import ctypes as C
@@ -526,7 +526,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         from lorikeet_amd import _lib
         from oracle import oracle
-        sub = batch.region_slice(0, min(256, batch.n_regions))
+        sub = batch.region_slice(0, min(1024, batch.n_regions))
         n = sub.n_reads
         alt_off, alt = sub.read_off, sub.read_bases
         reg_of_read = np.repeat(np.arange(sub.n_regions), np.diff(sub.region_read_off.astype(np.int64)))
@@ -549,7 +549,8 @@ def main():
         for _ in range(3):
             assert eng.lib.phmm_sw_align(*args) == 0
         dt = (time.perf_counter() - t) / 3
-        kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernel of the last call
+        kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernels of the last call
+        pe, pwhy = pmc_entry("smith_waterman", int(n), "phmm_sw_align_kernel", "i32")
         bt_bytes = eng.stat("sw_backtrack_bytes")
         # oracle (the reference's scalar arm in C) on a sample: equality, and the CPU rate beside it
         k = min(n, 4096)
@@ -580,13 +581,22 @@ def main():
                 "single_element_cigars": int(np.sum(n_cig == 1)),
                 "equal_to_oracle_on_sample": same, "sample": int(k),
                 "kernel": {"ms": round(kern_s * 1e3, 3), "gcups_i32": round(cells / max(kern_s, 1e-9) / 1e9, 1),
-                           "note": "phmm_sw_align_kernel<K> alone (HIP events in the library, phmm_get_stat)"},
+                           "shader_clock_mhz": int(eng.stat("sw_clock_mhz")),
+                           "note": "the phmm_sw_align_kernel<L,K> launches of the last call (HIP events in the library, phmm_get_stat)"},
                 "roofline": {"bound": "hbm", "achieved": round(bt_bytes / max(kern_s, 1e-9) / 1e9, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(bt_bytes / max(kern_s, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
                              "algorithmic_bytes_per_launch": int(bt_bytes),
-                             "note": "the backtrack matrix (int16 per cell slot) is the traffic that scales with the cells; "
-                                     "the other bound is INT32 VALU: 33 lane-ops per cell measured (SQ_INSTS_VALU, "
-                                     "profiles/r02_sw_bench_summary.txt) against 39.3 T lane-ops/s = 1.19 TCUPS"},
+                             "traffic": pe["hbm_bytes_per_launch"] if pe else None,
+                             "note": "the backtrack flags (4 bits per cell, two dwords per lane and step) are the traffic "
+                                     "that scales with the cells; the bound that binds is INT32 VALU issue, see valu_int32"
+                                     + ("" if pe else "; traffic: " + pwhy)},
+                "valu_int32": ({"valu_insts_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
+                                "achieved": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2), "peak": 39.3,
+                                "unit": "T lane-ops/s", "frac": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12 / 39.3, 4),
+                                "note": "SQ_INSTS_VALU of the call (profiles/pmc_traffic.json, same kernel sources) x 64 lanes over "
+                                        "this run's kernel time; peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (one wave64 INT32 "
+                                        "instruction per 4 clocks and SIMD: tools/ubench/sw_cell.hip measures 3.75); the cell "
+                                        "itself is 16 instructions"} if pe else None),
                 "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
                                "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
 

@@ -41,3 +41,10 @@ print("%d alignments, %.3g cells: %.3f ms per call, %.1f GCUPS-i32, %.2f M align
 kus = eng.stat("sw_kernel_us")
 print("kernel (HIP events around the launch): %.3f ms = %.1f GCUPS-i32; backtrack flags written: %.2f GB; shader clock %d MHz" %
       (kus / 1e3, cells / kus / 1e3, eng.stat("sw_backtrack_bytes") / 1e9, eng.stat("sw_clock_mhz")))
+import json  # noqa: E402
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench  # noqa: E402
+print(json.dumps({"sw_bench": {"alignments": int(n), "cells": cells, "calls": 6, "ms_per_call": round(dt * 1e3, 3), "kernel_ms": round(kus / 1e3, 3),
+                               "backtrack_bytes": int(eng.stat("sw_backtrack_bytes")), "clock_mhz": int(eng.stat("sw_clock_mhz")),
+                               "src_hash": bench.source_hash()}}))
