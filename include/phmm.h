@@ -303,6 +303,49 @@ int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32_t *ref_off
                   int32_t *alignment_offset);
 
 /*
+ * The same with shared references: alignment a pairs alternate sequence a with reference ref_index[a] -- reads against
+ * the few haplotypes of their region, which then cross the bus once instead of once per read.  ref_index[a] ==
+ * PHMM_SW_NO_REFERENCE skips the alignment (n_cigar 0, offset 0).  ref_off has n_references + 1 entries.
+ */
+#define PHMM_SW_NO_REFERENCE 0xffffffffu
+int phmm_sw_align_indexed(phmm_handle *h, uint32_t n_references, const uint32_t *ref_off, const uint8_t *ref_bases,
+                          uint32_t n_alignments, const uint32_t *ref_index, const uint32_t *alt_off,
+                          const uint8_t *alt_bases, const phmm_sw_parameters *params, int overhang_strategy,
+                          const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *alignment_offset);
+
+/*
+ * Best allele per read, ties broken by priority: AlleleLikelihoods::best_alleles_breaking_ties_main
+ * (src/model/allele_likelihoods.rs:1043-1095) = search_best_allele (:457-554, can_be_reference = true) + BestAllele::new
+ * (:1142-1160) for every read of n_regions regions -- the first step of realign_reads_to_their_best_haplotype
+ * (src/assembly/assembly_based_caller_utils.rs:208-246) and of the reference's read-allele maps.
+ *   likelihoods        per region row-major [read][hap] at out_off[g]: what phmm_engine_compute / phmm_compute return
+ *   keep [n_reads]     or NULL: 0 = evidence removed by filter_poorly_modeled_evidence, no best allele (-1)
+ *   hap_priority       [n_haps] one i32 per haplotype (haplotype_alignment_tiebreaking_priority, :187-195: is_ref +
+ *                      1 - cigar elements; reference_tiebreaking_priority, :197-199), or NULL: no tie breaking
+ *   informative_threshold   LOG_10_INFORMATIVE_THRESHOLD = 0.2 (:17) for log10 likelihoods
+ *   best_allele [n_reads]   index inside the region, -1 where there is none; likelihood / confidence as BestAllele
+ *                      holds them (BestAllele::is_informative: confidence > threshold)
+ */
+int phmm_best_alleles(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                      const uint64_t *out_off, const double *likelihoods, const uint8_t *keep, const int32_t *hap_priority,
+                      double informative_threshold, int32_t *best_allele, double *likelihood, double *confidence);
+
+/*
+ * Both steps of realign_reads_to_their_best_haplotype that are arithmetic, in one call: the best allele of every read
+ * (as phmm_best_alleles) and the read's Smith-Waterman alignment to that haplotype (as phmm_sw_align_indexed; the
+ * reference: SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, src/reads/alignment_utils.rs:40-70).  The index never
+ * leaves the device.  `read_bases` are the reads WITHOUT their soft clips (the caller hard-clips them, :47-50); reads
+ * without a best allele get n_cigar 0.  Projecting the read -> haplotype CIGAR onto the reference (:83-140) stays with
+ * the caller.
+ */
+int phmm_realign_to_best(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                         const uint32_t *read_off, const uint8_t *read_bases, const uint32_t *hap_off,
+                         const uint8_t *hap_bases, const uint64_t *out_off, const double *likelihoods, const uint8_t *keep,
+                         const int32_t *hap_priority, double informative_threshold, const phmm_sw_parameters *params,
+                         int overhang_strategy, const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar,
+                         int32_t *alignment_offset, int32_t *best_allele, double *likelihood, double *confidence);
+
+/*
  * Developer switches and counters (tests, A/B measurements; never needed in production).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",

@@ -40,6 +40,8 @@ pub const PHMM_SW_SOFTCLIP: c_int = 0;
 pub const PHMM_SW_INDEL: c_int = 1;
 pub const PHMM_SW_LEADING_INDEL: c_int = 2;
 pub const PHMM_SW_IGNORE: c_int = 3;
+/// `ref_index` value of `phmm_sw_align_indexed`: this alignment is skipped
+pub const PHMM_SW_NO_REFERENCE: u32 = 0xffff_ffff;
 
 /// `phmm_sw_parameters` == gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)
 #[repr(C)]
@@ -237,6 +239,63 @@ extern "C" {
         cigar: *mut u32,
         n_cigar: *mut u32,
         alignment_offset: *mut i32,
+    ) -> c_int;
+
+    pub fn phmm_sw_align_indexed(
+        h: *mut phmm_handle,
+        n_references: u32,
+        ref_off: *const u32,
+        ref_bases: *const u8,
+        n_alignments: u32,
+        ref_index: *const u32,
+        alt_off: *const u32,
+        alt_bases: *const u8,
+        params: *const phmm_sw_parameters,
+        overhang_strategy: c_int,
+        cigar_off: *const u64,
+        cigar: *mut u32,
+        n_cigar: *mut u32,
+        alignment_offset: *mut i32,
+    ) -> c_int;
+
+    pub fn phmm_best_alleles(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        out_off: *const u64,
+        likelihoods: *const f64,
+        keep: *const u8,
+        hap_priority: *const i32,
+        informative_threshold: f64,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
+    ) -> c_int;
+
+    pub fn phmm_realign_to_best(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        out_off: *const u64,
+        likelihoods: *const f64,
+        keep: *const u8,
+        hap_priority: *const i32,
+        informative_threshold: f64,
+        params: *const phmm_sw_parameters,
+        overhang_strategy: c_int,
+        cigar_off: *const u64,
+        cigar: *mut u32,
+        n_cigar: *mut u32,
+        alignment_offset: *mut i32,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
     ) -> c_int;
 
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;

@@ -18,6 +18,8 @@
 //   src/haplotype/haplotype.rs:263-275     Haplotype (Eq/Hash by bases)   Haplotype
 //   src/assembly/assembly_result_set.rs:35 AssemblyResultSet (ordered set of haplotypes)
 //   src/reads/read_utils.rs:23,372-416     BI/BD tags or flat Q45         HmmRead::base_{insertion,deletion}_qualities
+//   src/model/allele_likelihoods.rs:1043-1166  best_alleles_breaking_ties_main, BestAllele  AssemblyBasedCallerUtils::best_alleles_breaking_ties_main
+//   src/assembly/assembly_based_caller_utils.rs:187-246  tie-breaking priorities, realign_reads_to_their_best_haplotype (arithmetic)
 #pragma once
 
 #include <algorithm>
@@ -68,6 +70,7 @@ inline double qual_to_error_prob(uint8_t q) { return std::pow(10.0, q / -10.0); 
 struct Haplotype {
     Bytes bases_;
     bool is_ref = false;
+    size_t cigar_elements = 1;  // elements of the haplotype -> reference CIGAR (haplotype_alignment_tiebreaking_priority)
     Haplotype() = default;
     Haplotype(const Bytes &b, bool is_reference) : bases_(b), is_ref(is_reference) {}
     Haplotype(const std::string &b, bool is_reference) : bases_(bytes(b)), is_ref(is_reference) {}
@@ -505,6 +508,105 @@ public:
             out[a].cigar.assign(cigar.begin() + cig_off[a], cigar.begin() + cig_off[a] + n_cig[a]);
             out[a].alignment_offset = off[a];
         }
+        return out;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Best alleles and the realignment of reads to them (reference src/model/allele_likelihoods.rs:457-554, :1043-1166;
+// src/assembly/assembly_based_caller_utils.rs:187-246): phmm_best_alleles / phmm_realign_to_best.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BestAllele {  // allele_likelihoods.rs:1119-1166
+    std::optional<size_t> allele_index;
+    size_t sample_index = 0, evidence_index = 0;
+    double likelihood = 0.0, confidence = 0.0;
+    static constexpr double LOG_10_INFORMATIVE_THRESHOLD = 0.2;  // :17
+    bool is_informative() const { return confidence > LOG_10_INFORMATIVE_THRESHOLD; }
+};
+
+struct AssemblyBasedCallerUtils {
+    // :187-195 and :197-199
+    static int32_t haplotype_alignment_tiebreaking_priority(const Haplotype &h) { return (h.is_ref ? 1 : 0) + 1 - (int32_t)h.cigar_elements; }
+    static int32_t reference_tiebreaking_priority(const Haplotype &h) { return h.is_ref ? 1 : 0; }
+
+    // AlleleLikelihoods::best_alleles_breaking_ties_main(tie_breaking_priority) (:1043-1095): every sample, every unit
+    // of evidence.  With `alignments` the reads are also aligned to their best haplotype in the same call
+    // (realign_reads_to_their_best_haplotype, :208-246: SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS).
+    template <class Priority>
+    static std::vector<BestAllele> best_alleles_breaking_ties_main(const AlleleLikelihoods &lk, Priority tie_breaking_priority,
+                                                                   std::vector<SmithWatermanAlignmentResult> *alignments = nullptr) {
+        static std::mutex mu;
+        static detail::Handle handle = detail::make_handle(0, 0);
+        const size_t A = lk.alleles_.size(), S = lk.samples.size();
+        std::vector<uint32_t> rro{0}, rho{0}, read_off{0}, hap_off{0};
+        std::vector<uint64_t> oo{0};
+        std::vector<double> values;  // per sample [read][allele]
+        std::vector<int32_t> pri;
+        Bytes reads, haps;
+        for (size_t s = 0; s < S; ++s) {
+            const Matrix &m = lk.values_by_sample_index[s];
+            const auto ev = lk.evidence_by_sample_index.find(s);
+            const size_t n = std::min(ev == lk.evidence_by_sample_index.end() ? 0 : ev->second.size(), m.cols);  // :1083-1089
+            for (size_t r = 0; r < n; ++r) {
+                for (size_t a = 0; a < A; ++a) values.push_back(m(a, r));
+                const Bytes &b = ev->second[r].bases;
+                reads.insert(reads.end(), b.begin(), b.end());
+                read_off.push_back((uint32_t)reads.size());
+            }
+            for (const Haplotype &h : lk.alleles_) {  // every sample sees the same alleles
+                pri.push_back(tie_breaking_priority(h));
+                haps.insert(haps.end(), h.bases_.begin(), h.bases_.end());
+                hap_off.push_back((uint32_t)haps.size());
+            }
+            rro.push_back(rro.back() + (uint32_t)n);
+            rho.push_back(rho.back() + (uint32_t)A);
+            oo.push_back(oo.back() + (uint64_t)n * A);
+        }
+        const uint32_t n_reads = rro.back();
+        std::vector<int32_t> best(n_reads), off(n_reads);
+        std::vector<double> like(n_reads), conf(n_reads);
+        std::vector<uint64_t> cig_off(n_reads + 1, 0), cap(n_reads, 16);
+        std::vector<uint32_t> cigar, n_cig(n_reads);
+        const phmm_sw_parameters prm{ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.match_value, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.mismatch_penalty,
+                                     ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.gap_open_penalty, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.gap_extend_penalty};
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!alignments) {
+                detail::check(handle.get(), phmm_best_alleles(handle.get(), (uint32_t)S, rro.data(), rho.data(), oo.data(), values.data(), nullptr,
+                                                              pri.data(), BestAllele::LOG_10_INFORMATIVE_THRESHOLD, best.data(), like.data(), conf.data()));
+            } else {
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    for (uint32_t a = 0; a < n_reads; ++a) cig_off[a + 1] = cig_off[a] + cap[a];
+                    cigar.assign(cig_off[n_reads], 0);
+                    const int rc = phmm_realign_to_best(handle.get(), (uint32_t)S, rro.data(), rho.data(), read_off.data(), reads.data(), hap_off.data(),
+                                                        haps.data(), oo.data(), values.data(), nullptr, pri.data(), BestAllele::LOG_10_INFORMATIVE_THRESHOLD,
+                                                        &prm, PHMM_SW_SOFTCLIP, cig_off.data(), cigar.data(), n_cig.data(), off.data(), best.data(),
+                                                        like.data(), conf.data());
+                    if (rc == PHMM_ERR_CIGAR_CAPACITY && attempt == 0) {
+                        for (uint32_t a = 0; a < n_reads; ++a) cap[a] = std::max<uint64_t>(cap[a], n_cig[a]);
+                        continue;
+                    }
+                    detail::check(handle.get(), rc);
+                    break;
+                }
+            }
+        }
+        std::vector<BestAllele> out(n_reads);
+        if (alignments) alignments->assign(n_reads, SmithWatermanAlignmentResult());
+        for (size_t s = 0; s < S; ++s)
+            for (uint32_t r = rro[s]; r < rro[s + 1]; ++r) {
+                BestAllele &b = out[r];
+                b.sample_index = s;
+                b.evidence_index = r - rro[s];
+                if (best[r] >= 0) b.allele_index = (size_t)best[r];
+                b.likelihood = like[r];
+                b.confidence = conf[r];
+                if (alignments && best[r] >= 0) {
+                    (*alignments)[r].cigar.assign(cigar.begin() + cig_off[r], cigar.begin() + cig_off[r] + n_cig[r]);
+                    (*alignments)[r].alignment_offset = off[r];
+                }
+            }
         return out;
     }
 };

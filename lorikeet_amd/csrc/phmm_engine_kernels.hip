@@ -240,6 +240,76 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
     p.keep[r] = (best_all < p.threshold[r]) ? 0 : 1;
 }
 
+// ---- best allele per read (AlleleLikelihoods::search_best_allele, src/model/allele_likelihoods.rs:457-554, the way
+// best_alleles_tie_breaking calls it, :1069-1095: can_be_reference = true) with BestAllele::new (:1142-1160): the first
+// step of realign_reads_to_their_best_haplotype (src/assembly/assembly_based_caller_utils.rs:208-246).  One thread per
+// read; its row of the [read][hap] matrix is contiguous.
+__global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    uint32_t lo = 0, hi = p.n_regions;  // the region of read r: the last g with region_read_off[g] <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (p.region_read_off[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t g = lo, h0 = p.region_hap_off[g], nh = p.region_hap_off[g + 1] - h0;
+    int32_t best_out = -1;
+    double lk_out = -INFINITY, conf_out = (-INFINITY) - (-INFINITY);  // BestAllele::new(-inf, -inf): NaN (:465-475)
+    const bool kept = !p.keep || p.keep[r];
+    if (nh && kept) {
+        const double *v = p.likelihoods + p.out_off[g] + (uint64_t)(r - p.region_read_off[g]) * nh;
+        uint32_t best = 0, second = 0;  // :479-488
+        double best_lk = v[0], second_lk = -INFINITY;
+        for (uint32_t a = 1; a < nh; ++a) {  // :490-505
+            const double c = v[a];
+            if (c > best_lk) {
+                second = best;
+                best = a;
+                second_lk = best_lk;
+                best_lk = c;
+            } else if (c > second_lk) {
+                second = a;
+                second_lk = c;
+            }
+        }
+        if (p.priority && (best_lk - second_lk) < p.threshold) {  // :507-536
+            const int32_t *pri = p.priority + h0;
+            int32_t best_pri = pri[best], second_pri = pri[second];
+            for (uint32_t a = 0; a < nh; ++a) {
+                const double c = v[a];
+                if (a == best || (best_lk - c) > p.threshold) continue;
+                const int32_t cp = pri[a];
+                if (cp > best_pri) {
+                    second = best;
+                    best = a;
+                    second_pri = best_pri;
+                    best_pri = cp;
+                } else if (cp > second_pri) {
+                    second = a;
+                    second_pri = cp;
+                }
+            }
+        }
+        best_lk = v[best];  // :538-543
+        second_lk = second != best ? v[second] : -INFINITY;
+        best_out = (int32_t)best;
+        lk_out = best_lk;
+        const double d = best_lk - second_lk;  // :1149-1153
+        conf_out = fabs(d) < 2.220446049250313e-16 ? 0.0 : d;
+    }
+    p.best_allele[r] = best_out;
+    p.likelihood[r] = lk_out;
+    p.confidence[r] = conf_out;
+    if (p.ref_index) p.ref_index[r] = best_out >= 0 ? h0 + (uint32_t)best_out : SW_NO_REFERENCE;
+}
+
+hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream) {
+    if (!p.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(phmm_best_alleles_kernel, dim3((p.n_reads + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream) {
     if (!p.n_reads) return hipSuccess;
     const int wpb = 4;

@@ -136,6 +136,21 @@ struct PostParams {
 };
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 hipError_t launch_post(const PostParams &p, hipStream_t stream);
+// best allele per read, ties by priority (AlleleLikelihoods::search_best_allele, allele_likelihoods.rs:457-554)
+constexpr uint32_t SW_NO_REFERENCE = 0xffffffffu;  // ref_index value: this alignment is skipped (evidence removed / no allele)
+struct BestParams {
+    uint32_t n_reads, n_regions;
+    const uint32_t *region_read_off, *region_hap_off;
+    const uint64_t *out_off;
+    const double *likelihoods;     // per region row-major [read][hap], as phmm_engine_compute returns them
+    const uint8_t *keep;           // [n_reads] or null: 0 = the evidence was removed, no best allele
+    const int32_t *priority;       // [n_haps] or null (no tie breaking)
+    double threshold;              // get_informative_threshold (:309-315)
+    int32_t *best_allele;          // [n_reads] index inside the region, -1 = none
+    double *likelihood, *confidence;
+    uint32_t *ref_index;           // [n_reads] or null: region_hap_off[g] + best, SW_NO_REFERENCE where there is none
+};
+hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream);
 
 // ---- Smith-Waterman (phmm_sw_kernels.hip) -------------------------------------------------------------------------
 constexpr int PHMM_SW_STRATEGY_SOFTCLIP = 0, PHMM_SW_STRATEGY_INDEL = 1, PHMM_SW_STRATEGY_LEADING_INDEL = 2,
@@ -144,7 +159,8 @@ constexpr uint32_t SW_STATUS_EMPTY = 1u;     // an empty reference or alternate 
 constexpr uint32_t SW_STATUS_CAPACITY = 2u;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
 struct SwParams {
     uint32_t a_begin, n_alignments;        // this launch aligns [a_begin, n_alignments)
-    const uint32_t *ref_off, *alt_off;     // [n_alignments + 1]
+    const uint32_t *ref_off, *alt_off;     // [references + 1], [n_alignments + 1]
+    const uint32_t *ref_index;             // [n_alignments] reference of each alignment (SW_NO_REFERENCE: skipped), or null: alignment a has reference a
     const uint8_t *ref_bases, *alt_bases;
     int32_t w_match, w_mismatch, w_open, w_extend;
     int strategy;

@@ -1,6 +1,9 @@
-// phmm_sw_align (include/phmm.h): host side of the Smith-Waterman aligner -- staging, worker geometry, status.
-// The alignment itself (matrix, backtrack, CIGAR) runs in phmm_sw_kernels.hip; there is no CPU path here.
+// phmm_sw_align / phmm_sw_align_indexed / phmm_best_alleles / phmm_realign_to_best (include/phmm.h): host side of the
+// Smith-Waterman aligner and of the best-allele step in front of it -- validation, staging, worker geometry, the
+// pipeline of pieces, status.  The work itself (matrix, backtrack, CIGAR: phmm_sw_kernels.hip; best allele:
+// phmm_engine_kernels.hip) runs on the device; there is no CPU path here.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <new>
@@ -33,246 +36,529 @@ bool ok(phmm_handle *h, hipError_t e, const char *what) {
     return false;
 }
 
+// The best-allele step (phmm_best_alleles, and in front of the alignments of phmm_realign_to_best).
+struct BestJob {
+    uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
+    const uint32_t *region_read_off = nullptr, *region_hap_off = nullptr;
+    const uint64_t *out_off = nullptr;
+    const double *likelihoods = nullptr;
+    const uint8_t *keep = nullptr;
+    const int32_t *priority = nullptr;
+    double threshold = 0.2;
+    int32_t *best_allele = nullptr;
+    double *likelihood = nullptr, *confidence = nullptr;
+};
+
+// One batch of alignments: alignment a pairs alternate sequence a with reference ref_index[a] (or a when there is no index;
+// or the best allele's haplotype when `best` runs in front).
+struct SwJob {
+    const char *who = "phmm_sw_align";
+    uint32_t n_alignments = 0, n_refs = 0;
+    const uint32_t *ref_off = nullptr, *alt_off = nullptr, *ref_index = nullptr;
+    const uint8_t *ref_bases = nullptr, *alt_bases = nullptr;
+    const phmm_sw_parameters *params = nullptr;
+    int strategy = 0;
+    const uint64_t *cigar_off = nullptr;
+    uint32_t *cigar = nullptr, *n_cigar = nullptr;
+    int32_t *alignment_offset = nullptr;
+    const BestJob *best = nullptr;
+};
+
+int fail(phmm_handle *h, const std::string &msg) {
+    h->err = msg;
+    return h->err_code = PHMM_ERR_INVALID_ARG;
+}
+
+int check_best(phmm_handle *h, const char *who, const BestJob &b) {
+    const std::string w(who);
+    if (!b.n_regions) return PHMM_OK;
+    if (!b.region_read_off || !b.region_hap_off || !b.out_off) return fail(h, w + ": null array");
+    if (b.region_read_off[0] != 0 || b.region_hap_off[0] != 0) return fail(h, w + ": offset arrays must start at 0");
+    for (uint32_t g = 0; g < b.n_regions; ++g) {
+        if (b.region_read_off[g + 1] < b.region_read_off[g] || b.region_hap_off[g + 1] < b.region_hap_off[g] || b.out_off[g + 1] < b.out_off[g])
+            return fail(h, w + ": offsets not monotonic");
+        const uint64_t need = (uint64_t)(b.region_read_off[g + 1] - b.region_read_off[g]) * (b.region_hap_off[g + 1] - b.region_hap_off[g]);
+        if (b.out_off[g + 1] - b.out_off[g] < need) return fail(h, w + ": out_off leaves too little room for a region's matrix");
+    }
+    if (b.n_reads && (!b.best_allele || !b.likelihood || !b.confidence || (b.out_off[b.n_regions] && !b.likelihoods)))
+        return fail(h, w + ": null array");
+    if (!(b.threshold >= 0.0)) return fail(h, w + ": the informative threshold must be a non-negative number");
+    return PHMM_OK;
+}
+
+// staging layout of the best-allele step inside a buffer, starting at `base`: inputs up to `best`, results up to `end`
+struct BestLayout {
+    size_t rro, rho, oo, lk, keep, pri, best, olk, conf, end;
+    BestLayout(const BestJob *b, size_t base) {
+        const size_t ng = b ? b->n_regions : 0, nr = b ? b->n_reads : 0, nh = b ? b->n_haps : 0, no = b && ng ? b->out_off[ng] : 0;
+        rro = base;
+        rho = rro + (b ? up256(4 * (ng + 1)) : 0);
+        oo = rho + (b ? up256(4 * (ng + 1)) : 0);
+        lk = oo + (b ? up256(8 * (ng + 1)) : 0);
+        keep = lk + up256(8 * no);
+        pri = keep + (b && b->keep ? up256(nr) : 0);
+        best = pri + (b && b->priority ? up256(4 * nh) : 0);
+        olk = best + up256(4 * nr);
+        conf = olk + up256(8 * nr);
+        end = conf + up256(8 * nr);
+    }
+};
+
+void stage_best(const BestJob &b, const BestLayout &L, char *host) {
+    memcpy(host + L.rro, b.region_read_off, 4ull * (b.n_regions + 1));
+    memcpy(host + L.rho, b.region_hap_off, 4ull * (b.n_regions + 1));
+    memcpy(host + L.oo, b.out_off, 8ull * (b.n_regions + 1));
+    if (b.out_off[b.n_regions]) memcpy(host + L.lk, b.likelihoods, 8ull * b.out_off[b.n_regions]);
+    if (b.keep) memcpy(host + L.keep, b.keep, b.n_reads);
+    if (b.priority) memcpy(host + L.pri, b.priority, 4ull * b.n_haps);
+}
+
+BestParams best_params(const BestJob &b, const BestLayout &L, char *dev, uint32_t *d_ref_index) {
+    BestParams p{};
+    p.n_reads = b.n_reads;
+    p.n_regions = b.n_regions;
+    p.region_read_off = (const uint32_t *)(dev + L.rro);
+    p.region_hap_off = (const uint32_t *)(dev + L.rho);
+    p.out_off = (const uint64_t *)(dev + L.oo);
+    p.likelihoods = (const double *)(dev + L.lk);
+    p.keep = b.keep ? (const uint8_t *)(dev + L.keep) : nullptr;
+    p.priority = b.priority ? (const int32_t *)(dev + L.pri) : nullptr;
+    p.threshold = b.threshold;
+    p.best_allele = (int32_t *)(dev + L.best);
+    p.likelihood = (double *)(dev + L.olk);
+    p.confidence = (double *)(dev + L.conf);
+    p.ref_index = d_ref_index;
+    return p;
+}
+
+bool grow_staging(phmm_handle *h, size_t total) {
+    phmm_handle::SwWork &W = h->swork;
+    if (W.cap >= total) return true;
+    for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(h->streams[i]);
+    if (W.dev) (void)hipFree(W.dev);
+    if (W.host) (void)hipHostFree(W.host);
+    W.dev = W.host = nullptr;
+    W.cap = 0;
+    const size_t cap = std::max<size_t>(total + total / 2, 1 << 20);
+    if (!ok(h, hipMalloc((void **)&W.dev, cap), "hipMalloc(sw staging)") ||
+        !ok(h, hipHostMalloc((void **)&W.host, cap, hipHostMallocDefault), "hipHostMalloc(sw staging)"))
+        return false;
+    W.cap = cap;
+    return true;
+}
+
+int sw_run(phmm_handle *h, const SwJob &J) {
+    const std::string who(J.who);
+    h->err_code = PHMM_OK;
+    const phmm_sw_parameters *params = J.params;
+    const uint32_t n_alignments = J.n_alignments, n_refs = J.n_refs;
+    const uint32_t *ref_off = J.ref_off, *alt_off = J.alt_off;
+    if (!params) return fail(h, who + ": null parameters");
+    if (J.strategy < PHMM_SW_SOFTCLIP || J.strategy > PHMM_SW_IGNORE) return fail(h, who + ": unknown overhang strategy");
+    if (J.best) {
+        const int st = check_best(h, J.who, *J.best);
+        if (st != PHMM_OK) return st;
+    }
+    if (!n_alignments) return PHMM_OK;
+    if (!ref_off || !alt_off || !J.cigar_off || !J.n_cigar || !J.alignment_offset) return fail(h, who + ": null array");
+    if (ref_off[0] != 0 || alt_off[0] != 0 || J.cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
+    if (!n_refs) return fail(h, who + ": no reference sequences");
+    uint32_t max_ref = 0, max_alt = 0;
+    for (uint32_t r = 0; r < n_refs; ++r) {
+        if (ref_off[r + 1] < ref_off[r]) return fail(h, who + ": offsets not monotonic");
+        // the reference asserts / panics on empty input (smith_waterman_aligner.rs:65-68, :132-134)
+        if (ref_off[r + 1] == ref_off[r]) return fail(h, who + ": non-empty sequences are required for the Smith-Waterman calculation");
+        max_ref = std::max(max_ref, ref_off[r + 1] - ref_off[r]);
+    }
+    for (uint32_t a = 0; a < n_alignments; ++a) {
+        if (alt_off[a + 1] < alt_off[a] || J.cigar_off[a + 1] < J.cigar_off[a]) return fail(h, who + ": offsets not monotonic");
+        if (alt_off[a + 1] == alt_off[a]) return fail(h, who + ": non-empty sequences are required for the Smith-Waterman calculation");
+        max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
+        if (J.ref_index && J.ref_index[a] != SW_NO_REFERENCE && J.ref_index[a] >= n_refs) return fail(h, who + ": reference index out of range");
+    }
+    {
+        // the kernel carries scores times four with a two-bit tag and leaves out the reference's clamp at -1e8
+        // (MATRIX_MIN_CUTOFF): both are exact as long as no score can get near that clamp
+        const int64_t big = std::max(std::max(std::llabs((long long)params->match_value), std::llabs((long long)params->mismatch_penalty)),
+                                     std::max(std::llabs((long long)params->gap_open_penalty), std::llabs((long long)params->gap_extend_penalty)));
+        if (big * ((int64_t)max_ref + max_alt + 2) >= 100000000)
+            return fail(h, who + ": parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e8)");
+    }
+    const size_t rb = ref_off[n_refs], ab = alt_off[n_alignments];
+    const uint64_t n_cig = J.cigar_off[n_alignments];
+    if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar)) return fail(h, who + ": null array");
+    const bool indexed = J.ref_index || J.best;  // references are shared: they all travel with the first piece
+
+    DevGuard dg(h->device);
+    // ---- geometry ---------------------------------------------------------------------------------------------
+    // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate
+    // sequence: eight lanes (eight alignments per wave, fewer steps lost to the skew and less per-step work per
+    // cell) while 8 x 20 columns suffice, sixteen beyond; more than 512 columns take several strips of 512
+    int L = 16, K = kSwK16[kNumSwK16 - 1];
+    const int force_L = h->sw.sw_lanes;
+    if (force_L != 16 && (max_alt <= 8 * 20 || force_L == 8)) {
+        L = 8;
+        K = kSwK8[kNumSwK8 - 1];
+        for (int i = kNumSwK8 - 1; i >= 0; --i)
+            if ((size_t)kSwK8[i] * 8 >= max_alt) K = kSwK8[i];
+    } else {
+        for (int i = kNumSwK16 - 1; i >= 0; --i)
+            if ((size_t)kSwK16[i] * 16 >= max_alt) K = kSwK16[i];
+    }
+    const size_t strip_cols = (size_t)L * K;
+    const size_t strips = (max_alt + strip_cols - 1) / strip_cols;
+    const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
+    // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
+    const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
+    // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
+    const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
+    const size_t lds = gpb * lds_group;
+    if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 8 000 bases each)");
+    // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
+    // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
+    int per_cu = sw_blocks_per_cu(L, K, lds);
+    if (per_cu <= 0) {
+        h->err = who + ": the kernel does not fit a compute unit";
+        return h->err_code = PHMM_ERR_INTERNAL;
+    }
+    if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
+    // backtrack flags per block: strips x (rows + L - 1) steps x 2 ceil(K / 16) dwords x 64 lanes (four bits per cell)
+    const size_t flag_words = 2 * (((size_t)K + 15) / 16);
+    const size_t slab_stride = strips * (size_t)(max_ref + L) * flag_words * 64;
+    const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
+    // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on
+    // one stream and share the slabs).  A piece is a whole number of rounds of the persistent blocks, so that only
+    // the last piece of a call ends on a partly filled round.
+    const size_t tasks = ((size_t)n_alignments + gpb - 1) / gpb, rounds = (tasks + max_workers - 1) / max_workers;
+    int n_chunks = 1;
+    if (h->sw.sw_chunks > 0)
+        n_chunks = h->sw.sw_chunks;
+    else if (rb + ab >= (8u << 20))
+        n_chunks = (int)std::min<size_t>(phmm_handle::SwWork::kMaxChunks, rounds);
+    n_chunks = std::max(1, std::min<int>({n_chunks, phmm_handle::SwWork::kMaxChunks, (int)n_alignments}));
+    uint32_t cut[phmm_handle::SwWork::kMaxChunks + 1];
+    cut[0] = 0;
+    if (h->sw.sw_chunks > 0) {
+        for (int c = 1; c < n_chunks; ++c) cut[c] = (uint32_t)((uint64_t)n_alignments * c / n_chunks);  // forced: equal shares, ragged
+    } else {
+        const size_t rounds_per_chunk = (rounds + n_chunks - 1) / n_chunks;
+        for (int c = 1; c < n_chunks; ++c)
+            cut[c] = (uint32_t)std::min<uint64_t>(n_alignments, (uint64_t)c * rounds_per_chunk * max_workers * gpb);
+    }
+    cut[n_chunks] = n_alignments;
+    size_t most = 0;
+    for (int c = 0; c < n_chunks; ++c) most = std::max<size_t>(most, cut[c + 1] - cut[c]);
+    const size_t slab_bytes = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * slab_stride * 4;
+    phmm_handle::SwWork &W = h->swork;
+    hipStream_t S = h->streams[0], S_in = h->streams[1];
+    if (W.slab_bytes < slab_bytes) {
+        (void)hipStreamSynchronize(S);
+        if (W.slab) (void)hipFree(W.slab);
+        W.slab = nullptr;
+        W.slab_bytes = 0;
+        if (!ok(h, hipMalloc((void **)&W.slab, slab_bytes), "hipMalloc(sw backtrack)")) return PHMM_ERR_HIP;
+        W.slab_bytes = slab_bytes;
+    }
+    // ---- staging: [status | ref_off | alt_off | cigar_off | ref_index | best-allele inputs, results | ref | alt] in,
+    //               [status | n_cigar | offsets | cigar] out
+    const size_t o_ro = 256, o_ao = o_ro + up256(4ull * (n_refs + 1)), o_co = o_ao + up256(4ull * (n_alignments + 1)),
+                 o_ri = o_co + up256(8ull * (n_alignments + 1)), o_bi = o_ri + (indexed ? up256(4ull * n_alignments) : 0);
+    const BestLayout BL(J.best, o_bi);
+    const size_t o_rb = J.best ? BL.end : o_bi, o_ab = o_rb + up256(rb), in_bytes = o_ab + up256(ab);
+    const size_t o_st = in_bytes, o_nc = o_st + 256, o_of = o_nc + up256(4ull * n_alignments),
+                 o_cg = o_of + up256(4ull * n_alignments), total = o_cg + up256(4ull * n_cig);
+    if (!grow_staging(h, total)) return PHMM_ERR_HIP;
+    for (int c = 0; c < n_chunks; ++c)
+        if (!W.ev_in[c] && (!ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate") ||
+                            !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate") ||
+                            !ok(h, hipEventCreate(&W.ev_k0[c]), "hipEventCreate") || !ok(h, hipEventCreate(&W.ev_k1[c]), "hipEventCreate")))
+            return PHMM_ERR_HIP;
+    SwParams p{};
+    p.ref_off = (const uint32_t *)(W.dev + o_ro);
+    p.alt_off = (const uint32_t *)(W.dev + o_ao);
+    p.cigar_off = (const uint64_t *)(W.dev + o_co);
+    p.ref_index = indexed ? (const uint32_t *)(W.dev + o_ri) : nullptr;
+    p.ref_bases = (const uint8_t *)(W.dev + o_rb);
+    p.alt_bases = (const uint8_t *)(W.dev + o_ab);
+    p.w_match = params->match_value;
+    p.w_mismatch = params->mismatch_penalty;
+    p.w_open = params->gap_open_penalty;
+    p.w_extend = params->gap_extend_penalty;
+    p.strategy = J.strategy;
+    p.cigar = (uint32_t *)(W.dev + o_cg);
+    p.n_cigar = (uint32_t *)(W.dev + o_nc);
+    p.alignment_offset = (int32_t *)(W.dev + o_of);
+    p.slab = W.slab;
+    p.slab_stride = slab_stride;
+    p.status = (uint32_t *)(W.dev + 64);
+    p.max_ref = max_ref;
+    p.max_alt = max_alt;
+    p.lds_ref_bytes = (uint32_t)lds_ref;
+    p.lds_alt_bytes = (uint32_t)lds_alt;
+    p.lds_group_bytes = (uint32_t)lds_group;
+    p.groups_per_block = (uint32_t)gpb;
+    // the offset arrays, the status word, the index and the best-allele inputs travel with the first piece -- and, when
+    // the references are shared (reads -> their haplotypes), all the references
+    memset(W.host, 0, 256);
+    memcpy(W.host + o_ro, ref_off, 4ull * (n_refs + 1));
+    memcpy(W.host + o_ao, alt_off, 4ull * (n_alignments + 1));
+    memcpy(W.host + o_co, J.cigar_off, 8ull * (n_alignments + 1));
+    if (J.ref_index) memcpy(W.host + o_ri, J.ref_index, 4ull * n_alignments);
+    size_t head = J.ref_index ? o_bi : o_ri;
+    if (J.best) {
+        stage_best(*J.best, BL, W.host);
+        head = BL.best;
+    }
+    bool good = ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
+    if (good && J.best)  // the reads' best alleles become the index of their references, on the device
+        good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
+    if (good && indexed) {
+        memcpy(W.host + o_rb, J.ref_bases, rb);
+        good = ok(h, hipMemcpyAsync(W.dev + o_rb, W.host + o_rb, rb, hipMemcpyHostToDevice, S_in), "H2D sw");
+    }
+    h->stat_staged_bytes += rb + ab;
+    for (int c = 0; c < n_chunks && good; ++c) {
+        const uint32_t a0 = cut[c], a1 = cut[c + 1];
+        const size_t q0 = alt_off[a0], q1 = alt_off[a1];
+        if (!indexed) {  // one reference per alignment: they travel piece by piece like the alternates
+            const size_t r0 = ref_off[a0], r1 = ref_off[a1];
+            memcpy(W.host + o_rb + r0, J.ref_bases + r0, r1 - r0);
+            good = r1 == r0 || ok(h, hipMemcpyAsync(W.dev + o_rb + r0, W.host + o_rb + r0, r1 - r0, hipMemcpyHostToDevice, S_in), "H2D sw");
+        }
+        memcpy(W.host + o_ab + q0, J.alt_bases + q0, q1 - q0);
+        good = good && (q1 == q0 || ok(h, hipMemcpyAsync(W.dev + o_ab + q0, W.host + o_ab + q0, q1 - q0, hipMemcpyHostToDevice, S_in), "H2D sw")) &&
+               ok(h, hipEventRecord(W.ev_in[c], S_in), "hipEventRecord") && ok(h, hipStreamWaitEvent(S, W.ev_in[c], 0), "hipStreamWaitEvent");
+        if (!good || a1 == a0) continue;
+        p.a_begin = a0;
+        p.n_alignments = a1;
+        const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
+        (void)hipEventRecord(W.ev_k0[c], S);
+        good = ok(h, launch_sw(L, K, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        (void)hipEventRecord(W.ev_k1[c], S);
+    }
+    // (while the device works) what the kernels store per alignment: (rows + L - 1) steps x L lanes x flag words per strip
+    W.last_backtrack_bytes = 0;
+    for (uint32_t a = 0; a < n_alignments; ++a) {
+        const uint32_t ri = J.ref_index ? J.ref_index[a] : a;
+        if (ri == SW_NO_REFERENCE) continue;
+        const uint64_t rows = J.best ? max_ref : ref_off[ri + 1] - ref_off[ri];  // (the device chooses the haplotype: an upper bound)
+        W.last_backtrack_bytes += (uint64_t)((alt_off[a + 1] - alt_off[a] + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * flag_words * 4ull;
+    }
+    // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
+    // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, DESIGN.md
+    // section 9), and is unpacked into the caller's arrays while the later pieces compute.
+    hipStream_t S_out = h->streams[2];
+    auto unpack = [&](int c) {
+        const uint32_t a0 = cut[c], a1 = cut[c + 1];
+        if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
+        memcpy(J.n_cigar + a0, W.host + o_nc + 4ull * a0, 4ull * (a1 - a0));
+        memcpy(J.alignment_offset + a0, W.host + o_of + 4ull * a0, 4ull * (a1 - a0));
+        if (J.cigar_off[a1] > J.cigar_off[a0])
+            memcpy(J.cigar + J.cigar_off[a0], W.host + o_cg + 4ull * J.cigar_off[a0], 4ull * (J.cigar_off[a1] - J.cigar_off[a0]));
+        return true;
+    };
+    int prev = -1;
+    bool best_fetched = false;
+    for (int c = 0; c < n_chunks && good; ++c) {
+        const uint32_t a0 = cut[c], a1 = cut[c + 1];
+        if (a1 == a0) continue;
+        const uint64_t g0 = J.cigar_off[a0], g1 = J.cigar_off[a1];
+        good = ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)") &&
+               ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
+               ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
+               (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw")) &&
+               ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord");
+        if (good && J.best && !best_fetched) {  // the best alleles were final before the first kernel started
+            good = ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S_out), "D2H best alleles");
+            best_fetched = true;
+        }
+        if (good && prev >= 0) good = unpack(prev);
+        prev = c;
+    }
+    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw");
+    if (good && prev >= 0) good = unpack(prev);
+    good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
+    if (!good) {
+        (void)hipStreamSynchronize(S_in);
+        (void)hipStreamSynchronize(S);
+        (void)hipStreamSynchronize(S_out);
+        return PHMM_ERR_HIP;
+    }
+    if (J.best) {
+        memcpy(J.best->best_allele, W.host + BL.best, 4ull * J.best->n_reads);
+        memcpy(J.best->likelihood, W.host + BL.olk, 8ull * J.best->n_reads);
+        memcpy(J.best->confidence, W.host + BL.conf, 8ull * J.best->n_reads);
+    }
+    W.last_kernel_us = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        float ms = 0.f;
+        if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
+    }
+    const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0] status; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
+    W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
+    if (st[0] & SW_STATUS_CAPACITY) {
+        h->err = who + ": a CIGAR needs more elements than its slot holds (n_cigar has the sizes)";
+        return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
+    }
+    return PHMM_OK;
+}
+
+template <class F>
+int guarded(phmm_handle *h, const char *who, F &&body) {
+    if (!h) return PHMM_ERR_INVALID_ARG;
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        h->err = std::string(who) + ": out of host memory";
+        return h->err_code = PHMM_ERR_NO_MEMORY;
+    } catch (const std::exception &e) {
+        h->err = std::string(who) + ": " + e.what();
+        return h->err_code = PHMM_ERR_INTERNAL;
+    }
+}
+
 }  // namespace
 
 extern "C" int phmm_sw_align(phmm_handle *h, uint32_t n_alignments, const uint32_t *ref_off, const uint8_t *ref_bases,
                              const uint32_t *alt_off, const uint8_t *alt_bases, const phmm_sw_parameters *params,
                              int overhang_strategy, const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar,
                              int32_t *alignment_offset) {
-    if (!h) return PHMM_ERR_INVALID_ARG;
-    try {
-        h->err_code = PHMM_OK;
-        auto fail = [&](const char *msg) {
-            h->err = msg;
-            return h->err_code = PHMM_ERR_INVALID_ARG;
-        };
-        if (!params) return fail("phmm_sw_align: null parameters");
-        if (overhang_strategy < PHMM_SW_SOFTCLIP || overhang_strategy > PHMM_SW_IGNORE)
-            return fail("phmm_sw_align: unknown overhang strategy");
-        if (!n_alignments) return PHMM_OK;
-        if (!ref_off || !alt_off || !cigar_off || !n_cigar || !alignment_offset) return fail("phmm_sw_align: null array");
-        if (ref_off[0] != 0 || alt_off[0] != 0 || cigar_off[0] != 0) return fail("phmm_sw_align: offset arrays must start at 0");
-        uint32_t max_ref = 0, max_alt = 0;
-        for (uint32_t a = 0; a < n_alignments; ++a) {
-            if (ref_off[a + 1] < ref_off[a] || alt_off[a + 1] < alt_off[a] || cigar_off[a + 1] < cigar_off[a])
-                return fail("phmm_sw_align: offsets not monotonic");
-            // the reference asserts / panics on empty input (smith_waterman_aligner.rs:65-68, :132-134)
-            if (ref_off[a + 1] == ref_off[a] || alt_off[a + 1] == alt_off[a])
-                return fail("phmm_sw_align: non-empty sequences are required for the Smith-Waterman calculation");
-            max_ref = std::max(max_ref, ref_off[a + 1] - ref_off[a]);
-            max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
-        }
-        {
-            // the kernel carries scores times four with a two-bit tag and leaves out the reference's clamp at -1e8
-            // (MATRIX_MIN_CUTOFF): both are exact as long as no score can get near that clamp
-            const int64_t big = std::max(std::max(std::llabs((long long)params->match_value), std::llabs((long long)params->mismatch_penalty)),
-                                         std::max(std::llabs((long long)params->gap_open_penalty), std::llabs((long long)params->gap_extend_penalty)));
-            if (big * ((int64_t)max_ref + max_alt + 2) >= 100000000)
-                return fail("phmm_sw_align: parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e8)");
-        }
-        const size_t rb = ref_off[n_alignments], ab = alt_off[n_alignments];
-        const uint64_t n_cig = cigar_off[n_alignments];
-        if (!ref_bases || !alt_bases || (n_cig && !cigar)) return fail("phmm_sw_align: null array");
+    return guarded(h, "phmm_sw_align", [&]() -> int {
+        SwJob J;
+        J.n_alignments = J.n_refs = n_alignments;
+        J.ref_off = ref_off;
+        J.ref_bases = ref_bases;
+        J.alt_off = alt_off;
+        J.alt_bases = alt_bases;
+        J.params = params;
+        J.strategy = overhang_strategy;
+        J.cigar_off = cigar_off;
+        J.cigar = cigar;
+        J.n_cigar = n_cigar;
+        J.alignment_offset = alignment_offset;
+        return sw_run(h, J);
+    });
+}
 
+extern "C" int phmm_sw_align_indexed(phmm_handle *h, uint32_t n_references, const uint32_t *ref_off, const uint8_t *ref_bases,
+                                     uint32_t n_alignments, const uint32_t *ref_index, const uint32_t *alt_off,
+                                     const uint8_t *alt_bases, const phmm_sw_parameters *params, int overhang_strategy,
+                                     const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *alignment_offset) {
+    return guarded(h, "phmm_sw_align_indexed", [&]() -> int {
+        if (n_alignments && !ref_index) return fail(h, "phmm_sw_align_indexed: null array");
+        SwJob J;
+        J.who = "phmm_sw_align_indexed";
+        J.n_alignments = n_alignments;
+        J.n_refs = n_references;
+        J.ref_off = ref_off;
+        J.ref_bases = ref_bases;
+        J.ref_index = ref_index;
+        J.alt_off = alt_off;
+        J.alt_bases = alt_bases;
+        J.params = params;
+        J.strategy = overhang_strategy;
+        J.cigar_off = cigar_off;
+        J.cigar = cigar;
+        J.n_cigar = n_cigar;
+        J.alignment_offset = alignment_offset;
+        return sw_run(h, J);
+    });
+}
+
+extern "C" int phmm_best_alleles(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                                 const uint32_t *region_hap_off, const uint64_t *out_off, const double *likelihoods,
+                                 const uint8_t *keep, const int32_t *hap_priority, double informative_threshold,
+                                 int32_t *best_allele, double *likelihood, double *confidence) {
+    return guarded(h, "phmm_best_alleles", [&]() -> int {
+        h->err_code = PHMM_OK;
+        BestJob B;
+        B.n_regions = n_regions;
+        B.region_read_off = region_read_off;
+        B.region_hap_off = region_hap_off;
+        B.out_off = out_off;
+        B.likelihoods = likelihoods;
+        B.keep = keep;
+        B.priority = hap_priority;
+        B.threshold = informative_threshold;
+        B.best_allele = best_allele;
+        B.likelihood = likelihood;
+        B.confidence = confidence;
+        if (n_regions && region_read_off && region_hap_off) {
+            B.n_reads = region_read_off[n_regions];
+            B.n_haps = region_hap_off[n_regions];
+        }
+        const int st = check_best(h, "phmm_best_alleles", B);
+        if (st != PHMM_OK || !n_regions || !B.n_reads) return st;
         DevGuard dg(h->device);
-        // ---- geometry ---------------------------------------------------------------------------------------------
-        // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate
-        // sequence: eight lanes (eight alignments per wave, fewer steps lost to the skew and less per-step work per
-        // cell) while 8 x 20 columns suffice, sixteen beyond; more than 512 columns take several strips of 512
-        int L = 16, K = kSwK16[kNumSwK16 - 1];
-        const int force_L = h->sw.sw_lanes;
-        if (force_L != 16 && (max_alt <= 8 * 20 || force_L == 8)) {
-            L = 8;
-            K = kSwK8[kNumSwK8 - 1];
-            for (int i = kNumSwK8 - 1; i >= 0; --i)
-                if ((size_t)kSwK8[i] * 8 >= max_alt) K = kSwK8[i];
-        } else {
-            for (int i = kNumSwK16 - 1; i >= 0; --i)
-                if ((size_t)kSwK16[i] * 16 >= max_alt) K = kSwK16[i];
-        }
-        const size_t strip_cols = (size_t)L * K;
-        const size_t strips = (max_alt + strip_cols - 1) / strip_cols;
-        const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
-        // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
-        const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
-        // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
-        const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
-        const size_t lds = gpb * lds_group;
-        if (lds > 160 * 1024) return fail("phmm_sw_align: sequences too long for the LDS staging (about 8 000 bases each)");
-        // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
-        // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
-        int per_cu = sw_blocks_per_cu(L, K, lds);
-        if (per_cu <= 0) {
-            h->err = "phmm_sw_align: the kernel does not fit a compute unit";
-            return h->err_code = PHMM_ERR_INTERNAL;
-        }
-        if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
-        // backtrack flags per block: strips x (rows + L - 1) steps x 2 ceil(K / 16) dwords x 64 lanes (four bits per cell)
-        const size_t flag_words = 2 * (((size_t)K + 15) / 16);
-        const size_t slab_stride = strips * (size_t)(max_ref + L) * flag_words * 64;
-        const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
-        // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on
-        // one stream and share the slabs).  A piece is a whole number of rounds of the persistent blocks, so that only
-        // the last piece of a call ends on a partly filled round.
-        const size_t tasks = ((size_t)n_alignments + gpb - 1) / gpb, rounds = (tasks + max_workers - 1) / max_workers;
-        int n_chunks = 1;
-        if (h->sw.sw_chunks > 0)
-            n_chunks = h->sw.sw_chunks;
-        else if (rb + ab >= (8u << 20))
-            n_chunks = (int)std::min<size_t>(phmm_handle::SwWork::kMaxChunks, rounds);
-        n_chunks = std::max(1, std::min<int>({n_chunks, phmm_handle::SwWork::kMaxChunks, (int)n_alignments}));
-        uint32_t cut[phmm_handle::SwWork::kMaxChunks + 1];
-        cut[0] = 0;
-        if (h->sw.sw_chunks > 0) {
-            for (int c = 1; c < n_chunks; ++c) cut[c] = (uint32_t)((uint64_t)n_alignments * c / n_chunks);  // forced: equal shares, ragged
-        } else {
-            const size_t rounds_per_chunk = (rounds + n_chunks - 1) / n_chunks;
-            for (int c = 1; c < n_chunks; ++c)
-                cut[c] = (uint32_t)std::min<uint64_t>(n_alignments, (uint64_t)c * rounds_per_chunk * max_workers * gpb);
-        }
-        cut[n_chunks] = n_alignments;
-        size_t most = 0;
-        for (int c = 0; c < n_chunks; ++c) most = std::max<size_t>(most, cut[c + 1] - cut[c]);
-        const size_t slab_bytes = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * slab_stride * 4;
+        const BestLayout BL(&B, 0);
+        if (!grow_staging(h, BL.end)) return PHMM_ERR_HIP;
         phmm_handle::SwWork &W = h->swork;
-        hipStream_t S = h->streams[0], S_in = h->streams[1];
-        if (W.slab_bytes < slab_bytes) {
-            (void)hipStreamSynchronize(S);
-            if (W.slab) (void)hipFree(W.slab);
-            W.slab = nullptr;
-            W.slab_bytes = 0;
-            if (!ok(h, hipMalloc((void **)&W.slab, slab_bytes), "hipMalloc(sw backtrack)")) return PHMM_ERR_HIP;
-            W.slab_bytes = slab_bytes;
-        }
-        // ---- staging: [status | ref_off | alt_off | cigar_off | ref | alt] in, [status | n_cigar | offsets | cigar] out
-        const size_t o_ro = 256, o_ao = o_ro + up256(4ull * (n_alignments + 1)), o_co = o_ao + up256(4ull * (n_alignments + 1)),
-                     o_rb = o_co + up256(8ull * (n_alignments + 1)), o_ab = o_rb + up256(rb), in_bytes = o_ab + up256(ab);
-        const size_t o_st = in_bytes, o_nc = o_st + 256, o_of = o_nc + up256(4ull * n_alignments),
-                     o_cg = o_of + up256(4ull * n_alignments), total = o_cg + up256(4ull * n_cig);
-        if (W.cap < total) {
-            (void)hipStreamSynchronize(S);
-            (void)hipStreamSynchronize(S_in);
-            if (W.dev) (void)hipFree(W.dev);
-            if (W.host) (void)hipHostFree(W.host);
-            W.dev = W.host = nullptr;
-            W.cap = 0;
-            const size_t cap = std::max<size_t>(total + total / 2, 1 << 20);
-            if (!ok(h, hipMalloc((void **)&W.dev, cap), "hipMalloc(sw staging)") ||
-                !ok(h, hipHostMalloc((void **)&W.host, cap, hipHostMallocDefault), "hipHostMalloc(sw staging)"))
-                return PHMM_ERR_HIP;
-            W.cap = cap;
-        }
-        for (int c = 0; c < n_chunks; ++c)
-            if (!W.ev_in[c] && (!ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate") ||
-                                !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate") ||
-                                !ok(h, hipEventCreate(&W.ev_k0[c]), "hipEventCreate") || !ok(h, hipEventCreate(&W.ev_k1[c]), "hipEventCreate")))
-                return PHMM_ERR_HIP;
-        SwParams p{};
-        p.ref_off = (const uint32_t *)(W.dev + o_ro);
-        p.alt_off = (const uint32_t *)(W.dev + o_ao);
-        p.cigar_off = (const uint64_t *)(W.dev + o_co);
-        p.ref_bases = (const uint8_t *)(W.dev + o_rb);
-        p.alt_bases = (const uint8_t *)(W.dev + o_ab);
-        p.w_match = params->match_value;
-        p.w_mismatch = params->mismatch_penalty;
-        p.w_open = params->gap_open_penalty;
-        p.w_extend = params->gap_extend_penalty;
-        p.strategy = overhang_strategy;
-        p.cigar = (uint32_t *)(W.dev + o_cg);
-        p.n_cigar = (uint32_t *)(W.dev + o_nc);
-        p.alignment_offset = (int32_t *)(W.dev + o_of);
-        p.slab = W.slab;
-        p.slab_stride = slab_stride;
-        p.status = (uint32_t *)(W.dev + 64);
-        p.max_ref = max_ref;
-        p.max_alt = max_alt;
-        p.lds_ref_bytes = (uint32_t)lds_ref;
-        p.lds_alt_bytes = (uint32_t)lds_alt;
-        p.lds_group_bytes = (uint32_t)lds_group;
-        p.groups_per_block = (uint32_t)gpb;
-        // the offset arrays and the status word travel with the first piece
-        memset(W.host, 0, 256);
-        memcpy(W.host + o_ro, ref_off, 4ull * (n_alignments + 1));
-        memcpy(W.host + o_ao, alt_off, 4ull * (n_alignments + 1));
-        memcpy(W.host + o_co, cigar_off, 8ull * (n_alignments + 1));
-        if (!ok(h, hipMemcpyAsync(W.dev, W.host, o_rb, hipMemcpyHostToDevice, S_in), "H2D sw")) return PHMM_ERR_HIP;
-        h->stat_staged_bytes += rb + ab;
-        bool good = true;
-        for (int c = 0; c < n_chunks && good; ++c) {
-            const uint32_t a0 = cut[c], a1 = cut[c + 1];
-            const size_t r0 = ref_off[a0], r1 = ref_off[a1], q0 = alt_off[a0], q1 = alt_off[a1];
-            memcpy(W.host + o_rb + r0, ref_bases + r0, r1 - r0);
-            memcpy(W.host + o_ab + q0, alt_bases + q0, q1 - q0);
-            good = (r1 == r0 || ok(h, hipMemcpyAsync(W.dev + o_rb + r0, W.host + o_rb + r0, r1 - r0, hipMemcpyHostToDevice, S_in), "H2D sw")) &&
-                   (q1 == q0 || ok(h, hipMemcpyAsync(W.dev + o_ab + q0, W.host + o_ab + q0, q1 - q0, hipMemcpyHostToDevice, S_in), "H2D sw")) &&
-                   ok(h, hipEventRecord(W.ev_in[c], S_in), "hipEventRecord") && ok(h, hipStreamWaitEvent(S, W.ev_in[c], 0), "hipStreamWaitEvent");
-            if (!good || a1 == a0) continue;
-            p.a_begin = a0;
-            p.n_alignments = a1;
-            const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
-            (void)hipEventRecord(W.ev_k0[c], S);
-            good = ok(h, launch_sw(L, K, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
-            (void)hipEventRecord(W.ev_k1[c], S);
-        }
-        // (while the device works) what the kernels store per alignment: (rows + L - 1) steps x L lanes x flag words per strip
-        W.last_backtrack_bytes = 0;
-        for (uint32_t a = 0; a < n_alignments; ++a)
-            W.last_backtrack_bytes += (uint64_t)((alt_off[a + 1] - alt_off[a] + strip_cols - 1) / strip_cols) *
-                                      (ref_off[a + 1] - ref_off[a] + L - 1ull) * L * flag_words * 4ull;
-        // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
-        // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, DESIGN.md
-        // section 9), and is unpacked into the caller's arrays while the later pieces compute.
-        hipStream_t S_out = h->streams[2];
-        auto unpack = [&](int c) {
-            const uint32_t a0 = cut[c], a1 = cut[c + 1];
-            if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
-            memcpy(n_cigar + a0, W.host + o_nc + 4ull * a0, 4ull * (a1 - a0));
-            memcpy(alignment_offset + a0, W.host + o_of + 4ull * a0, 4ull * (a1 - a0));
-            if (cigar_off[a1] > cigar_off[a0]) memcpy(cigar + cigar_off[a0], W.host + o_cg + 4ull * cigar_off[a0], 4ull * (cigar_off[a1] - cigar_off[a0]));
-            return true;
-        };
-        int prev = -1;
-        for (int c = 0; c < n_chunks && good; ++c) {
-            const uint32_t a0 = cut[c], a1 = cut[c + 1];
-            if (a1 == a0) continue;
-            const uint64_t g0 = cigar_off[a0], g1 = cigar_off[a1];
-            good = ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)") &&
-                   ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
-                   ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
-                   (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw")) &&
-                   ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord");
-            if (good && prev >= 0) good = unpack(prev);
-            prev = c;
-        }
-        good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw");
-        if (good && prev >= 0) good = unpack(prev);
-        good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
-        if (!good) {
-            (void)hipStreamSynchronize(S_in);
-            (void)hipStreamSynchronize(S);
-            (void)hipStreamSynchronize(S_out);
+        hipStream_t S = h->streams[0];
+        stage_best(B, BL, W.host);
+        if (!ok(h, hipMemcpyAsync(W.dev, W.host, BL.best, hipMemcpyHostToDevice, S), "H2D best alleles") ||
+            !ok(h, launch_best_alleles(best_params(B, BL, W.dev, nullptr), S), "phmm_best_alleles_kernel") ||
+            !ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S), "D2H best alleles") ||
+            !ok(h, hipStreamSynchronize(S), "sync(best alleles)"))
             return PHMM_ERR_HIP;
-        }
-        W.last_kernel_us = 0;
-        for (int c = 0; c < n_chunks; ++c) {
-            float ms = 0.f;
-            if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
-        }
-        {
-            const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
-            W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
-        }
-        const uint32_t st = *(const uint32_t *)(W.host + o_st + 64);
-        if (st & SW_STATUS_CAPACITY) {
-            h->err = "phmm_sw_align: a CIGAR needs more elements than its slot holds (n_cigar has the sizes)";
-            return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
-        }
+        memcpy(best_allele, W.host + BL.best, 4ull * B.n_reads);
+        memcpy(likelihood, W.host + BL.olk, 8ull * B.n_reads);
+        memcpy(confidence, W.host + BL.conf, 8ull * B.n_reads);
         return PHMM_OK;
-    } catch (const std::bad_alloc &) {
-        h->err = "phmm_sw_align: out of host memory";
-        return h->err_code = PHMM_ERR_NO_MEMORY;
-    } catch (const std::exception &e) {
-        h->err = std::string("phmm_sw_align: ") + e.what();
-        return h->err_code = PHMM_ERR_INTERNAL;
-    }
+    });
+}
+
+extern "C" int phmm_realign_to_best(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
+                                    const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases,
+                                    const uint32_t *hap_off, const uint8_t *hap_bases, const uint64_t *out_off,
+                                    const double *likelihoods, const uint8_t *keep, const int32_t *hap_priority,
+                                    double informative_threshold, const phmm_sw_parameters *params, int overhang_strategy,
+                                    const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *alignment_offset,
+                                    int32_t *best_allele, double *likelihood, double *confidence) {
+    return guarded(h, "phmm_realign_to_best", [&]() -> int {
+        if (n_regions && (!region_read_off || !region_hap_off)) return fail(h, "phmm_realign_to_best: null array");
+        BestJob B;
+        B.n_regions = n_regions;
+        B.region_read_off = region_read_off;
+        B.region_hap_off = region_hap_off;
+        B.out_off = out_off;
+        B.likelihoods = likelihoods;
+        B.keep = keep;
+        B.priority = hap_priority;
+        B.threshold = informative_threshold;
+        B.best_allele = best_allele;
+        B.likelihood = likelihood;
+        B.confidence = confidence;
+        B.n_reads = n_regions ? region_read_off[n_regions] : 0;
+        B.n_haps = n_regions ? region_hap_off[n_regions] : 0;
+        SwJob J;
+        J.who = "phmm_realign_to_best";
+        J.n_alignments = B.n_reads;
+        J.n_refs = B.n_haps;
+        J.ref_off = hap_off;
+        J.ref_bases = hap_bases;
+        J.alt_off = read_off;
+        J.alt_bases = read_bases;
+        J.params = params;
+        J.strategy = overhang_strategy;
+        J.cigar_off = cigar_off;
+        J.cigar = cigar;
+        J.n_cigar = n_cigar;
+        J.alignment_offset = alignment_offset;
+        J.best = &B;
+        if (B.n_reads && !B.n_haps) {  // no alleles at all: search_best_allele's None for every read (:465-475), nothing to align
+            h->err_code = PHMM_OK;
+            const int st = check_best(h, J.who, B);
+            if (st != PHMM_OK) return st;
+            if (!n_cigar || !alignment_offset) return fail(h, "phmm_realign_to_best: null array");
+            for (uint32_t r = 0; r < B.n_reads; ++r) {
+                best_allele[r] = -1;
+                likelihood[r] = -HUGE_VAL;
+                confidence[r] = std::nan("");
+                n_cigar[r] = 0;
+                alignment_offset[r] = 0;
+            }
+            return PHMM_OK;
+        }
+        return sw_run(h, J);
+    });
 }

@@ -118,14 +118,23 @@ void phmm_sw_align_kernel(const SwParams p) {
     const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
     for (uint32_t base = p.a_begin + blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
         const uint32_t a = base + (uint32_t)g;
-        const bool valid = (uint32_t)g < gpb && a < p.n_alignments;
+        bool valid = (uint32_t)g < gpb && a < p.n_alignments;
         uint32_t ro = 0, ao = 0;
         int n = 0, m = 0;
         if (valid) {
-            ro = p.ref_off[a];
-            ao = p.alt_off[a];
-            n = (int)(p.ref_off[a + 1] - ro);
-            m = (int)(p.alt_off[a + 1] - ao);
+            const uint32_t ri = p.ref_index ? p.ref_index[a] : a;  // reads name their haplotype; pairs come one to one
+            if (ri == SW_NO_REFERENCE) {  // nothing to align (evidence removed / no allele): an empty CIGAR
+                if (l == 0) {
+                    p.n_cigar[a] = 0;
+                    p.alignment_offset[a] = 0;
+                }
+                valid = false;
+            } else {
+                ro = p.ref_off[ri];
+                ao = p.alt_off[a];
+                n = (int)(p.ref_off[ri + 1] - ro);
+                m = (int)(p.alt_off[a + 1] - ao);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         for (int k = l; k < n; k += SW_L) s_ref[k] = p.ref_bases[ro + k];

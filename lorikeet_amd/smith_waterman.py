@@ -81,15 +81,24 @@ class SmithWatermanAligner:
     def align_batch(self, pairs, parameters, overhang_strategy, capacity=None):
         """pairs: iterable of (reference, alternate).  capacity: CIGAR elements reserved per alignment (default 24;
         alignments that need more are redone with what they need -- the library reports the size)."""
-        refs = [_u8(r) for r, _ in pairs]
-        alts = [_u8(a) for _, a in pairs]
-        for r, a in zip(refs, alts):  # smith_waterman_aligner.rs:65-68
-            if len(r) == 0 or len(a) == 0:
+        pairs = list(pairs)
+        return self.align_indexed([r for r, _ in pairs], [a for _, a in pairs], None, parameters, overhang_strategy, capacity)
+
+    def align_indexed(self, references, alternates, ref_index, parameters, overhang_strategy, capacity=None):
+        """alternates[a] against references[ref_index[a]] (phmm_sw_align_indexed: shared references cross the bus once);
+        ref_index None = one reference per alternate; an index of -1 skips the alignment (None in the result)."""
+        refs = [_u8(r) for r in references]
+        alts = [_u8(a) for a in alternates]
+        for r in refs + alts:  # smith_waterman_aligner.rs:65-68
+            if len(r) == 0:
                 raise AssertionError("non-empty sequences are required for the Smith-Waterman calculation")
         st = OverhangStrategy.NAMES[overhang_strategy] if isinstance(overhang_strategy, str) else int(overhang_strategy)
-        n = len(refs)
+        n = len(alts)
         if n == 0:
             return []
+        idx = None
+        if ref_index is not None:
+            idx = np.where(np.asarray(ref_index, np.int64) < 0, _lib.PHMM_SW_NO_REFERENCE, np.asarray(ref_index, np.int64)).astype(np.uint32)
         ref_off = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint32)
         alt_off = np.concatenate([[0], np.cumsum([len(a) for a in alts])]).astype(np.uint32)
         rb, ab = np.ascontiguousarray(np.concatenate(refs)), np.ascontiguousarray(np.concatenate(alts))
@@ -101,14 +110,19 @@ class SmithWatermanAligner:
             cigar = np.zeros(int(cig_off[-1]), np.uint32)
             n_cig = np.zeros(n, np.uint32)
             off = np.zeros(n, np.int32)
-            code = eng.lib.phmm_sw_align(eng._h, n, ref_off.ctypes.data_as(_lib.u32p), rb.ctypes.data_as(_lib.u8p),
-                                         alt_off.ctypes.data_as(_lib.u32p), ab.ctypes.data_as(_lib.u8p), C.byref(prm), st,
-                                         cig_off.ctypes.data_as(_lib.u64p), cigar.ctypes.data_as(_lib.u32p),
-                                         n_cig.ctypes.data_as(_lib.u32p), off.ctypes.data_as(C.POINTER(C.c_int32)))
+            tail = (alt_off.ctypes.data_as(_lib.u32p), ab.ctypes.data_as(_lib.u8p), C.byref(prm), st,
+                    cig_off.ctypes.data_as(_lib.u64p), cigar.ctypes.data_as(_lib.u32p), n_cig.ctypes.data_as(_lib.u32p),
+                    off.ctypes.data_as(C.POINTER(C.c_int32)))
+            if idx is None:
+                code = eng.lib.phmm_sw_align(eng._h, n, ref_off.ctypes.data_as(_lib.u32p), rb.ctypes.data_as(_lib.u8p), *tail)
+            else:
+                code = eng.lib.phmm_sw_align_indexed(eng._h, len(refs), ref_off.ctypes.data_as(_lib.u32p), rb.ctypes.data_as(_lib.u8p), n,
+                                                     idx.ctypes.data_as(_lib.u32p), *tail)
             if code == _lib.PHMM_ERR_CIGAR_CAPACITY:
                 cap = np.maximum(cap, n_cig.astype(np.int64))
                 continue
             if code != _lib.PHMM_OK:
                 raise PhmmError(code, eng.last_error())
-            return [SmithWatermanAlignmentResult(cigar[int(cig_off[a]):int(cig_off[a]) + int(n_cig[a])], off[a]) for a in range(n)]
+            return [None if idx is not None and idx[a] == _lib.PHMM_SW_NO_REFERENCE else
+                    SmithWatermanAlignmentResult(cigar[int(cig_off[a]):int(cig_off[a]) + int(n_cig[a])], off[a]) for a in range(n)]
         raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, eng.last_error())

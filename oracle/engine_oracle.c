@@ -260,3 +260,60 @@ ORACLE_API size_t oracle_filter_poorly_modeled_evidence(double *values, size_t n
             for (size_t r = kept; r < n_reads; ++r) values[a * n_reads + r] = NAN;
     return kept;
 }
+
+/* ---- AlleleLikelihoods::search_best_allele (src/model/allele_likelihoods.rs:457-554) with BestAllele::new (:1142-1160),
+ * as best_alleles_tie_breaking calls it (:1069-1095): can_be_reference = true, priorities present.  `values` is the
+ * reference's [allele][evidence] matrix of one sample, `priorities` one i32 per allele (NULL = the `None` arm, no tie
+ * breaking), `threshold` get_informative_threshold (:309-315; 0.2 for log10 likelihoods, :17).  One result per unit of
+ * evidence: allele index (-1 = None: no alleles), likelihood, confidence. */
+ORACLE_API void oracle_best_alleles(const double *values, size_t n_alleles, size_t n_reads, const int32_t *priorities,
+                                    double threshold, int32_t *best_allele, double *likelihood, double *confidence) {
+#define V(a, r) values[(a) * n_reads + (r)]
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (n_alleles == 0) { /* :465-475 */
+            best_allele[r] = -1;
+            likelihood[r] = -INFINITY;
+            /* BestAllele::new(-inf, -inf): (-inf) - (-inf) is NaN, NaN.abs() < EPSILON is false, so confidence = NaN */
+            confidence[r] = (-INFINITY) - (-INFINITY);
+            continue;
+        }
+        size_t best = 0, second = 0; /* :479-488, can_be_reference */
+        double best_lk = V(0, r), second_lk = -INFINITY;
+        for (size_t a = best + 1; a < n_alleles; ++a) { /* :490-505 */
+            const double c = V(a, r);
+            if (c > best_lk) {
+                second = best;
+                best = a;
+                second_lk = best_lk;
+                best_lk = c;
+            } else if (c > second_lk) {
+                second = a;
+                second_lk = c;
+            }
+        }
+        if (priorities && (best_lk - second_lk) < threshold) { /* :507-536 */
+            int32_t best_pri = priorities[best], second_pri = priorities[second];
+            for (size_t a = 0; a < n_alleles; ++a) {
+                const double c = V(a, r);
+                if (a == best || (best_lk - c) > threshold) continue;
+                const int32_t cp = priorities[a];
+                if (cp > best_pri) {
+                    second = best;
+                    best = a;
+                    second_pri = best_pri;
+                    best_pri = cp;
+                } else if (cp > second_pri) {
+                    second = a;
+                    second_pri = cp;
+                }
+            }
+        }
+        best_lk = V(best, r); /* :538-543 */
+        second_lk = second != best ? V(second, r) : -INFINITY;
+        best_allele[r] = (int32_t)best;
+        likelihood[r] = best_lk;
+        const double d = best_lk - second_lk; /* :1149-1153 */
+        confidence[r] = fabs(d) < 2.220446049250313e-16 ? 0.0 : d;
+    }
+#undef V
+}

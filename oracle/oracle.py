@@ -77,6 +77,8 @@ def _load(path):
     lib.oracle_normalize_likelihoods.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_long]
     lib.oracle_filter_poorly_modeled_evidence.restype = C.c_size_t
     lib.oracle_filter_poorly_modeled_evidence.argtypes = [_f64p, C.c_size_t, C.c_size_t, _f64p, _u8p]
+    lib.oracle_best_alleles.restype = None
+    lib.oracle_best_alleles.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.c_double, C.POINTER(C.c_int32), _f64p, _f64p]
     return lib
 
 
@@ -270,3 +272,15 @@ def sw_align(reference, alternate, params, strategy):
     if n < 0:
         raise AssertionError("non-empty sequences are required for the Smith-Waterman calculation")
     return cig[:n].copy(), int(off.value)
+
+
+def best_alleles(values, priorities=None, threshold=0.2):
+    """AlleleLikelihoods::best_alleles_tie_breaking for one sample (src/model/allele_likelihoods.rs:457-554, :1069-1095):
+    `values` [allele, read] -> (best allele index per read, its likelihood, confidence)."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    na, nr = v.shape
+    pri = None if priorities is None else np.ascontiguousarray(priorities, dtype=np.int32)
+    best, lk, conf = np.zeros(nr, np.int32), np.zeros(nr), np.zeros(nr)
+    lib().oracle_best_alleles(v.ctypes.data_as(_f64p), na, nr, None if pri is None else pri.ctypes.data_as(C.POINTER(C.c_int32)),
+                              threshold, best.ctypes.data_as(C.POINTER(C.c_int32)), lk.ctypes.data_as(_f64p), conf.ctypes.data_as(_f64p))
+    return best, lk, conf

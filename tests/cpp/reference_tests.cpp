@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <fstream>
 #include <functional>
+#include <random>
 #include <sstream>
 #include <thread>
 
@@ -498,6 +499,79 @@ static void test_for_identical_alignments_with_differing_flank_lengths() {  // :
            bare.get_cigar().c_str());
 }
 
+// tests/allele_likelihoods_unit_tests.rs:250-365 (test_best_alleles): random likelihoods, the reference allele has priority
+// 1 and the others 0 -- the best allele is the arg-max unless the reference is within 0.2 of it, then the reference; its
+// likelihood and confidence follow.  Then the realignment step on top (assembly_based_caller_utils.rs:208-246): reads cut
+// out of their best haplotype align to it as one M element at the place they were cut from.
+static void test_best_alleles() {
+    std::mt19937_64 rng(20250928);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    auto random_bases = [&](size_t n) {
+        Bytes b(n);
+        for (auto &c : b) c = "ACGT"[rng() & 3];
+        return b;
+    };
+    for (size_t n_alleles : {1u, 2u, 3u, 5u, 8u})
+        for (size_t ref_at : {size_t(0), n_alleles - 1}) {
+            std::vector<Haplotype> alleles;
+            for (size_t a = 0; a < n_alleles; ++a) alleles.emplace_back(random_bases(120 + 7 * a), a == ref_at);
+            const std::vector<size_t> samples{0, 1, 2};
+            std::map<size_t, std::vector<HmmRead>> reads;
+            for (size_t s : samples)
+                for (size_t r = 0; r < 5 + 9 * s; ++r) reads[s].push_back(HmmRead(random_bases(30), Bytes(30, 30)));
+            AlleleLikelihoods original(alleles, samples, reads);
+            for (size_t s : samples)
+                for (size_t a = 0; a < n_alleles; ++a)
+                    for (size_t r = 0; r < reads[s].size(); ++r) original.sample_matrix(s)(a, r) = normal(rng);
+            const auto best_alleles = AssemblyBasedCallerUtils::best_alleles_breaking_ties_main(original, AssemblyBasedCallerUtils::reference_tiebreaking_priority);
+            size_t seen = 0;
+            for (const BestAllele &ba : best_alleles) {
+                const Matrix &m = original.sample_matrix(ba.sample_index);
+                const size_t r = ba.evidence_index;
+                size_t best_index = 0;
+                double best_lk = -INFINITY, second_lk = -INFINITY;
+                for (size_t a = 0; a < n_alleles; ++a) {  // :290-303
+                    const double lk = m(a, r);
+                    if (lk > best_lk) {
+                        second_lk = best_lk;
+                        best_lk = lk;
+                        best_index = a;
+                    } else if (lk > second_lk) {
+                        second_lk = lk;
+                    }
+                }
+                const double ref_lk = m(ref_at, r);
+                const bool ref_override = ref_at != best_index && best_lk - ref_lk < BestAllele::LOG_10_INFORMATIVE_THRESHOLD;  // :317-322
+                ASSERT(ba.allele_index && *ba.allele_index == (ref_override ? ref_at : best_index), "best allele of read %zu", r);
+                auto relative_eq = [](double x, double y) { return x == y || std::fabs(x - y) < 1e-12; };  // (a lone allele: +inf)
+                ASSERT(relative_eq(ba.likelihood, ref_override ? ref_lk : best_lk), "likelihood of read %zu", r);
+                ASSERT(relative_eq(ba.confidence, ref_override ? ref_lk - best_lk : best_lk - second_lk), "confidence of read %zu", r);
+                ++seen;
+            }
+            ASSERT(seen == 5 + 14 + 23, "one BestAllele per unit of evidence, %zu", seen);
+        }
+    // realignment: every read is a piece of one haplotype and likes that haplotype best
+    std::vector<Haplotype> alleles;
+    for (size_t a = 0; a < 4; ++a) alleles.emplace_back(random_bases(200), a == 0);
+    std::map<size_t, std::vector<HmmRead>> reads;
+    std::vector<std::pair<size_t, size_t>> origin;
+    for (size_t r = 0; r < 40; ++r) {
+        const size_t a = r % 4, start = (size_t)(rng() % 120);
+        reads[0].push_back(HmmRead(Bytes(alleles[a].bases_.begin() + start, alleles[a].bases_.begin() + start + 60), Bytes(60, 30)));
+        origin.push_back({a, start});
+    }
+    AlleleLikelihoods lk(alleles, {0}, reads);
+    for (size_t r = 0; r < 40; ++r)
+        for (size_t a = 0; a < 4; ++a) lk.sample_matrix(0)(a, r) = a == origin[r].first ? -1.0 : -9.0;
+    std::vector<SmithWatermanAlignmentResult> aligned;
+    const auto best = AssemblyBasedCallerUtils::best_alleles_breaking_ties_main(lk, AssemblyBasedCallerUtils::haplotype_alignment_tiebreaking_priority, &aligned);
+    for (size_t r = 0; r < 40; ++r) {
+        ASSERT(best[r].allele_index && *best[r].allele_index == origin[r].first && best[r].is_informative(), "best haplotype of read %zu", r);
+        ASSERT(aligned[r].get_cigar() == "60M" && aligned[r].alignment_offset == (int32_t)origin[r].second, "read %zu: %s @ %d", r,
+               aligned[r].get_cigar().c_str(), aligned[r].alignment_offset);
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
@@ -523,6 +597,7 @@ int main(int argc, char **argv) {
         {"rayon_worker_pattern (threads share one engine handle)", test_rayon_worker_pattern},
         {"smith_waterman_asserted_cases", test_smith_waterman_asserted_cases},
         {"test_for_identical_alignments_with_differing_flank_lengths", test_for_identical_alignments_with_differing_flank_lengths},
+        {"test_best_alleles + realignment to the best haplotype", test_best_alleles},
     };
     int failed = 0;
     for (const auto &t : tests) {

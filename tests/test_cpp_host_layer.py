@@ -26,7 +26,8 @@ def test_host_layer_mirrors_the_reference_surface():
                  "class PairHMMLikelihoodCalculationEngine", "compute_read_likelihoods", "class PairHMMInputScoreImputator",
                  "ins_open_penalties", "gap_continuation_penalties", "enum class PCRErrorModel", "enum class AVXMode",
                  "class AlleleLikelihoods", "class AssemblyResultSet", "class SmithWatermanAligner",
-                 "enum class OverhangStrategy", "struct SmithWatermanAlignmentResult", "NEW_SW_PARAMETERS"):
+                 "enum class OverhangStrategy", "struct SmithWatermanAlignmentResult", "NEW_SW_PARAMETERS", "struct BestAllele",
+                 "best_alleles_breaking_ties_main", "haplotype_alignment_tiebreaking_priority", "reference_tiebreaking_priority"):
         assert name in hpp, name
 
 
@@ -35,8 +36,8 @@ def test_reference_tests_in_cpp_pass_on_the_gpu():
     r = subprocess.run([EXE, os.path.join(GOLDEN, "pairhmm-testdata.txt")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "13 tests, 0 failed" in r.stdout
+    assert "14 tests, 0 failed" in r.stdout
     for name in ("test_likelihoods_avx", "make_basic_likelihood_tests", "test_compute_likelihoods",
                  "make_haplotype_indexing_provider", "make_big_read_hmm_provider", "rayon_worker_pattern",
-                 "smith_waterman_asserted_cases", "test_for_identical_alignments_with_differing_flank_lengths"):
+                 "smith_waterman_asserted_cases", "test_for_identical_alignments_with_differing_flank_lengths", "test_best_alleles"):
         assert "PASS " + name in r.stdout
