@@ -600,6 +600,69 @@ def main():
                 "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
                                "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
 
+    def realign(likelihoods):
+        """The step behind the likelihoods (assembly_based_caller_utils.rs:208-246): best allele per read with the
+        reference's tie-breaking priorities, and every read aligned to its best haplotype, in one call
+        (phmm_realign_to_best: the haplotypes cross the bus once, the index never leaves the device); host buffers."""
+        import numpy as np
+        from lorikeet_amd import realign as rl
+        from oracle import oracle
+        sub = batch.region_slice(0, min(1024, batch.n_regions))
+        lk = np.ascontiguousarray(likelihoods[:int(sub.out_off[-1])])
+        rng = np.random.default_rng(11)
+        # the first haplotype of a region is its reference, CIGARs of one to three elements (what assembled haplotypes have)
+        is_ref = np.zeros(sub.n_haps, bool)
+        is_ref[sub.region_hap_off[:-1]] = True
+        pri = rl.haplotype_alignment_tiebreaking_priority(is_ref, np.where(is_ref, 1, rng.integers(1, 4, sub.n_haps)))
+        best, res = rl.realign_reads_to_their_best_haplotype(eng, sub, lk, pri)
+        t = time.perf_counter()
+        for _ in range(3):
+            best, res = rl.realign_reads_to_their_best_haplotype(eng, sub, lk, pri)
+        dt_py = (time.perf_counter() - t) / 3
+        # the C call alone (the Python mirror builds one result object per read)
+        import ctypes as C
+        from lorikeet_amd import _lib
+        n = sub.n_reads
+        cap = 16
+        cig_off = np.arange(n + 1, dtype=np.uint64) * cap
+        cigar, n_cig, off = np.zeros(n * cap, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+        b_idx, b_lk, b_conf = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
+        prm = _lib.SwParameters(10, -15, -30, -5)
+        pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+        i32p = C.POINTER(C.c_int32)
+        args = (eng._h, sub.n_regions, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p), pp(sub.read_off, _lib.u32p),
+                pp(sub.read_bases, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p), pp(sub.out_off, _lib.u64p), pp(lk, _lib.f64p),
+                None, pp(pri, i32p), 0.2, C.byref(prm), _lib.PHMM_SW_SOFTCLIP, pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p),
+                pp(off, i32p), pp(b_idx, i32p), pp(b_lk, _lib.f64p), pp(b_conf, _lib.f64p))
+        assert eng.lib.phmm_realign_to_best(*args) == 0, eng.last_error()
+        t = time.perf_counter()
+        for _ in range(5):
+            assert eng.lib.phmm_realign_to_best(*args) == 0
+        dt = (time.perf_counter() - t) / 5
+        kern_s = eng.stat("sw_kernel_us") / 1e6
+        # oracle on a sample of regions: best alleles equal, CIGARs and offsets equal
+        same, checked = True, 0
+        nr = np.diff(sub.region_read_off.astype(np.int64))
+        nh = np.diff(sub.region_hap_off.astype(np.int64))
+        for g in range(0, sub.n_regions, max(1, sub.n_regions // 8)):
+            m = lk[int(sub.out_off[g]):int(sub.out_off[g]) + nr[g] * nh[g]].reshape(nr[g], nh[g])
+            wb, wl, wc = oracle.best_alleles(m.T, pri[sub.region_hap_off[g]:sub.region_hap_off[g + 1]], 0.2)
+            r0 = int(sub.region_read_off[g])
+            same = same and np.array_equal(wb, b_idx[r0:r0 + nr[g]]) and np.array_equal(wl, b_lk[r0:r0 + nr[g]]) and np.array_equal(wc, b_conf[r0:r0 + nr[g]])
+            for r in range(r0, r0 + min(int(nr[g]), 32)):
+                hp = int(sub.region_hap_off[g]) + int(wb[r - r0])
+                cg, of = oracle.sw_align(sub.hap_bases[int(sub.hap_off[hp]):int(sub.hap_off[hp + 1])],
+                                         sub.read_bases[int(sub.read_off[r]):int(sub.read_off[r + 1])], [10, -15, -30, -5], "SoftClip")
+                same = same and of == off[r] and np.array_equal(cg, cigar[r * cap:r * cap + int(n_cig[r])])
+                checked += 1
+        cells = int(np.sum(np.diff(sub.read_off.astype(np.int64)) * np.diff(sub.hap_off.astype(np.int64))[sub.region_hap_off[:-1].astype(np.int64)[np.repeat(np.arange(sub.n_regions), nr)] + b_idx]))
+        return {"call": "phmm_realign_to_best: best allele per read (haplotype_alignment_tiebreaking_priority) + SoftClip alignment of the read "
+                        "to it, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS; host buffers, PCIe included",
+                "reads": int(n), "regions": int(sub.n_regions), "ms_per_call": round(dt * 1e3, 3), "reads_per_s": round(n / dt, 1),
+                "gcups_i32": round(cells / dt / 1e9, 1), "sw_kernels_ms": round(kern_s * 1e3, 3),
+                "informative_reads": int(np.sum(b_conf > 0.2)), "python_mirror_ms_per_call": round(dt_py * 1e3, 1),
+                "equal_to_oracle_on_sample": bool(same), "sample_alignments": checked}
+
     class Dist1:  # rank-0-only rows: same timing code, no cross-rank barrier
         def __init__(self, d):
             self.torch, self.dev = d.torch, d.dev
@@ -680,6 +743,8 @@ def main():
         line["f32_first"] = f32_row
         line["engine_call"] = engine_row
         line["smith_waterman"] = sw_row
+        if a.workload == "config2" and extras:
+            line["realign_to_best"] = optional(lambda: realign(got))
         if calls_row is not None:
             line["host_calls"] = calls_row
         if world == 1 and not a.no_cpu_baseline and extras:
