@@ -156,11 +156,20 @@ def cpu_baselines(batch, budget_s=12.0):
     return scalar, simd
 
 
-def source_hash():
-    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match)."""
+def source_hash(family="pairhmm"):
+    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match):
+    every *.hip / *.hpp of lorikeet_amd/csrc that the family's kernels are compiled from -- the PairHMM and engine kernels
+    (everything but the Smith-Waterman kernel file), or the Smith-Waterman kernel with the shared parameter header.
+    Host-only headers (phmm_host.hpp) are in neither."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hpp"))):
+        name = os.path.basename(f)
+        if family == "sw":
+            if name not in ("phmm_sw_kernels.hip", "phmm_internal.hpp"):
+                continue
+        elif name in ("phmm_sw_kernels.hip", "phmm_host.hpp"):
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -174,7 +183,7 @@ def pmc_entry(workload, regions, kernel, precision="f64"):
         entries = json.load(open(path))
     except Exception:
         return None, "profiles/pmc_traffic.json missing"
-    src = source_hash()
+    src = source_hash("sw" if workload == "smith_waterman" else "pairhmm")
     why = "no PMC entry for workload %s x %s (%s)" % (workload, regions, precision)
     for e in entries:
         if e.get("workload") != workload or e.get("regions") != regions or e.get("precision", "f64") != precision:
