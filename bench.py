@@ -156,21 +156,21 @@ def cpu_baselines(batch, budget_s=12.0):
     return scalar, simd
 
 
+KERNEL_SOURCES = {  # what each kernel family is compiled from (lorikeet_amd/csrc)
+    "pairhmm": ("phmm_device.hpp", "phmm_internal.hpp", "phmm_kernels.hip", "phmm_chain_kernels.hip", "phmm_chain32_kernels.hip",
+                "phmm_exact_kernels.hip", "phmm_engine_kernels.hip"),
+    "sw": ("phmm_internal.hpp", "phmm_sw_kernels.hip"),
+}
+
+
 def source_hash(family="pairhmm"):
-    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match):
-    every *.hip / *.hpp of lorikeet_amd/csrc that the family's kernels are compiled from -- the PairHMM and engine kernels
-    (everything but the Smith-Waterman kernel file), or the Smith-Waterman kernel with the shared parameter header.
-    Host-only headers (phmm_host.hpp) are in neither."""
+    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match): the
+    files the family's kernels are compiled from -- the PairHMM and engine kernels, or the Smith-Waterman kernel with the
+    shared parameter header."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "lorikeet_amd", "csrc", "*.hpp"))):
-        name = os.path.basename(f)
-        if family == "sw":
-            if name not in ("phmm_sw_kernels.hip", "phmm_internal.hpp"):
-                continue
-        elif name in ("phmm_sw_kernels.hip", "phmm_host.hpp"):
-            continue
-        h.update(os.path.basename(f).encode())
+    for name in sorted(KERNEL_SOURCES[family]):
+        f = os.path.join(ROOT, "lorikeet_amd", "csrc", name)
+        h.update(name.encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

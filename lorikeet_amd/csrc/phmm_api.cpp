@@ -1282,6 +1282,12 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
             u += units(g1);
             ++g1;
         }
+        // ... and a remainder too small to chain on its own rides with this chunk instead of following as a per-read launch
+        if (g1 < n_regions) {
+            uint64_t rest = 0;
+            for (uint32_t g = g1; g < n_regions && rest < 8ull * 2 * kNumSimd * 4; ++g) rest += units(g);
+            if (rest < 8ull * 2 * kNumSimd * 4) g1 = n_regions;
+        }
     }
     c.g0 = g0;
     c.g1 = g1;

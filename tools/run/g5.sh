@@ -1,4 +1,2 @@
 cd /root/repo
-python tools/sw_bench.py 256 0 haps 2>&1 | grep -v "^{" | tail -2 | cut -c1-200
-python tools/sw_bench.py 1024 0 haps 2>&1 | grep -v "^{" | tail -2 | cut -c1-200
-PHMM_SW_LANES=8 python tools/sw_bench.py 1024 0 haps 2>&1 | grep -v "^{" | tail -1 | cut -c1-200
+for kb in 4096 8192 16384; do echo "PHMM_CHUNK_KB=$kb"; PHMM_CHUNK_KB=$kb python tools/hostpath_ragged.py 2>&1 | grep "call\|chunks" | tail -3; done

@@ -1,4 +1,12 @@
 cd /root/repo
-bash tools/profile.sh r02_config2_f64 --workload config2 > gpurun_out/prof_f64.log 2>&1
-bash tools/profile.sh r02_config2_f32 --workload config2 --f32-first > gpurun_out/prof_f32.log 2>&1
-tail -3 gpurun_out/prof_f64.log gpurun_out/prof_f32.log
+export BENCH_DIST_BACKEND=gloo
+time (timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_n2.json 2> gpurun_out/bench_n2.err)
+tail -c 400 gpurun_out/bench_n2.err
+python - <<'PY'
+import json
+l=json.loads(open("gpurun_out/bench_n2.json").read().strip().splitlines()[-1])
+print(l["n_gpus"], l["value"], l["ms_per_step"], l["scaling"])
+for k in ("config3_10k","config5_256"):
+    r=l[k]; print(k, r.get("gcups"), r.get("per_rank_cells"), r.get("imbalance"), r.get("error"))
+print([k for k in l.keys()])
+PY
