@@ -155,3 +155,31 @@ def test_realign_argument_errors(hip_engine):
         realign.best_alleles_breaking_ties(hip_engine, b, lk, threshold=float("nan"))
     best, res = realign.realign_reads_to_their_best_haplotype(hip_engine, b, lk, parameters=NEW_SW_PARAMETERS, capacity=1)
     assert all(r is not None for r in res)   # capacity 1 is retried with the sizes the library reports
+
+
+def test_edge_cases_of_the_realign_calls(hip_engine):
+    """Nothing to do, regions without alleles, every read removed: defined results, no device work where there is none."""
+    import ctypes as C
+    i32p = C.POINTER(C.c_int32)
+    lib, h = hip_engine.lib, hip_engine._h
+    assert lib.phmm_best_alleles(h, 0, None, None, None, None, None, None, 0.2, None, None, None) == _lib.PHMM_OK
+    prm = ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.as_struct()
+    assert lib.phmm_realign_to_best(h, 0, None, None, None, None, None, None, None, None, None, None, 0.2, C.byref(prm), 0,
+                                    None, None, None, None, None, None, None) == _lib.PHMM_OK
+    # three reads, no haplotype anywhere: search_best_allele's None (allele_likelihoods.rs:465-475), nothing aligned
+    rro, rho = np.array([0, 3], np.uint32), np.array([0, 0], np.uint32)
+    read_off, reads = np.array([0, 4, 8, 12], np.uint32), np.frombuffer(b"ACGTACGTACGT", np.uint8)
+    oo, cig_off = np.array([0, 0], np.uint64), np.array([0, 4, 8, 12], np.uint64)
+    cigar, n_cig, off = np.zeros(12, np.uint32), np.full(3, 9, np.uint32), np.full(3, 9, np.int32)
+    best, lk, conf = np.zeros(3, np.int32), np.zeros(3), np.zeros(3)
+    p = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
+    code = lib.phmm_realign_to_best(h, 1, p(rro, _lib.u32p), p(rho, _lib.u32p), p(read_off, _lib.u32p), p(reads, _lib.u8p),
+                                    p(np.zeros(1, np.uint32), _lib.u32p), None, p(oo, _lib.u64p), None, None, None, 0.2, C.byref(prm), 0,
+                                    p(cig_off, _lib.u64p), p(cigar, _lib.u32p), p(n_cig, _lib.u32p), p(off, i32p), p(best, i32p),
+                                    p(lk, _lib.f64p), p(conf, _lib.f64p))
+    assert code == _lib.PHMM_OK, hip_engine.last_error()
+    assert best.tolist() == [-1, -1, -1] and np.all(np.isneginf(lk)) and np.all(np.isnan(conf)) and n_cig.tolist() == [0, 0, 0]
+    # every read removed by the filter: no best allele, no alignment
+    b = synthetic.make_regions(2, 5, 3, 80, 40, seed=4)
+    got, res = realign.realign_reads_to_their_best_haplotype(hip_engine, b, hip_engine.compute(b), keep=np.zeros(b.n_reads, np.uint8))
+    assert np.all(got.allele_index == -1) and all(r is None for r in res)

@@ -1,2 +1,2 @@
 cd /root/repo
-for kb in 4096 8192 16384; do echo "PHMM_CHUNK_KB=$kb"; PHMM_CHUNK_KB=$kb python tools/hostpath_ragged.py 2>&1 | grep "call\|chunks" | tail -3; done
+timeout 600 python -m pytest tests/test_realign_hip.py -x -q --timeout 200 2>&1 | tail -12
