@@ -1882,7 +1882,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "trace") w.trace = value != 0;
     else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
-    else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 ? value : 0;
+    else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";
         return PHMM_ERR_INVALID_ARG;

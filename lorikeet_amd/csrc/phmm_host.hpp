@@ -36,7 +36,7 @@ struct Switches {
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
     int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
-    int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 lanes per Smith-Waterman alignment (0 = by the longest alternate sequence)
+    int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
 };
 

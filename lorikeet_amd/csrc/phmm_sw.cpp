@@ -191,20 +191,19 @@ int sw_run(phmm_handle *h, const SwJob &J) {
 
     DevGuard dg(h->device);
     // ---- geometry ---------------------------------------------------------------------------------------------
-    // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate
-    // sequence: eight lanes (eight alignments per wave, fewer steps lost to the skew and less per-step work per
-    // cell) while 8 x 20 columns suffice, sixteen beyond; more than 512 columns take several strips of 512
-    int L = 16, K = kSwK16[kNumSwK16 - 1];
+    // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate sequence
+    // (more than 512 columns take several strips of 512).  Throughput wants few lanes per alignment -- eight alignments
+    // per wave lose the fewest steps to the skew and spread the per-step work over the most cells -- latency wants many:
+    // a call that cannot fill the chip anyway (a round of the persistent blocks is 32 768 alignments at eight lanes) gets
+    // 16, 32 or 64 lanes per alignment, i.e. more waves with less work each (one region of 128 reads: 305 us at 8 lanes,
+    // 220 at 16).
     const int force_L = h->sw.sw_lanes;
-    if (force_L != 16 && (max_alt <= 8 * 20 || force_L == 8)) {
-        L = 8;
-        K = kSwK8[kNumSwK8 - 1];
-        for (int i = kNumSwK8 - 1; i >= 0; --i)
-            if ((size_t)kSwK8[i] * 8 >= max_alt) K = kSwK8[i];
-    } else {
-        for (int i = kNumSwK16 - 1; i >= 0; --i)
-            if ((size_t)kSwK16[i] * 16 >= max_alt) K = kSwK16[i];
-    }
+    int L = force_L ? force_L : max_alt <= 8 * 20 && n_alignments >= 32768 ? 8 : max_alt > 512 || n_alignments > 4096 ? 16 : n_alignments > 1024 ? 32 : 64;
+    const int *ks = L == 8 ? kSwK8 : L == 16 ? kSwK16 : L == 32 ? kSwK32 : kSwK64;
+    const int nks = L == 8 ? kNumSwK8 : L == 16 ? kNumSwK16 : L == 32 ? kNumSwK32 : kNumSwK64;
+    int K = ks[nks - 1];
+    for (int i = nks - 1; i >= 0; --i)
+        if ((size_t)ks[i] * L >= max_alt) K = ks[i];
     const size_t strip_cols = (size_t)L * K;
     const size_t strips = (max_alt + strip_cols - 1) / strip_cols;
     const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
@@ -250,7 +249,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks; ++c) most = std::max<size_t>(most, cut[c + 1] - cut[c]);
     const size_t slab_bytes = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * slab_stride * 4;
     phmm_handle::SwWork &W = h->swork;
-    hipStream_t S = h->streams[0], S_in = h->streams[1];
+    // one piece: everything in order on one stream, one copy each way, one wait (a region per call is the reference's pattern)
+    const bool one_piece = n_chunks == 1;
+    hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
     if (W.slab_bytes < slab_bytes) {
         (void)hipStreamSynchronize(S);
         if (W.slab) (void)hipFree(W.slab);
@@ -309,10 +310,15 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         stage_best(*J.best, BL, W.host);
         head = BL.best;
     }
+    if (one_piece) {  // the whole input is one contiguous block of the staging buffer
+        memcpy(W.host + o_rb, J.ref_bases, rb);
+        memcpy(W.host + o_ab, J.alt_bases, ab);
+        head = in_bytes;
+    }
     bool good = ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
     if (good && J.best)  // the reads' best alleles become the index of their references, on the device
         good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
-    if (good && indexed) {
+    if (good && indexed && !one_piece) {
         memcpy(W.host + o_rb, J.ref_bases, rb);
         good = ok(h, hipMemcpyAsync(W.dev + o_rb, W.host + o_rb, rb, hipMemcpyHostToDevice, S_in), "H2D sw");
     }
@@ -320,14 +326,16 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks && good; ++c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         const size_t q0 = alt_off[a0], q1 = alt_off[a1];
-        if (!indexed) {  // one reference per alignment: they travel piece by piece like the alternates
-            const size_t r0 = ref_off[a0], r1 = ref_off[a1];
-            memcpy(W.host + o_rb + r0, J.ref_bases + r0, r1 - r0);
-            good = r1 == r0 || ok(h, hipMemcpyAsync(W.dev + o_rb + r0, W.host + o_rb + r0, r1 - r0, hipMemcpyHostToDevice, S_in), "H2D sw");
+        if (!one_piece) {
+            if (!indexed) {  // one reference per alignment: they travel piece by piece like the alternates
+                const size_t r0 = ref_off[a0], r1 = ref_off[a1];
+                memcpy(W.host + o_rb + r0, J.ref_bases + r0, r1 - r0);
+                good = r1 == r0 || ok(h, hipMemcpyAsync(W.dev + o_rb + r0, W.host + o_rb + r0, r1 - r0, hipMemcpyHostToDevice, S_in), "H2D sw");
+            }
+            memcpy(W.host + o_ab + q0, J.alt_bases + q0, q1 - q0);
+            good = good && (q1 == q0 || ok(h, hipMemcpyAsync(W.dev + o_ab + q0, W.host + o_ab + q0, q1 - q0, hipMemcpyHostToDevice, S_in), "H2D sw")) &&
+                   ok(h, hipEventRecord(W.ev_in[c], S_in), "hipEventRecord") && ok(h, hipStreamWaitEvent(S, W.ev_in[c], 0), "hipStreamWaitEvent");
         }
-        memcpy(W.host + o_ab + q0, J.alt_bases + q0, q1 - q0);
-        good = good && (q1 == q0 || ok(h, hipMemcpyAsync(W.dev + o_ab + q0, W.host + o_ab + q0, q1 - q0, hipMemcpyHostToDevice, S_in), "H2D sw")) &&
-               ok(h, hipEventRecord(W.ev_in[c], S_in), "hipEventRecord") && ok(h, hipStreamWaitEvent(S, W.ev_in[c], 0), "hipStreamWaitEvent");
         if (!good || a1 == a0) continue;
         p.a_begin = a0;
         p.n_alignments = a1;
@@ -347,7 +355,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
     // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, DESIGN.md
     // section 9), and is unpacked into the caller's arrays while the later pieces compute.
-    hipStream_t S_out = h->streams[2];
+    hipStream_t S_out = one_piece ? S : h->streams[2];
     auto unpack = [&](int c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
@@ -363,7 +371,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (a1 == a0) continue;
         const uint64_t g0 = J.cigar_off[a0], g1 = J.cigar_off[a1];
-        good = ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)") &&
+        good = (one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)")) &&
                ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
                ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
                (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw")) &&

@@ -67,8 +67,10 @@ struct CigarOut {
 }  // namespace
 
 
-__device__ __forceinline__ int32_t row_shr1(int32_t v) {  // lane l <- lane l-1 inside each group of 16 (first lane: 0)
-    return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+template <int SW_L>
+__device__ __forceinline__ int32_t row_shr1(int32_t v) {  // lane l <- lane l-1 (first lane of a row of 16 / of the wave: 0)
+    if constexpr (SW_L <= 16) return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    else return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);                       // wave_shr:1
 }
 
 // Candidate start cells of the backtrack compare as the reference's scans do (:303-330): higher score first; among equal
@@ -88,11 +90,12 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
 #ifndef PHMM_SW_EU
 #define PHMM_SW_EU 5
 #endif
-// SW_L lanes per alignment (16 or 8: 4 or 8 alignments per wave), K columns per lane
+// SW_L lanes per alignment (8 / 16 / 32 / 64: 8 ... 1 alignments per wave), K columns per lane
 template <int SW_L, int K>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : K <= PHMM_SW_K4 ? 4 : K <= 26 ? 3 : 2)))
 void phmm_sw_align_kernel(const SwParams p) {
     constexpr int GMASK = WAVE - SW_L;  // lane & GMASK = first lane of the lane's group
+    constexpr uint64_t LMASK = SW_L == 64 ? ~0ull : (1ull << (SW_L & 63)) - 1;  // the group's lanes, shifted down
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, g = lane / SW_L, l = lane % SW_L;
     // LDS of this group: reference | alternate | bottom row | (several strips only) strip edge: sw, best_gap_h, -gap_size_h
@@ -151,8 +154,8 @@ void phmm_sw_align_kernel(const SwParams p) {
                 const int r = r0 - l;
                 bool ok = found < 0 && r0 >= 0 && r >= 0;
                 for (int q = 0; ok && q < m; ++q) ok = s_ref[r + q] == s_alt[q];
-                const uint32_t hit = (uint32_t)(__ballot(ok) >> (lane & GMASK)) & ((1u << SW_L) - 1);
-                if (hit && found < 0) found = r0 - (__ffs((int)hit) - 1);
+                const uint64_t hit = (__ballot(ok) >> (lane & GMASK)) & LMASK;
+                if (hit && found < 0) found = r0 - (__ffsll((long long)hit) - 1);
                 r0 -= SW_L;
             }
         }
@@ -190,7 +193,7 @@ void phmm_sw_align_kernel(const SwParams p) {
             const bool first_strip = s == 0;
             auto step = [&](const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
                 const int i = t - l + 1;                 // this lane's row at this step
-                int32_t left = row_shr1(o_sw), h_bg = row_shr1(o_bgh);
+                int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
                 const bool active = strip_on && i >= 1 && i <= n;
                 const int32_t a_base = a_next;
                 a_next = (int32_t)s_ref[max(i, 0)];      // row i + 1 (the LDS area is padded: one byte beyond the sequence is harmless)
@@ -325,8 +328,8 @@ void phmm_sw_align_kernel(const SwParams p) {
                     const bool inside = p1 - l >= 1 && p2 - l >= 1;
                     const uint32_t *w = cell_words(inside ? p1 - l : 1, inside ? p2 - l : 1, sh);
                     const uint32_t tag = inside ? (w[0] >> (30 - sh)) & 3u : 3u;
-                    const uint32_t diagonal = (uint32_t)(__ballot(tag == TAG_DIAG) >> (lane & GMASK)) & ((1u << SW_L) - 1);
-                    const int run = __ffs((int)(~diagonal & ((2u << SW_L) - 1))) - 1;  // 0 ... SW_L
+                    const uint64_t others = ~(__ballot(tag == TAG_DIAG) >> (lane & GMASK)) & LMASK;  // lanes that do not see a diagonal step
+                    const int run = others ? __ffsll((long long)others) - 1 : SW_L;                 // 0 ... SW_L
                     if (run > 0) {  // `run` times the reference's loop body with btrack == 0 (:372-417)
                         if (state != ST_MATCH) {
                             if (segment_length > 0) cig.push(make_element(state, (uint32_t)segment_length));
@@ -406,11 +409,16 @@ void phmm_sw_align_kernel(const SwParams p) {
 // instantiated <lanes per alignment, columns per lane>; the host side picks the pair (phmm_sw.cpp)
 #define PHMM_SW_LIST(X)                                                                                                \
     X(16, 2) X(16, 4) X(16, 6) X(16, 8) X(16, 10) X(16, 12) X(16, 14) X(16, 16) X(16, 20) X(16, 24) X(16, 28) X(16, 32) \
-    X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(8, 19) X(8, 22) X(8, 26) X(8, 32)
+    X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(8, 19) X(8, 22) X(8, 26) X(8, 32)                                             \
+    X(32, 3) X(32, 4) X(32, 5) X(32, 6) X(32, 8) X(32, 12) X(32, 16) X(64, 2) X(64, 3) X(64, 4) X(64, 6) X(64, 8)
 const int kSwK16[] = {2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32};
 const int kNumSwK16 = sizeof(kSwK16) / sizeof(int);
 const int kSwK8[] = {4, 8, 12, 16, 19, 22, 26, 32};
 const int kNumSwK8 = sizeof(kSwK8) / sizeof(int);
+const int kSwK32[] = {3, 4, 5, 6, 8, 12, 16};
+const int kNumSwK32 = sizeof(kSwK32) / sizeof(int);
+const int kSwK64[] = {2, 3, 4, 6, 8};
+const int kNumSwK64 = sizeof(kSwK64) / sizeof(int);
 
 // blocks (of one wave) of this instance a CU holds at once, by registers and LDS
 int sw_blocks_per_cu(int L, int K, size_t lds_bytes) {

@@ -187,7 +187,7 @@ def test_pipelined_pieces_equal_one_piece(hip_engine, aligner):
         pairs.append((ref, alt))
     base = None
     try:
-        for lanes in (8, 16):   # lanes per alignment: 8 while 160 columns suffice, 16 beyond -- forced either way here
+        for lanes in (8, 16, 32, 64):   # lanes per alignment: chosen by batch size and sequence length -- forced here
             hip_engine.set_switch("sw_lanes", lanes)
             for chunks in (1, 2, 3, 7):
                 hip_engine.set_switch("sw_chunks", chunks)
