@@ -159,7 +159,7 @@ def cpu_baselines(batch, budget_s=12.0):
 KERNEL_SOURCES = {  # what each kernel family is compiled from (lorikeet_amd/csrc)
     "pairhmm": ("phmm_device.hpp", "phmm_internal.hpp", "phmm_kernels.hip", "phmm_chain_kernels.hip", "phmm_chain32_kernels.hip",
                 "phmm_exact_kernels.hip", "phmm_engine_kernels.hip"),
-    "sw": ("phmm_internal.hpp", "phmm_sw_kernels.hip"),
+    "sw": ("phmm_sw_internal.hpp", "phmm_sw_kernels.hip"),
 }
 
 

@@ -152,35 +152,6 @@ struct BestParams {
 };
 hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream);
 
-// ---- Smith-Waterman (phmm_sw_kernels.hip) -------------------------------------------------------------------------
-constexpr int PHMM_SW_STRATEGY_SOFTCLIP = 0, PHMM_SW_STRATEGY_INDEL = 1, PHMM_SW_STRATEGY_LEADING_INDEL = 2,
-              PHMM_SW_STRATEGY_IGNORE = 3;  // == PHMM_SW_* of include/phmm.h
-constexpr uint32_t SW_STATUS_EMPTY = 1u;     // an empty reference or alternate sequence
-constexpr uint32_t SW_STATUS_CAPACITY = 2u;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
-struct SwParams {
-    uint32_t a_begin, n_alignments;        // this launch aligns [a_begin, n_alignments)
-    const uint32_t *ref_off, *alt_off;     // [references + 1], [n_alignments + 1]
-    const uint32_t *ref_index;             // [n_alignments] reference of each alignment (SW_NO_REFERENCE: skipped), or null: alignment a has reference a
-    const uint8_t *ref_bases, *alt_bases;
-    int32_t w_match, w_mismatch, w_open, w_extend;
-    int strategy;
-    const uint64_t *cigar_off;             // [n_alignments + 1]
-    uint32_t *cigar, *n_cigar;
-    int32_t *alignment_offset;
-    uint32_t *slab;                        // backtrack flags, one slab per block
-    size_t slab_stride;                    // dwords per slab: strips * (max_ref + 16) steps * 2 ceil(K / 16) words * 64 lanes
-    uint32_t *status;
-    uint32_t max_ref, max_alt;             // longest sequences of the batch
-    uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
-    uint32_t lds_group_bytes;              // LDS of one alignment
-    uint32_t groups_per_block;             // alignments a block works on side by side: 64 / L, or 1 for very long sequences
-};
-// L lanes per alignment (8 / 16 / 32 / 64), K columns per lane (one of kSwK<L>), 64 / L alignments per block
-hipError_t launch_sw(int L, int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes);  // what a CU holds at once (registers, LDS); 0 on failure
-extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[];
-extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64;
-
 // The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
 extern const int kInstantiatedK[];
 extern const int kNumInstantiatedK;

@@ -10,7 +10,7 @@
 #include <string>
 
 #include "phmm_host.hpp"
-#include "phmm_internal.hpp"
+#include "phmm_sw_internal.hpp"
 
 using namespace phmm;
 

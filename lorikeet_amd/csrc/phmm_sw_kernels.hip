@@ -28,7 +28,7 @@
 // MATRIX_MIN_CUTOFF clamp, :31, can never be active.)
 // Backtracking: the sixteen lanes of an alignment fetch sixteen cells down the diagonal at once and take the run of
 // diagonal steps among them in one go (every step is a dependent read from HBM otherwise); lane 0 writes the CIGAR.
-#include "phmm_internal.hpp"
+#include "phmm_sw_internal.hpp"
 
 namespace phmm {
 
