@@ -1,5 +1,6 @@
 #!/bin/bash
-# Re-embeds integration/hip_ffi.rs into integration/lorikeet-hip.patch (the patch adds it as src/pair_hmm/hip_ffi.rs).
+# Re-embeds integration/hip_ffi.rs and integration/hip_backend.rs into integration/lorikeet-hip.patch (the patch adds them
+# as src/pair_hmm/hip_ffi.rs and src/pair_hmm/hip_backend.rs).
 # Needs the reference tree (build container only): applies the current patch to a scratch copy of the files it touches,
 # replaces the FFI file, and diffs again.  usage: integration/refresh_patch.sh [/root/reference]
 set -e
@@ -13,6 +14,7 @@ done
 git add -A && git -c user.email=a@b -c user.name=x commit -q -m base
 git apply "$HERE/lorikeet-hip.patch"
 cp "$HERE/hip_ffi.rs" src/pair_hmm/hip_ffi.rs
+cp "$HERE/hip_backend.rs" src/pair_hmm/hip_backend.rs
 git add -A && git diff --cached > "$HERE/lorikeet-hip.patch"
 echo "refreshed: $(grep -c '^+' "$HERE/lorikeet-hip.patch") added lines"
 rm -rf "$W"

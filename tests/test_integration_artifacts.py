@@ -158,12 +158,45 @@ def test_every_export_is_callable_from_plain_c99():
         assert r.returncode == 0, r.stderr[-3000:]
 
 
-def test_the_patch_carries_the_ffi_file_verbatim():
-    want = open(FFI).read().splitlines()
+@pytest.mark.parametrize("name", ["hip_ffi.rs", "hip_backend.rs"])
+def test_the_patch_carries_the_rust_files_verbatim(name):
+    want = open(os.path.join(ROOT, "integration", name)).read().splitlines()
     patch = open(PATCH).read()
-    seg = patch.split("diff --git a/src/pair_hmm/hip_ffi.rs b/src/pair_hmm/hip_ffi.rs", 1)[1].split("\ndiff --git", 1)[0]
+    seg = patch.split("diff --git a/src/pair_hmm/%s b/src/pair_hmm/%s" % (name, name), 1)[1].split("\ndiff --git", 1)[0]
     got = [l[1:] for l in seg.splitlines() if l.startswith("+") and not l.startswith("+++")]
     assert got == want
+
+
+def test_the_safe_wrapper_calls_what_the_ffi_declares():
+    """Every phmm_* call in hip_backend.rs passes as many arguments as hip_ffi.rs declares (checked textually: a Rust
+    toolchain is not available here), and its brackets balance."""
+    ffi = open(FFI).read()
+    backend = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "integration", "hip_backend.rs")).read())
+    arity = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+             for m in re.finditer(r"pub fn (phmm_\w+)\(([^)]*)\)", ffi, flags=re.S)}
+    calls = 0
+    for m in re.finditer(r"\b(phmm_\w+)\(", backend):
+        name = m.group(1)
+        if name not in arity:
+            continue
+        depth, i, args, cur = 1, m.end(), [], ""
+        while depth:
+            ch = backend[i]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+            elif depth:
+                cur += ch
+            i += 1
+        args.append(cur)
+        n = len([a for a in args if a.strip()])
+        assert n == arity[name], (name, n, arity[name])
+        calls += 1
+    assert calls >= 6
+    for o, c in ("()", "[]", "{}"):
+        assert backend.count(o) == backend.count(c), (o, c)
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree only exists in the build container")
