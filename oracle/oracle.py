@@ -77,6 +77,23 @@ def _load(path):
     lib.oracle_normalize_likelihoods.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_long]
     lib.oracle_filter_poorly_modeled_evidence.restype = C.c_size_t
     lib.oracle_filter_poorly_modeled_evidence.argtypes = [_f64p, C.c_size_t, C.c_size_t, _f64p, _u8p]
+    _i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    lib.oracle_cigar_builder.restype = C.c_int
+    lib.oracle_cigar_builder.argtypes = [_u32p, C.c_uint32, C.c_int, C.c_int, _u32p, C.c_uint32, _u32p, _u32p, _u32p]
+    lib.oracle_read_start_on_reference_haplotype.restype = C.c_int
+    lib.oracle_read_start_on_reference_haplotype.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u32p]
+    lib.oracle_trim_cigar.restype = C.c_int
+    lib.oracle_trim_cigar.argtypes = [_u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u32p, C.c_uint32, _u32p, _u32p, _u32p]
+    lib.oracle_apply_cigar_to_cigar.restype = C.c_int
+    lib.oracle_apply_cigar_to_cigar.argtypes = [_u32p, C.c_uint32, _u32p, C.c_uint32, _u32p, C.c_uint32, _u32p]
+    lib.oracle_left_align_indels.restype = C.c_int
+    lib.oracle_left_align_indels.argtypes = [_u32p, C.c_uint32, _u8p, C.c_uint32, _u8p, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _u32p,
+                                             _u32p, _u32p]
+    lib.oracle_append_clipped_elements.restype = C.c_int
+    lib.oracle_append_clipped_elements.argtypes = [_u32p, C.c_uint32, _u32p, C.c_uint32, _u32p, C.c_uint32, _u32p]
+    lib.oracle_create_read_aligned_to_ref.restype = C.c_int
+    lib.oracle_create_read_aligned_to_ref.argtypes = [_u32p, C.c_uint32, C.c_int32, _u32p, C.c_uint32, C.c_uint32, C.c_uint64, _u8p, C.c_uint32,
+                                                      _u8p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _i64p, _u32p, C.c_uint32, _u32p]
     lib.oracle_best_alleles.restype = None
     lib.oracle_best_alleles.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.c_double, C.POINTER(C.c_int32), _f64p, _f64p]
     return lib
@@ -284,3 +301,109 @@ def best_alleles(values, priorities=None, threshold=0.2):
     lib().oracle_best_alleles(v.ctypes.data_as(_f64p), na, nr, None if pri is None else pri.ctypes.data_as(C.POINTER(C.c_int32)),
                               threshold, best.ctypes.data_as(C.POINTER(C.c_int32)), lk.ctypes.data_as(_f64p), conf.ctypes.data_as(_f64p))
     return best, lk, conf
+
+
+# ---- CIGAR algebra (oracle/cigar_oracle.c): src/reads/cigar_builder.rs, src/reads/alignment_utils.rs:60-566 ----------------------
+_CIGAR_OPS = "MIDNSHP=X"
+
+
+def _seq(a):
+    if isinstance(a, str):
+        a = a.encode()
+    return np.ascontiguousarray(np.frombuffer(bytes(a), dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+
+
+def parse_cigar(text):
+    """'3M2D4M' -> BAM-encoded elements, (length << 4) | op."""
+    import re
+    return np.array([(int(n) << 4) | _CIGAR_OPS.index(o) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", text)], np.uint32)
+
+
+def _elems(c):
+    return parse_cigar(c) if isinstance(c, str) else np.ascontiguousarray(c, dtype=np.uint32)
+
+
+def _pu32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+class CigarError(Exception):
+    """Where the reference returns Err or panics; .code is the status of oracle/cigar_oracle.c."""
+
+    def __init__(self, code):
+        super().__init__("cigar oracle status %d" % code)
+        self.code = code
+
+
+def cigar_builder(elements, remove_deletions_at_ends=True, allow_empty=False):
+    """CigarBuilder::new(remove).add(e)... .make(allow_empty) -> (cigar string, leading, trailing deletion bases removed)."""
+    e = np.concatenate([_elems(x) for x in elements]) if len(elements) else np.zeros(0, np.uint32)
+    out, n, lead, trail = np.zeros(len(e) + 4, np.uint32), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = lib().oracle_cigar_builder(_pu32(e), len(e), int(remove_deletions_at_ends), int(allow_empty), _pu32(out), len(out), C.byref(n),
+                                    C.byref(lead), C.byref(trail))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value]), lead.value, trail.value
+
+
+def read_start_on_reference_haplotype(cigar, read_start_on_haplotype):
+    c, out = _elems(cigar), C.c_uint32()
+    st = lib().oracle_read_start_on_reference_haplotype(_pu32(c), len(c), read_start_on_haplotype, C.byref(out))
+    if st:
+        raise CigarError(st)
+    return out.value
+
+
+def trim_cigar(cigar, start, end, by_reference):
+    """AlignmentUtils::trim_cigar_by_reference / trim_cigar_by_bases -> (cigar string, leading, trailing removed)."""
+    c = _elems(cigar)
+    out, n, lead, trail = np.zeros(len(c) + 4, np.uint32), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = lib().oracle_trim_cigar(_pu32(c), len(c), start, end, int(by_reference), _pu32(out), len(out), C.byref(n), C.byref(lead), C.byref(trail))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value]), lead.value, trail.value
+
+
+def apply_cigar_to_cigar(first_to_second, second_to_third):
+    a, b = _elems(first_to_second), _elems(second_to_third)
+    out, n = np.zeros(4096, np.uint32), C.c_uint32()
+    st = lib().oracle_apply_cigar_to_cigar(_pu32(a), len(a), _pu32(b), len(b), _pu32(out), len(out), C.byref(n))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value])
+
+
+def left_align_indels(cigar, ref, read, read_start):
+    c, r, q = _elems(cigar), _seq(ref), _seq(read)
+    out, n, lead, trail = np.zeros(4 * len(c) + 8, np.uint32), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = lib().oracle_left_align_indels(_pu32(c), len(c), r.ctypes.data_as(_u8p), len(r), q.ctypes.data_as(_u8p), len(q), read_start,
+                                        _pu32(out), len(out), C.byref(n), C.byref(lead), C.byref(trail))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value]), lead.value, trail.value
+
+
+def append_clipped_elements(cigar, original):
+    a, b = _elems(cigar), _elems(original)
+    out, n = np.zeros(len(a) + len(b) + 4, np.uint32), C.c_uint32()
+    st = lib().oracle_append_clipped_elements(_pu32(a), len(a), _pu32(b), len(b), _pu32(out), len(out), C.byref(n))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value])
+
+
+def create_read_aligned_to_ref(sw_cigar, sw_offset, hap_cigar, hap_start_wrt_ref, reference_start, ref_bases, read, original_cigar,
+                               original_read_len=None):
+    """create_read_aligned_to_ref from the alignment on (src/reads/alignment_utils.rs:60-165) -> None (read unchanged) or
+    (new position, new cigar string)."""
+    a, hc, oc, r, q = _elems(sw_cigar), _elems(hap_cigar), _elems(original_cigar), _seq(ref_bases), _seq(read)
+    out, n, pos = np.zeros(4 * (len(a) + len(hc)) + len(oc) + 16, np.uint32), C.c_uint32(), C.c_int64()
+    st = lib().oracle_create_read_aligned_to_ref(_pu32(a), len(a), int(sw_offset), _pu32(hc), len(hc), int(hap_start_wrt_ref), int(reference_start),
+                                                 r.ctypes.data_as(_u8p), len(r), q.ctypes.data_as(_u8p), len(q), _pu32(oc), len(oc),
+                                                 len(q) if original_read_len is None else int(original_read_len), C.byref(pos), _pu32(out),
+                                                 len(out), C.byref(n))
+    if st == 1:
+        return None
+    if st:
+        raise CigarError(st)
+    return pos.value, cigar_to_string(out[:n.value])

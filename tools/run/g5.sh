@@ -1,4 +1,4 @@
 cd /root/repo
-python tools/realign_small.py 2>&1 | grep -v amdgpu
-for L in 32 64; do PHMM_SW_LANES=$L timeout 600 python -m pytest tests/test_sw_hip.py tests/test_realign_hip.py -x -q --timeout 200 2>&1 | tail -3; done
-timeout 600 python -m pytest tests/test_sw_hip.py tests/test_realign_hip.py -x -q --timeout 200 2>&1 | tail -3
+for fc in -1 4 6 8 12 16 24; do echo -n "force_chain=$fc: "; PHMM_FORCE_CHAIN=$fc python bench.py --steps 6 --warmup 2 --main-only --workload ragged 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(l['value'], l['ms_per_step'])"; done
