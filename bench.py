@@ -160,6 +160,7 @@ KERNEL_SOURCES = {  # what each kernel family is compiled from (lorikeet_amd/csr
     "pairhmm": ("phmm_device.hpp", "phmm_internal.hpp", "phmm_kernels.hip", "phmm_chain_kernels.hip", "phmm_chain32_kernels.hip",
                 "phmm_exact_kernels.hip", "phmm_engine_kernels.hip"),
     "sw": ("phmm_sw_internal.hpp", "phmm_sw_kernels.hip"),
+    "cigar": ("phmm_cigar_internal.hpp", "phmm_cigar_kernels.hip"),
 }
 
 

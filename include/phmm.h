@@ -346,6 +346,38 @@ int phmm_realign_to_best(phmm_handle *h, uint32_t n_regions, const uint32_t *reg
                          int32_t *alignment_offset, int32_t *best_allele, double *likelihood, double *confidence);
 
 /*
+ * The rest of AlignmentUtils::create_read_aligned_to_ref (src/reads/alignment_utils.rs:40-165), for every read of n_regions
+ * regions: the read -> haplotype alignment phmm_realign_to_best returned is projected onto the reference through the
+ * haplotype's own CIGAR -- CigarBuilder clean-up (src/reads/cigar_builder.rs), get_consolidated_padded_cigar(1000)
+ * (src/haplotype/haplotype.rs:248-256), read_start_on_reference_haplotype (:283-311), trim_cigar_by_bases (:321-386),
+ * apply_cigar_to_cigar (:240-281), left_align_indels against the reference haplotype (:425-566), the clips of the read's
+ * original CIGAR put back (:173-213) and the length check (:151-161) -- one lane per read on the device.
+ *   read_off / read_bases     the reads minus their soft clips (what was aligned)
+ *   region_ref_hap [n_regions]          index INSIDE the region of the reference haplotype (left-alignment reads its bases)
+ *   region_reference_start [n_regions]  padded_reference_loc.get_start()
+ *   hap_cigar_off [n_haps+1], hap_cigar   Haplotype::cigar of every haplotype, BAM-encoded elements
+ *   hap_start_wrt_ref [n_haps]          Haplotype::alignment_start_hap_wrt_ref
+ *   best_allele, sw_cigar_off / sw_cigar / n_sw_cigar / sw_offset   as phmm_realign_to_best filled them
+ *   orig_cigar_off [n_reads+1], orig_cigar   the reads' CIGARs before realignment (only their clips are used)
+ *   out_cigar_off [n_reads+1]           element offsets into out_cigar (sw elements + haplotype elements + clips + 4 suffices)
+ *   status [n_reads]   PHMM_PROJECT_REALIGNED: new_pos / out_cigar / n_out_cigar are the read's new alignment;
+ *                      PHMM_PROJECT_UNCHANGED: no best allele or alignment_offset == -1, the read stays as it is (:60-63);
+ *                      negative: the reference panics or returns Err for this read (-1 ... -4 CigarBuilder errors in the
+ *                      order of cigar_builder.rs, -5 an assert such as "Read goes past end of reference")
+ * Returns PHMM_ERR_CIGAR_CAPACITY when an output slot is too small (n_out_cigar holds the sizes).
+ */
+#define PHMM_PROJECT_REALIGNED 0
+#define PHMM_PROJECT_UNCHANGED 1
+int phmm_project_to_reference(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                              const uint32_t *read_off, const uint8_t *read_bases, const uint32_t *hap_off,
+                              const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *region_reference_start,
+                              const uint32_t *hap_cigar_off, const uint32_t *hap_cigar, const uint32_t *hap_start_wrt_ref,
+                              const int32_t *best_allele, const uint64_t *sw_cigar_off, const uint32_t *sw_cigar,
+                              const uint32_t *n_sw_cigar, const int32_t *sw_offset, const uint32_t *orig_cigar_off,
+                              const uint32_t *orig_cigar, const uint64_t *out_cigar_off, uint32_t *out_cigar,
+                              uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status);
+
+/*
  * Developer switches and counters (tests, A/B measurements; never needed in production).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",

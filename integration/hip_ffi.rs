@@ -42,6 +42,9 @@ pub const PHMM_SW_LEADING_INDEL: c_int = 2;
 pub const PHMM_SW_IGNORE: c_int = 3;
 /// `ref_index` value of `phmm_sw_align_indexed`: this alignment is skipped
 pub const PHMM_SW_NO_REFERENCE: u32 = 0xffff_ffff;
+/// `status` of `phmm_project_to_reference` (negative values: the read is one the reference panics on)
+pub const PHMM_PROJECT_REALIGNED: c_int = 0;
+pub const PHMM_PROJECT_UNCHANGED: c_int = 1;
 
 /// `phmm_sw_parameters` == gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend)
 #[repr(C)]
@@ -296,6 +299,34 @@ extern "C" {
         best_allele: *mut i32,
         likelihood: *mut f64,
         confidence: *mut f64,
+    ) -> c_int;
+
+    pub fn phmm_project_to_reference(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        region_reference_start: *const u64,
+        hap_cigar_off: *const u32,
+        hap_cigar: *const u32,
+        hap_start_wrt_ref: *const u32,
+        best_allele: *const i32,
+        sw_cigar_off: *const u64,
+        sw_cigar: *const u32,
+        n_sw_cigar: *const u32,
+        sw_offset: *const i32,
+        orig_cigar_off: *const u32,
+        orig_cigar: *const u32,
+        out_cigar_off: *const u64,
+        out_cigar: *mut u32,
+        n_out_cigar: *mut u32,
+        new_pos: *mut i64,
+        status: *mut i32,
     ) -> c_int;
 
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;

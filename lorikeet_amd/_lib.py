@@ -28,6 +28,7 @@ PHMM_ERR_INTERNAL = 7
 PHMM_ERR_CIGAR_CAPACITY = 8
 PHMM_SW_SOFTCLIP, PHMM_SW_INDEL, PHMM_SW_LEADING_INDEL, PHMM_SW_IGNORE = 0, 1, 2, 3
 PHMM_SW_NO_REFERENCE = 0xffffffff
+PHMM_PROJECT_REALIGNED, PHMM_PROJECT_UNCHANGED = 0, 1
 
 class EngineConfig(C.Structure):
     """phmm_engine_config (include/phmm.h)."""
@@ -84,6 +85,9 @@ SYMBOLS = [
     ("phmm_realign_to_best", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u32p, u8p, u64p, f64p, u8p,
                                        C.POINTER(C.c_int32), C.c_double, C.c_void_p, C.c_int, u64p, u32p, u32p,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), f64p, f64p]),
+    ("phmm_project_to_reference", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u32p, u8p, C.POINTER(C.c_int32), u64p, u32p, u32p,
+                                            u32p, C.POINTER(C.c_int32), u64p, u32p, u32p, C.POINTER(C.c_int32), u32p, u32p, u64p, u32p, u32p,
+                                            C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),

@@ -1,0 +1,45 @@
+// Projection of read -> haplotype alignments onto the reference (phmm_cigar_kernels.hip): kernel parameters and status
+// codes, shared by the kernel file and phmm_cigar.cpp.
+#pragma once
+
+#include "phmm_internal.hpp"
+
+namespace phmm {
+
+// per-read status (== PHMM_PROJECT_* of include/phmm.h)
+constexpr int CIGAR_OK = 0;                 // realigned: new position and cigar are valid
+constexpr int CIGAR_UNCHANGED = 1;          // no best allele, or alignment_offset == -1: the read stays as it is
+constexpr int CIGAR_ERR_ORDER = -1;         // CigarBuilder: "Cigar has already reached its right (hard) clip"
+constexpr int CIGAR_ERR_SOFT_CLIPPED = -2;  // CigarBuilder: "Cigar is completely soft clipped"
+constexpr int CIGAR_ERR_NONE = -3;          // CigarBuilder: "Last element cannot be None at this point"
+constexpr int CIGAR_ERR_EMPTY = -4;         // CigarBuilder: "No cigar elements left after removing leading and trailing deletions."
+constexpr int CIGAR_ERR_PANIC = -5;         // an assert! / panic! of the reference (read past the reference, cigar does not cover the read, ...)
+constexpr int CIGAR_ERR_WORKSPACE = -6;     // more elements than the workspace reserves (never with the sizes the host side derives)
+
+struct ProjectParams {
+    uint32_t n_reads, n_regions;
+    const uint32_t *region_read_off, *region_hap_off;
+    const uint32_t *read_off;          // [n_reads + 1] the reads minus their soft clips
+    const uint8_t *read_bases;
+    const uint32_t *hap_off;           // [n_haps + 1]
+    const uint8_t *hap_bases;
+    const int32_t *region_ref_hap;     // [n_regions] reference haplotype inside the region
+    const uint64_t *region_reference_start;  // [n_regions]
+    const uint32_t *hap_cigar_off, *hap_cigar;   // [n_haps + 1], elements
+    const uint32_t *hap_start_wrt_ref;           // [n_haps]
+    const int32_t *best_allele;        // [n_reads]
+    const uint64_t *sw_cigar_off;      // [n_reads + 1]
+    const uint32_t *sw_cigar, *n_sw_cigar;
+    const int32_t *sw_offset;
+    const uint32_t *orig_cigar_off, *orig_cigar;  // [n_reads + 1], elements
+    const uint64_t *out_cigar_off;     // [n_reads + 1]
+    uint32_t *out_cigar, *n_out_cigar;
+    int64_t *new_pos;
+    int32_t *status;
+    uint32_t *flags;                   // bit 0: some cigar did not fit its slot
+    uint32_t *workspace;               // [n_reads][4][capacity]
+    uint32_t capacity;
+};
+hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
+
+}  // namespace phmm

@@ -87,3 +87,49 @@ def realign_reads_to_their_best_haplotype(engine, batch, likelihoods, hap_priori
                for a in range(n)]
         return BestAlleles(best, out_lk, conf), res
     raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, engine.last_error())
+
+
+class ProjectedReads:
+    """Per read: status (0 realigned, 1 unchanged, < 0 where the reference panics), new position, new CIGAR elements."""
+
+    def __init__(self, status, new_pos, cigars):
+        self.status, self.new_pos, self.cigars = status, new_pos, cigars
+
+
+def project_to_reference(engine, batch, best_allele, alignments, hap_cigars, hap_start_wrt_ref, region_ref_hap, region_reference_start,
+                         original_cigars, capacity=None):
+    """The rest of AlignmentUtils::create_read_aligned_to_ref (src/reads/alignment_utils.rs:83-165) for every read of the batch
+    (phmm_project_to_reference).  `alignments`: the SmithWatermanAlignmentResult per read realign_reads_to_their_best_haplotype
+    returned (None where there is none); `hap_cigars` / `original_cigars`: one array of BAM-encoded elements per haplotype / read."""
+    n, nh = batch.n_reads, batch.n_haps
+    best = np.ascontiguousarray(best_allele, dtype=np.int32)
+    sw_n = np.array([0 if a is None else len(a.elements) for a in alignments], np.uint32)
+    sw_off = np.concatenate([[0], np.cumsum(sw_n)]).astype(np.uint64)
+    sw = np.concatenate([np.zeros(0, np.uint32)] + [a.elements for a in alignments if a is not None]).astype(np.uint32)
+    sw_offset = np.array([-1 if a is None else a.alignment_offset for a in alignments], np.int32)
+    hc_off = np.concatenate([[0], np.cumsum([len(c) for c in hap_cigars])]).astype(np.uint32)
+    hc = np.concatenate([np.zeros(0, np.uint32)] + [np.asarray(c, np.uint32) for c in hap_cigars]).astype(np.uint32)
+    oc_off = np.concatenate([[0], np.cumsum([len(c) for c in original_cigars])]).astype(np.uint32)
+    oc = np.concatenate([np.zeros(0, np.uint32)] + [np.asarray(c, np.uint32) for c in original_cigars]).astype(np.uint32)
+    hs = np.ascontiguousarray(hap_start_wrt_ref, dtype=np.uint32)
+    rrh = np.ascontiguousarray(region_ref_hap, dtype=np.int32)
+    rs = np.ascontiguousarray(region_reference_start, dtype=np.uint64)
+    assert len(hap_cigars) == nh and len(original_cigars) == n and len(alignments) == n
+    cap = np.full(n, 16 if capacity is None else int(capacity), np.int64)
+    i64p = C.POINTER(C.c_int64)
+    for _attempt in range(2):
+        out_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+        out, n_out, pos, status = np.zeros(int(out_off[-1]), np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        code = engine.lib.phmm_project_to_reference(
+            engine._h, batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p), _p(batch.read_off, _lib.u32p),
+            _p(batch.read_bases, _lib.u8p), _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(rrh, _i32p), _p(rs, _lib.u64p),
+            _p(hc_off, _lib.u32p), _p(hc, _lib.u32p), _p(hs, _lib.u32p), _p(best, _i32p), _p(sw_off, _lib.u64p), _p(sw, _lib.u32p),
+            _p(sw_n, _lib.u32p), _p(sw_offset, _i32p), _p(oc_off, _lib.u32p), _p(oc, _lib.u32p), _p(out_off, _lib.u64p), _p(out, _lib.u32p),
+            _p(n_out, _lib.u32p), _p(pos, i64p), _p(status, _i32p))
+        if code == _lib.PHMM_ERR_CIGAR_CAPACITY:
+            cap = np.maximum(cap, n_out.astype(np.int64))
+            continue
+        if code != _lib.PHMM_OK:
+            raise PhmmError(code, engine.last_error())
+        return ProjectedReads(status, pos, [out[int(out_off[r]):int(out_off[r]) + int(n_out[r])] for r in range(n)])
+    raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, engine.last_error())

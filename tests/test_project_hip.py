@@ -1,0 +1,120 @@
+"""phmm_project_to_reference on the MI355X: the read -> haplotype alignment projected onto the reference, read
+by read EQUAL (status, position, CIGAR) to oracle/cigar_oracle.c, which the reference's own test data pin
+(tests/test_cigar_oracle.py); and the reference's create_read_aligned_to_ref cases through the device directly."""
+import numpy as np
+import pytest
+
+from lorikeet_amd import realign
+from lorikeet_amd.batch import RegionBatch
+from lorikeet_amd.smith_waterman import ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, SmithWatermanAligner
+from oracle import oracle
+
+from project_scenarios import make_read as _read, oracle_read as _oracle_read, scenario as _scenario
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,low_complexity", [(1, False), (2, False), (3, True), (4, True), (5, False)])
+def test_projection_equals_the_oracle(hip_engine, seed, low_complexity):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(seed, low_complexity=low_complexity)
+    lk = hip_engine.compute(b)
+    best, aligned = realign.realign_reads_to_their_best_haplotype(hip_engine, b, lk)
+    got = realign.project_to_reference(hip_engine, b, best.allele_index, aligned, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+    reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+    n_ok = n_indel = 0
+    for r in range(b.n_reads):
+        st, pos, cig = _oracle_read(b, r, reg[r], best.allele_index[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        assert got.status[r] == st, (r, got.status[r], st)
+        if st == 0:
+            assert got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig, (r, oracle.cigar_to_string(got.cigars[r]), cig)
+            n_ok += 1
+            n_indel += ("I" in cig) or ("D" in cig)
+    assert n_ok > b.n_reads // 2 and n_indel > 0
+
+
+def test_every_read_against_every_haplotype(hip_engine):
+    """Not only the best allele: every (read, haplotype) pair of a scenario, including hopeless ones -- statuses of the
+    reference's panics included."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(11, n_regions=3)
+    reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+    nh = np.diff(b.region_hap_off.astype(np.int64))
+    al = SmithWatermanAligner(hip_engine)
+    for k in range(int(nh.max())):
+        best = np.where(k < nh[reg], k, -1).astype(np.int32)
+        idx = np.where(best >= 0, b.region_hap_off[:-1].astype(np.int64)[reg] + best, -1)
+        haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(b.n_haps)]
+        reads = [b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])] for r in range(b.n_reads)]
+        aligned = al.align_indexed(haps, reads, idx, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")
+        got = realign.project_to_reference(hip_engine, b, best, aligned, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        for r in range(b.n_reads):
+            st, pos, cig = _oracle_read(b, r, reg[r], best[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+            assert got.status[r] == st, (k, r, got.status[r], st)
+            if st == 0:
+                assert got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig, (k, r)
+
+
+def _one(hip_engine, read, hap, hap_cigar, hap_start, reference, ref_start, original="10M"):
+    """One read, one haplotype + the reference haplotype, through phmm_sw_align + phmm_project_to_reference."""
+    u8 = lambda s: np.frombuffer(s.encode() if isinstance(s, str) else s, np.uint8)  # noqa: E731
+    haps = [u8(reference), u8(hap)] if hap != reference else [u8(reference)]
+    b = RegionBatch.from_regions([([_read(bytes(u8(read)))], haps)])
+    k = len(haps) - 1
+    aligned = SmithWatermanAligner(hip_engine).align_indexed(haps, [u8(read)], [k], ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")
+    cigs = [oracle.parse_cigar("%dM" % len(reference))] + ([oracle.parse_cigar(hap_cigar)] if k else [])
+    if not k:
+        cigs = [oracle.parse_cigar(hap_cigar)]
+    got = realign.project_to_reference(hip_engine, b, [k], aligned, cigs, [0, hap_start][:k + 1] if k else [hap_start], [0], [ref_start],
+                                       [oracle.parse_cigar(original)])
+    assert got.status[0] == 0
+    return int(got.new_pos[0]), oracle.cigar_to_string(got.cigars[0])
+
+
+def test_reference_cases_of_create_read_aligned_to_ref(hip_engine):
+    """tests/alignment_utils_unit_tests.rs:156-290 through the device."""
+    hap = "ACTGAAGGTTCC"
+    all_m = "%dM" % len(hap)
+    for i in range(-1, len(hap)):
+        read = bytearray(hap.encode())
+        if i != -1:
+            read[i] = ord("A")
+        assert _one(hip_engine, bytes(read), hap, all_m, 0, hap, 10) == (10, all_m)
+    for pad in range(1, 10):
+        assert _one(hip_engine, "N" * pad + hap, hap, all_m, 0, hap, 10) == (10, "%dI%s" % (pad, all_m))
+        assert _one(hip_engine, hap + "N" * pad, hap, all_m, 0, hap, 10) == (10, "%s%dI" % (all_m, pad))
+    for ref_start in range(1, 10, 3):
+        for hap_start in range(ref_start, 10 + ref_start, 3):
+            assert _one(hip_engine, hap, hap, all_m, hap_start, hap, ref_start) == (ref_start + hap_start, all_m)
+    reference = "GGGATCCTGCTACAAAGGTGAAACCCAGGAGAGTGTGGAGTCCAGAGTGTTGCCAGGACCCAGGCACAGGCATTAGTGCCCGTTGGAGAAAACAGGGGAATCCCGAAGAAATGGTGGGTCCTGGCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC"
+    haplotype = "GGGATCCTGCTACAAAGGTGAAACCCAGGAGAGTGTGGAGTCCAGAGTGTTGCCAGGACCCAGGCACAGGCATTAGTGCCCGTTGGAGAAAACGGGAATCCCGAAGAAATGGTGGGTCCTGGCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC"
+    read = "CCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC"
+    assert _one(hip_engine, read, haplotype, "93M2D92M", 553, reference, 13011) == (13011 + 553 + 123, "64M")
+
+
+def test_broken_inputs_fail_read_by_read_like_the_reference(hip_engine):
+    """Haplotype CIGARs that do not fit their bases (too short, too long, clips and skips in odd places): the reference
+    panics or returns Err for some reads (read past the end of the reference, builder errors, a cigar that does not cover
+    the read ...) -- the device gives those reads the same negative status as the oracle and realigns the others alike."""
+    rng = np.random.default_rng(99)
+    seen = {}
+    for trial in range(12):
+        b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(200 + trial, n_regions=3)
+        for a in range(b.n_haps):
+            if rng.random() < 0.7:
+                n = int(rng.integers(1, 6))
+                ops = rng.choice(list("MMMMIDDNSH=X"), n)
+                hap_cigars[a] = oracle.parse_cigar("".join("%d%s" % (int(rng.integers(1, 120)), o) for o in ops))
+        reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+        nh = np.diff(b.region_hap_off.astype(np.int64))
+        best = rng.integers(0, nh[reg]).astype(np.int32)
+        idx = b.region_hap_off[:-1].astype(np.int64)[reg] + best
+        haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(b.n_haps)]
+        reads = [b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])] for r in range(b.n_reads)]
+        aligned = SmithWatermanAligner(hip_engine).align_indexed(haps, reads, idx, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")
+        got = realign.project_to_reference(hip_engine, b, best, aligned, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        for r in range(b.n_reads):
+            st, pos, cig = _oracle_read(b, r, reg[r], best[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+            assert got.status[r] == st, (trial, r, got.status[r], st, oracle.cigar_to_string(hap_cigars[int(idx[r])]))
+            if st == 0:
+                assert got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig, (trial, r)
+            seen[st] = seen.get(st, 0) + 1
+    assert seen.get(0, 0) > 50 and sum(v for k, v in seen.items() if k < 0) > 20, seen

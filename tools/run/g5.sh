@@ -1,4 +1,3 @@
 cd /root/repo
-for fc in -1 4 6 8 12 16 24; do echo -n "force_chain=$fc: "; PHMM_FORCE_CHAIN=$fc python bench.py --steps 6 --warmup 2 --main-only --workload ragged 2>/dev/null | python -c "
-import json,sys
-l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(l['value'], l['ms_per_step'])"; done
+timeout 600 python -m pytest tests/test_project_hip.py -x -q --timeout 300 2>&1 | tail -5
+timeout 200 python tools/soak_project.py 60 3 2>&1 | tail -3
