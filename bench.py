@@ -666,12 +666,51 @@ def main():
                 same = same and of == off[r] and np.array_equal(cg, cigar[r * cap:r * cap + int(n_cig[r])])
                 checked += 1
         cells = int(np.sum(np.diff(sub.read_off.astype(np.int64)) * np.diff(sub.hap_off.astype(np.int64))[sub.region_hap_off[:-1].astype(np.int64)[np.repeat(np.arange(sub.n_regions), nr)] + b_idx]))
+        # ... and the projection of those alignments onto the reference (the rest of create_read_aligned_to_ref): the
+        # synthetic haplotypes differ from their region's first one by SNVs, so their CIGARs are one M element
+        hlen = np.diff(sub.hap_off.astype(np.int64))
+        hc_off = np.arange(sub.n_haps + 1, dtype=np.uint32)
+        hc = ((hlen << 4) | 0).astype(np.uint32)
+        hs = np.zeros(sub.n_haps, np.uint32)
+        rrh = np.zeros(sub.n_regions, np.int32)
+        rstart = (1000 + 1000 * np.arange(sub.n_regions)).astype(np.uint64)
+        rlen = np.diff(sub.read_off.astype(np.int64))
+        oc_off = np.arange(n + 1, dtype=np.uint32)
+        oc = ((rlen << 4) | 0).astype(np.uint32)
+        out_off = np.arange(n + 1, dtype=np.uint64) * 8
+        out_c, n_out, pos, status = np.zeros(n * 8, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        pargs = (eng._h, sub.n_regions, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p), pp(sub.read_off, _lib.u32p),
+                 pp(sub.read_bases, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p), pp(rrh, i32p), pp(rstart, _lib.u64p),
+                 pp(hc_off, _lib.u32p), pp(hc, _lib.u32p), pp(hs, _lib.u32p), pp(b_idx, i32p), pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p),
+                 pp(n_cig, _lib.u32p), pp(off, i32p), pp(oc_off, _lib.u32p), pp(oc, _lib.u32p), pp(out_off, _lib.u64p), pp(out_c, _lib.u32p),
+                 pp(n_out, _lib.u32p), pp(pos, C.POINTER(C.c_int64)), pp(status, i32p))
+        assert eng.lib.phmm_project_to_reference(*pargs) == 0, eng.last_error()
+        t = time.perf_counter()
+        for _ in range(5):
+            assert eng.lib.phmm_project_to_reference(*pargs) == 0
+        dt_proj = (time.perf_counter() - t) / 5
+        proj_same, proj_checked = True, 0
+        for g in range(0, sub.n_regions, max(1, sub.n_regions // 8)):
+            r0 = int(sub.region_read_off[g])
+            h0 = int(sub.region_hap_off[g])
+            ref = sub.hap_bases[int(sub.hap_off[h0]):int(sub.hap_off[h0 + 1])]
+            for r in range(r0, r0 + min(int(nr[g]), 32)):
+                hp = h0 + int(b_idx[r])
+                want = oracle.create_read_aligned_to_ref(cigar[r * cap:r * cap + int(n_cig[r])], int(off[r]), hc[hp:hp + 1], 0, int(rstart[g]), ref,
+                                                         sub.read_bases[int(sub.read_off[r]):int(sub.read_off[r + 1])], oc[r:r + 1])
+                proj_same = proj_same and status[r] == 0 and want == (int(pos[r]), oracle.cigar_to_string(out_c[r * 8:r * 8 + int(n_out[r])]))
+                proj_checked += 1
         return {"call": "phmm_realign_to_best: best allele per read (haplotype_alignment_tiebreaking_priority) + SoftClip alignment of the read "
                         "to it, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS; host buffers, PCIe included",
                 "reads": int(n), "regions": int(sub.n_regions), "ms_per_call": round(dt * 1e3, 3), "reads_per_s": round(n / dt, 1),
                 "gcups_i32": round(cells / dt / 1e9, 1), "sw_kernels_ms": round(kern_s * 1e3, 3),
                 "informative_reads": int(np.sum(b_conf > 0.2)), "python_mirror_ms_per_call": round(dt_py * 1e3, 1),
-                "equal_to_oracle_on_sample": bool(same), "sample_alignments": checked}
+                "equal_to_oracle_on_sample": bool(same), "sample_alignments": checked,
+                "project_to_reference": {"call": "phmm_project_to_reference on the same reads: the alignments projected through the haplotypes' "
+                                                 "CIGARs, left-aligned, clips restored (the rest of create_read_aligned_to_ref); host buffers",
+                                         "ms_per_call": round(dt_proj * 1e3, 3), "reads_per_s": round(n / dt_proj, 1),
+                                         "realigned": int(np.sum(status == 0)), "with_indels": int(np.sum(n_out > 1)),
+                                         "equal_to_oracle_on_sample": bool(proj_same), "sample_reads": proj_checked}}
 
     class Dist1:  # rank-0-only rows: same timing code, no cross-rank barrier
         def __init__(self, d):
