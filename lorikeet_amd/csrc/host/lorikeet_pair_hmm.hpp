@@ -20,6 +20,7 @@
 //   src/reads/read_utils.rs:23,372-416     BI/BD tags or flat Q45         HmmRead::base_{insertion,deletion}_qualities
 //   src/model/allele_likelihoods.rs:1043-1166  best_alleles_breaking_ties_main, BestAllele  AssemblyBasedCallerUtils::best_alleles_breaking_ties_main
 //   src/assembly/assembly_based_caller_utils.rs:187-246  tie-breaking priorities, realign_reads_to_their_best_haplotype (arithmetic)
+//   src/reads/alignment_utils.rs:40-165     AlignmentUtils::create_read_aligned_to_ref (position and CIGAR)
 #pragma once
 
 #include <algorithm>
@@ -71,6 +72,13 @@ struct Haplotype {
     Bytes bases_;
     bool is_ref = false;
     size_t cigar_elements = 1;  // elements of the haplotype -> reference CIGAR (haplotype_alignment_tiebreaking_priority)
+    std::vector<uint32_t> cigar;  // the haplotype -> reference CIGAR, BAM-encoded (empty: one M over the bases)
+    size_t alignment_start_hap_wrt_ref = 0;
+    void set_cigar(const std::vector<uint32_t> &c) {
+        cigar = c;
+        cigar_elements = c.size();
+    }
+    void set_alignment_start_hap_wrt_ref(size_t s) { alignment_start_hap_wrt_ref = s; }
     Haplotype() = default;
     Haplotype(const Bytes &b, bool is_reference) : bases_(b), is_ref(is_reference) {}
     Haplotype(const std::string &b, bool is_reference) : bases_(bytes(b)), is_ref(is_reference) {}
@@ -608,6 +616,86 @@ struct AssemblyBasedCallerUtils {
                 }
             }
         return out;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AlignmentUtils::create_read_aligned_to_ref (reference src/reads/alignment_utils.rs:40-165): the read aligned to the
+// haplotype (phmm_sw_align_indexed) and that alignment projected onto the reference (phmm_project_to_reference).
+// ---------------------------------------------------------------------------------------------------------------------
+inline std::vector<uint32_t> parse_cigar(const std::string &text) {  // CigarString::try_from
+    static const std::string ops = "MIDNSHP=X";
+    std::vector<uint32_t> out;
+    uint32_t n = 0;
+    for (char ch : text) {
+        if (ch >= '0' && ch <= '9') {
+            n = n * 10 + (uint32_t)(ch - '0');
+        } else {
+            const size_t op = ops.find(ch);
+            if (op == std::string::npos) throw Panic("bad CIGAR operator");
+            out.push_back((n << 4) | (uint32_t)op);
+            n = 0;
+        }
+    }
+    return out;
+}
+inline std::string cigar_to_string(const std::vector<uint32_t> &c) {
+    SmithWatermanAlignmentResult r;
+    r.cigar = c;
+    return r.get_cigar();
+}
+
+struct AlignedRead {  // what create_read_aligned_to_ref changes of the read: pos() and cigar(); `realigned` false = the clone
+    bool realigned = false;
+    int64_t pos = 0;
+    std::vector<uint32_t> cigar;
+};
+
+struct AlignmentUtils {
+    // original_read: the read minus its soft clips in `bases` (ReadClipper::hard_clip_soft_clipped_bases, :47-50) and its
+    // CIGAR before realignment in `original_cigar` (only the clips are used, :135-143)
+    static AlignedRead create_read_aligned_to_ref(const Bytes &read_minus_soft_clips, const std::vector<uint32_t> &original_cigar,
+                                                  const Haplotype &haplotype, const Haplotype &ref_haplotype, size_t reference_start) {
+        static std::mutex mu;
+        static detail::Handle handle = detail::make_handle(0, 0);
+        if (read_minus_soft_clips.empty() || haplotype.bases_.empty() || ref_haplotype.bases_.empty())
+            throw Panic("non-empty sequences are required for the Smith-Waterman calculation");
+        // one region: [reference haplotype, haplotype], one read
+        Bytes haps = ref_haplotype.bases_;
+        haps.insert(haps.end(), haplotype.bases_.begin(), haplotype.bases_.end());
+        const uint32_t hap_off[3] = {0, (uint32_t)ref_haplotype.bases_.size(), (uint32_t)haps.size()};
+        const uint32_t read_off[2] = {0, (uint32_t)read_minus_soft_clips.size()}, rro[2] = {0, 1}, rho[2] = {0, 2}, ref_index[1] = {1};
+        const phmm_sw_parameters prm{ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.match_value, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.mismatch_penalty,
+                                     ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.gap_open_penalty, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS.gap_extend_penalty};
+        auto whole = [](const Haplotype &h) { return h.cigar.empty() ? std::vector<uint32_t>{(uint32_t)h.bases_.size() << 4} : h.cigar; };
+        const std::vector<uint32_t> c_ref = whole(ref_haplotype), c_hap = whole(haplotype);
+        std::vector<uint32_t> hap_cigar = c_ref;
+        hap_cigar.insert(hap_cigar.end(), c_hap.begin(), c_hap.end());
+        const uint32_t hap_cigar_off[3] = {0, (uint32_t)c_ref.size(), (uint32_t)hap_cigar.size()};
+        const uint32_t hap_start[2] = {(uint32_t)ref_haplotype.alignment_start_hap_wrt_ref, (uint32_t)haplotype.alignment_start_hap_wrt_ref};
+        const uint32_t oc_off[2] = {0, (uint32_t)original_cigar.size()};
+        const int32_t region_ref_hap[1] = {0}, best[1] = {1};
+        const uint64_t ref_start[1] = {(uint64_t)reference_start};
+        const size_t cap = read_minus_soft_clips.size() + haplotype.bases_.size() + original_cigar.size() + hap_cigar.size() + 8;
+        const uint64_t cig_off[2] = {0, cap};
+        std::vector<uint32_t> sw(cap), out(cap);
+        uint32_t n_sw = 0, n_out = 0;
+        int32_t offset = 0, status = 0;
+        int64_t pos = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        detail::check(handle.get(), phmm_sw_align_indexed(handle.get(), 2, hap_off, haps.data(), 1, ref_index, read_off, read_minus_soft_clips.data(),
+                                                          &prm, PHMM_SW_SOFTCLIP, cig_off, sw.data(), &n_sw, &offset));
+        detail::check(handle.get(), phmm_project_to_reference(handle.get(), 1, rro, rho, read_off, read_minus_soft_clips.data(), hap_off, haps.data(),
+                                                              region_ref_hap, ref_start, hap_cigar_off, hap_cigar.data(), hap_start, best, cig_off,
+                                                              sw.data(), &n_sw, &offset, oc_off, original_cigar.data(), cig_off, out.data(), &n_out,
+                                                              &pos, &status));
+        if (status < 0) throw Panic("create_read_aligned_to_ref: the reference panics on this read (status " + std::to_string(status) + ")");
+        AlignedRead r;
+        r.realigned = status == PHMM_PROJECT_REALIGNED;
+        r.pos = pos;
+        r.cigar.assign(out.begin(), out.begin() + n_out);
+        return r;
     }
 };
 

@@ -572,6 +572,48 @@ static void test_best_alleles() {
     }
 }
 
+// tests/alignment_utils_unit_tests.rs:156-290 (make_read_aligned_to_ref_data): the read realigned through its haplotype
+// lands where the test says, with the CIGAR the test says.
+static void test_read_aligned_to_ref(const std::string &read, const Haplotype &hap, const Haplotype &ref_hap, size_t ref_start,
+                                     int64_t expected_start, const std::string &expected_cigar) {
+    const auto aligned = AlignmentUtils::create_read_aligned_to_ref(bytes(read), parse_cigar("10M"), hap, ref_hap, ref_start);
+    ASSERT(aligned.realigned && aligned.pos == expected_start && cigar_to_string(aligned.cigar) == expected_cigar,
+           "read %s: %s @ %lld, expected %s @ %lld", read.c_str(), cigar_to_string(aligned.cigar).c_str(), (long long)aligned.pos,
+           expected_cigar.c_str(), (long long)expected_start);
+}
+
+static void make_read_aligned_to_ref_data() {
+    const std::string hap_bases = "ACTGAAGGTTCC";
+    Haplotype all_m(hap_bases, false);
+    all_m.set_cigar(parse_cigar(std::to_string(hap_bases.size()) + "M"));
+    const std::string all_m_cigar = std::to_string(hap_bases.size()) + "M";
+    for (int i = -1; i < (int)hap_bases.size(); ++i) {
+        std::string read = hap_bases;
+        if (i != -1) read[i] = 'A';
+        test_read_aligned_to_ref(read, all_m, all_m, 10, 10, all_m_cigar);
+    }
+    for (int pad = 1; pad < 10; ++pad) {
+        test_read_aligned_to_ref(std::string(pad, 'N') + hap_bases, all_m, all_m, 10, 10, std::to_string(pad) + "I" + all_m_cigar);
+        test_read_aligned_to_ref(hap_bases + std::string(pad, 'N'), all_m, all_m, 10, 10, all_m_cigar + std::to_string(pad) + "I");
+    }
+    for (size_t ref_start = 1; ref_start < 10; ++ref_start)
+        for (size_t hap_start = ref_start; hap_start < 10 + ref_start; ++hap_start) {
+            Haplotype hap(hap_bases, false);
+            hap.set_cigar(all_m.cigar);
+            hap.set_alignment_start_hap_wrt_ref(hap_start);
+            test_read_aligned_to_ref(hap_bases, hap, all_m, ref_start, (int64_t)(ref_start + hap_start), all_m_cigar);
+        }
+    {
+        const std::string reference = "GGGATCCTGCTACAAAGGTGAAACCCAGGAGAGTGTGGAGTCCAGAGTGTTGCCAGGACCCAGGCACAGGCATTAGTGCCCGTTGGAGAAAACAGGGGAATCCCGAAGAAATGGTGGGTCCTGGCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC";
+        const std::string haplotype = "GGGATCCTGCTACAAAGGTGAAACCCAGGAGAGTGTGGAGTCCAGAGTGTTGCCAGGACCCAGGCACAGGCATTAGTGCCCGTTGGAGAAAACGGGAATCCCGAAGAAATGGTGGGTCCTGGCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC";
+        Haplotype hap(haplotype, false), ref_hap(reference, true);
+        hap.set_cigar(parse_cigar("93M2D92M"));
+        hap.set_alignment_start_hap_wrt_ref(553);
+        ref_hap.set_cigar(parse_cigar(std::to_string(reference.size()) + "M"));
+        test_read_aligned_to_ref("CCCATCCGTGAGATCTTCCCAGGGCAGCTCCCCTCTGTGGAATCCAATCTGTCTTCCATCCTGC", hap, ref_hap, 13011, 13011 + 553 + 123, "64M");
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
@@ -598,6 +640,7 @@ int main(int argc, char **argv) {
         {"smith_waterman_asserted_cases", test_smith_waterman_asserted_cases},
         {"test_for_identical_alignments_with_differing_flank_lengths", test_for_identical_alignments_with_differing_flank_lengths},
         {"test_best_alleles + realignment to the best haplotype", test_best_alleles},
+        {"make_read_aligned_to_ref_data", make_read_aligned_to_ref_data},
     };
     int failed = 0;
     for (const auto &t : tests) {
