@@ -689,6 +689,22 @@ def main():
         for _ in range(5):
             assert eng.lib.phmm_project_to_reference(*pargs) == 0
         dt_proj = (time.perf_counter() - t) / 5
+        # ... and all three steps in one call: nothing but the results comes back
+        b2, l2, c2 = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
+        out2, n_out2, pos2, status2 = np.zeros(n * 8, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        fargs = (eng._h, sub.n_regions, pp(sub.region_read_off, _lib.u32p), pp(sub.region_hap_off, _lib.u32p), pp(sub.read_off, _lib.u32p),
+                 pp(sub.read_bases, _lib.u8p), pp(sub.hap_off, _lib.u32p), pp(sub.hap_bases, _lib.u8p), pp(sub.out_off, _lib.u64p), pp(lk, _lib.f64p),
+                 None, pp(pri, i32p), 0.2, C.byref(prm), _lib.PHMM_SW_SOFTCLIP, pp(rrh, i32p), pp(rstart, _lib.u64p), pp(hc_off, _lib.u32p),
+                 pp(hc, _lib.u32p), pp(hs, _lib.u32p), pp(oc_off, _lib.u32p), pp(oc, _lib.u32p), pp(out_off, _lib.u64p), pp(out2, _lib.u32p),
+                 pp(n_out2, _lib.u32p), pp(pos2, C.POINTER(C.c_int64)), pp(status2, i32p), pp(b2, i32p), pp(l2, _lib.f64p), pp(c2, _lib.f64p))
+        assert eng.lib.phmm_realign_reads(*fargs) == 0, eng.last_error()
+        t = time.perf_counter()
+        for _ in range(5):
+            assert eng.lib.phmm_realign_reads(*fargs) == 0
+        dt_fused = (time.perf_counter() - t) / 5
+        used = np.arange(8)[None, :] < n_out[:, None]  # (what lies behind a CIGAR in its slot is not defined)
+        fused_same = bool(np.array_equal(b2, b_idx) and np.array_equal(status2, status) and np.array_equal(pos2, pos) and
+                          np.array_equal(n_out2, n_out) and np.array_equal(out2.reshape(n, 8)[used], out_c.reshape(n, 8)[used]))
         proj_same, proj_checked = True, 0
         for g in range(0, sub.n_regions, max(1, sub.n_regions // 8)):
             r0 = int(sub.region_read_off[g])
@@ -710,7 +726,10 @@ def main():
                                                  "CIGARs, left-aligned, clips restored (the rest of create_read_aligned_to_ref); host buffers",
                                          "ms_per_call": round(dt_proj * 1e3, 3), "reads_per_s": round(n / dt_proj, 1),
                                          "realigned": int(np.sum(status == 0)), "with_indels": int(np.sum(n_out > 1)),
-                                         "equal_to_oracle_on_sample": bool(proj_same), "sample_reads": proj_checked}}
+                                         "equal_to_oracle_on_sample": bool(proj_same), "sample_reads": proj_checked},
+                "realign_reads_one_call": {"call": "phmm_realign_reads: best alleles + alignments + projection, the alignments never leave the device",
+                                           "ms_per_call": round(dt_fused * 1e3, 3), "reads_per_s": round(n / dt_fused, 1),
+                                           "equal_to_the_separate_calls": fused_same}}
 
     class Dist1:  # rank-0-only rows: same timing code, no cross-rank barrier
         def __init__(self, d):

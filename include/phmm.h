@@ -378,6 +378,23 @@ int phmm_project_to_reference(phmm_handle *h, uint32_t n_regions, const uint32_t
                               uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status);
 
 /*
+ * realign_reads_to_their_best_haplotype (src/assembly/assembly_based_caller_utils.rs:208-246) in one call: the best allele
+ * of every read (phmm_best_alleles), the read's alignment to that haplotype (phmm_sw_align_indexed) and the alignment
+ * projected onto the reference (phmm_project_to_reference) -- the reads and haplotypes cross the bus once, the best
+ * alleles and the read -> haplotype alignments never leave the device.  Arguments as in those three calls; per read it
+ * returns BestAllele (best_allele / likelihood / confidence) and status / new_pos / out_cigar.  An alignment whose CIGAR
+ * outgrows the library's own slots (24 elements) is handled inside (the call runs once more with larger ones).
+ */
+int phmm_realign_reads(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                       const uint32_t *read_off, const uint8_t *read_bases, const uint32_t *hap_off, const uint8_t *hap_bases,
+                       const uint64_t *out_off, const double *likelihoods, const uint8_t *keep, const int32_t *hap_priority,
+                       double informative_threshold, const phmm_sw_parameters *params, int overhang_strategy,
+                       const int32_t *region_ref_hap, const uint64_t *region_reference_start, const uint32_t *hap_cigar_off,
+                       const uint32_t *hap_cigar, const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off,
+                       const uint32_t *orig_cigar, const uint64_t *out_cigar_off, uint32_t *out_cigar, uint32_t *n_out_cigar,
+                       int64_t *new_pos, int32_t *status, int32_t *best_allele, double *likelihood, double *confidence);
+
+/*
  * Developer switches and counters (tests, A/B measurements; never needed in production).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",

@@ -329,6 +329,39 @@ extern "C" {
         status: *mut i32,
     ) -> c_int;
 
+    pub fn phmm_realign_reads(
+        h: *mut phmm_handle,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        out_off: *const u64,
+        likelihoods: *const f64,
+        keep: *const u8,
+        hap_priority: *const i32,
+        informative_threshold: f64,
+        params: *const phmm_sw_parameters,
+        overhang_strategy: c_int,
+        region_ref_hap: *const i32,
+        region_reference_start: *const u64,
+        hap_cigar_off: *const u32,
+        hap_cigar: *const u32,
+        hap_start_wrt_ref: *const u32,
+        orig_cigar_off: *const u32,
+        orig_cigar: *const u32,
+        out_cigar_off: *const u64,
+        out_cigar: *mut u32,
+        n_out_cigar: *mut u32,
+        new_pos: *mut i64,
+        status: *mut i32,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
+    ) -> c_int;
+
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;
     pub fn phmm_get_stat(h: *mut phmm_handle, name: *const c_char) -> u64;
 

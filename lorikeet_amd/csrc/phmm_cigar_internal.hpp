@@ -17,7 +17,7 @@ constexpr int CIGAR_ERR_PANIC = -5;         // an assert! / panic! of the refere
 constexpr int CIGAR_ERR_WORKSPACE = -6;     // more elements than the workspace reserves (never with the sizes the host side derives)
 
 struct ProjectParams {
-    uint32_t n_reads, n_regions;
+    uint32_t r_begin, n_reads, n_regions;   // this launch projects reads [r_begin, n_reads)
     const uint32_t *region_read_off, *region_hap_off;
     const uint32_t *read_off;          // [n_reads + 1] the reads minus their soft clips
     const uint8_t *read_bases;
@@ -37,7 +37,7 @@ struct ProjectParams {
     int64_t *new_pos;
     int32_t *status;
     uint32_t *flags;                   // bit 0: some cigar did not fit its slot
-    uint32_t *workspace;               // [n_reads][4][capacity]
+    uint32_t *workspace;               // [n_reads - r_begin][4][capacity]
     uint32_t capacity;
 };
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream);

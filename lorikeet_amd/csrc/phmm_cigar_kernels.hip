@@ -134,12 +134,12 @@ __device__ __forceinline__ int32_t range_len(int32_t start, int32_t end) { retur
 }  // namespace
 
 __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n_reads) return;
     int status = CIGAR_UNCHANGED;
     int64_t new_pos = 0;
     uint32_t n_out = 0;
-    uint32_t *ws = p.workspace + (size_t)r * 4 * p.capacity;
+    uint32_t *ws = p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity;
     Builder A, B, T;
     uint32_t *rtl = ws + 3 * (size_t)p.capacity;
 
@@ -389,8 +389,8 @@ done:
 }
 
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream) {
-    if (!p.n_reads) return hipSuccess;
-    hipLaunchKernelGGL(phmm_project_kernel, dim3((p.n_reads + 63) / 64), dim3(64), 0, stream, p);
+    if (p.n_reads <= p.r_begin) return hipSuccess;
+    hipLaunchKernelGGL(phmm_project_kernel, dim3((p.n_reads - p.r_begin + 63) / 64), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -63,6 +63,8 @@ struct phmm_handle {
         size_t cap = 0;
         uint32_t *slab = nullptr;
         size_t slab_bytes = 0;
+        uint32_t *ws = nullptr;  // the projection's builders (phmm_realign_reads)
+        size_t ws_bytes = 0;
         static constexpr int kMaxChunks = 8;      // pieces of one call: piece c+1 is staged and copied while piece c computes
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)

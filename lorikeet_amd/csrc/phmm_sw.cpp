@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <vector>
 
+#include "phmm_cigar_internal.hpp"
 #include "phmm_host.hpp"
 #include "phmm_sw_internal.hpp"
 
@@ -49,6 +51,20 @@ struct BestJob {
     double *likelihood = nullptr, *confidence = nullptr;
 };
 
+// The projection onto the reference behind the alignments (phmm_realign_reads): the alignments never leave the device.
+struct ProjJob {
+    const int32_t *region_ref_hap = nullptr;
+    const uint64_t *region_reference_start = nullptr;
+    const uint32_t *hap_cigar_off = nullptr, *hap_cigar = nullptr, *hap_start_wrt_ref = nullptr;
+    const uint32_t *orig_cigar_off = nullptr, *orig_cigar = nullptr;
+    const uint64_t *out_cigar_off = nullptr;
+    uint32_t *out_cigar = nullptr, *n_out_cigar = nullptr;
+    int64_t *new_pos = nullptr;
+    int32_t *status = nullptr;
+    uint32_t sw_capacity = 24;  // CIGAR elements reserved per alignment on the device (grown and redone when one needs more)
+    uint32_t max_hap_cigar = 0;
+};
+
 // One batch of alignments: alignment a pairs alternate sequence a with reference ref_index[a] (or a when there is no index;
 // or the best allele's haplotype when `best` runs in front).
 struct SwJob {
@@ -62,6 +78,8 @@ struct SwJob {
     uint32_t *cigar = nullptr, *n_cigar = nullptr;
     int32_t *alignment_offset = nullptr;
     const BestJob *best = nullptr;
+    const ProjJob *proj = nullptr;  // with it: cigar / n_cigar / alignment_offset stay on the device (the pointers above are unused)
+    uint32_t *sw_capacity_needed = nullptr;  // out: the largest alignment CIGAR when the reserved slots were too small
 };
 
 int fail(phmm_handle *h, const std::string &msg) {
@@ -160,8 +178,34 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (st != PHMM_OK) return st;
     }
     if (!n_alignments) return PHMM_OK;
-    if (!ref_off || !alt_off || !J.cigar_off || !J.n_cigar || !J.alignment_offset) return fail(h, who + ": null array");
-    if (ref_off[0] != 0 || alt_off[0] != 0 || J.cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
+    const ProjJob *PJ = J.proj;
+    if (!ref_off || !alt_off || (!PJ && (!J.cigar_off || !J.n_cigar || !J.alignment_offset))) return fail(h, who + ": null array");
+    std::vector<uint64_t> own_cigar_off;  // with the projection behind them the alignments keep to slots of the library's own
+    if (PJ) {
+        own_cigar_off.resize((size_t)n_alignments + 1);
+        for (size_t a = 0; a <= n_alignments; ++a) own_cigar_off[a] = a * (uint64_t)PJ->sw_capacity;
+    }
+    const uint64_t *cigar_off = PJ ? own_cigar_off.data() : J.cigar_off;
+    if (ref_off[0] != 0 || alt_off[0] != 0 || cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
+    if (PJ) {
+        const BestJob &B = *J.best;
+        if (!PJ->region_ref_hap || !PJ->region_reference_start || !PJ->hap_cigar_off || !PJ->hap_start_wrt_ref || !PJ->orig_cigar_off ||
+            !PJ->out_cigar_off || !PJ->n_out_cigar || !PJ->new_pos || !PJ->status)
+            return fail(h, who + ": null array");
+        if (PJ->hap_cigar_off[0] != 0 || PJ->orig_cigar_off[0] != 0 || PJ->out_cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
+        for (uint32_t g = 0; g < B.n_regions; ++g)
+            if (B.region_read_off[g + 1] > B.region_read_off[g] &&
+                (PJ->region_ref_hap[g] < 0 || (uint32_t)PJ->region_ref_hap[g] >= B.region_hap_off[g + 1] - B.region_hap_off[g]))
+                return fail(h, who + ": every region with reads needs its reference haplotype (region_ref_hap inside the region)");
+        for (uint32_t a = 0; a < B.n_haps; ++a)
+            if (PJ->hap_cigar_off[a + 1] < PJ->hap_cigar_off[a]) return fail(h, who + ": offsets not monotonic");
+        for (uint32_t r = 0; r < B.n_reads; ++r)
+            if (PJ->orig_cigar_off[r + 1] < PJ->orig_cigar_off[r] || PJ->out_cigar_off[r + 1] < PJ->out_cigar_off[r])
+                return fail(h, who + ": offsets not monotonic");
+        if ((PJ->hap_cigar_off[B.n_haps] && !PJ->hap_cigar) || (PJ->orig_cigar_off[B.n_reads] && !PJ->orig_cigar) ||
+            (PJ->out_cigar_off[B.n_reads] && !PJ->out_cigar))
+            return fail(h, who + ": null array");
+    }
     if (!n_refs) return fail(h, who + ": no reference sequences");
     uint32_t max_ref = 0, max_alt = 0;
     for (uint32_t r = 0; r < n_refs; ++r) {
@@ -171,7 +215,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         max_ref = std::max(max_ref, ref_off[r + 1] - ref_off[r]);
     }
     for (uint32_t a = 0; a < n_alignments; ++a) {
-        if (alt_off[a + 1] < alt_off[a] || J.cigar_off[a + 1] < J.cigar_off[a]) return fail(h, who + ": offsets not monotonic");
+        if (alt_off[a + 1] < alt_off[a] || cigar_off[a + 1] < cigar_off[a]) return fail(h, who + ": offsets not monotonic");
         if (alt_off[a + 1] == alt_off[a]) return fail(h, who + ": non-empty sequences are required for the Smith-Waterman calculation");
         max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
         if (J.ref_index && J.ref_index[a] != SW_NO_REFERENCE && J.ref_index[a] >= n_refs) return fail(h, who + ": reference index out of range");
@@ -185,8 +229,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             return fail(h, who + ": parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e8)");
     }
     const size_t rb = ref_off[n_refs], ab = alt_off[n_alignments];
-    const uint64_t n_cig = J.cigar_off[n_alignments];
-    if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar)) return fail(h, who + ": null array");
+    const uint64_t n_cig = cigar_off[n_alignments];
+    if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar && !PJ)) return fail(h, who + ": null array");
     const bool indexed = J.ref_index || J.best;  // references are shared: they all travel with the first piece
 
     DevGuard dg(h->device);
@@ -265,10 +309,35 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const size_t o_ro = 256, o_ao = o_ro + up256(4ull * (n_refs + 1)), o_co = o_ao + up256(4ull * (n_alignments + 1)),
                  o_ri = o_co + up256(8ull * (n_alignments + 1)), o_bi = o_ri + (indexed ? up256(4ull * n_alignments) : 0);
     const BestLayout BL(J.best, o_bi);
-    const size_t o_rb = J.best ? BL.end : o_bi, o_ab = o_rb + up256(rb), in_bytes = o_ab + up256(ab);
+    // the projection's own inputs (phmm_realign_reads) sit behind the best-allele block, its results behind the alignments'
+    const uint32_t pj_regions = PJ ? J.best->n_regions : 0, pj_haps = PJ ? J.best->n_haps : 0;
+    const size_t pj_hc = PJ ? PJ->hap_cigar_off[pj_haps] : 0, pj_oc = PJ ? PJ->orig_cigar_off[n_alignments] : 0;
+    const uint64_t pj_out = PJ ? PJ->out_cigar_off[n_alignments] : 0;
+    const size_t o_pi = J.best ? BL.end : o_bi, p_rrh = o_pi, p_rs = p_rrh + (PJ ? up256(4ull * pj_regions) : 0),
+                 p_hco = p_rs + (PJ ? up256(8ull * pj_regions) : 0), p_hc = p_hco + (PJ ? up256(4ull * (pj_haps + 1)) : 0),
+                 p_hs = p_hc + (PJ ? up256(4ull * pj_hc) : 0), p_oco = p_hs + (PJ ? up256(4ull * pj_haps) : 0),
+                 p_oc = p_oco + (PJ ? up256(4ull * (n_alignments + 1)) : 0), p_oo = p_oc + (PJ ? up256(4ull * pj_oc) : 0),
+                 p_end = p_oo + (PJ ? up256(8ull * (n_alignments + 1)) : 0);
+    const size_t o_rb = p_end, o_ab = o_rb + up256(rb), in_bytes = o_ab + up256(ab);
     const size_t o_st = in_bytes, o_nc = o_st + 256, o_of = o_nc + up256(4ull * n_alignments),
-                 o_cg = o_of + up256(4ull * n_alignments), total = o_cg + up256(4ull * n_cig);
+                 o_cg = o_of + up256(4ull * n_alignments), o_pfl = o_cg + up256(4ull * n_cig);
+    const size_t o_pst = o_pfl + (PJ ? 256 : 0), o_pno = o_pst + (PJ ? up256(4ull * n_alignments) : 0),
+                 o_ppos = o_pno + (PJ ? up256(4ull * n_alignments) : 0), o_pout = o_ppos + (PJ ? up256(8ull * n_alignments) : 0),
+                 total = o_pout + (PJ ? up256(4ull * pj_out) : 0);
     if (!grow_staging(h, total)) return PHMM_ERR_HIP;
+    uint32_t pj_capacity = 0;
+    if (PJ) {  // the lanes' builders: see phmm_cigar.cpp
+        pj_capacity = 4 * (PJ->sw_capacity + PJ->max_hap_cigar + 2) + 8;
+        const size_t ws_bytes = most * 4ull * pj_capacity * 4ull;
+        if (W.ws_bytes < ws_bytes) {
+            (void)hipStreamSynchronize(S);
+            if (W.ws) (void)hipFree(W.ws);
+            W.ws = nullptr;
+            W.ws_bytes = 0;
+            if (!ok(h, hipMalloc((void **)&W.ws, ws_bytes), "hipMalloc(project workspace)")) return PHMM_ERR_HIP;
+            W.ws_bytes = ws_bytes;
+        }
+    }
     for (int c = 0; c < n_chunks; ++c)
         if (!W.ev_in[c] && (!ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate") ||
                             !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate") ||
@@ -303,12 +372,53 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     memset(W.host, 0, 256);
     memcpy(W.host + o_ro, ref_off, 4ull * (n_refs + 1));
     memcpy(W.host + o_ao, alt_off, 4ull * (n_alignments + 1));
-    memcpy(W.host + o_co, J.cigar_off, 8ull * (n_alignments + 1));
+    memcpy(W.host + o_co, cigar_off, 8ull * (n_alignments + 1));
     if (J.ref_index) memcpy(W.host + o_ri, J.ref_index, 4ull * n_alignments);
     size_t head = J.ref_index ? o_bi : o_ri;
     if (J.best) {
         stage_best(*J.best, BL, W.host);
         head = BL.best;
+    }
+    ProjectParams pp{};
+    if (PJ) {
+        auto put = [&](size_t at, const void *src, size_t bytes) {
+            if (bytes) memcpy(W.host + at, src, bytes);
+        };
+        put(p_rrh, PJ->region_ref_hap, 4ull * pj_regions);
+        put(p_rs, PJ->region_reference_start, 8ull * pj_regions);
+        put(p_hco, PJ->hap_cigar_off, 4ull * (pj_haps + 1));
+        put(p_hc, PJ->hap_cigar, 4ull * pj_hc);
+        put(p_hs, PJ->hap_start_wrt_ref, 4ull * pj_haps);
+        put(p_oco, PJ->orig_cigar_off, 4ull * (n_alignments + 1));
+        put(p_oc, PJ->orig_cigar, 4ull * pj_oc);
+        put(p_oo, PJ->out_cigar_off, 8ull * (n_alignments + 1));
+        pp.n_regions = pj_regions;
+        pp.region_read_off = (const uint32_t *)(W.dev + BL.rro);
+        pp.region_hap_off = (const uint32_t *)(W.dev + BL.rho);
+        pp.read_off = p.alt_off;
+        pp.read_bases = p.alt_bases;
+        pp.hap_off = p.ref_off;
+        pp.hap_bases = p.ref_bases;
+        pp.region_ref_hap = (const int32_t *)(W.dev + p_rrh);
+        pp.region_reference_start = (const uint64_t *)(W.dev + p_rs);
+        pp.hap_cigar_off = (const uint32_t *)(W.dev + p_hco);
+        pp.hap_cigar = (const uint32_t *)(W.dev + p_hc);
+        pp.hap_start_wrt_ref = (const uint32_t *)(W.dev + p_hs);
+        pp.best_allele = (const int32_t *)(W.dev + BL.best);
+        pp.sw_cigar_off = p.cigar_off;
+        pp.sw_cigar = p.cigar;
+        pp.n_sw_cigar = p.n_cigar;
+        pp.sw_offset = p.alignment_offset;
+        pp.orig_cigar_off = (const uint32_t *)(W.dev + p_oco);
+        pp.orig_cigar = (const uint32_t *)(W.dev + p_oc);
+        pp.out_cigar_off = (const uint64_t *)(W.dev + p_oo);
+        pp.out_cigar = (uint32_t *)(W.dev + o_pout);
+        pp.n_out_cigar = (uint32_t *)(W.dev + o_pno);
+        pp.new_pos = (int64_t *)(W.dev + o_ppos);
+        pp.status = (int32_t *)(W.dev + o_pst);
+        pp.flags = (uint32_t *)(W.dev + o_pfl);
+        pp.workspace = W.ws;
+        pp.capacity = pj_capacity;
     }
     if (one_piece) {  // the whole input is one contiguous block of the staging buffer
         memcpy(W.host + o_rb, J.ref_bases, rb);
@@ -318,6 +428,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     bool good = ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
     if (good && J.best)  // the reads' best alleles become the index of their references, on the device
         good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
+    if (good && PJ)  // the projection's flag word starts clear; (not one piece:) its inputs follow the head
+        good = ok(h, hipMemsetAsync(W.dev + o_pfl, 0, 256, S_in), "memset project flags") &&
+               (one_piece || ok(h, hipMemcpyAsync(W.dev + o_pi, W.host + o_pi, p_end - o_pi, hipMemcpyHostToDevice, S_in), "H2D project"));
     if (good && indexed && !one_piece) {
         memcpy(W.host + o_rb, J.ref_bases, rb);
         good = ok(h, hipMemcpyAsync(W.dev + o_rb, W.host + o_rb, rb, hipMemcpyHostToDevice, S_in), "H2D sw");
@@ -342,6 +455,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
         (void)hipEventRecord(W.ev_k0[c], S);
         good = ok(h, launch_sw(L, K, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        if (good && PJ) {  // ... and the piece's alignments projected onto the reference, where they lie
+            pp.r_begin = a0;
+            pp.n_reads = a1;
+            good = ok(h, launch_project(pp, S), "phmm_project_kernel");
+        }
         (void)hipEventRecord(W.ev_k1[c], S);
     }
     // (while the device works) what the kernels store per alignment: (rows + L - 1) steps x L lanes x flag words per strip
@@ -359,10 +477,18 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     auto unpack = [&](int c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
+        if (PJ) {
+            memcpy(PJ->status + a0, W.host + o_pst + 4ull * a0, 4ull * (a1 - a0));
+            memcpy(PJ->n_out_cigar + a0, W.host + o_pno + 4ull * a0, 4ull * (a1 - a0));
+            memcpy(PJ->new_pos + a0, W.host + o_ppos + 8ull * a0, 8ull * (a1 - a0));
+            const uint64_t q0 = PJ->out_cigar_off[a0], q1 = PJ->out_cigar_off[a1];
+            if (q1 > q0) memcpy(PJ->out_cigar + q0, W.host + o_pout + 4ull * q0, 4ull * (q1 - q0));
+            return true;
+        }
         memcpy(J.n_cigar + a0, W.host + o_nc + 4ull * a0, 4ull * (a1 - a0));
         memcpy(J.alignment_offset + a0, W.host + o_of + 4ull * a0, 4ull * (a1 - a0));
-        if (J.cigar_off[a1] > J.cigar_off[a0])
-            memcpy(J.cigar + J.cigar_off[a0], W.host + o_cg + 4ull * J.cigar_off[a0], 4ull * (J.cigar_off[a1] - J.cigar_off[a0]));
+        if (cigar_off[a1] > cigar_off[a0])
+            memcpy(J.cigar + cigar_off[a0], W.host + o_cg + 4ull * cigar_off[a0], 4ull * (cigar_off[a1] - cigar_off[a0]));
         return true;
     };
     int prev = -1;
@@ -370,12 +496,22 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks && good; ++c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (a1 == a0) continue;
-        const uint64_t g0 = J.cigar_off[a0], g1 = J.cigar_off[a1];
-        good = (one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)")) &&
-               ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
-               ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
-               (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw")) &&
-               ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord");
+        const uint64_t g0 = cigar_off[a0], g1 = cigar_off[a1];
+        good = one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)");
+        if (PJ) {
+            const uint64_t q0 = PJ->out_cigar_off[a0], q1 = PJ->out_cigar_off[a1];
+            good = good &&
+                   ok(h, hipMemcpyAsync(W.host + o_pst + 4ull * a0, W.dev + o_pst + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
+                   ok(h, hipMemcpyAsync(W.host + o_pno + 4ull * a0, W.dev + o_pno + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
+                   ok(h, hipMemcpyAsync(W.host + o_ppos + 8ull * a0, W.dev + o_ppos + 8ull * a0, 8ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
+                   (q1 == q0 || ok(h, hipMemcpyAsync(W.host + o_pout + 4ull * q0, W.dev + o_pout + 4ull * q0, 4ull * (q1 - q0), hipMemcpyDeviceToHost, S_out), "D2H project"));
+        } else {
+            good = good &&
+                   ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
+                   ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
+                   (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw"));
+        }
+        good = good && ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord");
         if (good && J.best && !best_fetched) {  // the best alleles were final before the first kernel started
             good = ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S_out), "D2H best alleles");
             best_fetched = true;
@@ -383,7 +519,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (good && prev >= 0) good = unpack(prev);
         prev = c;
     }
-    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw");
+    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw") &&
+           (!PJ || ok(h, hipMemcpyAsync(W.host + o_pfl, W.dev + o_pfl, 256, hipMemcpyDeviceToHost, S_out), "D2H project"));
     if (good && prev >= 0) good = unpack(prev);
     good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
     if (!good) {
@@ -405,7 +542,16 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0] status; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
     W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
     if (st[0] & SW_STATUS_CAPACITY) {
+        if (PJ) {  // an alignment outgrew the library's own slots: tell the caller how large the largest is (it runs again)
+            std::vector<uint32_t> n_cig_host(n_alignments);
+            if (!ok(h, hipMemcpy(n_cig_host.data(), W.dev + o_nc, 4ull * n_alignments, hipMemcpyDeviceToHost), "D2H sw")) return PHMM_ERR_HIP;
+            if (J.sw_capacity_needed) *J.sw_capacity_needed = *std::max_element(n_cig_host.begin(), n_cig_host.end());
+        }
         h->err = who + ": a CIGAR needs more elements than its slot holds (n_cigar has the sizes)";
+        return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
+    }
+    if (PJ && (*(const uint32_t *)(W.host + o_pfl) & 1u)) {
+        h->err = who + ": a CIGAR needs more elements than its slot holds (n_out_cigar has the sizes)";
         return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
     }
     return PHMM_OK;
@@ -568,5 +714,85 @@ extern "C" int phmm_realign_to_best(phmm_handle *h, uint32_t n_regions, const ui
             return PHMM_OK;
         }
         return sw_run(h, J);
+    });
+}
+
+extern "C" int phmm_realign_reads(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                                  const uint32_t *read_off, const uint8_t *read_bases, const uint32_t *hap_off,
+                                  const uint8_t *hap_bases, const uint64_t *out_off, const double *likelihoods, const uint8_t *keep,
+                                  const int32_t *hap_priority, double informative_threshold, const phmm_sw_parameters *params,
+                                  int overhang_strategy, const int32_t *region_ref_hap, const uint64_t *region_reference_start,
+                                  const uint32_t *hap_cigar_off, const uint32_t *hap_cigar, const uint32_t *hap_start_wrt_ref,
+                                  const uint32_t *orig_cigar_off, const uint32_t *orig_cigar, const uint64_t *out_cigar_off,
+                                  uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status,
+                                  int32_t *best_allele, double *likelihood, double *confidence) {
+    return guarded(h, "phmm_realign_reads", [&]() -> int {
+        if (n_regions && (!region_read_off || !region_hap_off)) return fail(h, "phmm_realign_reads: null array");
+        BestJob B;
+        B.n_regions = n_regions;
+        B.region_read_off = region_read_off;
+        B.region_hap_off = region_hap_off;
+        B.out_off = out_off;
+        B.likelihoods = likelihoods;
+        B.keep = keep;
+        B.priority = hap_priority;
+        B.threshold = informative_threshold;
+        B.best_allele = best_allele;
+        B.likelihood = likelihood;
+        B.confidence = confidence;
+        B.n_reads = n_regions ? region_read_off[n_regions] : 0;
+        B.n_haps = n_regions ? region_hap_off[n_regions] : 0;
+        ProjJob P;
+        P.region_ref_hap = region_ref_hap;
+        P.region_reference_start = region_reference_start;
+        P.hap_cigar_off = hap_cigar_off;
+        P.hap_cigar = hap_cigar;
+        P.hap_start_wrt_ref = hap_start_wrt_ref;
+        P.orig_cigar_off = orig_cigar_off;
+        P.orig_cigar = orig_cigar;
+        P.out_cigar_off = out_cigar_off;
+        P.out_cigar = out_cigar;
+        P.n_out_cigar = n_out_cigar;
+        P.new_pos = new_pos;
+        P.status = status;
+        if (hap_cigar_off)
+            for (uint32_t a = 0; a < B.n_haps; ++a)
+                if (hap_cigar_off[a + 1] >= hap_cigar_off[a]) P.max_hap_cigar = std::max(P.max_hap_cigar, hap_cigar_off[a + 1] - hap_cigar_off[a]);
+        SwJob J;
+        J.who = "phmm_realign_reads";
+        J.n_alignments = B.n_reads;
+        J.n_refs = B.n_haps;
+        J.ref_off = hap_off;
+        J.ref_bases = hap_bases;
+        J.alt_off = read_off;
+        J.alt_bases = read_bases;
+        J.params = params;
+        J.strategy = overhang_strategy;
+        J.best = &B;
+        J.proj = &P;
+        uint32_t needed = 0;
+        J.sw_capacity_needed = &needed;
+        if (B.n_reads && !B.n_haps) {  // no alleles at all: nothing to align, every read stays as it is
+            h->err_code = PHMM_OK;
+            const int st = check_best(h, J.who, B);
+            if (st != PHMM_OK) return st;
+            if (!n_out_cigar || !new_pos || !status) return fail(h, "phmm_realign_reads: null array");
+            for (uint32_t r = 0; r < B.n_reads; ++r) {
+                best_allele[r] = -1;
+                likelihood[r] = -HUGE_VAL;
+                confidence[r] = std::nan("");
+                n_out_cigar[r] = 0;
+                new_pos[r] = 0;
+                status[r] = CIGAR_UNCHANGED;
+            }
+            return PHMM_OK;
+        }
+        int st = sw_run(h, J);
+        if (st == PHMM_ERR_CIGAR_CAPACITY && needed > P.sw_capacity) {  // once more with slots as large as the largest alignment needs
+            P.sw_capacity = needed;
+            needed = 0;
+            st = sw_run(h, J);
+        }
+        return st;
     });
 }

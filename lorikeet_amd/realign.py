@@ -133,3 +133,44 @@ def project_to_reference(engine, batch, best_allele, alignments, hap_cigars, hap
             raise PhmmError(code, engine.last_error())
         return ProjectedReads(status, pos, [out[int(out_off[r]):int(out_off[r]) + int(n_out[r])] for r in range(n)])
     raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, engine.last_error())
+
+
+def realign_reads(engine, batch, likelihoods, hap_cigars, hap_start_wrt_ref, region_ref_hap, region_reference_start, original_cigars,
+                  hap_priority=None, keep=None, parameters=ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS,
+                  overhang_strategy=OverhangStrategy.SoftClip, threshold=LOG_10_INFORMATIVE_THRESHOLD, capacity=None):
+    """realign_reads_to_their_best_haplotype in one call (phmm_realign_reads): best alleles, alignments to them and their
+    projection onto the reference -> (BestAlleles, ProjectedReads)."""
+    n, nh = batch.n_reads, batch.n_haps
+    lk = np.ascontiguousarray(likelihoods, dtype=np.float64)
+    pri = None if hap_priority is None else np.ascontiguousarray(hap_priority, dtype=np.int32)
+    kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    st = OverhangStrategy.NAMES[overhang_strategy] if isinstance(overhang_strategy, str) else int(overhang_strategy)
+    hc_off = np.concatenate([[0], np.cumsum([len(c) for c in hap_cigars])]).astype(np.uint32)
+    hc = np.concatenate([np.zeros(0, np.uint32)] + [np.asarray(c, np.uint32) for c in hap_cigars]).astype(np.uint32)
+    oc_off = np.concatenate([[0], np.cumsum([len(c) for c in original_cigars])]).astype(np.uint32)
+    oc = np.concatenate([np.zeros(0, np.uint32)] + [np.asarray(c, np.uint32) for c in original_cigars]).astype(np.uint32)
+    hs = np.ascontiguousarray(hap_start_wrt_ref, dtype=np.uint32)
+    rrh = np.ascontiguousarray(region_ref_hap, dtype=np.int32)
+    rs = np.ascontiguousarray(region_reference_start, dtype=np.uint64)
+    assert len(hap_cigars) == nh and len(original_cigars) == n
+    best, out_lk, conf = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
+    cap = np.full(n, 16 if capacity is None else int(capacity), np.int64)
+    prm = parameters.as_struct()
+    i64p = C.POINTER(C.c_int64)
+    for _attempt in range(2):
+        out_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+        out, n_out, pos, status = np.zeros(int(out_off[-1]), np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        code = engine.lib.phmm_realign_reads(
+            engine._h, batch.n_regions, _p(batch.region_read_off, _lib.u32p), _p(batch.region_hap_off, _lib.u32p), _p(batch.read_off, _lib.u32p),
+            _p(batch.read_bases, _lib.u8p), _p(batch.hap_off, _lib.u32p), _p(batch.hap_bases, _lib.u8p), _p(batch.out_off, _lib.u64p),
+            _p(lk, _lib.f64p), _p(kp, _lib.u8p), _p(pri, _i32p), float(threshold), C.byref(prm), st, _p(rrh, _i32p), _p(rs, _lib.u64p),
+            _p(hc_off, _lib.u32p), _p(hc, _lib.u32p), _p(hs, _lib.u32p), _p(oc_off, _lib.u32p), _p(oc, _lib.u32p), _p(out_off, _lib.u64p),
+            _p(out, _lib.u32p), _p(n_out, _lib.u32p), _p(pos, i64p), _p(status, _i32p), _p(best, _i32p), _p(out_lk, _lib.f64p),
+            _p(conf, _lib.f64p))
+        if code == _lib.PHMM_ERR_CIGAR_CAPACITY:
+            cap = np.maximum(cap, n_out.astype(np.int64))
+            continue
+        if code != _lib.PHMM_OK:
+            raise PhmmError(code, engine.last_error())
+        return BestAlleles(best, out_lk, conf), ProjectedReads(status, pos, [out[int(out_off[r]):int(out_off[r]) + int(n_out[r])] for r in range(n)])
+    raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, engine.last_error())

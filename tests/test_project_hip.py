@@ -118,3 +118,50 @@ def test_broken_inputs_fail_read_by_read_like_the_reference(hip_engine):
                 assert got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig, (trial, r)
             seen[st] = seen.get(st, 0) + 1
     assert seen.get(0, 0) > 50 and sum(v for k, v in seen.items() if k < 0) > 20, seen
+
+
+@pytest.mark.parametrize("seed,low_complexity,chunks", [(21, False, 0), (22, True, 0), (23, False, 3), (24, True, 5)])
+def test_realign_reads_in_one_call_equals_the_three_steps(hip_engine, seed, low_complexity, chunks):
+    """phmm_realign_reads == phmm_realign_to_best followed by phmm_project_to_reference (and both equal the oracle): the
+    alignments stay on the device; also cut into pipelined pieces, and with output slots that are too small at first."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(seed, n_regions=7, low_complexity=low_complexity)
+    lk = hip_engine.compute(b)
+    rng = np.random.default_rng(seed)
+    pri = rng.integers(-2, 2, b.n_haps).astype(np.int32)
+    keep = (rng.random(b.n_reads) > 0.1).astype(np.uint8)
+    best0, aligned = realign.realign_reads_to_their_best_haplotype(hip_engine, b, lk, pri, keep)
+    want = realign.project_to_reference(hip_engine, b, best0.allele_index, aligned, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+    try:
+        hip_engine.set_switch("sw_chunks", chunks)
+        best, got = realign.realign_reads(hip_engine, b, lk, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, pri, keep, capacity=2)
+    finally:
+        hip_engine.set_switch("sw_chunks", 0)
+    assert np.array_equal(best.allele_index, best0.allele_index) and np.array_equal(best.confidence, best0.confidence, equal_nan=True)
+    assert np.array_equal(got.status, want.status) and np.array_equal(got.new_pos, want.new_pos)
+    for r in range(b.n_reads):
+        assert np.array_equal(got.cigars[r], want.cigars[r]), r
+    reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+    for r in range(0, b.n_reads, 3):
+        st, pos, cig = _oracle_read(b, r, reg[r], best.allele_index[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        assert got.status[r] == st and (st != 0 or (got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig)), r
+
+
+def test_realign_reads_grows_its_own_alignment_slots(hip_engine):
+    """A read whose alignment to its haplotype has more CIGAR elements than the 24 the library reserves per read on the
+    device: the call notices, runs again with larger slots, and the result is the oracle's."""
+    rng = np.random.default_rng(5)
+    unit = b"ACGTTGCAAGCT"
+    hap = b"".join(unit + bytes([b"ACGT"[int(x)]]) * 3 for x in rng.integers(0, 4, 40))
+    read = bytearray(hap[5:5 + 420])
+    for k in range(14):   # a deletion every 30 bases: 29 elements
+        del read[30 * k + 10 - 2 * k:30 * k + 12 - 2 * k]
+    read = bytes(read)
+    u8 = lambda s: np.frombuffer(s, np.uint8)  # noqa: E731
+    b = RegionBatch.from_regions([([_read(read), _read(hap[50:130])], [u8(hap)])])
+    cigs = [oracle.parse_cigar("%dM" % len(hap))]
+    orig = [oracle.parse_cigar("%dM" % len(read)), oracle.parse_cigar("80M")]
+    best, got = realign.realign_reads(hip_engine, b, hip_engine.compute(b), cigs, [0], [0], [100], orig)
+    for r in range(2):
+        st, pos, cig = _oracle_read(b, r, 0, 0, cigs, [0], [0], [100], orig)
+        assert got.status[r] == st == 0 and got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig
+    assert len(got.cigars[0]) > 24
