@@ -235,3 +235,147 @@ pub fn realign_to_best(
         })
         .collect()
 }
+
+/// One read after `realign_reads`: its `BestAllele` and, when `realigned`, the position and CIGAR
+/// `AlignmentUtils::create_read_aligned_to_ref` would give it (BAM-encoded elements, clips of the original CIGAR
+/// included).  `realigned == false`: the reference returns the read unchanged (no best allele, or
+/// `alignment_offset == -1`, src/reads/alignment_utils.rs:60-63).
+pub struct RealignedRead {
+    pub allele_index: Option<usize>,
+    pub likelihood: f64,
+    pub confidence: f64,
+    pub realigned: bool,
+    pub pos: i64,
+    pub cigar: Vec<u32>,
+}
+
+/// `AssemblyBasedCallerUtils::realign_reads_to_their_best_haplotype`
+/// (src/assembly/assembly_based_caller_utils.rs:208-246) for one region in one call of the library: best alleles,
+/// the reads' alignments to them and `create_read_aligned_to_ref`'s projection onto the reference
+/// (src/reads/alignment_utils.rs:83-165).  `haplotype_cigars[a]` / `alignment_start_hap_wrt_ref[a]` are
+/// `Haplotype::cigar` / `alignment_start_hap_wrt_ref` of haplotype `a`, `reference_haplotype` its index,
+/// `reference_start` is `padded_reference_loc.get_start()`, `original_cigars[r]` the read's CIGAR before realignment.
+/// Panics where the reference panics ("Read goes past end of reference", builder errors ...).
+#[allow(clippy::too_many_arguments)]
+pub fn realign_reads(
+    haplotypes: &[&[u8]],
+    haplotype_cigars: &[&[u32]],
+    alignment_start_hap_wrt_ref: &[u32],
+    reference_haplotype: usize,
+    reference_start: u64,
+    reads_minus_soft_clips: &[&[u8]],
+    original_cigars: &[&[u32]],
+    likelihoods: &[f64],
+    priorities: &[i32],
+) -> Vec<RealignedRead> {
+    let n_reads = reads_minus_soft_clips.len();
+    let n_haps = haplotypes.len();
+    assert!(likelihoods.len() == n_reads * n_haps && priorities.len() == n_haps, "one likelihood per read and haplotype, one priority per haplotype");
+    assert!(haplotype_cigars.len() == n_haps && alignment_start_hap_wrt_ref.len() == n_haps && original_cigars.len() == n_reads);
+    let flatten_u8 = |parts: &[&[u8]]| {
+        let mut off: Vec<u32> = vec![0];
+        let mut all: Vec<u8> = Vec::new();
+        for p in parts {
+            all.extend_from_slice(p);
+            off.push(all.len() as u32);
+        }
+        (off, all)
+    };
+    let flatten_u32 = |parts: &[&[u32]]| {
+        let mut off: Vec<u32> = vec![0];
+        let mut all: Vec<u32> = Vec::new();
+        for p in parts {
+            all.extend_from_slice(p);
+            off.push(all.len() as u32);
+        }
+        (off, all)
+    };
+    let (read_off, bases) = flatten_u8(reads_minus_soft_clips);
+    let (hap_off, haps) = flatten_u8(haplotypes);
+    let (hap_cigar_off, hap_cigar) = flatten_u32(haplotype_cigars);
+    let (orig_cigar_off, orig_cigar) = flatten_u32(original_cigars);
+    let region_read_off = [0u32, n_reads as u32];
+    let region_hap_off = [0u32, n_haps as u32];
+    let out_off = [0u64, (n_reads * n_haps) as u64];
+    let region_ref_hap = [reference_haplotype as i32];
+    let region_reference_start = [reference_start];
+    let params = phmm_sw_parameters { match_value: 10, mismatch_penalty: -15, gap_open_penalty: -30, gap_extend_penalty: -5 };
+    let mut capacity = vec![16u64; n_reads];
+    let mut best = vec![0i32; n_reads];
+    let mut likelihood = vec![0.0f64; n_reads];
+    let mut confidence = vec![0.0f64; n_reads];
+    let mut n_out = vec![0u32; n_reads];
+    let mut pos = vec![0i64; n_reads];
+    let mut status = vec![0i32; n_reads];
+    let mut out_cigar_off = vec![0u64; n_reads + 1];
+    let mut out_cigar: Vec<u32> = Vec::new();
+    with_engine(|h| {
+        for attempt in 0..2 {
+            for r in 0..n_reads {
+                out_cigar_off[r + 1] = out_cigar_off[r] + capacity[r];
+            }
+            out_cigar = vec![0u32; out_cigar_off[n_reads] as usize];
+            let rc = unsafe {
+                phmm_realign_reads(
+                    h,
+                    1,
+                    region_read_off.as_ptr(),
+                    region_hap_off.as_ptr(),
+                    read_off.as_ptr(),
+                    bases.as_ptr(),
+                    hap_off.as_ptr(),
+                    haps.as_ptr(),
+                    out_off.as_ptr(),
+                    likelihoods.as_ptr(),
+                    std::ptr::null(),
+                    priorities.as_ptr(),
+                    0.2,
+                    &params,
+                    PHMM_SW_SOFTCLIP,
+                    region_ref_hap.as_ptr(),
+                    region_reference_start.as_ptr(),
+                    hap_cigar_off.as_ptr(),
+                    hap_cigar.as_ptr(),
+                    alignment_start_hap_wrt_ref.as_ptr(),
+                    orig_cigar_off.as_ptr(),
+                    orig_cigar.as_ptr(),
+                    out_cigar_off.as_ptr(),
+                    out_cigar.as_mut_ptr(),
+                    n_out.as_mut_ptr(),
+                    pos.as_mut_ptr(),
+                    status.as_mut_ptr(),
+                    best.as_mut_ptr(),
+                    likelihood.as_mut_ptr(),
+                    confidence.as_mut_ptr(),
+                )
+            };
+            if rc == PHMM_ERR_CIGAR_CAPACITY && attempt == 0 {
+                for r in 0..n_reads {
+                    capacity[r] = capacity[r].max(n_out[r] as u64);
+                }
+                continue;
+            }
+            if rc != PHMM_OK {
+                panic!("HIP realignment failed ({}): {}", rc, last_error(h));
+            }
+            break;
+        }
+    });
+    (0..n_reads)
+        .map(|r| {
+            if status[r] < 0 {
+                // the reference panics on this read (builder error, read past the end of the reference, ...)
+                panic!("Failed to realign read {} (status {})", r, status[r]);
+            }
+            let start = out_cigar_off[r] as usize;
+            RealignedRead {
+                allele_index: if best[r] >= 0 { Some(best[r] as usize) } else { None },
+                likelihood: likelihood[r],
+                confidence: confidence[r],
+                realigned: status[r] == PHMM_PROJECT_REALIGNED,
+                pos: pos[r],
+                cigar: out_cigar[start..start + n_out[r] as usize].to_vec(),
+            }
+        })
+        .collect()
+}
