@@ -572,3 +572,71 @@ ORACLE_API int oracle_create_read_aligned_to_ref(const uint32_t *sw_cigar, uint3
     free(b);
     return st;
 }
+
+/* ---- CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457): the CIGAR of a haplotype against the reference --------
+ * Smith-Waterman between the two sequences, each padded with SW_PAD ("NNNNNNNNNN", :11) on both sides, the padding
+ * trimmed off again, indels left-aligned, and leading / trailing deletions -- which the builder strips -- put back so that
+ * the reference span stays.  Returns 0 with the cigar, 1 for None (is_s_w_failure, :469-487), negative where the
+ * reference panics.  The aligner is the other oracle file's (oracle_sw_align). */
+int oracle_sw_align(const uint8_t *reference, uint32_t ref_len, const uint8_t *alternate, uint32_t alt_len, int32_t w_match,
+                    int32_t w_mismatch, int32_t w_open, int32_t w_extend, int strategy, uint32_t *cigar, int32_t *alignment_offset);
+
+ORACLE_API int oracle_calculate_cigar(const uint8_t *ref_seq, uint32_t ref_len, const uint8_t *alt_seq, uint32_t alt_len, int32_t w_match,
+                                      int32_t w_mismatch, int32_t w_open, int32_t w_extend, int strategy, uint32_t *out, uint32_t cap,
+                                      uint32_t *n_out) {
+    if (cap < 1) return CIG_ERR_CAPACITY;
+    if (alt_len == 0) { /* :365-368 "horrible edge case from the unit tests, where this path has no bases" */
+        out[0] = mk(OP_D, ref_len);
+        *n_out = 1;
+        return CIG_OK;
+    }
+    if (alt_len == ref_len) { /* :370-385: equal lengths and at most two mismatches: all M */
+        uint32_t mismatches = 0;
+        for (uint32_t i = 0; i < ref_len; ++i) mismatches += alt_seq[i] != ref_seq[i];
+        if (mismatches <= 2) {
+            out[0] = mk(OP_M, ref_len);
+            *n_out = 1;
+            return CIG_OK;
+        }
+    }
+    enum { PAD = 10 };
+    const uint32_t pr = ref_len + 2 * PAD, pa = alt_len + 2 * PAD;
+    uint8_t *padded_ref = (uint8_t *)malloc(pr), *padded_alt = (uint8_t *)malloc(pa);
+    memset(padded_ref, 'N', pr);
+    memset(padded_alt, 'N', pa);
+    memcpy(padded_ref + PAD, ref_seq, ref_len);
+    memcpy(padded_alt + PAD, alt_seq, alt_len);
+    uint32_t *sw = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)pr + pa + 4));
+    int32_t offset = 0;
+    const int n_sw = oracle_sw_align(padded_ref, pr, padded_alt, pa, w_match, w_mismatch, w_open, w_extend, strategy, sw, &offset);
+    free(padded_ref);
+    free(padded_alt);
+    int st = CIG_OK;
+    builder_t *b = (builder_t *)malloc(2 * sizeof *b), *b2 = b + 1;
+    uint32_t lead = 0, trail = 0, lead2 = 0, trail2 = 0;
+    if (n_sw < 0) st = CIG_ERR_PANIC;
+    if (st == CIG_OK && offset > 0) st = 1; /* is_s_w_failure: the alignment must start at the first base ... */
+    for (int i = 0; st == CIG_OK && i < n_sw; ++i)
+        if (e_op(sw[i]) == OP_S) st = 1;    /* ... and have no S operators */
+    /* :421-428 cut off the padding bases */
+    if (st == CIG_OK) st = trim_cigar(sw, (size_t)n_sw, PAD, pa - PAD - 1, 0, b, &lead, &trail);
+    if (st == CIG_OK && trail > 0) { /* :430-435 the trailing deletion goes back on for the left-alignment */
+        if (b->n >= CAP) st = CIG_ERR_CAPACITY;
+        else b->el[b->n++] = mk(OP_D, trail);
+    }
+    if (st == CIG_OK) st = left_align_indels(b->el, b->n, ref_seq, ref_len, alt_seq, alt_len, lead, b2, &lead2, &trail2);
+    if (st == CIG_OK) { /* :444-466 */
+        const uint32_t total_leading = lead + lead2, total_trailing = trail2;
+        uint32_t m = 0;
+        if ((size_t)b2->n + 2 > cap) st = CIG_ERR_CAPACITY;
+        else {
+            if (total_leading > 0) out[m++] = mk(OP_D, total_leading);
+            for (size_t i = 0; i < b2->n; ++i) out[m++] = b2->el[i];
+            if (total_trailing > 0) out[m++] = mk(OP_D, total_trailing);
+            *n_out = m;
+        }
+    }
+    free(sw);
+    free(b);
+    return st;
+}

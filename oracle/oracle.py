@@ -94,6 +94,9 @@ def _load(path):
     lib.oracle_create_read_aligned_to_ref.restype = C.c_int
     lib.oracle_create_read_aligned_to_ref.argtypes = [_u32p, C.c_uint32, C.c_int32, _u32p, C.c_uint32, C.c_uint32, C.c_uint64, _u8p, C.c_uint32,
                                                       _u8p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _i64p, _u32p, C.c_uint32, _u32p]
+    lib.oracle_calculate_cigar.restype = C.c_int
+    lib.oracle_calculate_cigar.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, _u32p,
+                                           C.c_uint32, _u32p]
     lib.oracle_best_alleles.restype = None
     lib.oracle_best_alleles.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.c_double, C.POINTER(C.c_int32), _f64p, _f64p]
     return lib
@@ -407,3 +410,16 @@ def create_read_aligned_to_ref(sw_cigar, sw_offset, hap_cigar, hap_start_wrt_ref
     if st:
         raise CigarError(st)
     return pos.value, cigar_to_string(out[:n.value])
+
+
+def calculate_cigar(ref_seq, alt_seq, parameters=(200, -150, -260, -11), strategy="InDel"):
+    """CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) -> cigar string, or None (is_s_w_failure)."""
+    r, a = _seq(ref_seq), _seq(alt_seq)
+    out, n = np.zeros(len(r) + len(a) + 48, np.uint32), C.c_uint32()
+    st = lib().oracle_calculate_cigar(r.ctypes.data_as(_u8p), len(r), a.ctypes.data_as(_u8p), len(a), *[int(x) for x in parameters],
+                                      SW_STRATEGIES[strategy] if isinstance(strategy, str) else int(strategy), _pu32(out), len(out), C.byref(n))
+    if st == 1:
+        return None
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value])

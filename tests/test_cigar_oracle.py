@@ -253,3 +253,13 @@ def test_complex_read_aligned_to_ref():  # make_complex_read_aligned_to_ref :442
             assert _mismatches(read, cigar, padded, pos) <= hap_mis + read_mis, (hap, read, cigar, pos)
             checked += 1
     assert checked == len(subsets) ** 2
+
+
+# ---- CigarUtils::calculate_cigar: tests/cigar_utils_unit_tests.rs:21-283, the data in tests/golden/calculate_cigar_cases.json -------
+def test_calculate_cigar_cases_of_the_reference():
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "calculate_cigar_cases.json")))
+    assert len(gold["cases"]) >= 110
+    for c in gold["cases"]:
+        assert oracle.calculate_cigar(c["reference"], c["alternate"], gold["parameters"], gold["strategy"]) == c["expected_cigar"], c
