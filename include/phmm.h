@@ -395,6 +395,19 @@ int phmm_realign_reads(phmm_handle *h, uint32_t n_regions, const uint32_t *regio
                        int64_t *new_pos, int32_t *status, int32_t *best_allele, double *likelihood, double *confidence);
 
 /*
+ * CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) for n (reference, haplotype) pairs: the haplotype's CIGAR
+ * against the reference -- the two shortcuts (empty haplotype: one D; equal lengths and at most two mismatches: one M),
+ * otherwise Smith-Waterman between the sequences padded with "NNNNNNNNNN" on both sides (as phmm_sw_align; the reference's
+ * callers use NEW_SW_PARAMETERS and OverhangStrategy::InDel or SoftClip), the padding trimmed off, indels left-aligned,
+ * the leading / trailing deletions kept.  Empty sequences are allowed here.
+ *   status [n]   0: cigar / n_cigar hold the result; 1: None (is_s_w_failure, :469-487); negative: the reference panics
+ * Returns PHMM_ERR_CIGAR_CAPACITY when a slot is too small (n_cigar holds the sizes; ref + alt elements + 2 always suffice).
+ */
+int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, const uint8_t *ref_bases, const uint32_t *alt_off,
+                         const uint8_t *alt_bases, const phmm_sw_parameters *params, int overhang_strategy,
+                         const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *status);
+
+/*
  * Developer switches and counters (tests, A/B measurements; never needed in production).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",

@@ -362,6 +362,21 @@ extern "C" {
         confidence: *mut f64,
     ) -> c_int;
 
+    pub fn phmm_calculate_cigar(
+        h: *mut phmm_handle,
+        n: u32,
+        ref_off: *const u32,
+        ref_bases: *const u8,
+        alt_off: *const u32,
+        alt_bases: *const u8,
+        params: *const phmm_sw_parameters,
+        overhang_strategy: c_int,
+        cigar_off: *const u64,
+        cigar: *mut u32,
+        n_cigar: *mut u32,
+        status: *mut i32,
+    ) -> c_int;
+
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;
     pub fn phmm_get_stat(h: *mut phmm_handle, name: *const c_char) -> u64;
 

@@ -91,6 +91,7 @@ SYMBOLS = [
     ("phmm_realign_reads", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u32p, u8p, u64p, f64p, u8p, C.POINTER(C.c_int32), C.c_double,
                                      C.c_void_p, C.c_int, C.POINTER(C.c_int32), u64p, u32p, u32p, u32p, u32p, u32p, u64p, u32p, u32p,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), f64p, f64p]),
+    ("phmm_calculate_cigar", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p, C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),

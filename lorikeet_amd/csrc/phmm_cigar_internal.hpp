@@ -42,4 +42,23 @@ struct ProjectParams {
 };
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
 
+// CigarUtils::calculate_cigar behind the padded alignments (phmm_calculate_cigar): one lane per haplotype
+constexpr int CIGAR_SW_FAILURE = 1;  // is_s_w_failure: the reference returns None
+constexpr uint32_t SW_PAD_BASES = 10;  // SW_PAD = "NNNNNNNNNN" (cigar_utils.rs:11)
+struct CalcParams {
+    uint32_t n;
+    const uint32_t *ref_off, *alt_off;       // [n + 1] the PADDED sequences (pad + bases + pad)
+    const uint8_t *ref_bases, *alt_bases;
+    const uint64_t *sw_cigar_off;            // [n + 1] the alignments of the padded sequences, where the aligner left them
+    const uint32_t *sw_cigar, *n_sw_cigar;
+    const int32_t *sw_offset;
+    const uint64_t *out_cigar_off;           // [n + 1]
+    uint32_t *out_cigar, *n_out_cigar;
+    int32_t *status;                         // 0 a cigar, 1 None (is_s_w_failure), < 0 where the reference panics
+    uint32_t *flags;                         // bit 0: some cigar did not fit its slot
+    uint32_t *workspace;                     // [n][3][capacity]
+    uint32_t capacity;
+};
+hipError_t launch_calculate_cigar(const CalcParams &p, hipStream_t stream);
+
 }  // namespace phmm

@@ -65,6 +65,18 @@ struct ProjJob {
     uint32_t max_hap_cigar = 0;
 };
 
+// For a caller inside the library that works on the alignments where they lie (phmm_calculate_cigar): they stay on the device.
+struct SwDeviceView {
+    uint32_t sw_capacity = 32;   // in: CIGAR elements reserved per alignment
+    size_t extra_bytes = 0;      // in: room behind everything else in the staging buffers, for the caller's own results
+    const uint32_t *ref_off = nullptr, *alt_off = nullptr;  // out: device pointers
+    const uint8_t *ref_bases = nullptr, *alt_bases = nullptr;
+    const uint64_t *cigar_off = nullptr;
+    const uint32_t *cigar = nullptr, *n_cigar = nullptr;
+    const int32_t *alignment_offset = nullptr;
+    char *extra_dev = nullptr, *extra_host = nullptr;
+};
+
 // One batch of alignments: alignment a pairs alternate sequence a with reference ref_index[a] (or a when there is no index;
 // or the best allele's haplotype when `best` runs in front).
 struct SwJob {
@@ -79,6 +91,7 @@ struct SwJob {
     int32_t *alignment_offset = nullptr;
     const BestJob *best = nullptr;
     const ProjJob *proj = nullptr;  // with it: cigar / n_cigar / alignment_offset stay on the device (the pointers above are unused)
+    SwDeviceView *view = nullptr;   // likewise, for a caller that launches its own kernel on them afterwards
     uint32_t *sw_capacity_needed = nullptr;  // out: the largest alignment CIGAR when the reserved slots were too small
 };
 
@@ -179,13 +192,15 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     if (!n_alignments) return PHMM_OK;
     const ProjJob *PJ = J.proj;
-    if (!ref_off || !alt_off || (!PJ && (!J.cigar_off || !J.n_cigar || !J.alignment_offset))) return fail(h, who + ": null array");
-    std::vector<uint64_t> own_cigar_off;  // with the projection behind them the alignments keep to slots of the library's own
-    if (PJ) {
+    const bool on_device = PJ || J.view;  // the alignments are consumed where they lie
+    if (!ref_off || !alt_off || (!on_device && (!J.cigar_off || !J.n_cigar || !J.alignment_offset))) return fail(h, who + ": null array");
+    std::vector<uint64_t> own_cigar_off;  // ... and keep to slots of the library's own
+    if (on_device) {
+        const uint64_t slot = PJ ? PJ->sw_capacity : J.view->sw_capacity;
         own_cigar_off.resize((size_t)n_alignments + 1);
-        for (size_t a = 0; a <= n_alignments; ++a) own_cigar_off[a] = a * (uint64_t)PJ->sw_capacity;
+        for (size_t a = 0; a <= n_alignments; ++a) own_cigar_off[a] = a * slot;
     }
-    const uint64_t *cigar_off = PJ ? own_cigar_off.data() : J.cigar_off;
+    const uint64_t *cigar_off = on_device ? own_cigar_off.data() : J.cigar_off;
     if (ref_off[0] != 0 || alt_off[0] != 0 || cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
     if (PJ) {
         const BestJob &B = *J.best;
@@ -230,7 +245,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     const size_t rb = ref_off[n_refs], ab = alt_off[n_alignments];
     const uint64_t n_cig = cigar_off[n_alignments];
-    if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar && !PJ)) return fail(h, who + ": null array");
+    if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar && !on_device)) return fail(h, who + ": null array");
     const bool indexed = J.ref_index || J.best;  // references are shared: they all travel with the first piece
 
     DevGuard dg(h->device);
@@ -323,7 +338,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                  o_cg = o_of + up256(4ull * n_alignments), o_pfl = o_cg + up256(4ull * n_cig);
     const size_t o_pst = o_pfl + (PJ ? 256 : 0), o_pno = o_pst + (PJ ? up256(4ull * n_alignments) : 0),
                  o_ppos = o_pno + (PJ ? up256(4ull * n_alignments) : 0), o_pout = o_ppos + (PJ ? up256(8ull * n_alignments) : 0),
-                 total = o_pout + (PJ ? up256(4ull * pj_out) : 0);
+                 o_extra = o_pout + (PJ ? up256(4ull * pj_out) : 0), total = o_extra + (J.view ? up256(J.view->extra_bytes) : 0);
     if (!grow_staging(h, total)) return PHMM_ERR_HIP;
     uint32_t pj_capacity = 0;
     if (PJ) {  // the lanes' builders: see phmm_cigar.cpp
@@ -477,6 +492,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     auto unpack = [&](int c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
+        if (J.view && !PJ) return true;
         if (PJ) {
             memcpy(PJ->status + a0, W.host + o_pst + 4ull * a0, 4ull * (a1 - a0));
             memcpy(PJ->n_out_cigar + a0, W.host + o_pno + 4ull * a0, 4ull * (a1 - a0));
@@ -505,7 +521,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                    ok(h, hipMemcpyAsync(W.host + o_pno + 4ull * a0, W.dev + o_pno + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
                    ok(h, hipMemcpyAsync(W.host + o_ppos + 8ull * a0, W.dev + o_ppos + 8ull * a0, 8ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
                    (q1 == q0 || ok(h, hipMemcpyAsync(W.host + o_pout + 4ull * q0, W.dev + o_pout + 4ull * q0, 4ull * (q1 - q0), hipMemcpyDeviceToHost, S_out), "D2H project"));
-        } else {
+        } else if (!J.view) {
             good = good &&
                    ok(h, hipMemcpyAsync(W.host + o_nc + 4ull * a0, W.dev + o_nc + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
                    ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
@@ -542,7 +558,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0] status; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
     W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
     if (st[0] & SW_STATUS_CAPACITY) {
-        if (PJ) {  // an alignment outgrew the library's own slots: tell the caller how large the largest is (it runs again)
+        if (on_device) {  // an alignment outgrew the library's own slots: tell the caller how large the largest is (it runs again)
             std::vector<uint32_t> n_cig_host(n_alignments);
             if (!ok(h, hipMemcpy(n_cig_host.data(), W.dev + o_nc, 4ull * n_alignments, hipMemcpyDeviceToHost), "D2H sw")) return PHMM_ERR_HIP;
             if (J.sw_capacity_needed) *J.sw_capacity_needed = *std::max_element(n_cig_host.begin(), n_cig_host.end());
@@ -553,6 +569,18 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     if (PJ && (*(const uint32_t *)(W.host + o_pfl) & 1u)) {
         h->err = who + ": a CIGAR needs more elements than its slot holds (n_out_cigar has the sizes)";
         return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
+    }
+    if (J.view) {
+        J.view->ref_off = p.ref_off;
+        J.view->alt_off = p.alt_off;
+        J.view->ref_bases = p.ref_bases;
+        J.view->alt_bases = p.alt_bases;
+        J.view->cigar_off = p.cigar_off;
+        J.view->cigar = p.cigar;
+        J.view->n_cigar = p.n_cigar;
+        J.view->alignment_offset = p.alignment_offset;
+        J.view->extra_dev = W.dev + o_extra;
+        J.view->extra_host = W.host + o_extra;
     }
     return PHMM_OK;
 }
@@ -794,5 +822,101 @@ extern "C" int phmm_realign_reads(phmm_handle *h, uint32_t n_regions, const uint
             st = sw_run(h, J);
         }
         return st;
+    });
+}
+
+extern "C" int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, const uint8_t *ref_bases, const uint32_t *alt_off,
+                                    const uint8_t *alt_bases, const phmm_sw_parameters *params, int overhang_strategy,
+                                    const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *status) {
+    return guarded(h, "phmm_calculate_cigar", [&]() -> int {
+        h->err_code = PHMM_OK;
+        if (!n) return PHMM_OK;
+        if (!ref_off || !alt_off || !cigar_off || !n_cigar || !status) return fail(h, "phmm_calculate_cigar: null array");
+        if (ref_off[0] != 0 || alt_off[0] != 0 || cigar_off[0] != 0) return fail(h, "phmm_calculate_cigar: offset arrays must start at 0");
+        for (uint32_t a = 0; a < n; ++a)
+            if (ref_off[a + 1] < ref_off[a] || alt_off[a + 1] < alt_off[a] || cigar_off[a + 1] < cigar_off[a])
+                return fail(h, "phmm_calculate_cigar: offsets not monotonic");
+        if ((ref_off[n] && !ref_bases) || (alt_off[n] && !alt_bases) || (cigar_off[n] && !cigar)) return fail(h, "phmm_calculate_cigar: null array");
+        // both sequences of every pair between two runs of SW_PAD (cigar_utils.rs:387-398)
+        std::vector<uint32_t> p_ref_off(n + 1), p_alt_off(n + 1);
+        for (uint32_t a = 0; a <= n; ++a) {
+            p_ref_off[a] = ref_off[a] + 2 * SW_PAD_BASES * a;
+            p_alt_off[a] = alt_off[a] + 2 * SW_PAD_BASES * a;
+        }
+        std::vector<uint8_t> p_ref(p_ref_off[n], (uint8_t)'N'), p_alt(p_alt_off[n], (uint8_t)'N');
+        for (uint32_t a = 0; a < n; ++a) {
+            if (ref_off[a + 1] > ref_off[a]) memcpy(p_ref.data() + p_ref_off[a] + SW_PAD_BASES, ref_bases + ref_off[a], ref_off[a + 1] - ref_off[a]);
+            if (alt_off[a + 1] > alt_off[a]) memcpy(p_alt.data() + p_alt_off[a] + SW_PAD_BASES, alt_bases + alt_off[a], alt_off[a + 1] - alt_off[a]);
+        }
+        const uint64_t n_out = cigar_off[n];
+        SwDeviceView V;
+        const size_t x_fl = 0, x_st = 256, x_no = x_st + up256(4ull * n), x_oo = x_no + up256(4ull * n), x_out = x_oo + up256(8ull * (n + 1));
+        V.extra_bytes = x_out + up256(4ull * n_out);
+        SwJob J;
+        J.who = "phmm_calculate_cigar";
+        J.n_alignments = J.n_refs = n;
+        J.ref_off = p_ref_off.data();
+        J.ref_bases = p_ref.data();
+        J.alt_off = p_alt_off.data();
+        J.alt_bases = p_alt.data();
+        J.params = params;
+        J.strategy = overhang_strategy;
+        J.view = &V;
+        uint32_t needed = 0;
+        J.sw_capacity_needed = &needed;
+        int st = sw_run(h, J);
+        if (st == PHMM_ERR_CIGAR_CAPACITY && needed > V.sw_capacity) {  // once more with slots as large as the largest alignment needs
+            V.sw_capacity = needed;
+            st = sw_run(h, J);
+        }
+        if (st != PHMM_OK) return st;
+        DevGuard dg(h->device);
+        phmm_handle::SwWork &W = h->swork;
+        hipStream_t S = h->streams[0];
+        // three arrays per lane: the trimmed cigar (+ one element), left_align_indels' right-to-left list (four per element + 2), its result
+        const uint32_t capacity = 4 * (V.sw_capacity + 2) + 8;
+        const size_t ws_bytes = (size_t)n * 3 * capacity * 4;
+        if (W.ws_bytes < ws_bytes) {
+            (void)hipStreamSynchronize(S);
+            if (W.ws) (void)hipFree(W.ws);
+            W.ws = nullptr;
+            W.ws_bytes = 0;
+            if (!ok(h, hipMalloc((void **)&W.ws, ws_bytes), "hipMalloc(cigar workspace)")) return PHMM_ERR_HIP;
+            W.ws_bytes = ws_bytes;
+        }
+        memset(V.extra_host + x_fl, 0, 256);
+        memcpy(V.extra_host + x_oo, cigar_off, 8ull * (n + 1));
+        CalcParams c{};
+        c.n = n;
+        c.ref_off = V.ref_off;
+        c.alt_off = V.alt_off;
+        c.ref_bases = V.ref_bases;
+        c.alt_bases = V.alt_bases;
+        c.sw_cigar_off = V.cigar_off;
+        c.sw_cigar = V.cigar;
+        c.n_sw_cigar = V.n_cigar;
+        c.sw_offset = V.alignment_offset;
+        c.out_cigar_off = (const uint64_t *)(V.extra_dev + x_oo);
+        c.out_cigar = (uint32_t *)(V.extra_dev + x_out);
+        c.n_out_cigar = (uint32_t *)(V.extra_dev + x_no);
+        c.status = (int32_t *)(V.extra_dev + x_st);
+        c.flags = (uint32_t *)(V.extra_dev + x_fl);
+        c.workspace = W.ws;
+        c.capacity = capacity;
+        if (!ok(h, hipMemcpyAsync(V.extra_dev + x_fl, V.extra_host + x_fl, 256, hipMemcpyHostToDevice, S), "H2D cigar") ||
+            !ok(h, hipMemcpyAsync(V.extra_dev + x_oo, V.extra_host + x_oo, 8ull * (n + 1), hipMemcpyHostToDevice, S), "H2D cigar") ||
+            !ok(h, launch_calculate_cigar(c, S), "phmm_calculate_cigar_kernel") ||
+            !ok(h, hipMemcpyAsync(V.extra_host, V.extra_dev, x_oo, hipMemcpyDeviceToHost, S), "D2H cigar") ||
+            (n_out && !ok(h, hipMemcpyAsync(V.extra_host + x_out, V.extra_dev + x_out, 4ull * n_out, hipMemcpyDeviceToHost, S), "D2H cigar")) ||
+            !ok(h, hipStreamSynchronize(S), "sync(cigar)"))
+            return PHMM_ERR_HIP;
+        memcpy(status, V.extra_host + x_st, 4ull * n);
+        memcpy(n_cigar, V.extra_host + x_no, 4ull * n);
+        if (n_out) memcpy(cigar, V.extra_host + x_out, 4ull * n_out);
+        if (*(const uint32_t *)(V.extra_host + x_fl) & 1u) {
+            h->err = "phmm_calculate_cigar: a CIGAR needs more elements than its slot holds (n_cigar has the sizes)";
+            return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
+        }
+        return PHMM_OK;
     });
 }

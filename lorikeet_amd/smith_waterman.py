@@ -126,3 +126,37 @@ class SmithWatermanAligner:
             return [None if idx is not None and idx[a] == _lib.PHMM_SW_NO_REFERENCE else
                     SmithWatermanAlignmentResult(cigar[int(cig_off[a]):int(cig_off[a]) + int(n_cig[a])], off[a]) for a in range(n)]
         raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, eng.last_error())
+
+
+def calculate_cigar(engine, pairs, parameters=NEW_SW_PARAMETERS, overhang_strategy=OverhangStrategy.InDel, capacity=None):
+    """CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) for a batch of (reference, haplotype) pairs
+    (phmm_calculate_cigar) -> per pair the BAM-encoded elements, or None where the reference returns None (is_s_w_failure).
+    Raises PhmmError where the reference would panic."""
+    refs = [_u8(r) for r, _ in pairs]
+    alts = [_u8(a) for _, a in pairs]
+    n = len(refs)
+    if n == 0:
+        return []
+    st = OverhangStrategy.NAMES[overhang_strategy] if isinstance(overhang_strategy, str) else int(overhang_strategy)
+    ref_off = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint32)
+    alt_off = np.concatenate([[0], np.cumsum([len(a) for a in alts])]).astype(np.uint32)
+    rb = np.ascontiguousarray(np.concatenate(refs + [np.zeros(0, np.uint8)]))
+    ab = np.ascontiguousarray(np.concatenate(alts + [np.zeros(0, np.uint8)]))
+    cap = np.full(n, 16 if capacity is None else int(capacity), np.int64)
+    prm = parameters.as_struct()
+    for _attempt in range(2):
+        cig_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+        cigar, n_cig, status = np.zeros(int(cig_off[-1]), np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+        code = engine.lib.phmm_calculate_cigar(engine._h, n, ref_off.ctypes.data_as(_lib.u32p), rb.ctypes.data_as(_lib.u8p),
+                                               alt_off.ctypes.data_as(_lib.u32p), ab.ctypes.data_as(_lib.u8p), C.byref(prm), st,
+                                               cig_off.ctypes.data_as(_lib.u64p), cigar.ctypes.data_as(_lib.u32p),
+                                               n_cig.ctypes.data_as(_lib.u32p), status.ctypes.data_as(C.POINTER(C.c_int32)))
+        if code == _lib.PHMM_ERR_CIGAR_CAPACITY:
+            cap = np.maximum(cap, n_cig.astype(np.int64))
+            continue
+        if code != _lib.PHMM_OK:
+            raise PhmmError(code, engine.last_error())
+        if np.any(status < 0):
+            raise PhmmError(_lib.PHMM_ERR_INTERNAL, "calculate_cigar: the reference panics on pair %d (status %d)" % (int(np.argmax(status < 0)), int(status.min())))
+        return [None if status[a] == 1 else cigar[int(cig_off[a]):int(cig_off[a]) + int(n_cig[a])] for a in range(n)]
+    raise PhmmError(_lib.PHMM_ERR_CIGAR_CAPACITY, engine.last_error())
