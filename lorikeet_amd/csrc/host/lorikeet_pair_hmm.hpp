@@ -699,4 +699,28 @@ struct AlignmentUtils {
     }
 };
 
+
+struct CigarUtils {
+    // calculate_cigar(ref_seq, alt_seq, strategy, sw_parameters, avx_mode) (src/reads/cigar_utils.rs:358-457): None -> nullopt
+    static std::optional<std::vector<uint32_t>> calculate_cigar(const Bytes &ref_seq, const Bytes &alt_seq, OverhangStrategy strategy,
+                                                                const Parameters &sw_parameters, AVXMode = AVXMode::Hip) {
+        static std::mutex mu;
+        static detail::Handle handle = detail::make_handle(0, 0);
+        const uint32_t ref_off[2] = {0, (uint32_t)ref_seq.size()}, alt_off[2] = {0, (uint32_t)alt_seq.size()};
+        const phmm_sw_parameters prm{sw_parameters.match_value, sw_parameters.mismatch_penalty, sw_parameters.gap_open_penalty,
+                                     sw_parameters.gap_extend_penalty};
+        const uint64_t cig_off[2] = {0, ref_seq.size() + alt_seq.size() + 4};
+        std::vector<uint32_t> cigar(cig_off[1]);
+        uint32_t n_cig = 0;
+        int32_t status = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        detail::check(handle.get(), phmm_calculate_cigar(handle.get(), 1, ref_off, ref_seq.data(), alt_off, alt_seq.data(), &prm, (int)strategy,
+                                                         cig_off, cigar.data(), &n_cig, &status));
+        if (status < 0) throw Panic("calculate_cigar: the reference panics on this pair (status " + std::to_string(status) + ")");
+        if (status != 0) return std::nullopt;
+        cigar.resize(n_cig);
+        return cigar;
+    }
+};
+
 }  // namespace lorikeet

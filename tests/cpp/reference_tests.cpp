@@ -614,6 +614,29 @@ static void make_read_aligned_to_ref_data() {
     }
 }
 
+// tests/cigar_utils_unit_tests.rs:21-283 (make_test_compute_cigar_data), a cross-section (all 114 cases run through the C ABI
+// in tests/test_calculate_cigar_hip.py)
+static void make_test_compute_cigar_data() {
+    auto test_compute_cigar = [](const std::string &s1, const std::string &s2, const std::string &expected) {
+        const auto c = CigarUtils::calculate_cigar(bytes(s1), bytes(s2), OverhangStrategy::InDel, NEW_SW_PARAMETERS);
+        ASSERT(c && cigar_to_string(*c) == expected, "%s vs %s: %s, expected %s", s1.c_str(), s2.c_str(), c ? cigar_to_string(*c).c_str() : "None",
+               expected.c_str());
+    };
+    test_compute_cigar("ATGGAGGGGC", "ATGGTGGGGC", "10M");
+    test_compute_cigar("ATGGAGGGGC", "ATGGAAAATGGGGC", "5M4I5M");
+    test_compute_cigar("ATGGAAAAAGGGGC", "ATGGTGGGGC", "4M4D6M");
+    test_compute_cigar("ATGGAAAAAAAAAAGGGGC", "ATGGAAAATGGGGC", "4M5D10M");
+    test_compute_cigar("NNNTGTGTGTGTGTGTGACAGAGAGAGAGAGAGAGAGAGAGAGAGAGANNN", "NNNACAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGAGANNN", "3M6I48M");
+    test_compute_cigar("TCCCCCGGGT", "TAAACCCCCT", "1M3I5M3D1M");
+    test_compute_cigar("G", "", "1D");
+    test_compute_cigar("", "C", "1I");
+    test_compute_cigar("AAAAACC", "CCGGGGGG", "5D2M6I");
+    test_compute_cigar("GX", "X", "1D1M");
+    test_compute_cigar("XAAAAACC", "XCCGGGGGG", "1M5D2M6I");
+    test_compute_cigar("XG", "X", "1M1D");
+    test_compute_cigar("XXXXXXXXXXXXXGXXXXXXXXXXXXX", "XXXXXXXXXXXXXXXXXXXXXXXXXX", "13M1D13M");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s pairhmm-testdata.txt\n", argv[0]);
@@ -641,6 +664,7 @@ int main(int argc, char **argv) {
         {"test_for_identical_alignments_with_differing_flank_lengths", test_for_identical_alignments_with_differing_flank_lengths},
         {"test_best_alleles + realignment to the best haplotype", test_best_alleles},
         {"make_read_aligned_to_ref_data", make_read_aligned_to_ref_data},
+        {"make_test_compute_cigar_data", make_test_compute_cigar_data},
     };
     int failed = 0;
     for (const auto &t : tests) {

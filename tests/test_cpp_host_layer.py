@@ -28,7 +28,7 @@ def test_host_layer_mirrors_the_reference_surface():
                  "class AlleleLikelihoods", "class AssemblyResultSet", "class SmithWatermanAligner",
                  "enum class OverhangStrategy", "struct SmithWatermanAlignmentResult", "NEW_SW_PARAMETERS", "struct BestAllele",
                  "best_alleles_breaking_ties_main", "haplotype_alignment_tiebreaking_priority", "reference_tiebreaking_priority",
-                 "struct AlignmentUtils", "create_read_aligned_to_ref"):
+                 "struct AlignmentUtils", "create_read_aligned_to_ref", "struct CigarUtils", "calculate_cigar"):
         assert name in hpp, name
 
 
@@ -37,8 +37,8 @@ def test_reference_tests_in_cpp_pass_on_the_gpu():
     r = subprocess.run([EXE, os.path.join(GOLDEN, "pairhmm-testdata.txt")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "15 tests, 0 failed" in r.stdout
+    assert "16 tests, 0 failed" in r.stdout
     for name in ("test_likelihoods_avx", "make_basic_likelihood_tests", "test_compute_likelihoods",
                  "make_haplotype_indexing_provider", "make_big_read_hmm_provider", "rayon_worker_pattern",
-                 "smith_waterman_asserted_cases", "test_for_identical_alignments_with_differing_flank_lengths", "test_best_alleles", "make_read_aligned_to_ref_data"):
+                 "smith_waterman_asserted_cases", "test_for_identical_alignments_with_differing_flank_lengths", "test_best_alleles", "make_read_aligned_to_ref_data", "make_test_compute_cigar_data"):
         assert "PASS " + name in r.stdout
