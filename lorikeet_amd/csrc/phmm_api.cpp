@@ -35,6 +35,11 @@ using namespace phmm;
 
 namespace {
 
+#ifndef PHMM_MIXED_RUNS
+#define PHMM_MIXED_RUNS 32
+#endif
+constexpr unsigned kMixedRunsPerSlot = PHMM_MIXED_RUNS;  // runs per wave slot of a mixed batch (see the planner)
+
 std::mutex g_err_mu;
 std::string g_create_err = "";
 // phmm_submit / phmm_wait are the only entry points several threads may call on one handle, so their messages are kept
@@ -621,14 +626,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) c.pair_first.push_back(s.nh);
     }
 
-    // Reads per run, region by region.  `chain_reads` is right for the batch's AVERAGE read (about eight runs per wave
-    // slot); a long-tailed mix has regions whose reads are several times longer or whose K is several times larger,
-    // and with equal read counts their runs would be the stragglers of the launch.  So the count is scaled by the
-    // region's cost per read -- (rows + SUM + RESET) x (7 VALU per column + ~11 per step) -- relative to the batch's
-    // mean: every work item then costs about the same.  Uniform batches get exactly `chain_reads`; a forced value
-    // (tests) is taken as is.
+    // Reads per run.  Uniform batches get `chain_reads` (about eight runs per wave slot), mixed ones a quarter of that (below).
+    // Scaling a region's count by its cost per read -- (rows + SUM + RESET) x (7 VALU per column + ~11 per step) relative to
+    // the batch's mean, so that every work item costs about the same -- looked right and measured wrong once the items were
+    // sorted by cost and spread over the XCDs (1 536 mixed regions: 17.4 ms with it, 16.8 without): short runs of expensive
+    // reads pay the pipeline's fill more often than they save at the tail.  PHMM_COST_SCALED_RUNS builds it back in (A/B).
     std::vector<uint32_t> reg_run(n_regions, 0);
     {
+#ifdef PHMM_COST_SCALED_RUNS
         auto read_cost = [&](uint32_t g, int K) { return (double)(shape[g].mean_r + 2) * (7.0 * K + 11.0); };
         double cost_sum = 0.0, unit_sum = 0.0;
         for (const auto &kv : by_shape)
@@ -640,6 +645,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     unit_sum += u;
                 }
         const double mean_cost = unit_sum > 0 ? cost_sum / unit_sum : 1.0;
+#endif
         // A uniform batch balances with eight equal runs per wave slot; a mix of classes does not -- its items differ in
         // cost whatever the estimate, and the launch ends when the last long item does.  Mixed batches therefore get runs
         // a quarter as long (32 per slot, never below 4 reads): 1 536 mixed regions 20.4 -> 16.9 ms.
@@ -647,12 +653,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         for (const auto &kv : by_shape) n_chain_classes += kv.second.chain ? 1 : 0;
         uint32_t base_reads = chain_reads;
         if (n_chain_classes > 1 && !chain_forced)
-            base_reads = std::max<uint32_t>(4, std::min<uint32_t>(chain_reads, (uint32_t)(units / (32ull * 2 * kNumSimd))));
+            base_reads = std::max<uint32_t>(4, std::min<uint32_t>(chain_reads, (uint32_t)(units / ((uint64_t)kMixedRunsPerSlot * 2 * kNumSimd))));
         for (const auto &kv : by_shape)
             if (kv.second.chain)
                 for (uint32_t g : kv.second.regions) {
                     double r = base_reads;
+#ifdef PHMM_COST_SCALED_RUNS
                     if (!chain_forced) r = std::min<double>(CHAIN_MAX_READS, std::max(4.0, r * mean_cost / read_cost(g, kv.second.K) + 0.5));
+#endif
                     reg_run[g] = std::min<uint32_t>(CHAIN_MAX_READS, (uint32_t)r * (uint32_t)kv.second.streams);
                 }
     }
