@@ -1,4 +1,5 @@
 cd /root/repo
-timeout 200 python tools/soak.py 90 21 2>&1 | tail -2
-timeout 200 python tools/soak_engine.py 60 22 2>&1 | tail -2
-timeout 200 python tools/soak_sw.py 60 23 2>&1 | tail -1
+timeout 400 python tools/soak.py 240 31 2>&1 | tail -1
+timeout 300 python tools/soak_engine.py 120 32 2>&1 | tail -1
+timeout 300 python tools/soak_sw.py 180 33 2>&1 | tail -1
+timeout 300 python tools/soak_project.py 120 34 2>&1 | tail -1
