@@ -837,6 +837,8 @@ extern "C" int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *
             if (ref_off[a + 1] < ref_off[a] || alt_off[a + 1] < alt_off[a] || cigar_off[a + 1] < cigar_off[a])
                 return fail(h, "phmm_calculate_cigar: offsets not monotonic");
         if ((ref_off[n] && !ref_bases) || (alt_off[n] && !alt_bases) || (cigar_off[n] && !cigar)) return fail(h, "phmm_calculate_cigar: null array");
+        if ((uint64_t)ref_off[n] + 2ull * SW_PAD_BASES * n > 0xffffffffull || (uint64_t)alt_off[n] + 2ull * SW_PAD_BASES * n > 0xffffffffull)
+            return fail(h, "phmm_calculate_cigar: too many bases for one call (4 GB with the padding)");
         // both sequences of every pair between two runs of SW_PAD (cigar_utils.rs:387-398)
         std::vector<uint32_t> p_ref_off(n + 1), p_alt_off(n + 1);
         for (uint32_t a = 0; a <= n; ++a) {

@@ -1,2 +1,4 @@
 cd /root/repo
-python -m pytest tests/test_cpp_host_layer.py -m gpu -x -q 2>&1 | tail -12
+export TMPDIR=/tmp
+bash tools/profile.sh r02_ragged --workload ragged > gpurun_out/prof_e.log 2>&1
+ls gpurun_out/r02_ragged/bench.json
