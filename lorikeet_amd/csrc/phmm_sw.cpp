@@ -431,7 +431,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         pp.n_out_cigar = (uint32_t *)(W.dev + o_pno);
         pp.new_pos = (int64_t *)(W.dev + o_ppos);
         pp.status = (int32_t *)(W.dev + o_pst);
-        pp.flags = (uint32_t *)(W.dev + o_pfl);
+        pp.flags = (uint32_t *)(W.dev + 128);  // in the status block: cleared with it, fetched with it
         pp.workspace = W.ws;
         pp.capacity = pj_capacity;
     }
@@ -443,9 +443,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     bool good = ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
     if (good && J.best)  // the reads' best alleles become the index of their references, on the device
         good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
-    if (good && PJ)  // the projection's flag word starts clear; (not one piece:) its inputs follow the head
-        good = ok(h, hipMemsetAsync(W.dev + o_pfl, 0, 256, S_in), "memset project flags") &&
-               (one_piece || ok(h, hipMemcpyAsync(W.dev + o_pi, W.host + o_pi, p_end - o_pi, hipMemcpyHostToDevice, S_in), "H2D project"));
+    if (good && PJ && !one_piece)  // the projection's inputs follow the head
+        good = ok(h, hipMemcpyAsync(W.dev + o_pi, W.host + o_pi, p_end - o_pi, hipMemcpyHostToDevice, S_in), "H2D project");
     if (good && indexed && !one_piece) {
         memcpy(W.host + o_rb, J.ref_bases, rb);
         good = ok(h, hipMemcpyAsync(W.dev + o_rb, W.host + o_rb, rb, hipMemcpyHostToDevice, S_in), "H2D sw");
@@ -514,7 +513,10 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (a1 == a0) continue;
         const uint64_t g0 = cigar_off[a0], g1 = cigar_off[a1];
         good = one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)");
-        if (PJ) {
+        if (one_piece) {  // the piece is the call: its results are one contiguous block of the staging buffer
+            const size_t from = PJ ? o_pst : o_nc, to = PJ ? o_extra : o_pfl;
+            good = good && (J.view && !PJ ? true : ok(h, hipMemcpyAsync(W.host + from, W.dev + from, to - from, hipMemcpyDeviceToHost, S_out), "D2H sw"));
+        } else if (PJ) {
             const uint64_t q0 = PJ->out_cigar_off[a0], q1 = PJ->out_cigar_off[a1];
             good = good &&
                    ok(h, hipMemcpyAsync(W.host + o_pst + 4ull * a0, W.dev + o_pst + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H project") &&
@@ -535,8 +537,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (good && prev >= 0) good = unpack(prev);
         prev = c;
     }
-    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw") &&
-           (!PJ || ok(h, hipMemcpyAsync(W.host + o_pfl, W.dev + o_pfl, 256, hipMemcpyDeviceToHost, S_out), "D2H project"));
+    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw");
     if (good && prev >= 0) good = unpack(prev);
     good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
     if (!good) {
@@ -566,7 +567,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         h->err = who + ": a CIGAR needs more elements than its slot holds (n_cigar has the sizes)";
         return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
     }
-    if (PJ && (*(const uint32_t *)(W.host + o_pfl) & 1u)) {
+    if (PJ && (*(const uint32_t *)(W.host + o_st + 128) & 1u)) {
         h->err = who + ": a CIGAR needs more elements than its slot holds (n_out_cigar has the sizes)";
         return h->err_code = PHMM_ERR_CIGAR_CAPACITY;
     }

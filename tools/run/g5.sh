@@ -1,2 +1,4 @@
 cd /root/repo
-python tools/hostpath_ragged.py 2>&1 | grep "call\|chunks\|enqueue" | head -14
+timeout 600 python -m pytest tests/test_sw_hip.py tests/test_realign_hip.py tests/test_project_hip.py tests/test_calculate_cigar_hip.py -x -q --timeout 300 2>&1 | tail -3
+TB_MODE=pipeline TB_THREADS=1,4,8,16 tools/threads_bench 1.5
+python tools/realign_small.py 2>&1 | grep -v amdgpu | head -3

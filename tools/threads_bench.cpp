@@ -3,6 +3,7 @@
 // assembly_region_walker.rs:210-273).  Two ways to serve it through include/phmm.h:
 //   own     every thread has its own handle and calls phmm_compute
 //   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
+//   pipeline (TB_MODE=pipeline only)  own handles; per call phmm_compute and then phmm_realign_reads with its likelihoods
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
 // env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>
 #include <atomic>
@@ -22,6 +23,13 @@ struct Region {
     std::vector<uint8_t> bases, q, iq, dq, gcp, haps;
     std::vector<double> out;
     uint64_t cells = 0;
+    // what phmm_realign_reads takes besides (mode "pipeline"): priorities, reference haplotype / start per region, the
+    // haplotypes' CIGARs (SNVs only: one M element), the reads' original CIGARs, and room for the results
+    std::vector<int32_t> pri, ref_hap, best, status;
+    std::vector<uint64_t> rstart, out_cig_off;
+    std::vector<uint32_t> hc_off, hc, hs, oc_off, oc, cig, n_cig;
+    std::vector<int64_t> pos;
+    std::vector<double> lk, conf;
 };
 
 static uint64_t rng_state;
@@ -73,6 +81,22 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_c
   }
     g.out.assign((size_t)nr * nh * per_call, 0.0);
     g.cells = (uint64_t)nr * R * (uint64_t)nh * H * per_call;
+    const size_t n_reads = (size_t)nr * per_call, n_haps = (size_t)nh * per_call;
+    g.pri.assign(n_haps, 0);
+    g.ref_hap.assign(per_call, 0);
+    for (int reg = 0; reg < per_call; ++reg) g.rstart.push_back(1000ull * (reg + 1));
+    for (size_t a = 0; a <= n_haps; ++a) g.hc_off.push_back((uint32_t)a);
+    g.hc.assign(n_haps, (uint32_t)H << 4);
+    g.hs.assign(n_haps, 0);
+    for (size_t r = 0; r <= n_reads; ++r) g.oc_off.push_back((uint32_t)r), g.out_cig_off.push_back(8ull * r);
+    g.oc.assign(n_reads, (uint32_t)R << 4);
+    g.cig.assign(8 * n_reads, 0);
+    g.n_cig.assign(n_reads, 0);
+    g.pos.assign(n_reads, 0);
+    g.status.assign(n_reads, 0);
+    g.best.assign(n_reads, 0);
+    g.lk.assign(n_reads, 0.0);
+    g.conf.assign(n_reads, 0.0);
     return g;
 }
 
@@ -86,6 +110,17 @@ static int call_shared(phmm_handle *h, Region &g) {
     int st = phmm_submit(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
                          g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data(), &t);
     return st ? st : phmm_wait(h, t);
+}
+
+// likelihoods, then the reads realigned with them (best alleles, alignments, projection onto the reference)
+static int call_pipeline(phmm_handle *h, Region &g) {
+    int st = call_own(h, g);
+    if (st) return st;
+    static const phmm_sw_parameters prm{10, -15, -30, -5};
+    return phmm_realign_reads(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.ho.data(), g.haps.data(),
+                              g.oo.data(), g.out.data(), nullptr, g.pri.data(), 0.2, &prm, PHMM_SW_SOFTCLIP, g.ref_hap.data(), g.rstart.data(),
+                              g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(), g.out_cig_off.data(), g.cig.data(),
+                              g.n_cig.data(), g.pos.data(), g.status.data(), g.best.data(), g.lk.data(), g.conf.data());
 }
 
 int main(int argc, char **argv) {
@@ -106,12 +141,12 @@ int main(int argc, char **argv) {
             if (Ts.back() < 1) return 2;
         }
     }
-    const char *only = getenv("TB_MODE");  // "own" or "shared": just that one
-    for (int mode = 0; mode < 2; ++mode) {
-        if (only && only[0] != (mode == 0 ? 'o' : 's')) continue;
+    const char *only = getenv("TB_MODE");  // "own", "shared" or "pipeline": just that one (pipeline only when asked for)
+    for (int mode = 0; mode < 3; ++mode) {
+        if (only ? only[0] != "osp"[mode] : mode == 2) continue;
         for (int T : Ts) {
             std::vector<phmm_handle *> hs;
-            for (int i = 0; i < (mode == 0 ? T : 1); ++i) {
+            for (int i = 0; i < (mode != 1 ? T : 1); ++i) {
                 hs.push_back(phmm_create(0, getenv("TB_FLAGS") ? (unsigned)atoi(getenv("TB_FLAGS")) : 0u));
                 if (!hs.back()) {
                     fprintf(stderr, "phmm_create: %s\n", phmm_last_error(nullptr));
@@ -128,13 +163,14 @@ int main(int argc, char **argv) {
             std::vector<std::thread> th;
             for (int t = 0; t < T; ++t)
                 th.emplace_back([&, t] {
-                    phmm_handle *h = hs[mode == 0 ? t : 0];
+                    phmm_handle *h = hs[mode != 1 ? t : 0];
+                    auto call = mode == 0 ? call_own : mode == 1 ? call_shared : call_pipeline;
                     for (int k = 0; k < 3; ++k)  // warm the arenas
-                        if ((mode == 0 ? call_own : call_shared)(h, regs[t][k])) failed = 1;
+                        if (call(h, regs[t][k])) failed = 1;
                     while (!go.load()) std::this_thread::yield();
                     uint64_t n = 0;
                     for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
-                        if ((mode == 0 ? call_own : call_shared)(h, regs[t][k & 3])) {
+                        if (call(h, regs[t][k & 3])) {
                             failed = 1;
                             break;
                         }
@@ -157,7 +193,7 @@ int main(int argc, char **argv) {
                 return 1;
             }
             const double rate = n_calls * per_call / dt;
-            printf("%-6s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : "shared", T,
+            printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : "pipeline", T,
                    rate, rate * regs[0][0].cells / per_call / 1e9, dt * T / (double)n_calls * 1e6);
             if (mode == 1) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
             printf("\n");
