@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "phmm_cigar_internal.hpp"
 #include "phmm_host.hpp"
 #include "phmm_internal.hpp"
 #include "phmm_tables.hpp"
@@ -58,6 +59,7 @@ constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
 static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
+static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (256u << 10);
 static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
 static const int kForcedEagerD2H = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
 // (these five are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
@@ -288,6 +290,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
         env("PHMM_SW_CHUNKS", w.sw_chunks);
         env("PHMM_SW_LANES", w.sw_lanes);
+        w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
         w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
         w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
         w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
@@ -1210,8 +1213,14 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             else
                 zero_copy = false;
         }
-        if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch"))
+        // ... and its inputs are fetched from the mirror by a kernel instead of the copy engine (no cross-engine
+        // dependency in front of the first launch; phmm_cigar_kernels.hip)
+        void *host_dp = nullptr;
+        if (zero_copy && in_bytes + 256 <= kStageInBytes && hipHostGetDevicePointer(&host_dp, A.host, 0) == hipSuccess && host_dp) {
+            if (!hip_ok(h, launch_stage_in(host_dp, A.dev, in_bytes + 256, h->S()), "phmm_stage_in_kernel")) st = PHMM_ERR_HIP;
+        } else if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch")) {
             st = PHMM_ERR_HIP;
+        }
         // (slots the kernels never write -- gaps the caller left in out_off -- are never copied back either)
         if (st == PHMM_OK) st = phmm_batch_bind_device(b, d[0], d[1], d[2], d[3], d[4], d[5], d_out);
         t_h2d = now();
@@ -1891,6 +1900,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "trace") w.trace = value != 0;
     else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
+    else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";

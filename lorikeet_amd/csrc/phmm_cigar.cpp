@@ -111,7 +111,7 @@ extern "C" int phmm_project_to_reference(phmm_handle *h, uint32_t n_regions, con
             for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(h->streams[i]);
             if (W.dev) (void)hipFree(W.dev);
             if (W.host) (void)hipHostFree(W.host);
-            W.dev = W.host = nullptr;
+            W.dev = W.host = W.host_dev = nullptr;
             W.cap = 0;
             const size_t cap = std::max<size_t>(total + total / 2, 1 << 20);
             if (!ok(h, hipMalloc((void **)&W.dev, cap), "hipMalloc(project staging)") ||

@@ -41,6 +41,8 @@ struct ProjectParams {
     uint32_t capacity;
 };
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
+// `bytes` (rounded up to 16; both buffers are 256-aligned and padded) from pinned host memory, by its device address, to `dev`
+hipError_t launch_stage_in(const void *host_as_device, void *dev, size_t bytes, hipStream_t stream);
 
 // CigarUtils::calculate_cigar behind the padded alignments (phmm_calculate_cigar): one lane per haplotype
 constexpr int CIGAR_SW_FAILURE = 1;  // is_s_w_failure: the reference returns None

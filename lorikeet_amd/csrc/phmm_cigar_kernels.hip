@@ -401,7 +401,7 @@ done:
     p.status[r] = status;
     p.new_pos[r] = status == CIGAR_OK ? new_pos : 0;
     p.n_out_cigar[r] = status == CIGAR_OK ? n_out : 0;
-    if (status == CIGAR_OK && n_out > out_cap) atomicOr(p.flags, 1u);
+    if (status == CIGAR_OK && n_out > out_cap) *p.flags = 1u;
 }
 
 // CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) behind the Smith-Waterman alignment of the padded
@@ -458,7 +458,23 @@ __global__ __launch_bounds__(64) void phmm_calculate_cigar_kernel(const CalcPara
     }
     p.status[a] = status;
     p.n_out_cigar[a] = status == CIGAR_OK ? n_out : 0;
-    if (status == CIGAR_OK && n_out > out_cap) atomicOr(p.flags, 1u);
+    if (status == CIGAR_OK && n_out > out_cap) *p.flags = 1u;
+}
+
+// The inputs of a small call, fetched from the pinned mirror by the compute queue itself: 16 bytes per lane straight over
+// the link.  (A copy-engine transfer of a few tens of KB costs more in queueing and in the cross-engine dependency of
+// the launch behind it than the transfer itself.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) phmm_stage_in_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, uint32_t n16) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+hipError_t launch_stage_in(const void *host_as_device, void *dev, size_t bytes, hipStream_t stream) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (!n16) return hipSuccess;
+    hipLaunchKernelGGL(phmm_stage_in_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (const u32x4 *)host_as_device, (u32x4 *)dev, n16);
+    return hipGetLastError();
 }
 
 hipError_t launch_calculate_cigar(const CalcParams &p, hipStream_t stream) {

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // Grow-only device arena with a pinned host mirror at identical offsets.  phmm_compute() places the
@@ -38,6 +39,7 @@ struct Switches {
     int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
+    int sw_no_zero_copy = 0;    // PHMM_SW_NO_ZERO_COPY: small one-piece calls fetch their results by copies like large ones (A/B only)
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
@@ -60,6 +62,7 @@ struct phmm_handle {
     Switches sw;
     struct SwWork {  // phmm_sw_align (phmm_sw.cpp): grow-only staging and backtrack slabs
         char *dev = nullptr, *host = nullptr;
+        char *host_dev = nullptr;  // the pinned mirror as the device sees it (small calls: kernels store their results there)
         size_t cap = 0;
         uint32_t *slab = nullptr;
         size_t slab_bytes = 0;
@@ -69,6 +72,7 @@ struct phmm_handle {
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
         uint64_t last_kernel_us = 0, last_backtrack_bytes = 0, last_clock_mhz = 0;
+        std::unordered_map<uint64_t, int> blocks_per_cu;  // by (lanes, columns, LDS bytes): asked of the runtime once
     } swork;
     uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
     uint64_t stat_rescue_passes = 0;  // how many batches needed the exact pass (phmm_get_stat)

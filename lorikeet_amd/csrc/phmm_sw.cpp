@@ -144,7 +144,12 @@ void stage_best(const BestJob &b, const BestLayout &L, char *host) {
     if (b.priority) memcpy(host + L.pri, b.priority, 4ull * b.n_haps);
 }
 
-BestParams best_params(const BestJob &b, const BestLayout &L, char *dev, uint32_t *d_ref_index) {
+// results of at most this many bytes are stored into the pinned mirror by the kernels themselves (sw_run)
+constexpr size_t kZeroCopyResultBytes = 64u << 10;
+// ... and inputs of at most this many are fetched from it by a kernel instead of the copy engine
+constexpr size_t kStageInBytes = 256u << 10;
+
+BestParams best_params(const BestJob &b, const BestLayout &L, char *dev, char *out, uint32_t *d_ref_index) {
     BestParams p{};
     p.n_reads = b.n_reads;
     p.n_regions = b.n_regions;
@@ -155,9 +160,9 @@ BestParams best_params(const BestJob &b, const BestLayout &L, char *dev, uint32_
     p.keep = b.keep ? (const uint8_t *)(dev + L.keep) : nullptr;
     p.priority = b.priority ? (const int32_t *)(dev + L.pri) : nullptr;
     p.threshold = b.threshold;
-    p.best_allele = (int32_t *)(dev + L.best);
-    p.likelihood = (double *)(dev + L.olk);
-    p.confidence = (double *)(dev + L.conf);
+    p.best_allele = (int32_t *)(out + L.best);
+    p.likelihood = (double *)(out + L.olk);
+    p.confidence = (double *)(out + L.conf);
     p.ref_index = d_ref_index;
     return p;
 }
@@ -168,7 +173,7 @@ bool grow_staging(phmm_handle *h, size_t total) {
     for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(h->streams[i]);
     if (W.dev) (void)hipFree(W.dev);
     if (W.host) (void)hipHostFree(W.host);
-    W.dev = W.host = nullptr;
+    W.dev = W.host = W.host_dev = nullptr;
     W.cap = 0;
     const size_t cap = std::max<size_t>(total + total / 2, 1 << 20);
     if (!ok(h, hipMalloc((void **)&W.dev, cap), "hipMalloc(sw staging)") ||
@@ -274,7 +279,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 8 000 bases each)");
     // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
     // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
-    int per_cu = sw_blocks_per_cu(L, K, lds);
+    int per_cu;
+    {
+        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)lds;
+        auto it = h->swork.blocks_per_cu.find(key);
+        if (it == h->swork.blocks_per_cu.end()) it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds)).first;
+        per_cu = it->second;
+    }
     if (per_cu <= 0) {
         h->err = who + ": the kernel does not fit a compute unit";
         return h->err_code = PHMM_ERR_INTERNAL;
@@ -340,6 +351,21 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                  o_ppos = o_pno + (PJ ? up256(4ull * n_alignments) : 0), o_pout = o_ppos + (PJ ? up256(8ull * n_alignments) : 0),
                  o_extra = o_pout + (PJ ? up256(4ull * pj_out) : 0), total = o_extra + (J.view ? up256(J.view->extra_bytes) : 0);
     if (!grow_staging(h, total)) return PHMM_ERR_HIP;
+    // A small call in one piece (a region per call, the reference's pattern): the kernels store the results -- and the
+    // status block -- straight into the pinned mirror, so that nothing is copied back (each copy costs the call some
+    // 10 us, and the copy engine is what concurrent callers end up queueing for).  What a later kernel reads again (the
+    // reference index, the alignments the projection consumes) stays in device memory.
+    const size_t result_bytes = (PJ ? o_extra - o_pst : J.view ? 0 : o_pfl - o_nc) + (J.best ? BL.end - BL.best : 0);
+    bool zero_copy = one_piece && !h->sw.sw_no_zero_copy && result_bytes <= kZeroCopyResultBytes;
+    if (zero_copy && !W.host_dev) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, W.host, 0) == hipSuccess && dp)
+            W.host_dev = (char *)dp;
+        else
+            zero_copy = false;
+    }
+    char *const out_base = zero_copy ? W.host_dev : W.dev;          // results
+    char *const st_base = zero_copy ? W.host_dev + o_st : W.dev;    // the status block
     uint32_t pj_capacity = 0;
     if (PJ) {  // the lanes' builders: see phmm_cigar.cpp
         pj_capacity = 4 * (PJ->sw_capacity + PJ->max_hap_cigar + 2) + 8;
@@ -370,12 +396,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     p.w_open = params->gap_open_penalty;
     p.w_extend = params->gap_extend_penalty;
     p.strategy = J.strategy;
-    p.cigar = (uint32_t *)(W.dev + o_cg);
-    p.n_cigar = (uint32_t *)(W.dev + o_nc);
-    p.alignment_offset = (int32_t *)(W.dev + o_of);
+    char *const sw_out = on_device ? W.dev : out_base;  // (alignments that a kernel consumes stay on the device)
+    p.cigar = (uint32_t *)(sw_out + o_cg);
+    p.n_cigar = (uint32_t *)(sw_out + o_nc);
+    p.alignment_offset = (int32_t *)(sw_out + o_of);
     p.slab = W.slab;
     p.slab_stride = slab_stride;
-    p.status = (uint32_t *)(W.dev + 64);
+    p.status = (uint32_t *)(st_base + 64);
     p.max_ref = max_ref;
     p.max_alt = max_alt;
     p.lds_ref_bytes = (uint32_t)lds_ref;
@@ -385,6 +412,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     // the offset arrays, the status word, the index and the best-allele inputs travel with the first piece -- and, when
     // the references are shared (reads -> their haplotypes), all the references
     memset(W.host, 0, 256);
+    if (zero_copy) memset(W.host + o_st, 0, 256);
     memcpy(W.host + o_ro, ref_off, 4ull * (n_refs + 1));
     memcpy(W.host + o_ao, alt_off, 4ull * (n_alignments + 1));
     memcpy(W.host + o_co, cigar_off, 8ull * (n_alignments + 1));
@@ -419,7 +447,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         pp.hap_cigar_off = (const uint32_t *)(W.dev + p_hco);
         pp.hap_cigar = (const uint32_t *)(W.dev + p_hc);
         pp.hap_start_wrt_ref = (const uint32_t *)(W.dev + p_hs);
-        pp.best_allele = (const int32_t *)(W.dev + BL.best);
+        pp.best_allele = (const int32_t *)(out_base + BL.best);
         pp.sw_cigar_off = p.cigar_off;
         pp.sw_cigar = p.cigar;
         pp.n_sw_cigar = p.n_cigar;
@@ -427,11 +455,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         pp.orig_cigar_off = (const uint32_t *)(W.dev + p_oco);
         pp.orig_cigar = (const uint32_t *)(W.dev + p_oc);
         pp.out_cigar_off = (const uint64_t *)(W.dev + p_oo);
-        pp.out_cigar = (uint32_t *)(W.dev + o_pout);
-        pp.n_out_cigar = (uint32_t *)(W.dev + o_pno);
-        pp.new_pos = (int64_t *)(W.dev + o_ppos);
-        pp.status = (int32_t *)(W.dev + o_pst);
-        pp.flags = (uint32_t *)(W.dev + 128);  // in the status block: cleared with it, fetched with it
+        pp.out_cigar = (uint32_t *)(out_base + o_pout);
+        pp.n_out_cigar = (uint32_t *)(out_base + o_pno);
+        pp.new_pos = (int64_t *)(out_base + o_ppos);
+        pp.status = (int32_t *)(out_base + o_pst);
+        pp.flags = (uint32_t *)(st_base + 128);  // in the status block: cleared with it, fetched with it
         pp.workspace = W.ws;
         pp.capacity = pj_capacity;
     }
@@ -440,9 +468,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         memcpy(W.host + o_ab, J.alt_bases, ab);
         head = in_bytes;
     }
-    bool good = ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
+    // (a small call's inputs are fetched by a kernel: no copy engine, no cross-engine dependency for the launches behind it)
+    bool good = zero_copy && head <= kStageInBytes ? ok(h, launch_stage_in(W.host_dev, W.dev, head, S_in), "phmm_stage_in_kernel")
+                                                   : ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
     if (good && J.best)  // the reads' best alleles become the index of their references, on the device
-        good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
+        good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, out_base, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
     if (good && PJ && !one_piece)  // the projection's inputs follow the head
         good = ok(h, hipMemcpyAsync(W.dev + o_pi, W.host + o_pi, p_end - o_pi, hipMemcpyHostToDevice, S_in), "H2D project");
     if (good && indexed && !one_piece) {
@@ -490,7 +520,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     hipStream_t S_out = one_piece ? S : h->streams[2];
     auto unpack = [&](int c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
-        if (!ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;
+        if (!one_piece && !ok(h, hipEventSynchronize(W.ev_out[c]), "sync(sw results)")) return false;  // (one piece: the stream has been waited for)
         if (J.view && !PJ) return true;
         if (PJ) {
             memcpy(PJ->status + a0, W.host + o_pst + 4ull * a0, 4ull * (a1 - a0));
@@ -513,7 +543,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (a1 == a0) continue;
         const uint64_t g0 = cigar_off[a0], g1 = cigar_off[a1];
         good = one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)");
-        if (one_piece) {  // the piece is the call: its results are one contiguous block of the staging buffer
+        if (zero_copy) {
+            // nothing to fetch
+        } else if (one_piece) {  // the piece is the call: its results are one contiguous block of the staging buffer
             const size_t from = PJ ? o_pst : o_nc, to = PJ ? o_extra : o_pfl;
             good = good && (J.view && !PJ ? true : ok(h, hipMemcpyAsync(W.host + from, W.dev + from, to - from, hipMemcpyDeviceToHost, S_out), "D2H sw"));
         } else if (PJ) {
@@ -529,17 +561,22 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                    ok(h, hipMemcpyAsync(W.host + o_of + 4ull * a0, W.dev + o_of + 4ull * a0, 4ull * (a1 - a0), hipMemcpyDeviceToHost, S_out), "D2H sw") &&
                    (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw"));
         }
-        good = good && ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord");
-        if (good && J.best && !best_fetched) {  // the best alleles were final before the first kernel started
+        good = good && (one_piece || ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord"));
+        if (good && J.best && !best_fetched && !zero_copy) {  // the best alleles were final before the first kernel started
             good = ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S_out), "D2H best alleles");
             best_fetched = true;
         }
         if (good && prev >= 0) good = unpack(prev);
         prev = c;
     }
-    good = good && ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw");
-    if (good && prev >= 0) good = unpack(prev);
-    good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
+    good = good && (zero_copy || ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw"));
+    if (one_piece) {
+        good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
+        if (good && prev >= 0) good = unpack(prev);
+    } else {
+        if (good && prev >= 0) good = unpack(prev);
+        good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
+    }
     if (!good) {
         (void)hipStreamSynchronize(S_in);
         (void)hipStreamSynchronize(S);
@@ -556,9 +593,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         float ms = 0.f;
         if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
     }
-    const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0] status; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
+    const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0], [1] conditions; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
     W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
-    if (st[0] & SW_STATUS_CAPACITY) {
+    if (st[SW_STATUS_CAPACITY]) {
         if (on_device) {  // an alignment outgrew the library's own slots: tell the caller how large the largest is (it runs again)
             std::vector<uint32_t> n_cig_host(n_alignments);
             if (!ok(h, hipMemcpy(n_cig_host.data(), W.dev + o_nc, 4ull * n_alignments, hipMemcpyDeviceToHost), "D2H sw")) return PHMM_ERR_HIP;
@@ -679,7 +716,7 @@ extern "C" int phmm_best_alleles(phmm_handle *h, uint32_t n_regions, const uint3
         hipStream_t S = h->streams[0];
         stage_best(B, BL, W.host);
         if (!ok(h, hipMemcpyAsync(W.dev, W.host, BL.best, hipMemcpyHostToDevice, S), "H2D best alleles") ||
-            !ok(h, launch_best_alleles(best_params(B, BL, W.dev, nullptr), S), "phmm_best_alleles_kernel") ||
+            !ok(h, launch_best_alleles(best_params(B, BL, W.dev, W.dev, nullptr), S), "phmm_best_alleles_kernel") ||
             !ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S), "D2H best alleles") ||
             !ok(h, hipStreamSynchronize(S), "sync(best alleles)"))
             return PHMM_ERR_HIP;

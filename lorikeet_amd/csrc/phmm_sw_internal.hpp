@@ -7,8 +7,10 @@ namespace phmm {
 
 constexpr int PHMM_SW_STRATEGY_SOFTCLIP = 0, PHMM_SW_STRATEGY_INDEL = 1, PHMM_SW_STRATEGY_LEADING_INDEL = 2,
               PHMM_SW_STRATEGY_IGNORE = 3;  // == PHMM_SW_* of include/phmm.h
-constexpr uint32_t SW_STATUS_EMPTY = 1u;     // an empty reference or alternate sequence
-constexpr uint32_t SW_STATUS_CAPACITY = 2u;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
+// the status block: one word per condition, set by plain stores (no atomics: for small calls the block lies in pinned
+// host memory), then [2], [3] = shader clocks / 100 MHz ticks of block 0
+constexpr int SW_STATUS_EMPTY = 0;     // an empty reference or alternate sequence
+constexpr int SW_STATUS_CAPACITY = 1;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
 struct SwParams {
     uint32_t a_begin, n_alignments;        // this launch aligns [a_begin, n_alignments)
     const uint32_t *ref_off, *alt_off;     // [references + 1], [n_alignments + 1]

@@ -304,7 +304,7 @@ void phmm_sw_align_kernel(const SwParams p) {
             CigarOut cig{p.cigar + p.cigar_off[a], p.cigar_off[a + 1] - p.cigar_off[a], l == 0};
             int32_t alignment_offset = 0;
             if (n == 0 || m == 0) {  // the reference asserts (:65-68, :132-134); the host refuses such input beforehand
-                if (l == 0) atomicOr(p.status, SW_STATUS_EMPTY);
+                if (l == 0) p.status[SW_STATUS_EMPTY] = 1u;
             } else if (found >= 0) {
                 cig.push(make_element(ST_MATCH, (uint32_t)m));
                 alignment_offset = found;
@@ -395,7 +395,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 cig.finish();
                 p.n_cigar[a] = cig.n;
                 p.alignment_offset[a] = alignment_offset;
-                if (cig.n > cig.cap) atomicOr(p.status, SW_STATUS_CAPACITY);
+                if (cig.n > cig.cap) p.status[SW_STATUS_CAPACITY] = 1u;
             }
         }
         __builtin_amdgcn_s_barrier();  // (one wave per block: a scheduling point between rounds)

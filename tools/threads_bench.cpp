@@ -4,6 +4,7 @@
 //   own     every thread has its own handle and calls phmm_compute
 //   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
 //   pipeline (TB_MODE=pipeline only)  own handles; per call phmm_compute and then phmm_realign_reads with its likelihoods
+//   realign  (TB_MODE=realign only)   own handles; phmm_realign_reads alone, on likelihoods computed beforehand
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
 // env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>
 #include <atomic>
@@ -123,6 +124,14 @@ static int call_pipeline(phmm_handle *h, Region &g) {
                               g.n_cig.data(), g.pos.data(), g.status.data(), g.best.data(), g.lk.data(), g.conf.data());
 }
 
+static int call_realign(phmm_handle *h, Region &g) {
+    static const phmm_sw_parameters prm{10, -15, -30, -5};
+    return phmm_realign_reads(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.ho.data(), g.haps.data(),
+                              g.oo.data(), g.out.data(), nullptr, g.pri.data(), 0.2, &prm, PHMM_SW_SOFTCLIP, g.ref_hap.data(), g.rstart.data(),
+                              g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(), g.out_cig_off.data(), g.cig.data(),
+                              g.n_cig.data(), g.pos.data(), g.status.data(), g.best.data(), g.lk.data(), g.conf.data());
+}
+
 int main(int argc, char **argv) {
     const double dur = argc > 1 ? atof(argv[1]) : 1.0;
     const int nr = argc > 5 ? atoi(argv[2]) : 128, nh = argc > 5 ? atoi(argv[3]) : 8, R = argc > 5 ? atoi(argv[4]) : 150,
@@ -142,8 +151,8 @@ int main(int argc, char **argv) {
         }
     }
     const char *only = getenv("TB_MODE");  // "own", "shared" or "pipeline": just that one (pipeline only when asked for)
-    for (int mode = 0; mode < 3; ++mode) {
-        if (only ? only[0] != "osp"[mode] : mode == 2) continue;
+    for (int mode = 0; mode < 4; ++mode) {
+        if (only ? only[0] != "ospr"[mode] : mode >= 2) continue;
         for (int T : Ts) {
             std::vector<phmm_handle *> hs;
             for (int i = 0; i < (mode != 1 ? T : 1); ++i) {
@@ -164,9 +173,9 @@ int main(int argc, char **argv) {
             for (int t = 0; t < T; ++t)
                 th.emplace_back([&, t] {
                     phmm_handle *h = hs[mode != 1 ? t : 0];
-                    auto call = mode == 0 ? call_own : mode == 1 ? call_shared : call_pipeline;
-                    for (int k = 0; k < 3; ++k)  // warm the arenas
-                        if (call(h, regs[t][k])) failed = 1;
+                    auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : call_realign;
+                    for (int k = 0; k < 4; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
+                        if ((mode == 3 && call_own(h, regs[t][k])) || call(h, regs[t][k])) failed = 1;
                     while (!go.load()) std::this_thread::yield();
                     uint64_t n = 0;
                     for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
@@ -193,7 +202,7 @@ int main(int argc, char **argv) {
                 return 1;
             }
             const double rate = n_calls * per_call / dt;
-            printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : "pipeline", T,
+            printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : "realign", T,
                    rate, rate * regs[0][0].cells / per_call / 1e9, dt * T / (double)n_calls * 1e6);
             if (mode == 1) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
             printf("\n");
