@@ -62,7 +62,7 @@ static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(get
 static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (256u << 10);
 static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
 static const int kForcedEagerD2H = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
-// (these five are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
+// (these six are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
