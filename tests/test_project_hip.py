@@ -165,3 +165,37 @@ def test_realign_reads_grows_its_own_alignment_slots(hip_engine):
         st, pos, cig = _oracle_read(b, r, 0, 0, cigs, [0], [0], [100], orig)
         assert got.status[r] == st == 0 and got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig
     assert len(got.cigars[0]) > 24
+
+
+def test_small_calls_store_results_into_the_mirror_or_copy_them_same_answer(hip_engine):
+    """A call of one region fetches its inputs from the pinned mirror with a kernel and stores results and status words
+    into it (no copy engine); switch `sw_no_zero_copy` takes the copies of large calls instead.  Same answer either
+    way, for the fused call, the plain alignment and a call whose output slots are too small."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(77, n_regions=1)
+    lk = hip_engine.compute(b)
+    haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(b.n_haps)]
+    reads = [b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])] for r in range(b.n_reads)]
+    idx = np.arange(b.n_reads) % b.n_haps
+    results = []
+    try:
+        for off in (0, 1):
+            hip_engine.set_switch("sw_no_zero_copy", off)
+            best, got = realign.realign_reads(hip_engine, b, lk, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+            aligned = SmithWatermanAligner(hip_engine).align_indexed(haps, reads, idx, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")
+            gapped = [(b"ACGTACGTAC" * 6, b"ACGTAC" + b"TTT" + b"GTACACGTAC" * 3 + b"GG" + b"ACGTACGTAC")]
+            tight = SmithWatermanAligner(hip_engine).align_batch(gapped, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip", capacity=1)[0]
+            roomy = SmithWatermanAligner(hip_engine).align_batch(gapped, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")[0]
+            assert len(roomy.elements) > 1 and np.array_equal(tight.elements, roomy.elements)  # (the status word said so)
+            results.append((best, got, aligned))
+    finally:
+        hip_engine.set_switch("sw_no_zero_copy", 0)
+    (b0, g0, a0), (b1, g1, a1) = results
+    assert np.array_equal(b0.allele_index, b1.allele_index) and np.array_equal(b0.likelihood, b1.likelihood)
+    assert np.array_equal(b0.confidence, b1.confidence, equal_nan=True)
+    assert np.array_equal(g0.status, g1.status) and np.array_equal(g0.new_pos, g1.new_pos)
+    for r in range(b.n_reads):
+        assert np.array_equal(g0.cigars[r], g1.cigars[r]) and np.array_equal(a0[r].elements, a1[r].elements) and a0[r].alignment_offset == a1[r].alignment_offset
+    reg = np.zeros(b.n_reads, np.int64)
+    for r in range(b.n_reads):
+        st, pos, cig = _oracle_read(b, r, reg[r], b0.allele_index[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        assert g0.status[r] == st and (st != 0 or (g0.new_pos[r] == pos and oracle.cigar_to_string(g0.cigars[r]) == cig)), r
