@@ -291,8 +291,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         return h->err_code = PHMM_ERR_INTERNAL;
     }
     if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
-    // backtrack flags per block: strips x (rows + L - 1) steps x 2 ceil(K / 16) dwords x 64 lanes (four bits per cell)
-    const size_t flag_words = 2 * (((size_t)K + 15) / 16);
+    // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
+    const size_t flag_words = (size_t)sw_flag_words(K);
     const size_t slab_stride = strips * (size_t)(max_ref + L) * flag_words * 64;
     const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
     // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on

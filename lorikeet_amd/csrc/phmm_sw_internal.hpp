@@ -11,6 +11,10 @@ constexpr int PHMM_SW_STRATEGY_SOFTCLIP = 0, PHMM_SW_STRATEGY_INDEL = 1, PHMM_SW
 // host memory), then [2], [3] = shader clocks / 100 MHz ticks of block 0
 constexpr int SW_STATUS_EMPTY = 0;     // an empty reference or alternate sequence
 constexpr int SW_STATUS_CAPACITY = 1;  // some CIGAR did not fit its slot (n_cigar holds the size it needs)
+// Flag dwords a lane stores per step for its K cells (four bits each): a pair -- candidate tags, gap-open bits -- per 16
+// cells, and for a remainder of at most 8 cells ONE dword with the tags in its top and the gap bits in its bottom half.
+constexpr int sw_flag_words(int K) { return 2 * (K / 16) + (K % 16 == 0 ? 0 : K % 16 <= 8 ? 1 : 2); }
+
 struct SwParams {
     uint32_t a_begin, n_alignments;        // this launch aligns [a_begin, n_alignments)
     const uint32_t *ref_off, *alt_off;     // [references + 1], [n_alignments + 1]

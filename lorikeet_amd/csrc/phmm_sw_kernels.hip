@@ -107,7 +107,10 @@ void phmm_sw_align_kernel(const SwParams p) {
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     // backtrack flags of this block, [strip][step][dword][lane]
-    constexpr int NH = (K + 15) / 16;  // flag-word pairs per lane and step
+    constexpr int NH = (K + 15) / 16;  // flag accumulator pairs per lane: candidate tags, gap-open bits of 16 cells each
+    constexpr int NW = sw_flag_words(K);  // dwords stored per lane and step
+    constexpr int REM = K % 16;
+    constexpr bool LAST_PACKED = REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
     uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
     // scores times four; the low two bits name the candidate
     int32_t x_match = 4 * p.w_match + TAG_DIAG, x_mismatch = 4 * p.w_mismatch + TAG_DIAG;
@@ -115,7 +118,7 @@ void phmm_sw_align_kernel(const SwParams p) {
     const int32_t x_open = 4 * p.w_open, x_open_r = 4 * p.w_open + TAG_RIGHT, x_extend = 4 * p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
-    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * (2 * NH) * WAVE;  // flag dwords of one strip
+    const size_t strip_stride = (size_t)(p.max_ref + SW_L) * NW * WAVE;  // flag dwords of one strip
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
     const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
@@ -223,11 +226,18 @@ void phmm_sw_align_kernel(const SwParams p) {
                         acc_c[k / 16] = __builtin_amdgcn_alignbit((uint32_t)cx, acc_c[k / 16], 2);
                         left = out[k] = cx & ~3;
                     }
-                    uint32_t *row_bt = bt + (size_t)t * (2 * NH) * WAVE;
+                    // (streaming stores: 0.6 bytes per cell that nobody reads before the backtrack -- the flags are a quarter of
+                    // the kernel's time, in proportion to their volume)
+                    uint32_t *row_bt = bt + (size_t)t * NW * WAVE;
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh) {
-                        row_bt[(2 * hh) * WAVE] = acc_c[hh];
-                        row_bt[(2 * hh + 1) * WAVE] = acc_e[hh];
+                        if (LAST_PACKED && hh == NH - 1) {
+                            constexpr uint32_t LO = REM >= 16 ? ~0u : (1u << (2 * (REM & 15))) - 1u;
+                            __builtin_nontemporal_store((acc_c[hh] & ~(~0u >> (2 * (REM & 15)))) | (acc_e[hh] & LO), row_bt + (2 * hh) * WAVE);
+                        } else {
+                            __builtin_nontemporal_store(acc_c[hh], row_bt + (2 * hh) * WAVE);
+                            __builtin_nontemporal_store(acc_e[hh], row_bt + (2 * hh + 1) * WAVE);
+                        }
                     }
                     diag = diag_next;
                     o_sw = left;
@@ -309,12 +319,14 @@ void phmm_sw_align_kernel(const SwParams p) {
                 cig.push(make_element(ST_MATCH, (uint32_t)m));
                 alignment_offset = found;
             } else {
-                // flag words of cell (i, jj): [0] candidate tags, [WAVE] gap-open bits; `sh` = 2 x (cells after it in the word)
-                auto cell_words = [&](int i, int jj, int &sh) -> const uint32_t * {
+                // flag words of cell (i, jj): [0] candidate tags, [eo] gap-open bits (eo = 0 where the two share a dword);
+                // `sh` = 2 x (cells after it in the word)
+                auto cell_words = [&](int i, int jj, int &sh, int &eo) -> const uint32_t * {
                     const int ss = (jj - 1) / strip_cols, cc = (jj - 1) % strip_cols, ll = cc / K, kk = cc % K;
                     const int hh = kk >> 4, nq = min(K - 16 * hh, 16);
                     sh = 2 * (nq - 1 - (kk & 15));
-                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * (2 * NH) + 2 * hh) * WAVE + (lane & GMASK) + ll;
+                    eo = LAST_PACKED && hh == NH - 1 ? 0 : WAVE;
+                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * NW + 2 * hh) * WAVE + (lane & GMASK) + ll;
                 };
                 int p1 = best.p1, p2 = best.p2;
                 if (segment_length > 0 && p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
@@ -324,9 +336,9 @@ void phmm_sw_align_kernel(const SwParams p) {
                 int state = ST_MATCH;
                 for (;;) {
                     // lane l looks at cell (p1 - l, p2 - l); `run` = diagonal steps from (p1, p2) before anything else
-                    int sh;
+                    int sh, eo;
                     const bool inside = p1 - l >= 1 && p2 - l >= 1;
-                    const uint32_t *w = cell_words(inside ? p1 - l : 1, inside ? p2 - l : 1, sh);
+                    const uint32_t *w = cell_words(inside ? p1 - l : 1, inside ? p2 - l : 1, sh, eo);
                     const uint32_t tag = inside ? (w[0] >> (30 - sh)) & 3u : 3u;
                     const uint64_t others = ~(__ballot(tag == TAG_DIAG) >> (lane & GMASK)) & LMASK;  // lanes that do not see a diagonal step
                     const int run = others ? __ffsll((long long)others) - 1 : SW_L;                 // 0 ... SW_L
@@ -347,21 +359,21 @@ void phmm_sw_align_kernel(const SwParams p) {
                     // previous cell of the column / row
                     const int src = (lane & GMASK) | run;  // the lane that fetched this cell
                     const uint32_t gtag = (uint32_t)__shfl((int)tag, src, WAVE);
-                    w = cell_words(p1, p2, sh);
-                    uint32_t e = w[WAVE];
+                    w = cell_words(p1, p2, sh, eo);
+                    uint32_t e = w[eo];
                     int32_t k = 1;
                     if (gtag == TAG_RIGHT) {
                         for (int j2 = p2; !((e >> sh) & 1u) && j2 > 1;) {
                             ++k;
                             --j2;
-                            e = cell_words(p1, j2, sh)[WAVE];
+                            e = cell_words(p1, j2, sh, eo)[eo];
                         }
                         p2 -= k;
                     } else {
                         for (int i2 = p1; !((e >> (sh + 1)) & 1u) && i2 > 1;) {
                             ++k;
                             --i2;
-                            e = cell_words(i2, p2, sh)[WAVE];
+                            e = cell_words(i2, p2, sh, eo)[eo];
                         }
                         p1 -= k;
                     }
