@@ -28,6 +28,7 @@
 // MATRIX_MIN_CUTOFF clamp, :31, can never be active.)
 // Backtracking: the sixteen lanes of an alignment fetch sixteen cells down the diagonal at once and take the run of
 // diagonal steps among them in one go (every step is a dependent read from HBM otherwise); lane 0 writes the CIGAR.
+#include <type_traits>
 #include "phmm_sw_internal.hpp"
 
 namespace phmm {
@@ -194,19 +195,26 @@ void phmm_sw_align_kernel(const SwParams p) {
             // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
             int32_t a_next = (int32_t)s_ref[max(-l, 0)];
             const bool first_strip = s == 0;
-            auto step = [&](const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
+            // RAMP: the first SW_L - 1 steps, while lanes are still waiting for their first row -- a lane computes only
+            // inside its matrix.  After that every lane computes every step, predicate-free (8 % of the kernel): rows
+            // beyond the alignment's last (other alignments of the wave are longer) and strips it does not have produce
+            // values nobody reads -- their flag stores land in the slab's unused part -- and only what leaves the lane's
+            // registers for LDS or the best-cell bookkeeping asks `live`.
+            auto step = [&](auto ramp_c, const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
+                constexpr bool RAMP = decltype(ramp_c)::value;
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
-                const bool active = strip_on && i >= 1 && i <= n;
+                const bool live = strip_on && i >= 1 && i <= n;
+                const bool active = RAMP ? live : true;
                 const int32_t a_base = a_next;
-                a_next = (int32_t)s_ref[max(i, 0)];      // row i + 1 (the LDS area is padded: one byte beyond the sequence is harmless)
+                a_next = (int32_t)s_ref[max(i, 0)];      // row i + 1 (the LDS area is padded: bytes beyond the sequence are harmless)
                 if (active) {
                     if (first_strip) {                   // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
                         left = l == 0 ? (edge_gaps ? x_open + (i - 1) * x_extend : 0) : left;
                         h_bg = l == 0 ? (SW_LOW_INIT | TAG_RIGHT) : h_bg;
                     } else if (l == 0) {                 // the right edge of the previous strip
-                        left = e_sw[i];
-                        h_bg = e_bgh[i];
+                        left = e_sw[min(i, n)];
+                        h_bg = e_bgh[min(i, n)];
                     }
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
 #pragma unroll
@@ -242,11 +250,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
-                    if (l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
+                    if (live && l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
                         e_sw[i] = left;
                         e_bgh[i] = h_bg;
                     }
-                    if (s == sm && l == lm) {
+                    if (live && s == sm && l == lm) {
                         int32_t v = out[0];
 #pragma unroll
                         for (int k = 1; k < K; ++k) v = (k == km) ? out[k] : v;
@@ -255,17 +263,22 @@ void phmm_sw_align_kernel(const SwParams p) {
                             lc_row = i;
                         }
                     }
-                    if (i == n) {
+                    if (live && i == n) {
 #pragma unroll
                         for (int k = 0; k < K; ++k)
                             if (j0 + k + 1 <= m) bottom[j0 + k + 1] = out[k];
                     }
                 }
             };
-            const int steps = (n_max + SW_L) & ~1;      // rounded up to even; nobody is active in the extra step
-            for (int t = 0; t < steps; t += 2) {
-                step(t, up_a, up_b);
-                step(t + 1, up_b, up_a);
+            const int steps = (n_max + SW_L) & ~1;      // rounded up to even (the extra step is nobody's row)
+            constexpr int RAMP_STEPS = SW_L & ~1;       // (even: the register sets swap roles every step)
+            for (int t = 0; t < min(RAMP_STEPS, steps); t += 2) {
+                step(std::true_type{}, t, up_a, up_b);
+                step(std::true_type{}, t + 1, up_b, up_a);
+            }
+            for (int t = RAMP_STEPS; t < steps; t += 2) {
+                step(std::false_type{}, t, up_a, up_b);
+                step(std::false_type{}, t + 1, up_b, up_a);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
