@@ -1642,7 +1642,7 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
     const size_t rbytes = align_up((size_t)read_off[n_reads], 256);
     // originals (4 x read bytes + mapq + ref index) and device-only copies (4 x read bytes, thresholds, keep)
     const size_t extra = 4 * rbytes + 4 * rbytes + align_up((size_t)n_reads, 256) * 2 + align_up((size_t)n_reads * 8, 256) +
-                         align_up((size_t)n_regions * 4, 256) + 16 * 256;
+                         align_up((size_t)n_regions * 4, 256) + 18 * 256;
     phmm_batch *b = batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true, extra);
     if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     int st = PHMM_OK;
@@ -1671,6 +1671,9 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         const uint8_t *d_mapq = (const uint8_t *)place(mapq, n_reads);
         const uint8_t *d_haps = (const uint8_t *)place(hap_bases, b->hap_bytes);
         const int32_t *d_ref = region_ref_hap ? (const int32_t *)place(region_ref_hap, (size_t)n_regions * 4) : nullptr;
+        // (a zeroed status block that travels with the inputs: what the kernels of a small call flag, see below)
+        uint32_t *d_status_in = (uint32_t *)place(nullptr, 256);
+        if (fits) memset(A.host + ((char *)d_status_in - A.dev), 0, 256);
         const size_t in_bytes = align_up(A.used, 256);
         // device-only
         uint8_t *d_q = (uint8_t *)place(nullptr, b->read_bytes), *d_i = (uint8_t *)place(nullptr, b->read_bytes),
@@ -1690,8 +1693,23 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         b->d_status = (uint32_t *)(A.dev + res_off);
         uint8_t *d_keep = (uint8_t *)(A.dev + res_off + 256);
         double *d_out = (double *)(A.dev + res_off + 256 + keep_bytes);
-        bool ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->S()), "H2D batch") &&
-                  hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->S()), "memset status");
+        const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
+        // A small one-shot call (a region per call, the reference's pattern) does without the copy engine, like
+        // phmm_compute: a kernel fetches the inputs from the pinned mirror, and the post-step stores keep flags and
+        // normalised likelihoods -- and hands on the status word -- straight into it.
+        char *mirror = nullptr;
+        if (eager_d2h(h) && b->tight_out && n_reads && in_bytes <= kStageInBytes && res_bytes <= kZeroCopyOutBytes) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, A.host, 0) == hipSuccess && dp) mirror = (char *)dp;
+        }
+        bool ok;
+        if (mirror) {
+            b->d_status = d_status_in;
+            ok = hip_ok(h, launch_stage_in(mirror, A.dev, in_bytes, h->S()), "phmm_stage_in_kernel");
+        } else {
+            ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->S()), "H2D batch") &&
+                 hip_ok(h, hipMemsetAsync(b->d_status, 0, 256, h->S()), "memset status");
+        }
         // the post-step consumes the likelihoods on the device, so the exact pass below kRescueBelow rides in-stream
         // between the forward kernels and the post-step (phmm_batch_launch); nothing of this slot is in flight now
         if (ok && n_reads && !h->sw.no_rescue) {
@@ -1738,19 +1756,21 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         po.out_off = b->d_out_off;
         po.region_ref_hap = d_ref;
         po.out = d_out;
+        po.out_final = mirror ? (double *)(mirror + res_off + 256 + keep_bytes) : nullptr;
         po.threshold = d_thr;
-        po.keep = d_keep;
+        po.keep = mirror ? (uint8_t *)(mirror + res_off + 256) : d_keep;
+        po.status_in = mirror ? b->d_status : nullptr;
+        po.status_out = mirror ? (uint32_t *)(mirror + res_off) : nullptr;
         po.max_likelihood_difference_cap = cfg->log10_global_read_mismapping_rate;
         po.symmetric = cfg->symmetrically_normalize_alleles_to_reference;
         if (ok) ok = hip_ok(h, launch_post(po, h->S()), "phmm_post_reads");
-        const size_t res_bytes = 256 + keep_bytes + b->n_out * 8;
         const bool eager = eager_d2h(h);  // otherwise engine_finish fetches the results
-        if (ok && eager)
+        if (ok && eager && !mirror)
             ok = hip_ok(h, hipMemcpyAsync(A.host + res_off, A.dev + res_off, res_bytes, hipMemcpyDeviceToHost, h->S()),
                         "D2H results");
         if (ok) {
             pending->res_bytes = res_bytes;
-            pending->d2h_pending = !eager;
+            pending->d2h_pending = !eager && !mirror;
             pending->b = b;
             pending->slot = h->slot;
             pending->out = out;

@@ -213,9 +213,11 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
 __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n_reads) return;
+    if (r == 0 && p.status_out) *p.status_out = *p.status_in;
     const uint32_t g = p.read_region[r];
     const uint32_t nh = p.region_hap_off[g + 1] - p.region_hap_off[g];
-    double *row = p.out + p.out_off[g] + (uint64_t)(r - p.region_read_off[g]) * nh;
+    const uint64_t at = p.out_off[g] + (uint64_t)(r - p.region_read_off[g]) * nh;
+    double *row = p.out + at;
     const int ref = p.region_ref_hap ? p.region_ref_hap[g] : -1;
     double best_all = -INFINITY;  // maximum_likelihood_over_all_alleles (:1026-1041)
     for (uint32_t a = 0; a < nh; ++a) best_all = row[a] > best_all ? row[a] : best_all;
@@ -230,11 +232,17 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
             best = row[a] > best ? row[a] : best;
         }
         const double worst = best + p.max_likelihood_difference_cap;
-        for (uint32_t a = 0; a < nh; ++a)
-            if (row[a] < worst) row[a] = worst;
+        if (p.out_final) {
+            for (uint32_t a = 0; a < nh; ++a) p.out_final[at + a] = row[a] < worst ? worst : row[a];
+        } else {
+            for (uint32_t a = 0; a < nh; ++a)
+                if (row[a] < worst) row[a] = worst;
+        }
         // the cap can only raise values up to `worst` <= best: the all-allele maximum is unchanged unless
         // every allele sat below `worst` (asymmetric mode with only the reference above the alts)
         best_all = best_all > worst ? best_all : worst;
+    } else if (p.out_final) {
+        for (uint32_t a = 0; a < nh; ++a) p.out_final[at + a] = row[a];
     }
     // filter_poorly_modeled_evidence removes evidence whose best likelihood is below its threshold (:941-958)
     p.keep[r] = (best_all < p.threshold[r]) ? 0 : 1;

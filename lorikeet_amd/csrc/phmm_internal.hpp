@@ -128,9 +128,12 @@ struct PostParams {
     const uint32_t *read_region, *region_read_off, *region_hap_off;
     const uint64_t *out_off;
     const int32_t *region_ref_hap;  // [n_regions] reference haplotype index inside the region, -1 = none; may be null
-    double *out;                    // [region][read][hap], normalised in place
+    double *out;                    // [region][read][hap], normalised in place ...
+    double *out_final;              // ... or (small calls) read from `out` and stored here, the caller's pinned mirror; null = in place
     const double *threshold;        // [n_reads]
     uint8_t *keep;                  // [n_reads] 1 = evidence survives filter_poorly_modeled_evidence
+    const uint32_t *status_in;      // small calls: the forward kernels' status word, final by now, is handed on to
+    uint32_t *status_out;           // the mirror as well (both null otherwise)
     double max_likelihood_difference_cap;
     uint32_t symmetric;
 };

@@ -283,7 +283,10 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     {
         const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)lds;
         auto it = h->swork.blocks_per_cu.find(key);
-        if (it == h->swork.blocks_per_cu.end()) it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds)).first;
+        if (it == h->swork.blocks_per_cu.end()) {
+            if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
+            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds)).first;
+        }
         per_cu = it->second;
     }
     if (per_cu <= 0) {

@@ -279,3 +279,21 @@ def test_ragged_mix_matches_the_oracle(hip_engine):
     plan.close()
     host = hip_engine.compute(full)
     assert np.max(np.abs(resident - host)) <= 1e-9 and (resident <= 0).all()
+
+
+def test_one_region_per_call_equals_the_region_inside_a_large_batch():
+    """A call of one region does without the copy engine (inputs fetched from the pinned mirror by a kernel, keep flags,
+    normalised likelihoods and the status word stored into it by the post-step); a large batch goes through copies and
+    the chunked host path.  Same keep flags, same likelihoods (other kernel shapes: 1e-12)."""
+    eng = PairHMMLikelihoodCalculationEngine(10, -4.5 * math.log10(math.e), PCRErrorModel.CONSERVATIVE, 18, True, 1.0, 0.02, True, False)
+    regions = _random_regions(np.random.default_rng(31), 40, True)
+    filler = _random_regions(np.random.default_rng(32), 6, False)
+    big = eng.compute_regions(regions + filler * 400)
+    removed = 0
+    for k, reg in enumerate(regions):
+        (m, keep), = eng.compute_regions([reg])
+        assert m.shape == big[k][0].shape and np.array_equal(keep, big[k][1]), k
+        if m.size:
+            assert np.max(np.abs(m - big[k][0])) <= 1e-12, k
+        removed += int((~keep).sum())
+    assert removed > 0
