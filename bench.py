@@ -498,7 +498,12 @@ def main():
         return {"note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
                 "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
                 "one_region_per_call_32_threads_shared_handle_submit_wait": point("shared", 32, 1),
-                "eight_regions_per_call_4_threads_own_handles": point("own", 4, 8)}
+                "eight_regions_per_call_4_threads_own_handles": point("own", 4, 8),
+                # ... and with the realignment behind it (phmm_compute, then phmm_realign_reads: best alleles, alignments,
+                # projection onto the reference), as the reference's region loop goes on
+                "likelihoods_then_realignment_one_region_per_call_1_thread": point("pipeline", 1, 1),
+                "likelihoods_then_realignment_one_region_per_call_8_threads": point("pipeline", 8, 1),
+                "likelihoods_then_realignment_eight_regions_per_call_4_threads": point("pipeline", 4, 8)}
 
     def ragged():
         """Real regions span 3 x 2 ... 5 000 x 128: the planner on a long-tailed mix, resident and through host buffers."""
