@@ -43,6 +43,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SW_CELL_CEILING_GCUPS = 2570.0  # tools/ubench/sw_cell.hip: K = 10, 4-5 waves per SIMD (profiles/r02_ubench_sw_cell.txt)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_F64_PEAK_TFLOPS = 78.6  # vector FP64 peak (256 CU * 2.4 GHz * 128 flop/clk)
 VALU_F32_PEAK_TFLOPS = 157.3
@@ -602,16 +603,21 @@ def main():
                              "unit": "GB/s", "frac": round(bt_bytes / max(kern_s, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
                              "algorithmic_bytes_per_launch": int(bt_bytes),
                              "traffic": pe["hbm_bytes_per_launch"] if pe else None,
-                             "note": "the backtrack flags (4 bits per cell, two dwords per lane and step) are the traffic "
-                                     "that scales with the cells; the bound that binds is INT32 VALU issue, see valu_int32"
+                             "note": "the backtrack flags (4 bits per cell, K/8 dwords per lane and step) are the traffic "
+                                     "that scales with the cells; the bound that binds is VALU issue, see valu_int32"
                                      + ("" if pe else "; traffic: " + pwhy)},
+                # the cell is 16 instructions: 9 that issue every 2.55 clocks per wave64 (add, and, cndmask) and 7 that issue
+                # every 4.3-4.8 (max, max3, alignbit, compare) -- tools/ubench/rates.hip; the cell body alone, no memory, no
+                # branches, runs at 56-61 clocks per wave-level cell (tools/ubench/sw_cell.hip): that is `peak`
                 "valu_int32": ({"valu_insts_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
-                                "achieved": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2), "peak": 39.3,
-                                "unit": "T lane-ops/s", "frac": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12 / 39.3, 4),
-                                "note": "SQ_INSTS_VALU of the call (profiles/pmc_traffic.json, same kernel sources) x 64 lanes over "
-                                        "this run's kernel time; peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (one wave64 INT32 "
-                                        "instruction per 4 clocks and SIMD: tools/ubench/sw_cell.hip measures 3.75); the cell "
-                                        "itself is 16 instructions"} if pe else None),
+                                "achieved": round(cells / max(kern_s, 1e-9) / 1e9, 1), "peak": SW_CELL_CEILING_GCUPS,
+                                "unit": "GCUPS-i32", "frac": round(cells / max(kern_s, 1e-9) / 1e9 / SW_CELL_CEILING_GCUPS, 4),
+                                "lane_ops_per_s": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2),
+                                "note": "peak = what the 16-instruction cell body alone sustains on the whole chip at four waves per "
+                                        "SIMD (tools/ubench/sw_cell.hip, profiles/r02_ubench_sw_cell.txt: 61 clocks per wave-level "
+                                        "cell at 2.4 GHz; nine of the instructions issue every 2.55 clocks, seven every 4.3-4.8: "
+                                        "profiles/r02_ubench_rates.txt); valu_insts_per_cell = SQ_INSTS_VALU of the call "
+                                        "(profiles/pmc_traffic.json, same kernel sources) x 64 lanes / cells"} if pe else None),
                 "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
                                "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
 
