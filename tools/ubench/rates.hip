@@ -11,13 +11,13 @@
 
 enum Op { ADD_U32, MAX_I32, MAX3_I32, ADD_F32, MAX_F32, MAX3_F32, FMA_F32, PK_FMA_F32, PK_ADD_F32, PK_MAX_F16, ALIGNBIT, CNDMASK, AND_B32, CMP_U32, FMA_F64,
           SUB_F32, MUL_F32, PK_MUL_F32, ADD_I16_PK, MAX_I16_PK,
-          SUB_CO, ADDC_CO, CMP_CND, LSHL_ADD, LSHL_OR, OR_B32, XOR_B32, LSHLREV, MAD_U24, ADD3, MAX_U32, MIN_I32, BFE, AND_OR, MOV, MOV_DPP, SUBCO_ADDC_CND, ADD_SDWA, N_OPS };
+          SUB_CO, ADDC_CO, CMP_CND, LSHL_ADD, LSHL_OR, OR_B32, XOR_B32, LSHLREV, MAD_U24, ADD3, MAX_U32, MIN_I32, BFE, AND_OR, MOV, MOV_DPP, SUBCO_ADDC_CND, ADD_SDWA, SUB_ALIGN_MAX, CMP_ADDC_CND, N_OPS };
 static const char *kNames[] = {"v_add_u32", "v_max_i32", "v_max3_i32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32",
                                "v_pk_max_f16", "v_alignbit_b32", "v_cndmask_b32", "v_and_b32", "v_cmp_ne_u32", "v_fma_f64", "v_sub_f32", "v_mul_f32", "v_pk_mul_f32",
                                "v_pk_add_i16", "v_pk_max_i16",
                                "v_sub_co_u32", "v_addc_co_u32", "v_cmp+v_cndmask (pair)", "v_lshl_add_u32", "v_lshl_or_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32",
                                "v_mad_u32_u24", "v_add3_u32", "v_max_u32", "v_min_i32", "v_bfe_u32", "v_and_or_b32", "v_mov_b32", "v_mov_b32 dpp row_shr:1",
-                               "sub_co+addc+cndmask (triple)", "v_add_u32 sdwa"};
+                               "sub_co+addc+cndmask (triple)", "v_add_u32 sdwa", "sub+alignbit+max (triple)", "cmp+addc+cndmask (triple)"};
 
 template <int OP>
 __global__ __launch_bounds__(64) void rate(uint32_t *out, int iters, uint32_t seed) {
@@ -76,6 +76,8 @@ __global__ __launch_bounds__(64) void rate(uint32_t *out, int iters, uint32_t se
     else if constexpr (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));                                   \
     else if constexpr (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i])); \
     else if constexpr (OP == SUBCO_ADDC_CND) asm volatile("v_sub_co_u32 %2, vcc, %0, %1\n\tv_addc_co_u32 %3, s[20:21], %3, %3, vcc\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]), "+v"(b), "=&v"(c), "+v"(a[(i + 1) & 7]) : : "vcc", "s20", "s21"); \
+    else if constexpr (OP == SUB_ALIGN_MAX) asm volatile("v_sub_u32 %2, %0, %1\n\tv_alignbit_b32 %3, %3, %2, 31\n\tv_max_i32 %0, %0, %1" : "+v"(a[i]), "+v"(b), "=&v"(c), "+v"(a[(i + 1) & 7]) : : ); \
+    else if constexpr (OP == CMP_ADDC_CND) asm volatile("v_cmp_gt_i32 vcc, %0, %1\n\tv_addc_co_u32 %2, s[20:21], %2, %2, vcc\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]), "+v"(b), "+v"(a[(i + 1) & 7]) : : "vcc", "s20", "s21"); \
     else if constexpr (OP == ADD_SDWA) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(a[i]) : "v"(b));
             REP8(ONE)
 #undef ONE
@@ -118,7 +120,8 @@ void run(uint32_t *dbuf, int wps) {
 template <int OP>
 void all(uint32_t *d) {
     if constexpr (OP < N_OPS) {
-        for (int w : {1, 2, 4}) run<OP>(d, w);
+        if (!getenv("RATES_FROM") || OP >= atoi(getenv("RATES_FROM")))
+            for (int w : {1, 2, 4}) run<OP>(d, w);
         all<OP + 1>(d);
     }
 }
