@@ -1733,6 +1733,7 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         pp.out_gcp = d_g;
         pp.threshold = d_thr;
         pp.lds_rows = (uint32_t)align_up((size_t)max_r + 1, 8);
+        pp.waves_per_read = n_reads <= 2048 ? std::max<uint32_t>(1, (max_r + 63) / 64) : 1;  // few reads: a wave per 64 positions
         pp.default_indel_qual = 45;  // ReadUtils::DEFAULT_INSERTION_DELETION_QUAL (read_utils.rs:23)
         pp.constant_gcp = cfg->constant_gcp;
         pp.base_quality_score_threshold = cfg->base_quality_score_threshold;

@@ -146,10 +146,15 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
+    // a small batch spreads every read over several waves (a region per call: 128 reads would occupy 128 of the chip's
+    // 1024 SIMDs for three rounds of 64 positions each; with one round per wave the call is 12 us shorter)
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint32_t r = gw / p.waves_per_read, c = gw % p.waves_per_read;
     if (r >= p.n_reads) return;
     const uint32_t ro = p.read_off[r];
     const int n = (int)(p.read_off[r + 1] - ro);
+    if (c && (int)(64 * c) >= n) return;
+    const int stride = 64 * (int)p.waves_per_read;
     // wave-private LDS: [mean f64 x rows | variance f64 x rows | bases u8 x rows]
     const uint32_t rows = p.lds_rows;
     double *s_mean = reinterpret_cast<double *>(smem + (size_t)wave * rows * 17);
@@ -161,13 +166,16 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const uint32_t mapq = p.mapq[r];
-    for (int i = lane; i < n; i += 64) {
-        uint32_t q = p.base_q[ro + i];
-        if (p.dynamic_disqualification) {  // table rows for the ORIGINAL qual (the "HMMQuals" lookup never hits, :268)
+    if (p.dynamic_disqualification && c == 0) {  // table rows for the ORIGINAL qual (the "HMMQuals" lookup never hits, :268)
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t q = p.base_q[ro + i];
             const uint32_t idx = q <= 1 ? 0u : min(40u, q) - 1u;
             s_mean[i] = kDynQualTable[idx][0];
             s_var[i] = kDynQualTable[idx][1];
         }
+    }
+    for (int i = 64 * (int)c + lane; i < n; i += stride) {
+        uint32_t q = p.base_q[ro + i];
         uint32_t iq = p.ins_q ? p.ins_q[ro + i] : p.default_indel_qual;  // ReadUtils default Q45 (read_utils.rs:23)
         uint32_t dq = p.del_q ? p.del_q[ro + i] : p.default_indel_qual;
         if (p.pcr_cache && i < n - 1) {  // apply_pcr_error_model touches every base but the last (:513-523)
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
+    if (lane == 0 && c == 0) {
         const double e = ceil((double)n * p.expected_error_rate_per_base);  // log10_min_true_likelihood (:293-319)
         double thr;
         if (!p.dynamic_disqualification) {
@@ -327,7 +335,8 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t stream) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(phmm_prep_reads, dim3((p.n_reads + wpb - 1) / wpb), dim3(64 * wpb), lds, stream, p);
+    const size_t waves = (size_t)p.n_reads * p.waves_per_read;
+    hipLaunchKernelGGL(phmm_prep_reads, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds, stream, p);
     return hipGetLastError();
 }
 

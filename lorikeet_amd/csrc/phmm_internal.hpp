@@ -119,6 +119,7 @@ struct PrepParams {
     uint8_t *out_q, *out_ins, *out_del, *out_gcp;        // modified copies the forward kernel reads
     double *threshold;                                   // [n_reads] read-disqualification threshold
     uint32_t lds_rows;                                   // >= longest read, multiple of 8 (17 B of LDS per row)
+    uint32_t waves_per_read;                             // >= 1: wave c of a read takes positions 64 c + lane, then strides on
     uint32_t default_indel_qual, constant_gcp, base_quality_score_threshold, disable_cap_to_mapq,
         dynamic_disqualification;
     double read_disqualification_scale, expected_error_rate_per_base;
