@@ -167,11 +167,12 @@ void phmm_sw_align_kernel(const SwParams p) {
 
         // ---- calculate_matrix (:124-271) -----------------------------------------------------------------------------
         const int my_strips = dp ? (m + strip_cols - 1) / strip_cols : 0;
-        int n_strips = my_strips, n_max = dp ? n : 0;
+        int n_strips = my_strips, n_max = dp ? n : 0, m_max = dp ? m : 0;
 #pragma unroll
         for (int o = 32; o >= SW_L; o >>= 1) {  // over the groups
             n_strips = max(n_strips, __shfl_xor(n_strips, o, WAVE));
             n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
+            m_max = max(m_max, __shfl_xor(m_max, o, WAVE));
         }
         // the last column's best cell, tracked by the lane that owns column m (`>=`: the lowest of equals, :303-309)
         const int lm = ((m - 1) % strip_cols) / K, km = (m - 1) % K, sm = (m - 1) / strip_cols;
@@ -270,7 +271,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                     }
                 }
             };
-            const int steps = (n_max + SW_L) & ~1;      // rounded up to even (the extra step is nobody's row)
+            // the sweep ends when the last lane that owns columns has done its last row (a 150-base read on 64 lanes of
+            // three columns: 50 lanes); rounded up to even (the extra step is nobody's row)
+            const int lanes_in_use = min(SW_L, (m_max - s * strip_cols + K - 1) / K);
+            const int steps = (n_max + lanes_in_use) & ~1;
             constexpr int RAMP_STEPS = SW_L & ~1;       // (even: the register sets swap roles every step)
             for (int t = 0; t < min(RAMP_STEPS, steps); t += 2) {
                 step(std::true_type{}, t, up_a, up_b);
