@@ -290,6 +290,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
         env("PHMM_SW_CHUNKS", w.sw_chunks);
         env("PHMM_SW_LANES", w.sw_lanes);
+        env("PHMM_SW_TRANSPOSE", w.sw_transpose);
         w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
         w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
         w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
@@ -1921,6 +1922,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "trace") w.trace = value != 0;
     else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
+    else if (n == "sw_transpose") w.sw_transpose = value < 0 ? -1 : value > 0 ? 1 : 0;
     else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {

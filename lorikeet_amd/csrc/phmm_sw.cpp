@@ -268,8 +268,24 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     int K = ks[nks - 1];
     for (int i = nks - 1; i >= 0; --i)
         if ((size_t)ks[i] * L >= max_alt) K = ks[i];
+    // A small call whose references are longer than its alternates (reads against their haplotypes) sweeps along the
+    // ALTERNATE instead, the reference's rows shared out over the 64 lanes: fewer steps of more cells each, and a step's
+    // fixed cost (~50 instructions next to 16 per cell) is what a lone wave per SIMD feels -- 150 x 300: 350 steps of
+    // three cells against 210 of five.  One strip only.
+    bool transposed = false;
+    if (L == 64 && h->sw.sw_transpose != 0 && max_ref <= 64u * (uint32_t)kSwK64T[kNumSwK64T - 1]) {
+        int KT = kSwK64T[kNumSwK64T - 1];
+        for (int i = kNumSwK64T - 1; i >= 0; --i)
+            if ((size_t)kSwK64T[i] * 64 >= max_ref) KT = kSwK64T[i];
+        auto cost = [](size_t sweep, size_t across, int k) { return (sweep + (across + k - 1) / k) * (16ull * k + 50); };
+        const bool one_strip = (size_t)K * 64 >= max_alt;
+        if (h->sw.sw_transpose > 0 || !one_strip || cost(max_alt, max_ref, KT) < cost(max_ref, max_alt, K)) {
+            transposed = true;
+            K = KT;
+        }
+    }
     const size_t strip_cols = (size_t)L * K;
-    const size_t strips = (max_alt + strip_cols - 1) / strip_cols;
+    const size_t strips = transposed ? 1 : (max_alt + strip_cols - 1) / strip_cols;
     const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
     // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
     const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
@@ -281,11 +297,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
     int per_cu;
     {
-        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)lds;
+        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)lds;
         auto it = h->swork.blocks_per_cu.find(key);
         if (it == h->swork.blocks_per_cu.end()) {
             if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
-            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds)).first;
+            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed)).first;
         }
         per_cu = it->second;
     }
@@ -296,7 +312,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
     // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
     const size_t flag_words = (size_t)sw_flag_words(K);
-    const size_t slab_stride = strips * (size_t)(max_ref + L) * flag_words * 64;
+    const size_t slab_stride = strips * (size_t)((transposed ? std::max(max_ref, max_alt) : max_ref) + L) * flag_words * 64;
     const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
     // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on
     // one stream and share the slabs).  A piece is a whole number of rounds of the persistent blocks, so that only
@@ -501,7 +517,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         p.n_alignments = a1;
         const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
         (void)hipEventRecord(W.ev_k0[c], S);
-        good = ok(h, launch_sw(L, K, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        good = ok(h, launch_sw(L, K, transposed, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
         if (good && PJ) {  // ... and the piece's alignments projected onto the reference, where they lie
             pp.r_begin = a0;
             pp.n_reads = a1;
@@ -515,7 +531,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         const uint32_t ri = J.ref_index ? J.ref_index[a] : a;
         if (ri == SW_NO_REFERENCE) continue;
         const uint64_t rows = J.best ? max_ref : ref_off[ri + 1] - ref_off[ri];  // (the device chooses the haplotype: an upper bound)
-        W.last_backtrack_bytes += (uint64_t)((alt_off[a + 1] - alt_off[a] + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * flag_words * 4ull;
+        const uint64_t cols = alt_off[a + 1] - alt_off[a];
+        W.last_backtrack_bytes += transposed ? (cols + L - 1ull) * L * flag_words * 4ull
+                                             : (uint64_t)((cols + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * flag_words * 4ull;
     }
     // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
     // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, DESIGN.md

@@ -34,9 +34,9 @@ struct SwParams {
     uint32_t groups_per_block;             // alignments a block works on side by side: 64 / L, or 1 for very long sequences
 };
 // L lanes per alignment (8 / 16 / 32 / 64), K columns per lane (one of kSwK<L>), 64 / L alignments per block
-hipError_t launch_sw(int L, int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes);  // what a CU holds at once (registers, LDS); 0 on failure
-extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[];
-extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64;
+hipError_t launch_sw(int L, int K, bool transposed, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed);  // what a CU holds at once (registers, LDS); 0 on failure
+extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[], kSwK64T[];  // (T: rows per lane of the sweep along the alternate)
+extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64, kNumSwK64T;
 
 }  // namespace phmm

@@ -92,9 +92,13 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
 #define PHMM_SW_EU 5
 #endif
 // SW_L lanes per alignment (8 / 16 / 32 / 64: 8 ... 1 alignments per wave), K columns per lane
-template <int SW_L, int K>
+template <int SW_L, int K, bool TR = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : K <= PHMM_SW_K4 ? 4 : K <= 26 ? 3 : 2)))
 void phmm_sw_align_kernel(const SwParams p) {
+    // TR: the sweep runs along the ALTERNATE sequence and the lanes share out the reference's rows (K rows per lane) --
+    // the same cells in another order.  For a small call of reads against longer haplotypes that is fewer steps of more
+    // cells each (150 x 300 on 64 lanes: 210 steps of five cells instead of 350 of three), and a step's fixed cost is
+    // what a lone wave per SIMD feels.  One strip only (the host sees to it).
     constexpr int GMASK = WAVE - SW_L;  // lane & GMASK = first lane of the lane's group
     constexpr uint64_t LMASK = SW_L == 64 ? ~0ull : (1ull << (SW_L & 63)) - 1;  // the group's lanes, shifted down
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,7 +120,10 @@ void phmm_sw_align_kernel(const SwParams p) {
     // scores times four; the low two bits name the candidate
     int32_t x_match = 4 * p.w_match + TAG_DIAG, x_mismatch = 4 * p.w_mismatch + TAG_DIAG;
     asm volatile("" : "+s"(x_match), "+s"(x_mismatch));  // opaque: or the compiler selects between the raw weights and scales per cell
-    const int32_t x_open = 4 * p.w_open, x_open_r = 4 * p.w_open + TAG_RIGHT, x_extend = 4 * p.w_extend;
+    // the gap that runs along the sweep is kept per lane position in registers, the one across it travels through the
+    // step and on to the next lane: vertical (tag: down) and horizontal (tag: right), or the other way round
+    constexpr int32_t TAG_S = TR ? TAG_RIGHT : TAG_DOWN, TAG_L = TR ? TAG_DOWN : TAG_RIGHT;
+    const int32_t x_open = 4 * p.w_open, x_open_s = 4 * p.w_open + TAG_S, x_open_l = 4 * p.w_open + TAG_L, x_extend = 4 * p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
     const size_t strip_stride = (size_t)(p.max_ref + SW_L) * NW * WAVE;  // flag dwords of one strip
@@ -166,8 +173,10 @@ void phmm_sw_align_kernel(const SwParams p) {
         const bool dp = valid && found < 0;  // this group runs the matrix
 
         // ---- calculate_matrix (:124-271) -----------------------------------------------------------------------------
-        const int my_strips = dp ? (m + strip_cols - 1) / strip_cols : 0;
-        int n_strips = my_strips, n_max = dp ? n : 0, m_max = dp ? m : 0;
+        const int ns = TR ? m : n, nl = TR ? n : m;  // lengths along the sweep and across the lanes
+        const uint8_t *seq_s = TR ? s_alt : s_ref, *seq_l = TR ? s_ref : s_alt;
+        const int my_strips = dp ? (nl + strip_cols - 1) / strip_cols : 0;
+        int n_strips = my_strips, n_max = dp ? ns : 0, m_max = dp ? nl : 0;
 #pragma unroll
         for (int o = 32; o >= SW_L; o >>= 1) {  // over the groups
             n_strips = max(n_strips, __shfl_xor(n_strips, o, WAVE));
@@ -175,7 +184,9 @@ void phmm_sw_align_kernel(const SwParams p) {
             m_max = max(m_max, __shfl_xor(m_max, o, WAVE));
         }
         // the last column's best cell, tracked by the lane that owns column m (`>=`: the lowest of equals, :303-309)
-        const int lm = ((m - 1) % strip_cols) / K, km = (m - 1) % K, sm = (m - 1) / strip_cols;
+        // (TR: the owner of the last row; it writes the bottom row, and every lane looks at the last column when the sweep
+        // reaches it)
+        const int lm = ((nl - 1) % strip_cols) / K, km = (nl - 1) % K, sm = (nl - 1) / strip_cols;
         int32_t lc_score = INT32_MIN, lc_row = 0;
         for (int s = 0; s < n_strips; ++s) {
             const bool strip_on = dp && s < my_strips;
@@ -185,16 +196,16 @@ void phmm_sw_align_kernel(const SwParams p) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = j0 + k + 1;
-                bb[k] = (strip_on && j <= m) ? (int32_t)s_alt[j - 1] : 0x1000;
+                bb[k] = (strip_on && j <= nl) ? (int32_t)seq_l[j - 1] : 0x1000;
                 up_a[k] = up_b[k] = row0(j);             // (a lane's first row may fall on either set)
-                bgv[k] = SW_LOW_INIT;
+                bgv[k] = SW_LOW_INIT | TAG_S;
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
             uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
             uint32_t *bt = slab + (size_t)s * strip_stride + lane;
             // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
-            int32_t a_next = (int32_t)s_ref[max(-l, 0)];
+            int32_t a_next = (int32_t)seq_s[max(-l, 0)];
             const bool first_strip = s == 0;
             // RAMP: the first SW_L - 1 steps, while lanes are still waiting for their first row -- a lane computes only
             // inside its matrix.  After that every lane computes every step, predicate-free (8 % of the kernel): rows
@@ -205,28 +216,28 @@ void phmm_sw_align_kernel(const SwParams p) {
                 constexpr bool RAMP = decltype(ramp_c)::value;
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
-                const bool live = strip_on && i >= 1 && i <= n;
+                const bool live = strip_on && i >= 1 && i <= ns;
                 const bool active = RAMP ? live : true;
                 const int32_t a_base = a_next;
-                a_next = (int32_t)s_ref[max(i, 0)];      // row i + 1 (the LDS area is padded: bytes beyond the sequence are harmless)
+                a_next = (int32_t)seq_s[max(i, 0)];      // row i + 1 (the LDS area is padded: bytes beyond the sequence are harmless)
                 if (active) {
                     if (first_strip) {                   // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
                         left = l == 0 ? (edge_gaps ? x_open + (i - 1) * x_extend : 0) : left;
-                        h_bg = l == 0 ? (SW_LOW_INIT | TAG_RIGHT) : h_bg;
+                        h_bg = l == 0 ? (SW_LOW_INIT | TAG_L) : h_bg;
                     } else if (l == 0) {                 // the right edge of the previous strip
-                        left = e_sw[min(i, n)];
-                        h_bg = e_bgh[min(i, n)];
+                        left = e_sw[min(i, ns)];
+                        h_bg = e_bgh[min(i, ns)];
                     }
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int32_t d = k ? up[k - 1] : diag;
                         const int32_t step_diag = d + (a_base == bb[k] ? x_match : x_mismatch);   // :194-199 (tag: diagonal)
-                        const int32_t pv = up[k] + x_open;                                         // :207-218
+                        const int32_t pv = up[k] + x_open_s;                                       // :207-218
                         const int32_t ev = bgv[k] + x_extend;
                         acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(ev - pv), 31);  // 1: pv > ev, the gap opens here
                         bgv[k] = max(pv, ev);
-                        const int32_t ph = left + x_open_r;                                        // :229-240 (tag: right)
+                        const int32_t ph = left + x_open_l;                                        // :229-240 (tag: right)
                         const int32_t eh = h_bg + x_extend;
                         acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(eh - ph), 31);
                         h_bg = max(ph, eh);
@@ -259,15 +270,25 @@ void phmm_sw_align_kernel(const SwParams p) {
                         int32_t v = out[0];
 #pragma unroll
                         for (int k = 1; k < K; ++k) v = (k == km) ? out[k] : v;
-                        if (v >= lc_score) {
+                        if constexpr (TR) {
+                            bottom[i] = v;               // the last row, column by column
+                        } else if (v >= lc_score) {
                             lc_score = v;
                             lc_row = i;
                         }
                     }
-                    if (live && i == n) {
+                    if (live && i == ns) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k)
-                            if (j0 + k + 1 <= m) bottom[j0 + k + 1] = out[k];
+                        for (int k = 0; k < K; ++k) {
+                            if constexpr (TR) {          // the last column: this lane's rows, top down (`>=`, as above)
+                                if (j0 + k + 1 <= nl && out[k] >= lc_score) {
+                                    lc_score = out[k];
+                                    lc_row = j0 + k + 1;
+                                }
+                            } else if (j0 + k + 1 <= nl) {
+                                bottom[j0 + k + 1] = out[k];
+                            }
+                        }
                     }
                 }
             };
@@ -298,7 +319,19 @@ void phmm_sw_align_kernel(const SwParams p) {
             } else {
                 // the owner of the last column holds its best cell; everybody gets it
                 const int src = (lane & GMASK) | lm;
-                const int32_t sc = __shfl(lc_score, src, WAVE), rw = __shfl(lc_row, src, WAVE);
+                int32_t sc = __shfl(lc_score, src, WAVE), rw = __shfl(lc_row, src, WAVE);
+                if constexpr (TR) {  // every lane holds the best of its rows: the highest, among equals the lowest row down
+                    sc = lc_score;
+                    rw = lc_row;
+#pragma unroll
+                    for (int o = SW_L / 2; o >= 1; o >>= 1) {
+                        const int32_t s2 = __shfl_xor(sc, o, WAVE), r2 = __shfl_xor(rw, o, WAVE);
+                        if (s2 > sc || (s2 == sc && r2 > rw)) {
+                            sc = s2;
+                            rw = r2;
+                        }
+                    }
+                }
                 best = Start{sc, abs(rw - m), 0, rw, m};
                 if (p.strategy != PHMM_SW_STRATEGY_LEADING_INDEL) {
                     for (int j = l + 1; j <= m; j += SW_L) {  // bottom row, every lane a share of the columns
@@ -339,6 +372,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                 // flag words of cell (i, jj): [0] candidate tags, [eo] gap-open bits (eo = 0 where the two share a dword);
                 // `sh` = 2 x (cells after it in the word)
                 auto cell_words = [&](int i, int jj, int &sh, int &eo) -> const uint32_t * {
+                    if constexpr (TR) {  // rows across the lanes, columns along the sweep
+                        const int t2 = i;
+                        i = jj;
+                        jj = t2;
+                    }
                     const int ss = (jj - 1) / strip_cols, cc = (jj - 1) % strip_cols, ll = cc / K, kk = cc % K;
                     const int hh = kk >> 4, nq = min(K - 16 * hh, 16);
                     sh = 2 * (nq - 1 - (kk & 15));
@@ -351,6 +389,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                     segment_length = 0;
                 }
                 int state = ST_MATCH;
+                constexpr int HB = TR ? 1 : 0, VB = TR ? 0 : 1;  // the sweep's gap is shifted in first, the lanes' second
                 for (;;) {
                     // lane l looks at cell (p1 - l, p2 - l); `run` = diagonal steps from (p1, p2) before anything else
                     int sh, eo;
@@ -380,14 +419,14 @@ void phmm_sw_align_kernel(const SwParams p) {
                     uint32_t e = w[eo];
                     int32_t k = 1;
                     if (gtag == TAG_RIGHT) {
-                        for (int j2 = p2; !((e >> sh) & 1u) && j2 > 1;) {
+                        for (int j2 = p2; !((e >> (sh + HB)) & 1u) && j2 > 1;) {
                             ++k;
                             --j2;
                             e = cell_words(p1, j2, sh, eo)[eo];
                         }
                         p2 -= k;
                     } else {
-                        for (int i2 = p1; !((e >> (sh + 1)) & 1u) && i2 > 1;) {
+                        for (int i2 = p1; !((e >> (sh + VB)) & 1u) && i2 > 1;) {
                             ++k;
                             --i2;
                             e = cell_words(i2, p2, sh, eo)[eo];
@@ -448,12 +487,16 @@ const int kSwK32[] = {3, 4, 5, 6, 8, 12, 16};
 const int kNumSwK32 = sizeof(kSwK32) / sizeof(int);
 const int kSwK64[] = {2, 3, 4, 6, 8};
 const int kNumSwK64 = sizeof(kSwK64) / sizeof(int);
+// ... and <64 lanes, rows per lane> of the sweep along the alternate sequence (small calls, reference longer than alternate)
+#define PHMM_SW_LIST_T(X) X(64, 2) X(64, 3) X(64, 4) X(64, 5) X(64, 6) X(64, 8)
+const int kSwK64T[] = {2, 3, 4, 5, 6, 8};
+const int kNumSwK64T = sizeof(kSwK64T) / sizeof(int);
 
 // blocks (of one wave) of this instance a CU holds at once, by registers and LDS
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes) {
-#define PHMM_CASE(LL, KK)                                                                                          \
-    if (L == LL && K == KK) {                                                                                      \
-        auto kern = phmm_sw_align_kernel<LL, KK>;                                                                  \
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed) {
+#define PHMM_CASE_T(LL, KK, TT)                                                                                    \
+    if (L == LL && K == KK && transposed == TT) {                                                                  \
+        auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \
         if (lds_bytes > 64 * 1024 &&                                                                               \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds_bytes) != hipSuccess)                                                     \
@@ -462,16 +505,21 @@ int sw_blocks_per_cu(int L, int K, size_t lds_bytes) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;        \
         return nb;                                                                                                 \
     }
+#define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
+#define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)
+    PHMM_SW_LIST_T(PHMM_CASE_TR)
 #undef PHMM_CASE
+#undef PHMM_CASE_TR
+#undef PHMM_CASE_T
     return 0;
 }
 
-hipError_t launch_sw(int L, int K, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_sw(int L, int K, bool transposed, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
     if (p.n_alignments <= p.a_begin) return hipSuccess;
-#define PHMM_CASE(LL, KK)                                                                                          \
-    if (L == LL && K == KK) {                                                                                      \
-        auto kern = phmm_sw_align_kernel<LL, KK>;                                                                  \
+#define PHMM_CASE_T(LL, KK, TT)                                                                                    \
+    if (L == LL && K == KK && transposed == TT) {                                                                  \
+        auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \
         if (lds_bytes > 64 * 1024) {                                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
@@ -480,8 +528,13 @@ hipError_t launch_sw(int L, int K, const SwParams &p, uint32_t n_blocks, size_t 
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);                                \
         return hipGetLastError();                                                                                  \
     }
+#define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
+#define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)
+    PHMM_SW_LIST_T(PHMM_CASE_TR)
 #undef PHMM_CASE
+#undef PHMM_CASE_TR
+#undef PHMM_CASE_T
     return hipErrorInvalidValue;
 }
 

@@ -209,3 +209,41 @@ def test_parameters_beyond_the_exact_range_are_refused(aligner):
     |weight| x (ref + alt) < 1e8, refused beyond (nobody aligns with weights of a million)."""
     with pytest.raises(PhmmError, match="parameters too large"):
         aligner.align(b"ACGT" * 50, b"ACGT" * 40, Parameters(1000000, -1000000, -2000000, -500000), "SoftClip")
+
+
+def test_small_calls_sweep_along_the_alternate_sequence_same_alignments(hip_engine, aligner):
+    """A small call whose references are longer than its alternates (at most 512 rows) runs the same matrix with the
+    reference's rows shared out over the lanes and the sweep along the alternate (switch `sw_transpose`: 1 = whenever
+    possible, 0 = never, -1 = by cost): same CIGARs and offsets as the oracle either way, every strategy, ragged pairs,
+    references shorter than their alternates and alternates that would need several strips the other way round."""
+    rng = np.random.default_rng(41)
+    alpha = b"ACGT"
+    pairs = []
+    for k in range(150):
+        ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 500))))
+        kind = k % 5
+        if kind == 0:
+            alt = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 700))))       # unrelated, any length
+        elif kind == 1:
+            alt = _mutate(rng, ref, 0.02, 0.03)                                                       # haplotype-like
+        elif kind == 2:
+            alt = _mutate(rng, b"ACGTTG" * 3 + ref[len(ref) // 3:] + b"TTGCA" * 2, 0.03, 0.02)       # overhanging both ends
+        else:
+            s = int(rng.integers(0, max(1, len(ref) - 20)))
+            alt = _mutate(rng, ref[s:s + int(rng.integers(20, 200))], 0.03, 0.03) or b"A"            # read-like
+        pairs.append((ref, alt))
+    pairs += [(b"A" * 300, b"A" * 150), (b"AC" * 200, b"CA" * 80), (b"ACGT" * 100, b"T")]
+    try:
+        hip_engine.set_switch("sw_lanes", 64)
+        for params in (ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, Parameters(3, -2, -4, -1), Parameters(1, -3, -2, 0)):
+            for strategy in STRATEGIES:
+                got = {}
+                for mode in (1, 0):
+                    hip_engine.set_switch("sw_transpose", mode)
+                    got[mode] = aligner.align_batch(pairs, params, strategy, capacity=128)
+                for k, ((r, a), g1, g0) in enumerate(zip(pairs, got[1], got[0])):
+                    _same(g1, r, a, params, strategy, k)
+                    assert g1.alignment_offset == g0.alignment_offset and np.array_equal(g1.elements, g0.elements), (strategy, k)
+    finally:
+        hip_engine.set_switch("sw_transpose", -1)
+        hip_engine.set_switch("sw_lanes", 0)
