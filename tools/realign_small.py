@@ -13,7 +13,8 @@ from lorikeet_amd import HipPairHMMEngine, _lib, synthetic  # noqa: E402
 eng = HipPairHMMEngine(0)
 i32p = C.POINTER(C.c_int32)
 pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
-for nreg, nr, nh in ((1, 16, 2), (1, 128, 8), (1, 1024, 8), (8, 128, 8), (64, 128, 8)):
+SHAPES = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(1, 16, 2), (1, 128, 8), (1, 1024, 8), (8, 128, 8), (64, 128, 8)]
+for nreg, nr, nh in SHAPES:
     b = synthetic.make_regions(nreg, nr, nh, 300, 150, seed=5)
     lk = eng.compute(b)
     n = b.n_reads
