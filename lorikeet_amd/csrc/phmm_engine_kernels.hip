@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
 // step of realign_reads_to_their_best_haplotype (src/assembly/assembly_based_caller_utils.rs:208-246).  One thread per
 // read; its row of the [read][hap] matrix is contiguous.
 __global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams p) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n_reads) return;
     uint32_t lo = 0, hi = p.n_regions;  // the region of read r: the last g with region_read_off[g] <= r
     while (hi - lo > 1) {
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams
 }
 
 hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream) {
-    if (!p.n_reads) return hipSuccess;
-    hipLaunchKernelGGL(phmm_best_alleles_kernel, dim3((p.n_reads + 255) / 256), dim3(256), 0, stream, p);
+    if (p.n_reads <= p.r_begin) return hipSuccess;
+    hipLaunchKernelGGL(phmm_best_alleles_kernel, dim3((p.n_reads - p.r_begin + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -143,7 +143,7 @@ hipError_t launch_post(const PostParams &p, hipStream_t stream);
 // best allele per read, ties by priority (AlleleLikelihoods::search_best_allele, allele_likelihoods.rs:457-554)
 constexpr uint32_t SW_NO_REFERENCE = 0xffffffffu;  // ref_index value: this alignment is skipped (evidence removed / no allele)
 struct BestParams {
-    uint32_t n_reads, n_regions;
+    uint32_t r_begin, n_reads, n_regions;  // this launch: reads [r_begin, n_reads)
     const uint32_t *region_read_off, *region_hap_off;
     const uint64_t *out_off;
     const double *likelihoods;     // per region row-major [read][hap], as phmm_engine_compute returns them

@@ -135,11 +135,12 @@ struct BestLayout {
     }
 };
 
-void stage_best(const BestJob &b, const BestLayout &L, char *host) {
+// (`with_likelihoods` = false: a call in pieces stages the matrix piece by piece, see sw_run)
+void stage_best(const BestJob &b, const BestLayout &L, char *host, bool with_likelihoods = true) {
     memcpy(host + L.rro, b.region_read_off, 4ull * (b.n_regions + 1));
     memcpy(host + L.rho, b.region_hap_off, 4ull * (b.n_regions + 1));
     memcpy(host + L.oo, b.out_off, 8ull * (b.n_regions + 1));
-    if (b.out_off[b.n_regions]) memcpy(host + L.lk, b.likelihoods, 8ull * b.out_off[b.n_regions]);
+    if (with_likelihoods && b.out_off[b.n_regions]) memcpy(host + L.lk, b.likelihoods, 8ull * b.out_off[b.n_regions]);
     if (b.keep) memcpy(host + L.keep, b.keep, b.n_reads);
     if (b.priority) memcpy(host + L.pri, b.priority, 4ull * b.n_haps);
 }
@@ -440,7 +441,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     if (J.ref_index) memcpy(W.host + o_ri, J.ref_index, 4ull * n_alignments);
     size_t head = J.ref_index ? o_bi : o_ri;
     if (J.best) {
-        stage_best(*J.best, BL, W.host);
+        stage_best(*J.best, BL, W.host, one_piece);
         head = BL.best;
     }
     ProjectParams pp{};
@@ -489,10 +490,18 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         memcpy(W.host + o_ab, J.alt_bases, ab);
         head = in_bytes;
     }
-    // (a small call's inputs are fetched by a kernel: no copy engine, no cross-engine dependency for the launches behind it)
-    bool good = zero_copy && head <= kStageInBytes ? ok(h, launch_stage_in(W.host_dev, W.dev, head, S_in), "phmm_stage_in_kernel")
-                                                   : ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
-    if (good && J.best)  // the reads' best alleles become the index of their references, on the device
+    bool good;
+    if (J.best && !one_piece) {
+        // a call in pieces: everything of the head but the likelihood matrix, which is the bulk of it (8 bytes per read
+        // and haplotype) and travels with the pieces -- each piece's rows, then the best alleles of its reads
+        good = ok(h, hipMemcpyAsync(W.dev, W.host, BL.lk, hipMemcpyHostToDevice, S_in), "H2D sw") &&
+               (BL.best == BL.keep || ok(h, hipMemcpyAsync(W.dev + BL.keep, W.host + BL.keep, BL.best - BL.keep, hipMemcpyHostToDevice, S_in), "H2D sw"));
+    } else {
+        // (a small call's inputs are fetched by a kernel: no copy engine, no cross-engine dependency for the launches behind it)
+        good = zero_copy && head <= kStageInBytes ? ok(h, launch_stage_in(W.host_dev, W.dev, head, S_in), "phmm_stage_in_kernel")
+                                                  : ok(h, hipMemcpyAsync(W.dev, W.host, head, hipMemcpyHostToDevice, S_in), "H2D sw");
+    }
+    if (good && J.best && one_piece)  // the reads' best alleles become the index of their references, on the device
         good = ok(h, launch_best_alleles(best_params(*J.best, BL, W.dev, out_base, (uint32_t *)(W.dev + o_ri)), S_in), "phmm_best_alleles_kernel");
     if (good && PJ && !one_piece)  // the projection's inputs follow the head
         good = ok(h, hipMemcpyAsync(W.dev + o_pi, W.host + o_pi, p_end - o_pi, hipMemcpyHostToDevice, S_in), "H2D project");
@@ -504,6 +513,25 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks && good; ++c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         const size_t q0 = alt_off[a0], q1 = alt_off[a1];
+        if (!one_piece && J.best && a1 > a0 && good) {
+            // the likelihood rows of reads [a0, a1) are one range of the region-major matrix; then their best alleles
+            const BestJob &B = *J.best;
+            auto row_of = [&](uint32_t r, uint32_t *nh) -> uint64_t {
+                const uint32_t g = (uint32_t)(std::upper_bound(B.region_read_off, B.region_read_off + B.n_regions + 1, r) - B.region_read_off) - 1;
+                *nh = B.region_hap_off[g + 1] - B.region_hap_off[g];
+                return B.out_off[g] + (uint64_t)(r - B.region_read_off[g]) * *nh;
+            };
+            uint32_t nh0 = 0, nh1 = 0;
+            const uint64_t lo = row_of(a0, &nh0), hi = row_of(a1 - 1, &nh1) + nh1;
+            if (hi > lo) {
+                memcpy(W.host + BL.lk + 8ull * lo, B.likelihoods + lo, 8ull * (hi - lo));
+                good = ok(h, hipMemcpyAsync(W.dev + BL.lk + 8ull * lo, W.host + BL.lk + 8ull * lo, 8ull * (hi - lo), hipMemcpyHostToDevice, S_in), "H2D sw");
+            }
+            BestParams bp = best_params(B, BL, W.dev, out_base, (uint32_t *)(W.dev + o_ri));
+            bp.r_begin = a0;
+            bp.n_reads = a1;
+            good = good && ok(h, launch_best_alleles(bp, S_in), "phmm_best_alleles_kernel");
+        }
         if (!one_piece) {
             if (!indexed) {  // one reference per alignment: they travel piece by piece like the alternates
                 const size_t r0 = ref_off[a0], r1 = ref_off[a1];
@@ -559,7 +587,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             memcpy(J.cigar + cigar_off[a0], W.host + o_cg + 4ull * cigar_off[a0], 4ull * (cigar_off[a1] - cigar_off[a0]));
         return true;
     };
-    int prev = -1;
+    int prev = -1, last_piece = 0;
+    for (int c = 0; c < n_chunks; ++c)
+        if (cut[c + 1] > cut[c]) last_piece = c;
     bool best_fetched = false;
     for (int c = 0; c < n_chunks && good; ++c) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
@@ -585,7 +615,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                    (g1 == g0 || ok(h, hipMemcpyAsync(W.host + o_cg + 4ull * g0, W.dev + o_cg + 4ull * g0, 4ull * (g1 - g0), hipMemcpyDeviceToHost, S_out), "D2H sw"));
         }
         good = good && (one_piece || ok(h, hipEventRecord(W.ev_out[c], S_out), "hipEventRecord"));
-        if (good && J.best && !best_fetched && !zero_copy) {  // the best alleles were final before the first kernel started
+        if (good && J.best && !best_fetched && !zero_copy && c == last_piece) {  // (final once the last piece's kernel has been seen to end)
             good = ok(h, hipMemcpyAsync(W.host + BL.best, W.dev + BL.best, BL.end - BL.best, hipMemcpyDeviceToHost, S_out), "D2H best alleles");
             best_fetched = true;
         }
