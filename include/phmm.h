@@ -395,6 +395,61 @@ int phmm_realign_reads(phmm_handle *h, uint32_t n_regions, const uint32_t *regio
                        int64_t *new_pos, int32_t *status, int32_t *best_allele, double *likelihood, double *confidence);
 
 /*
+ * One call per region for the whole arithmetic path: what the reference does between
+ * PairHMMLikelihoodCalculationEngine::compute_read_likelihoods and AssemblyBasedCallerUtils::
+ * realign_reads_to_their_best_haplotype (src/haplotype/haplotype_caller_engine.rs:1311-1357 -- nothing lies between the
+ * two but an early return when only one allele is left) in ONE enqueue on one stream:
+ *   pre-step (phmm_engine_compute 1.) -> PairHMM forward kernels -> the exact pass below -600 -> normalize_likelihoods +
+ *   filter_poorly_modeled_evidence -> best allele per read (phmm_best_alleles) -> the read's Smith-Waterman alignment to
+ *   that haplotype -> its projection onto the reference (phmm_project_to_reference).
+ * The likelihood matrix, the keep flags, the best alleles and the read -> haplotype alignments never leave the device
+ * between the steps; the reads and haplotypes cross the bus once.  Returns what phmm_engine_compute and phmm_realign_reads
+ * return together, and equals them field by field (`keep` of the first feeding the second).
+ *
+ *   cfg / region arrays / read arrays / haplotype arrays / out_off / out / keep     as phmm_engine_compute
+ *   read_soft_clip [2 n_reads] or NULL   (leading, trailing) bases of each read that are soft clips: the reference aligns the
+ *                      read minus its soft clips (src/reads/alignment_utils.rs:47-50) while the PairHMM sees what
+ *                      modify_read_qualities leaves (engine.rs:352-423: all of it with modify_soft_clipped_bases, else the
+ *                      clipped read -- then there is nothing to clip here: NULL)
+ *   region_ref_hap     REQUIRED here for every region with reads and haplotypes (left-alignment reads the reference haplotype)
+ *   rcfg               Smith-Waterman parameters + overhang strategy (the reference: ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS,
+ *                      SoftClip), LOG_10_INFORMATIVE_THRESHOLD, flags
+ *   hap_priority ... out_cigar_off, best_allele ... status                          as phmm_realign_reads
+ * PHMM_REGION_SKIP_SINGLE_ALLELE: a region with exactly one haplotype is not realigned (the reference returns before it
+ * gets there, haplotype_caller_engine.rs:1339-1345): its reads keep status PHMM_PROJECT_UNCHANGED, BestAllele is still filled.
+ * Any number of regions per call; large calls are pipelined in chunks of regions like phmm_engine_compute.
+ *
+ * phmm_region_submit is the same call through the shared, thread-safe queue of phmm_submit (phmm_wait is the one above;
+ * submissions with equal configurations and the same optional arrays share a flush).
+ */
+#define PHMM_REGION_SKIP_SINGLE_ALLELE 1u
+typedef struct phmm_realign_config {
+    phmm_sw_parameters sw_parameters;   /* cigar_utils.rs:22 ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS = (10, -15, -30, -5) */
+    int32_t overhang_strategy;          /* PHMM_SW_SOFTCLIP at the reference's call site (alignment_utils.rs:58) */
+    uint32_t flags;                     /* PHMM_REGION_* */
+    double informative_threshold;       /* LOG_10_INFORMATIVE_THRESHOLD = 0.2 (allele_likelihoods.rs:17) */
+} phmm_realign_config;
+int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions,
+                        const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                        const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                        const uint8_t *mapq, const uint32_t *read_soft_clip, const uint32_t *hap_off, const uint8_t *hap_bases,
+                        const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                        const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                        const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar,
+                        const uint64_t *out_cigar_off, double *out, uint8_t *keep, int32_t *best_allele, double *likelihood,
+                        double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status);
+int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions,
+                       const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                       const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                       const uint8_t *mapq, const uint32_t *read_soft_clip, const uint32_t *hap_off, const uint8_t *hap_bases,
+                       const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                       const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                       const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar,
+                       const uint64_t *out_cigar_off, double *out, uint8_t *keep, int32_t *best_allele, double *likelihood,
+                       double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status,
+                       uint64_t *ticket);
+
+/*
  * CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) for n (reference, haplotype) pairs: the haplotype's CIGAR
  * against the reference -- the two shortcuts (empty haplotype: one D; equal lengths and at most two mismatches: one M),
  * otherwise Smith-Waterman between the sequences padded with "NNNNNNNNNN" on both sides (as phmm_sw_align; the reference's

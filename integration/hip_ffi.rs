@@ -56,6 +56,21 @@ pub struct phmm_sw_parameters {
     pub gap_extend_penalty: i32,
 }
 
+/// `flags` of `phmm_realign_config`: a region with exactly one haplotype is not realigned
+/// (src/haplotype/haplotype_caller_engine.rs:1339-1345 returns before it gets there)
+pub const PHMM_REGION_SKIP_SINGLE_ALLELE: c_uint = 1;
+
+/// `phmm_realign_config`: what `realign_reads_to_their_best_haplotype` fixes at its call site
+/// (src/reads/alignment_utils.rs:52-58, src/model/allele_likelihoods.rs:17)
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct phmm_realign_config {
+    pub sw_parameters: phmm_sw_parameters,
+    pub overhang_strategy: i32,
+    pub flags: u32,
+    pub informative_threshold: f64,
+}
+
 /// `phmm_engine_config`: the arguments of `PairHMMLikelihoodCalculationEngine::new`
 /// (src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs:129-141) the device needs.
 #[repr(C)]
@@ -360,6 +375,81 @@ extern "C" {
         best_allele: *mut i32,
         likelihood: *mut f64,
         confidence: *mut f64,
+    ) -> c_int;
+
+    pub fn phmm_region_compute(
+        h: *mut phmm_handle,
+        cfg: *const phmm_engine_config,
+        rcfg: *const phmm_realign_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        read_soft_clip: *const u32,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        hap_priority: *const i32,
+        region_reference_start: *const u64,
+        hap_cigar_off: *const u32,
+        hap_cigar: *const u32,
+        hap_start_wrt_ref: *const u32,
+        orig_cigar_off: *const u32,
+        orig_cigar: *const u32,
+        out_cigar_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
+        out_cigar: *mut u32,
+        n_out_cigar: *mut u32,
+        new_pos: *mut i64,
+        status: *mut i32,
+    ) -> c_int;
+
+    pub fn phmm_region_submit(
+        h: *mut phmm_handle,
+        cfg: *const phmm_engine_config,
+        rcfg: *const phmm_realign_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        read_soft_clip: *const u32,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        hap_priority: *const i32,
+        region_reference_start: *const u64,
+        hap_cigar_off: *const u32,
+        hap_cigar: *const u32,
+        hap_start_wrt_ref: *const u32,
+        orig_cigar_off: *const u32,
+        orig_cigar: *const u32,
+        out_cigar_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
+        out_cigar: *mut u32,
+        n_out_cigar: *mut u32,
+        new_pos: *mut i64,
+        status: *mut i32,
+        ticket: *mut u64,
     ) -> c_int;
 
     pub fn phmm_calculate_cigar(

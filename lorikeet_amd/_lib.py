@@ -29,6 +29,7 @@ PHMM_ERR_CIGAR_CAPACITY = 8
 PHMM_SW_SOFTCLIP, PHMM_SW_INDEL, PHMM_SW_LEADING_INDEL, PHMM_SW_IGNORE = 0, 1, 2, 3
 PHMM_SW_NO_REFERENCE = 0xffffffff
 PHMM_PROJECT_REALIGNED, PHMM_PROJECT_UNCHANGED = 0, 1
+PHMM_REGION_SKIP_SINGLE_ALLELE = 1
 
 class EngineConfig(C.Structure):
     """phmm_engine_config (include/phmm.h)."""
@@ -45,6 +46,16 @@ class SwParameters(C.Structure):
     _fields_ = [("match_value", C.c_int32), ("mismatch_penalty", C.c_int32), ("gap_open_penalty", C.c_int32),
                 ("gap_extend_penalty", C.c_int32)]
 
+
+class RealignConfig(C.Structure):
+    """phmm_realign_config (include/phmm.h)."""
+    _fields_ = [("sw_parameters", SwParameters), ("overhang_strategy", C.c_int32), ("flags", C.c_uint32),
+                ("informative_threshold", C.c_double)]
+
+
+_REGION_ARGS = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p,
+                C.POINTER(C.c_int32), u64p, C.POINTER(C.c_int32), u64p, u32p, u32p, u32p, u32p, u32p, u64p, f64p, u8p,
+                C.POINTER(C.c_int32), f64p, f64p, u32p, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
 
 # every symbol include/phmm.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -91,6 +102,8 @@ SYMBOLS = [
     ("phmm_realign_reads", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u32p, u8p, u64p, f64p, u8p, C.POINTER(C.c_int32), C.c_double,
                                      C.c_void_p, C.c_int, C.POINTER(C.c_int32), u64p, u32p, u32p, u32p, u32p, u32p, u64p, u32p, u32p,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), f64p, f64p]),
+    ("phmm_region_compute", C.c_int, _REGION_ARGS),
+    ("phmm_region_submit", C.c_int, _REGION_ARGS + [C.POINTER(C.c_uint64)]),
     ("phmm_calculate_cigar", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p, C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),

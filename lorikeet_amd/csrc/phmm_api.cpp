@@ -366,6 +366,7 @@ void phmm_destroy(phmm_handle *h) {
     for (int c = 0; c < phmm_handle::SwWork::kMaxChunks; ++c)
         for (hipEvent_t e : {h->swork.ev_in[c], h->swork.ev_out[c], h->swork.ev_k0[c], h->swork.ev_k1[c]})
             if (e) (void)hipEventDestroy(e);
+    if (h->swork.region_sw_done) (void)hipEventDestroy(h->swork.region_sw_done);
     delete h;
 }
 
@@ -1253,22 +1254,10 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     return PHMM_OK;
 }
 
-// Regions [g0, g1) of a caller's batch with every offset array rebased to zero: what one pipelined chunk is made of.
-struct ChunkView {
-    uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
-    uint32_t index = 0;  // how many chunks came before this one
-    bool started = false;
-    bool mixed = false;  // regions of different shapes: a chunk also has to be large enough for the chained kernel
-    bool f32_first = false;  // the handle's precision mode (decides the chunk sizes)
-    size_t read_byte0 = 0, hap_byte0 = 0;
-    std::vector<uint32_t> rro, rho, ro, ho;
-    std::vector<uint64_t> oo;
-};
-
 // Next chunk after `c` of the regions [.., n_regions) (start with c.g1 == first region, c.started == false): grows while
 // every per-base array stays below the direct-copy limit; `whole` takes everything that is left in one chunk.
 bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
-                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool whole = false) {
+                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool whole) {
     const uint32_t g0 = c.g1;
     if (g0 >= n_regions) return false;
     uint32_t g1 = g0 + 1;
@@ -1409,6 +1398,48 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
     p->b = nullptr;
     return st;
 }
+
+
+phmm_batch *batch_create_in_arena(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                                  const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, size_t extra_arena_bytes) {
+    return batch_create_impl(h, n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, true, extra_arena_bytes);
+}
+BatchView batch_view(const phmm_batch *b) {
+    BatchView v{};
+    v.n_regions = b->n_regions;
+    v.n_reads = b->n_reads;
+    v.n_haps = b->n_haps;
+    v.max_h = b->max_h;
+    v.n_out = b->n_out;
+    v.read_bytes = b->read_bytes;
+    v.hap_bytes = b->hap_bytes;
+    v.tight_out = b->tight_out;
+    v.d_read_region = b->d_read_region;
+    v.d_region_read_off = b->d_region_read_off;
+    v.d_region_hap_off = b->d_region_hap_off;
+    v.d_read_off = b->d_read_off;
+    v.d_hap_off = b->d_hap_off;
+    v.d_out_off = b->d_out_off;
+    return v;
+}
+void batch_set_status(phmm_batch *b, uint32_t *d_status) { b->d_status = d_status; }
+bool batch_set_inline_rescue(phmm_handle *h, phmm_batch *b) {
+    if (!b->n_reads || h->sw.no_rescue) return true;
+    if (!ensure_arena_rescue(h, *b->arena, b->max_h, &b->rescue_blocks)) return false;
+    b->rescue_scratch = b->arena->rescue;
+    return true;
+}
+void batch_copy_out(const phmm_batch *b, const double *src, double *out) {
+    if (b->tight_out) {
+        if (b->n_out) memcpy(out, src, b->n_out * 8);
+    } else {  // gaps the caller left in out_off stay untouched
+        for (const auto &e : b->out_extents)
+            if (e.second) memcpy(out + e.first, src + e.first, e.second * 8);
+    }
+}
+size_t one_shot_bytes() { return kOneShotBytes; }
+size_t stage_in_bytes() { return kStageInBytes; }
+size_t zero_copy_out_bytes() { return kZeroCopyOutBytes; }
 
 }  // namespace phmm_host
 

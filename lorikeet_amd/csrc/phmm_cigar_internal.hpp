@@ -28,7 +28,10 @@ struct ProjectParams {
     const uint32_t *hap_cigar_off, *hap_cigar;   // [n_haps + 1], elements
     const uint32_t *hap_start_wrt_ref;           // [n_haps]
     const int32_t *best_allele;        // [n_reads]
-    const uint64_t *sw_cigar_off;      // [n_reads + 1]
+    const uint64_t *sw_cigar_off;      // [n_reads + 1], or null: read r owns the slot [r * sw_cigar_slot, (r + 1) * sw_cigar_slot)
+    uint32_t sw_cigar_slot;
+    const uint32_t *read_clip;         // [2 * n_reads] or null: (leading, trailing) soft-clipped bases inside read_bases that were not aligned
+    const uint32_t *ref_index;         // [n_reads] or null: SW_NO_REFERENCE = the read was not aligned (it stays as it is)
     const uint32_t *sw_cigar, *n_sw_cigar;
     const int32_t *sw_offset;
     const uint32_t *orig_cigar_off, *orig_cigar;  // [n_reads + 1], elements

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
         else hi = mid;
     }
     const uint32_t g = lo;
-    const int32_t best = p.best_allele[r];
+    // (phmm_region_compute keeps the best alleles in the caller's pinned memory and the reads' reference index on the device)
+    const int32_t best = p.best_allele ? p.best_allele[r]
+                         : p.ref_index[r] == SW_NO_REFERENCE ? -1 : (int32_t)(p.ref_index[r] - p.region_hap_off[g]);
     const int32_t sw_offset = p.sw_offset[r];
     const int32_t ref_in_region = p.region_ref_hap[g];
     uint32_t *out = p.out_cigar + p.out_cigar_off[r];
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
     } while (0)
 
     if (best < 0 || sw_offset == -1) goto done;  // no best allele / "sw can fail ... just don't realign the read" (:60-63)
+    if (p.ref_index && p.ref_index[r] == SW_NO_REFERENCE) goto done;  // not aligned (a region with a single allele is not realigned)
     if (sw_offset < 0 || ref_in_region < 0 || (uint32_t)best >= p.region_hap_off[g + 1] - p.region_hap_off[g]) {
         status = CIGAR_ERR_PANIC;
         goto done;
@@ -292,13 +295,14 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
         const uint32_t hp = p.region_hap_off[g] + (uint32_t)best, hr = p.region_hap_off[g] + (uint32_t)ref_in_region;
         const uint8_t *ref_seq = p.hap_bases + p.hap_off[hr];
         const uint32_t ref_seq_len = p.hap_off[hr + 1] - p.hap_off[hr];
-        const uint8_t *read = p.read_bases + p.read_off[r];
-        const uint32_t read_len = p.read_off[r + 1] - p.read_off[r];
+        const uint32_t clip_l = p.read_clip ? p.read_clip[2 * r] : 0u, clip_r = p.read_clip ? p.read_clip[2 * r + 1] : 0u;
+        const uint8_t *read = p.read_bases + p.read_off[r] + clip_l;  // the read minus its soft clips (:47-50)
+        const uint32_t read_len = p.read_off[r + 1] - p.read_off[r] - clip_l - clip_r;
 
         // :65-72 the alignment's cigar through a builder
         A.init(ws, p.capacity, true);
         {
-            const uint32_t *sw = p.sw_cigar + p.sw_cigar_off[r];
+            const uint32_t *sw = p.sw_cigar + (p.sw_cigar_off ? p.sw_cigar_off[r] : (uint64_t)r * p.sw_cigar_slot);
             for (uint32_t i = 0; i < p.n_sw_cigar[r]; ++i)
                 if (A.add(sw[i]) != CIGAR_OK) break;
             CHECK(A.error);

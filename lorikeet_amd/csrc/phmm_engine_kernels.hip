@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n_reads) return;
+// normalize_likelihoods + the keep / remove decision for read r (in place in p.out; small calls: also into p.out_final);
+// returns keep[r]
+__device__ __forceinline__ uint8_t post_read(const PostParams &p, const uint32_t r, const bool in_place_too) {
     if (r == 0 && p.status_out) *p.status_out = *p.status_in;
     const uint32_t g = p.read_region[r];
     const uint32_t nh = p.region_hap_off[g + 1] - p.region_hap_off[g];
@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
         }
         const double worst = best + p.max_likelihood_difference_cap;
         if (p.out_final) {
-            for (uint32_t a = 0; a < nh; ++a) p.out_final[at + a] = row[a] < worst ? worst : row[a];
+            for (uint32_t a = 0; a < nh; ++a) {
+                const double v = row[a] < worst ? worst : row[a];
+                p.out_final[at + a] = v;
+                if (in_place_too) row[a] = v;  // (the best-allele search behind it reads the row from device memory)
+            }
         } else {
             for (uint32_t a = 0; a < nh; ++a)
                 if (row[a] < worst) row[a] = worst;
@@ -253,26 +257,27 @@ __global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
         for (uint32_t a = 0; a < nh; ++a) p.out_final[at + a] = row[a];
     }
     // filter_poorly_modeled_evidence removes evidence whose best likelihood is below its threshold (:941-958)
-    p.keep[r] = (best_all < p.threshold[r]) ? 0 : 1;
+    const uint8_t keep = (best_all < p.threshold[r]) ? 0 : 1;
+    p.keep[r] = keep;
+    return keep;
+}
+
+__global__ __launch_bounds__(256) void phmm_post_reads(const PostParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    (void)post_read(p, r, false);
 }
 
 // ---- best allele per read (AlleleLikelihoods::search_best_allele, src/model/allele_likelihoods.rs:457-554, the way
 // best_alleles_tie_breaking calls it, :1069-1095: can_be_reference = true) with BestAllele::new (:1142-1160): the first
 // step of realign_reads_to_their_best_haplotype (src/assembly/assembly_based_caller_utils.rs:208-246).  One thread per
 // read; its row of the [read][hap] matrix is contiguous.
-__global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams p) {
-    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n_reads) return;
-    uint32_t lo = 0, hi = p.n_regions;  // the region of read r: the last g with region_read_off[g] <= r
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) / 2;
-        if (p.region_read_off[mid] <= r) lo = mid;
-        else hi = mid;
-    }
-    const uint32_t g = lo, h0 = p.region_hap_off[g], nh = p.region_hap_off[g + 1] - h0;
+// best allele of read r of region g; `kept`: the evidence survived filter_poorly_modeled_evidence; `aligned`: false leaves
+// the read without a reference to align to (ref_index = SW_NO_REFERENCE) although it has a best allele
+__device__ __forceinline__ void best_allele_of(const BestParams &p, const uint32_t r, const uint32_t g, const bool kept, const bool aligned) {
+    const uint32_t h0 = p.region_hap_off[g], nh = p.region_hap_off[g + 1] - h0;
     int32_t best_out = -1;
     double lk_out = -INFINITY, conf_out = (-INFINITY) - (-INFINITY);  // BestAllele::new(-inf, -inf): NaN (:465-475)
-    const bool kept = !p.keep || p.keep[r];
     if (nh && kept) {
         const double *v = p.likelihoods + p.out_off[g] + (uint64_t)(r - p.region_read_off[g]) * nh;
         uint32_t best = 0, second = 0;  // :479-488
@@ -317,7 +322,37 @@ __global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams
     p.best_allele[r] = best_out;
     p.likelihood[r] = lk_out;
     p.confidence[r] = conf_out;
-    if (p.ref_index) p.ref_index[r] = best_out >= 0 ? h0 + (uint32_t)best_out : SW_NO_REFERENCE;
+    if (p.ref_index) p.ref_index[r] = best_out >= 0 && aligned ? h0 + (uint32_t)best_out : SW_NO_REFERENCE;
+}
+
+__global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams p) {
+    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    uint32_t lo = 0, hi = p.n_regions;  // the region of read r: the last g with region_read_off[g] <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (p.region_read_off[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    best_allele_of(p, r, lo, !p.keep || p.keep[r], true);
+}
+
+// Both steps for the same read in one launch (phmm_region_compute): the row the post-step has just normalised in device
+// memory is the row the best-allele search reads -- nothing leaves the device in between.
+__global__ __launch_bounds__(256) void phmm_post_best_reads(const PostBestParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.post.n_reads) return;
+    const uint8_t keep = post_read(p.post, r, true);
+    if (p.keep_final) p.keep_final[r] = keep;
+    const uint32_t g = p.post.read_region[r];
+    const uint32_t nh = p.post.region_hap_off[g + 1] - p.post.region_hap_off[g];
+    best_allele_of(p.best, r, g, keep != 0, !(p.skip_single_allele && nh == 1));
+}
+
+hipError_t launch_post_best(const PostBestParams &p, hipStream_t stream) {
+    if (!p.post.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(phmm_post_best_reads, dim3((p.post.n_reads + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream) {

@@ -73,6 +73,8 @@ struct phmm_handle {
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
         uint64_t last_kernel_us = 0, last_backtrack_bytes = 0, last_clock_mhz = 0;
+        hipEvent_t region_sw_done = nullptr;  // phmm_region_compute in chunks: the slab and the workspace are one per handle, so
+        bool region_sw_pending = false;       // a chunk's alignment kernels wait for those of the chunk before it
         std::unordered_map<uint64_t, int> blocks_per_cu;  // by (lanes, columns, LDS bytes): asked of the runtime once
     } swork;
     uint64_t stat_staged_bytes = 0;   // payload bytes copied into pinned staging by this handle (phmm_get_stat)
@@ -126,6 +128,79 @@ int compute_list(phmm_handle *h, const uint32_t *list, uint32_t n_list, const ui
                  const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
                  const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
                  const uint8_t *hap_bases, const uint64_t *out_off, double *out);
+
+// ---- internals the per-region pipeline (phmm_region.cpp) builds on ------------------------------------------------------
+// Plan a batch (shape classes, work lists) with its device metadata placed in the current slot's arena; `extra_arena_bytes`
+// of room are reserved behind it for the caller's own staging (phmm_api.cpp).
+phmm_batch *batch_create_in_arena(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                                  const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, size_t extra_arena_bytes);
+struct BatchView {  // what a caller that launches its own kernels around the forward kernels needs to know of a batch
+    uint32_t n_regions, n_reads, n_haps, max_h;
+    uint64_t n_out, read_bytes, hap_bytes;
+    bool tight_out;
+    const uint32_t *d_read_region, *d_region_read_off, *d_region_hap_off, *d_read_off, *d_hap_off;
+    const uint64_t *d_out_off;
+};
+BatchView batch_view(const phmm_batch *b);
+void batch_set_status(phmm_batch *b, uint32_t *d_status);                       // the device status word the forward kernels raise
+bool batch_set_inline_rescue(phmm_handle *h, phmm_batch *b);                    // the exact pass rides behind the forward kernels (arena scratch)
+void batch_copy_out(const phmm_batch *b, const double *src, double *out);        // results -> caller, gaps of out_off untouched
+bool eager_d2h(const phmm_handle *h);
+
+// Regions [g0, g1) of a caller's batch with every offset array rebased to zero: what one pipelined chunk is made of.
+struct ChunkView {
+    uint32_t g0 = 0, g1 = 0, r0 = 0, r1 = 0, h0 = 0, h1 = 0;
+    uint32_t index = 0;  // how many chunks came before this one
+    bool started = false;
+    bool mixed = false;  // regions of different shapes: a chunk also has to be large enough for the chained kernel
+    bool f32_first = false;  // the handle's precision mode (decides the chunk sizes)
+    size_t read_byte0 = 0, hap_byte0 = 0;
+    std::vector<uint32_t> rro, rho, ro, ho;
+    std::vector<uint64_t> oo;
+};
+bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
+                const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool whole = false);
+size_t one_shot_bytes();     // per-array bytes up to which a host-buffer call goes in one shot
+size_t stage_in_bytes();     // inputs up to this size are fetched from the pinned mirror by a kernel
+size_t zero_copy_out_bytes();  // results up to this size are stored into the pinned mirror by the kernels
+
+// Worker geometry of one batch of Smith-Waterman alignments (phmm_sw.cpp).
+struct SwGeometry {
+    int L = 0, K = 0, per_cu = 0;
+    bool transposed = false;
+    size_t strips = 0, lds_ref = 0, lds_alt = 0, lds_group = 0, gpb = 0, lds = 0, flag_words = 0, slab_stride = 0, max_workers = 0;
+};
+int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt, SwGeometry *G);
+
+// The caller's arrays of one phmm_region_compute call (include/phmm.h), or of one chunk / one combined flush of it.
+struct RegionArgs {
+    phmm_engine_config cfg{};
+    phmm_realign_config rcfg{};
+    uint32_t n_regions = 0;
+    const uint32_t *region_read_off = nullptr, *region_hap_off = nullptr, *read_off = nullptr;
+    const uint8_t *read_bases = nullptr, *base_q = nullptr, *ins_q = nullptr, *del_q = nullptr, *mapq = nullptr;
+    const uint32_t *read_soft_clip = nullptr;
+    const uint32_t *hap_off = nullptr;
+    const uint8_t *hap_bases = nullptr;
+    const int32_t *region_ref_hap = nullptr;
+    const uint64_t *out_off = nullptr;
+    const int32_t *hap_priority = nullptr;
+    const uint64_t *region_reference_start = nullptr;
+    const uint32_t *hap_cigar_off = nullptr, *hap_cigar = nullptr, *hap_start_wrt_ref = nullptr, *orig_cigar_off = nullptr, *orig_cigar = nullptr;
+    const uint64_t *out_cigar_off = nullptr;
+    double *out = nullptr;
+    uint8_t *keep = nullptr;
+    int32_t *best_allele = nullptr;
+    double *likelihood = nullptr, *confidence = nullptr;
+    uint32_t *out_cigar = nullptr, *n_out_cigar = nullptr;
+    int64_t *new_pos = nullptr;
+    int32_t *status = nullptr;
+};
+// argument check of phmm_region_compute / phmm_region_submit: the message of the first violation, or empty
+std::string region_validate(const RegionArgs &a);
+// the call itself on validated arguments (phmm_region.cpp); one thread per handle
+int region_compute(phmm_handle *h, const RegionArgs &a);
+int region_compute_parts(phmm_handle *h, const RegionArgs &combined, const std::vector<RegionArgs> &parts);
 
 // What every entry point checks before it touches the arrays; returns the message of the first violation or nullptr.
 const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,

@@ -155,6 +155,19 @@ struct BestParams {
     uint32_t *ref_index;           // [n_reads] or null: region_hap_off[g] + best, SW_NO_REFERENCE where there is none
 };
 hipError_t launch_best_alleles(const BestParams &p, hipStream_t stream);
+// post-step and best alleles of the same reads in ONE launch (phmm_region_compute): thread r normalises its row, decides
+// keep[r] and goes straight on to the best-allele search over the row it has just written -- the likelihood matrix and the
+// keep flags never leave the device between compute_read_likelihoods and realign_reads_to_their_best_haplotype
+// (haplotype_caller_engine.rs:1311-1357).  post.n_reads == best.n_reads, best.r_begin == 0, best.likelihoods == post.out,
+// best.keep == post.keep.
+struct PostBestParams {
+    PostParams post;
+    BestParams best;
+    uint32_t skip_single_allele;   // 1: a region with exactly one haplotype is not realigned (the caller returns before
+                                   // realign_reads_to_their_best_haplotype, :1339-1345): ref_index = SW_NO_REFERENCE there
+    uint8_t *keep_final;           // small calls: keep flags stored into the caller's pinned mirror as well (or null)
+};
+hipError_t launch_post_best(const PostBestParams &p, hipStream_t stream);
 
 // The instantiated K values (for every L in {16,32,64}); the planner rounds K up to one of these.
 extern const int kInstantiatedK[];

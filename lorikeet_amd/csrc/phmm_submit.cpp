@@ -31,6 +31,9 @@ struct Submission {
     uint64_t n_out = 0;
     // phmm_engine_submit: payload = {read_bases, base_q, ins_q | NULL, del_q | NULL, unused, hap_bases}
     bool engine = false;
+    // phmm_region_submit: everything is in `ra` (the fields above but read_bytes are unused)
+    bool region = false;
+    RegionArgs ra;
     phmm_engine_config cfg{};
     const uint8_t *mapq = nullptr;
     const int32_t *ref_hap = nullptr;
@@ -41,7 +44,11 @@ struct Submission {
     // may share a flush with `o`: same entry point and, for the engine-level call, the same configuration and the same
     // optional arrays present
     bool compatible(const Submission &o) const {
-        if (engine != o.engine) return false;
+        if (engine != o.engine || region != o.region) return false;
+        if (region)
+            return memcmp(&ra.cfg, &o.ra.cfg, sizeof ra.cfg) == 0 && memcmp(&ra.rcfg, &o.ra.rcfg, sizeof ra.rcfg) == 0 &&
+                   !ra.ins_q == !o.ra.ins_q && !ra.del_q == !o.ra.del_q && !ra.hap_priority == !o.ra.hap_priority &&
+                   !ra.read_soft_clip == !o.ra.read_soft_clip;
         if (!engine) return true;
         return memcmp(&cfg, &o.cfg, sizeof cfg) == 0 && !payload[2] == !o.payload[2] && !payload[3] == !o.payload[3] &&
                !ref_hap == !o.ref_hap;
@@ -70,6 +77,10 @@ struct Combiner {
         std::vector<uint8_t> bytes[5], mapq, keep;  // bytes: read_bases, base_q, ins_q, del_q, hap_bases
         std::vector<int32_t> ref;
         std::vector<double> out;
+        // region-level flushes: only the offset arrays are concatenated, payload and results go straight from / to their owners
+        std::vector<uint32_t> hco, oco;
+        std::vector<uint64_t> outco;
+        std::vector<RegionArgs> rparts;
     } scratch[kMaxLanes];
 };
 
@@ -103,7 +114,9 @@ uint64_t combiner_stat(Combiner *c, const char *name) {
 namespace {
 
 int submission_alone(phmm_handle *lane, Submission *s) {
-    if (s->engine)
+    if (s->region)
+        s->status = region_compute(lane, s->ra);
+    else if (s->engine)
         s->status = phmm_engine_compute(lane, &s->cfg, s->n_regions, s->region_read_off, s->region_hap_off, s->read_off,
                                         s->payload[0], s->payload[1], s->payload[2], s->payload[3], s->mapq, s->hap_off,
                                         s->payload[5], s->ref_hap, s->out_off, s->out, s->keep);
@@ -139,6 +152,7 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
     parts.n_out.clear();
     parts.first_region.assign(1, 0);
     for (const Submission *s : subs) {
+        if (s->region) break;  // (region-level flushes build their own, below)
         const uint32_t r0 = w.rro.back(), h0 = w.rho.back(), rb0 = w.ro.back(), hb0 = w.ho.back();
         const uint64_t o0 = w.oo.back();
         for (uint32_t g = 1; g <= s->n_regions; ++g) {
@@ -154,6 +168,67 @@ void run_flush(phmm_handle *lane, Combiner::Scratch &w, std::vector<Submission *
         parts.out.push_back(s->out);
         parts.n_out.push_back(s->n_out);
         parts.first_region.push_back(parts.first_region.back() + s->n_regions);
+    }
+    if (subs[0]->region) {
+        // phmm_region_submit: the regions of all waiting workers as ONE enqueue of the whole per-region pipeline
+        w.rro.assign(1, 0);
+        w.rho.assign(1, 0);
+        w.ro.assign(1, 0);
+        w.ho.assign(1, 0);
+        w.oo.assign(1, 0);
+        w.hco.assign(1, 0);
+        w.oco.assign(1, 0);
+        w.outco.assign(1, 0);
+        w.rparts.clear();
+        bool holes = false;
+        for (const Submission *s : subs) {
+            const RegionArgs &q = s->ra;
+            const uint32_t r0 = w.rro.back(), h0 = w.rho.back(), rb0 = w.ro.back(), hb0 = w.ho.back(), hc0 = w.hco.back(), oc0 = w.oco.back();
+            const uint64_t o0 = w.oo.back(), oc_out0 = w.outco.back();
+            const uint32_t nr = q.region_read_off[q.n_regions], nh = q.region_hap_off[q.n_regions];
+            for (uint32_t g = 1; g <= q.n_regions; ++g) {
+                w.rro.push_back(r0 + q.region_read_off[g]);
+                w.rho.push_back(h0 + q.region_hap_off[g]);
+                // (the combined matrix is tight: a submission's own gaps in out_off are honoured when its results are handed back)
+                w.oo.push_back(w.oo.back() + (uint64_t)(q.region_read_off[g] - q.region_read_off[g - 1]) * (q.region_hap_off[g] - q.region_hap_off[g - 1]));
+            }
+            (void)o0;
+            for (uint32_t r = 1; r <= nr; ++r) {
+                w.ro.push_back(rb0 + q.read_off[r]);
+                w.oco.push_back(oc0 + (nr ? q.orig_cigar_off[r] : 0));
+                w.outco.push_back(oc_out0 + (nr ? q.out_cigar_off[r] : 0));
+            }
+            for (uint32_t a = 1; a <= nh; ++a) {
+                w.ho.push_back(hb0 + q.hap_off[a]);
+                w.hco.push_back(hc0 + (q.hap_cigar_off ? q.hap_cigar_off[a] : 0));
+            }
+            holes = holes || (nh && !q.hap_cigar_off);
+            w.rparts.push_back(q);
+        }
+        if (holes) {  // (a submission without reads may come without the realignment arrays: nothing to combine it with)
+            for (Submission *s : subs) submission_alone(lane, s);
+            return;
+        }
+        RegionArgs c = subs[0]->ra;  // configuration and which optional arrays are present
+        c.n_regions = (uint32_t)w.rro.size() - 1;
+        c.region_read_off = w.rro.data();
+        c.region_hap_off = w.rho.data();
+        c.read_off = w.ro.data();
+        c.hap_off = w.ho.data();
+        c.out_off = w.oo.data();
+        c.hap_cigar_off = w.hco.data();
+        c.orig_cigar_off = w.oco.data();
+        c.out_cigar_off = w.outco.data();
+        const int st = region_compute_parts(lane, c, w.rparts);
+        if (st != PHMM_OK && st != PHMM_ERR_HIP) {  // somebody's region is at fault: find out whose
+            for (Submission *s : subs) submission_alone(lane, s);
+            return;
+        }
+        for (Submission *s : subs) {
+            s->status = st;
+            if (st != PHMM_OK) s->err = lane->err;
+        }
+        return;
     }
     if (subs[0]->engine) {
         const Submission &f = *subs[0];
@@ -302,6 +377,66 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
         (s.n_out && !out))
         return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_engine_submit: null pointer");
     return submit_impl(h, s, ticket);
+}
+
+int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions,
+                       const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                       const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                       const uint8_t *mapq, const uint32_t *read_soft_clip, const uint32_t *hap_off, const uint8_t *hap_bases,
+                       const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                       const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                       const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar,
+                       const uint64_t *out_cigar_off, double *out, uint8_t *keep, int32_t *best_allele, double *likelihood,
+                       double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status,
+                       uint64_t *ticket) {
+    if (!h || !cfg || !rcfg || !ticket) return PHMM_ERR_INVALID_ARG;
+    try {
+        Submission s;
+        s.region = true;
+        RegionArgs &a = s.ra;
+        a.cfg = *cfg;
+        a.rcfg = *rcfg;
+        a.n_regions = n_regions;
+        a.region_read_off = region_read_off;
+        a.region_hap_off = region_hap_off;
+        a.read_off = read_off;
+        a.read_bases = read_bases;
+        a.base_q = base_q;
+        a.ins_q = ins_q;
+        a.del_q = del_q;
+        a.mapq = mapq;
+        a.read_soft_clip = read_soft_clip;
+        a.hap_off = hap_off;
+        a.hap_bases = hap_bases;
+        a.region_ref_hap = region_ref_hap;
+        a.out_off = out_off;
+        a.hap_priority = hap_priority;
+        a.region_reference_start = region_reference_start;
+        a.hap_cigar_off = hap_cigar_off;
+        a.hap_cigar = hap_cigar;
+        a.hap_start_wrt_ref = hap_start_wrt_ref;
+        a.orig_cigar_off = orig_cigar_off;
+        a.orig_cigar = orig_cigar;
+        a.out_cigar_off = out_cigar_off;
+        a.out = out;
+        a.keep = keep;
+        a.best_allele = best_allele;
+        a.likelihood = likelihood;
+        a.confidence = confidence;
+        a.out_cigar = out_cigar;
+        a.n_out_cigar = n_out_cigar;
+        a.new_pos = new_pos;
+        a.status = status;
+        const std::string bad = region_validate(a);
+        if (!bad.empty()) return submit_fail(h, PHMM_ERR_INVALID_ARG, bad.c_str());
+        s.n_regions = n_regions;
+        s.n_reads = region_read_off[n_regions];
+        s.n_haps = region_hap_off[n_regions];
+        s.read_bytes = read_off[s.n_reads];
+        return submit_impl(h, s, ticket);
+    } catch (const std::exception &e) {
+        return submit_fail(h, PHMM_ERR_NO_MEMORY, e.what());
+    }
 }
 
 int phmm_wait(phmm_handle *h, uint64_t ticket) {

@@ -184,6 +184,94 @@ bool grow_staging(phmm_handle *h, size_t total) {
     return true;
 }
 
+}  // namespace
+
+namespace phmm_host {
+
+// Worker geometry of one batch of alignments (shared by sw_run and the per-region pipeline, phmm_region.cpp).
+int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt, SwGeometry *G) {
+    // ---- geometry ---------------------------------------------------------------------------------------------
+    // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate sequence
+    // (more than 512 columns take several strips of 512).  Throughput wants few lanes per alignment -- eight alignments
+    // per wave lose the fewest steps to the skew and spread the per-step work over the most cells -- latency wants many:
+    // a call that cannot fill the chip anyway (a round of the persistent blocks is 32 768 alignments at eight lanes) gets
+    // 16, 32 or 64 lanes per alignment, i.e. more waves with less work each (one region of 128 reads: 305 us at 8 lanes,
+    // 220 at 16).
+    const int force_L = h->sw.sw_lanes;
+    // (64 lanes up to 2 048 alignments where the sweep along the alternate applies, below: 16 regions of 128 reads 248 -> 228 us)
+    const uint32_t most_at_64 = h->sw.sw_transpose != 0 && max_ref > max_alt && max_ref <= 512 ? 2048 : 1024;
+    int L = force_L ? force_L : max_alt <= 8 * 20 && n_alignments >= 32768 ? 8 : max_alt > 512 || n_alignments > 4096 ? 16 : n_alignments > most_at_64 ? 32 : 64;
+    const int *ks = L == 8 ? kSwK8 : L == 16 ? kSwK16 : L == 32 ? kSwK32 : kSwK64;
+    const int nks = L == 8 ? kNumSwK8 : L == 16 ? kNumSwK16 : L == 32 ? kNumSwK32 : kNumSwK64;
+    int K = ks[nks - 1];
+    for (int i = nks - 1; i >= 0; --i)
+        if ((size_t)ks[i] * L >= max_alt) K = ks[i];
+    // A small call whose references are longer than its alternates (reads against their haplotypes) sweeps along the
+    // ALTERNATE instead, the reference's rows shared out over the 64 lanes: fewer steps of more cells each, and a step's
+    // fixed cost (~50 instructions next to 16 per cell) is what a lone wave per SIMD feels -- 150 x 300: 350 steps of
+    // three cells against 210 of five.  One strip only.
+    bool transposed = false;
+    if (L == 64 && h->sw.sw_transpose != 0 && max_ref <= 64u * (uint32_t)kSwK64T[kNumSwK64T - 1]) {
+        int KT = kSwK64T[kNumSwK64T - 1];
+        for (int i = kNumSwK64T - 1; i >= 0; --i)
+            if ((size_t)kSwK64T[i] * 64 >= max_ref) KT = kSwK64T[i];
+        auto cost = [](size_t sweep, size_t across, int k) { return (sweep + (across + k - 1) / k) * (16ull * k + 50); };
+        const bool one_strip = (size_t)K * 64 >= max_alt;
+        if (h->sw.sw_transpose > 0 || !one_strip || cost(max_alt, max_ref, KT) < cost(max_ref, max_alt, K)) {
+            transposed = true;
+            K = KT;
+        }
+    }
+    const size_t strip_cols = (size_t)L * K;
+    const size_t strips = transposed ? 1 : (max_alt + strip_cols - 1) / strip_cols;
+    const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
+    // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
+    const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
+    // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
+    const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
+    const size_t lds = gpb * lds_group;
+    if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 8 000 bases each)");
+    // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
+    // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
+    int per_cu;
+    {
+        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)lds;
+        auto it = h->swork.blocks_per_cu.find(key);
+        if (it == h->swork.blocks_per_cu.end()) {
+            if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
+            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed)).first;
+        }
+        per_cu = it->second;
+    }
+    if (per_cu <= 0) {
+        h->err = who + ": the kernel does not fit a compute unit";
+        return h->err_code = PHMM_ERR_INTERNAL;
+    }
+    if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
+    // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
+    const size_t flag_words = (size_t)sw_flag_words(K);
+    const size_t slab_stride = strips * (size_t)((transposed ? std::max(max_ref, max_alt) : max_ref) + L) * flag_words * 64;
+    const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
+    G->L = L;
+    G->K = K;
+    G->transposed = transposed;
+    G->strips = strips;
+    G->lds_ref = lds_ref;
+    G->lds_alt = lds_alt;
+    G->lds_group = lds_group;
+    G->gpb = gpb;
+    G->lds = lds;
+    G->per_cu = per_cu;
+    G->flag_words = flag_words;
+    G->slab_stride = slab_stride;
+    G->max_workers = max_workers;
+    return PHMM_OK;
+}
+
+}  // namespace phmm_host
+
+namespace {
+
 int sw_run(phmm_handle *h, const SwJob &J) {
     const std::string who(J.who);
     h->err_code = PHMM_OK;
@@ -255,68 +343,16 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const bool indexed = J.ref_index || J.best;  // references are shared: they all travel with the first piece
 
     DevGuard dg(h->device);
-    // ---- geometry ---------------------------------------------------------------------------------------------
-    // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate sequence
-    // (more than 512 columns take several strips of 512).  Throughput wants few lanes per alignment -- eight alignments
-    // per wave lose the fewest steps to the skew and spread the per-step work over the most cells -- latency wants many:
-    // a call that cannot fill the chip anyway (a round of the persistent blocks is 32 768 alignments at eight lanes) gets
-    // 16, 32 or 64 lanes per alignment, i.e. more waves with less work each (one region of 128 reads: 305 us at 8 lanes,
-    // 220 at 16).
-    const int force_L = h->sw.sw_lanes;
-    // (64 lanes up to 2 048 alignments where the sweep along the alternate applies, below: 16 regions of 128 reads 248 -> 228 us)
-    const uint32_t most_at_64 = h->sw.sw_transpose != 0 && max_ref > max_alt && max_ref <= 512 ? 2048 : 1024;
-    int L = force_L ? force_L : max_alt <= 8 * 20 && n_alignments >= 32768 ? 8 : max_alt > 512 || n_alignments > 4096 ? 16 : n_alignments > most_at_64 ? 32 : 64;
-    const int *ks = L == 8 ? kSwK8 : L == 16 ? kSwK16 : L == 32 ? kSwK32 : kSwK64;
-    const int nks = L == 8 ? kNumSwK8 : L == 16 ? kNumSwK16 : L == 32 ? kNumSwK32 : kNumSwK64;
-    int K = ks[nks - 1];
-    for (int i = nks - 1; i >= 0; --i)
-        if ((size_t)ks[i] * L >= max_alt) K = ks[i];
-    // A small call whose references are longer than its alternates (reads against their haplotypes) sweeps along the
-    // ALTERNATE instead, the reference's rows shared out over the 64 lanes: fewer steps of more cells each, and a step's
-    // fixed cost (~50 instructions next to 16 per cell) is what a lone wave per SIMD feels -- 150 x 300: 350 steps of
-    // three cells against 210 of five.  One strip only.
-    bool transposed = false;
-    if (L == 64 && h->sw.sw_transpose != 0 && max_ref <= 64u * (uint32_t)kSwK64T[kNumSwK64T - 1]) {
-        int KT = kSwK64T[kNumSwK64T - 1];
-        for (int i = kNumSwK64T - 1; i >= 0; --i)
-            if ((size_t)kSwK64T[i] * 64 >= max_ref) KT = kSwK64T[i];
-        auto cost = [](size_t sweep, size_t across, int k) { return (sweep + (across + k - 1) / k) * (16ull * k + 50); };
-        const bool one_strip = (size_t)K * 64 >= max_alt;
-        if (h->sw.sw_transpose > 0 || !one_strip || cost(max_alt, max_ref, KT) < cost(max_ref, max_alt, K)) {
-            transposed = true;
-            K = KT;
-        }
-    }
-    const size_t strip_cols = (size_t)L * K;
-    const size_t strips = transposed ? 1 : (max_alt + strip_cols - 1) / strip_cols;
-    const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
-    // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
-    const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
-    // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
-    const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
-    const size_t lds = gpb * lds_group;
-    if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 8 000 bases each)");
-    // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
-    // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
-    int per_cu;
+    // ---- geometry (sw_plan above) ------------------------------------------------------------------------------
+    phmm_host::SwGeometry G;
     {
-        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)lds;
-        auto it = h->swork.blocks_per_cu.find(key);
-        if (it == h->swork.blocks_per_cu.end()) {
-            if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
-            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed)).first;
-        }
-        per_cu = it->second;
+        const int gst = phmm_host::sw_plan(h, who, n_alignments, max_ref, max_alt, &G);
+        if (gst != PHMM_OK) return gst;
     }
-    if (per_cu <= 0) {
-        h->err = who + ": the kernel does not fit a compute unit";
-        return h->err_code = PHMM_ERR_INTERNAL;
-    }
-    if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
-    // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
-    const size_t flag_words = (size_t)sw_flag_words(K);
-    const size_t slab_stride = strips * (size_t)((transposed ? std::max(max_ref, max_alt) : max_ref) + L) * flag_words * 64;
-    const size_t max_workers = std::max<size_t>(1, std::min<size_t>(256 * (size_t)per_cu, (6ull << 30) / (slab_stride * 4)));
+    const int L = G.L, K = G.K;
+    const bool transposed = G.transposed;
+    const size_t strip_cols = (size_t)L * K, lds_ref = G.lds_ref, lds_alt = G.lds_alt, lds_group = G.lds_group, gpb = G.gpb, lds = G.lds,
+                 flag_words = G.flag_words, slab_stride = G.slab_stride, max_workers = G.max_workers;
     // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on
     // one stream and share the slabs).  A piece is a whole number of rounds of the persistent blocks, so that only
     // the last piece of a call ends on a partly filled round.

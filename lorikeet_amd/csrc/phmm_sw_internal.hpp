@@ -22,7 +22,10 @@ struct SwParams {
     const uint8_t *ref_bases, *alt_bases;
     int32_t w_match, w_mismatch, w_open, w_extend;
     int strategy;
-    const uint64_t *cigar_off;             // [n_alignments + 1]
+    const uint64_t *cigar_off;             // [n_alignments + 1], or null: alignment a owns the slot [a * cigar_slot, (a + 1) * cigar_slot)
+    uint32_t cigar_slot;
+    const uint32_t *alt_clip;              // [2 * n_alignments] or null: (leading, trailing) bases of alternate a that are left out
+                                           // (soft clips: the reference aligns the read minus its soft clips, alignment_utils.rs:47-50)
     uint32_t *cigar, *n_cigar;
     int32_t *alignment_offset;
     uint32_t *slab;                        // backtrack flags, one slab per block

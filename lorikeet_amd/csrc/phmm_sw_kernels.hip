@@ -148,6 +148,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                 ao = p.alt_off[a];
                 n = (int)(p.ref_off[ri + 1] - ro);
                 m = (int)(p.alt_off[a + 1] - ao);
+                if (p.alt_clip) {  // the read minus its soft clips (alignment_utils.rs:47-50)
+                    const uint32_t cl = p.alt_clip[2 * a], cr = p.alt_clip[2 * a + 1];
+                    ao += cl;
+                    m -= (int)(cl + cr);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -361,7 +366,8 @@ void phmm_sw_align_kernel(const SwParams p) {
         // per lane, and the run of diagonal steps among them is taken in one go -- a read of 150 bases is traced in a
         // dozen round trips instead of 150.  Gap cells (rare) are handled one at a time, every lane doing the same.
         if (valid) {
-            CigarOut cig{p.cigar + p.cigar_off[a], p.cigar_off[a + 1] - p.cigar_off[a], l == 0};
+            CigarOut cig{p.cigar + (p.cigar_off ? p.cigar_off[a] : (uint64_t)a * p.cigar_slot),
+                         p.cigar_off ? p.cigar_off[a + 1] - p.cigar_off[a] : (uint64_t)p.cigar_slot, l == 0};
             int32_t alignment_offset = 0;
             if (n == 0 || m == 0) {  // the reference asserts (:65-68, :132-134); the host refuses such input beforehand
                 if (l == 0) p.status[SW_STATUS_EMPTY] = 1u;

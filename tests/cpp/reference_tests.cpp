@@ -444,6 +444,126 @@ static void test_rayon_worker_pattern() {
     ASSERT(good_ok == 100, "%d of 100 neighbouring calls were served", good_ok.load());
 }
 
+// The same pattern for the WHOLE per-region path (haplotype_caller_engine.rs:1311-1357: compute_read_likelihoods, then
+// realign_reads_to_their_best_haplotype): every worker hands one region at a time to phmm_region_submit / phmm_wait on
+// the one shared handle; whatever regions share a flush, every field a worker gets back equals what a lone caller of
+// phmm_region_compute gets (likelihoods to 1e-12: which regions share a launch selects the kernel shape).
+struct RegionIo {
+    std::vector<uint32_t> rro, rho, ro, ho, hco, hc, hs, oco, oc, cig, n_cig;
+    std::vector<uint64_t> oo, rstart, outco;
+    Bytes bases, quals, mapq, haps, keep;
+    std::vector<int32_t> ref, pri, best, status;
+    std::vector<double> out, lk, conf;
+    std::vector<int64_t> pos;
+};
+static RegionIo region_io(const WorkerRegion &g) {
+    RegionIo io;
+    io.rro = {0, (uint32_t)g.reads.size()};
+    io.rho = {0, (uint32_t)g.haps.size()};
+    io.ro = {0};
+    io.ho = {0};
+    io.hco = {0};
+    io.oco = {0};
+    io.outco = {0};
+    for (const auto &r : g.reads) {
+        io.bases.insert(io.bases.end(), r.bases.begin(), r.bases.end());
+        io.quals.insert(io.quals.end(), r.quals.begin(), r.quals.end());
+        io.mapq.push_back(r.mapq);
+        io.ro.push_back((uint32_t)io.bases.size());
+        io.oc.push_back((uint32_t)r.bases.size() << 4);  // <length>M
+        io.oco.push_back((uint32_t)io.oc.size());
+        io.outco.push_back(io.outco.back() + 12);
+    }
+    for (const auto &h : g.haps) {
+        io.haps.insert(io.haps.end(), h.get_bases().begin(), h.get_bases().end());
+        io.ho.push_back((uint32_t)io.haps.size());
+        io.hc.push_back((uint32_t)h.get_bases().size() << 4);
+        io.hco.push_back((uint32_t)io.hc.size());
+        io.hs.push_back(0);
+        io.pri.push_back(AssemblyBasedCallerUtils::haplotype_alignment_tiebreaking_priority(h));
+    }
+    const size_t nr = g.reads.size(), nh = g.haps.size();
+    io.oo = {0, (uint64_t)nr * nh};
+    io.rstart = {4000};
+    io.ref = {0};
+    io.out.assign(nr * nh, 0.0);
+    io.keep.assign(nr, 0);
+    io.best.assign(nr, 0);
+    io.status.assign(nr, 0);
+    io.lk.assign(nr, 0.0);
+    io.conf.assign(nr, 0.0);
+    io.pos.assign(nr, 0);
+    io.cig.assign(12 * nr, 0);
+    io.n_cig.assign(nr, 0);
+    return io;
+}
+static int region_call(phmm_handle *h, RegionIo &io, bool dynamic, bool shared) {
+    phmm_engine_config cfg{};
+    cfg.constant_gcp = 10;
+    cfg.pcr_error_model = 3;
+    cfg.base_quality_score_threshold = 18;
+    cfg.dynamic_read_disqualification = dynamic;
+    cfg.symmetrically_normalize_alleles_to_reference = 1;
+    cfg.log10_global_read_mismapping_rate = -4.5;
+    cfg.read_disqualification_scale = 1.0;
+    cfg.expected_error_rate_per_base = 0.02;
+    const phmm_realign_config rcfg{{10, -15, -30, -5}, PHMM_SW_SOFTCLIP, PHMM_REGION_SKIP_SINGLE_ALLELE, 0.2};
+    if (!shared)
+        return phmm_region_compute(h, &cfg, &rcfg, 1, io.rro.data(), io.rho.data(), io.ro.data(), io.bases.data(), io.quals.data(), nullptr, nullptr,
+                                   io.mapq.data(), nullptr, io.ho.data(), io.haps.data(), io.ref.data(), io.oo.data(), io.pri.data(), io.rstart.data(),
+                                   io.hco.data(), io.hc.data(), io.hs.data(), io.oco.data(), io.oc.data(), io.outco.data(), io.out.data(), io.keep.data(),
+                                   io.best.data(), io.lk.data(), io.conf.data(), io.cig.data(), io.n_cig.data(), io.pos.data(), io.status.data());
+    uint64_t ticket = 0;
+    const int rc = phmm_region_submit(h, &cfg, &rcfg, 1, io.rro.data(), io.rho.data(), io.ro.data(), io.bases.data(), io.quals.data(), nullptr, nullptr,
+                                      io.mapq.data(), nullptr, io.ho.data(), io.haps.data(), io.ref.data(), io.oo.data(), io.pri.data(), io.rstart.data(),
+                                      io.hco.data(), io.hc.data(), io.hs.data(), io.oco.data(), io.oc.data(), io.outco.data(), io.out.data(), io.keep.data(),
+                                      io.best.data(), io.lk.data(), io.conf.data(), io.cig.data(), io.n_cig.data(), io.pos.data(), io.status.data(), &ticket);
+    return rc ? rc : phmm_wait(h, ticket);
+}
+static void test_region_pipeline_worker_pattern() {
+    const int T = 8, per_thread = 16;
+    std::vector<std::vector<WorkerRegion>> regions(T);
+    std::vector<std::vector<RegionIo>> want(T), got(T);
+    detail::Handle lone = detail::make_handle(0, 0);
+    int realigned = 0, single = 0;
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < per_thread; ++k) {
+            regions[t].push_back(random_region(77000 + 100 * t + k));
+            want[t].push_back(region_io(regions[t].back()));
+            got[t].push_back(region_io(regions[t].back()));
+            ASSERT(region_call(lone.get(), want[t].back(), (t + k) % 2, false) == PHMM_OK, "lone call: %s", phmm_last_error(lone.get()));
+            for (int32_t st : want[t].back().status) realigned += st == PHMM_PROJECT_REALIGNED;
+            single += regions[t].back().haps.size() == 1;
+        }
+    ASSERT(realigned > 200 && single > 0, "%d reads realigned, %d single-allele regions", realigned, single);
+    phmm_handle *shared = detail::shared_handle(0);
+    std::atomic<int> failed{0}, mismatches{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            for (int rep = 0; rep < 3; ++rep)
+                for (int k = 0; k < per_thread; ++k) {
+                    RegionIo &g = got[t][k];
+                    const RegionIo &w = want[t][k];
+                    if (region_call(shared, g, (t + k) % 2, true) != PHMM_OK) {
+                        ++failed;
+                        continue;
+                    }
+                    bool same = g.keep == w.keep && g.best == w.best && g.status == w.status && g.pos == w.pos && g.n_cig == w.n_cig && g.cig == w.cig;
+                    for (size_t i = 0; same && i < g.out.size(); ++i) same = std::fabs(g.out[i] - w.out[i]) <= 1e-12;
+                    for (size_t i = 0; same && i < g.lk.size(); ++i)
+                        same = std::fabs(g.lk[i] - w.lk[i]) <= 1e-12 && (std::fabs(g.conf[i] - w.conf[i]) <= 1e-12 || (std::isnan(g.conf[i]) && std::isnan(w.conf[i])));
+                    if (!same) ++mismatches;
+                }
+        });
+    for (auto &x : th) x.join();
+    ASSERT(failed == 0, "%d calls failed: %s", failed.load(), phmm_last_error(shared));
+    ASSERT(mismatches == 0, "%d regions differ from the lone caller's results", mismatches.load());
+    uint64_t flushes = 0, subs = 0;
+    phmm_submit_stats(shared, &flushes, &subs);
+    ASSERT(flushes <= subs, "flushes %llu, submissions %llu", (unsigned long long)flushes, (unsigned long long)subs);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // tests/smith_waterman_aligner_unit_tests.rs: the asserted cases (:228-318, :380-400) and the flank-length
 // property (:320-378), through the mirrored SmithWatermanAligner
@@ -660,6 +780,7 @@ int main(int argc, char **argv) {
         {"test_compute_likelihoods", test_compute_likelihoods},
         {"error_behaviour", test_error_behaviour},
         {"rayon_worker_pattern (threads share one engine handle)", test_rayon_worker_pattern},
+        {"region_pipeline_worker_pattern (likelihoods + realignment, threads share one engine handle)", test_region_pipeline_worker_pattern},
         {"smith_waterman_asserted_cases", test_smith_waterman_asserted_cases},
         {"test_for_identical_alignments_with_differing_flank_lengths", test_for_identical_alignments_with_differing_flank_lengths},
         {"test_best_alleles + realignment to the best haplotype", test_best_alleles},

@@ -25,11 +25,12 @@ REFERENCE = "/root/reference"
 
 C_SCALARS = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64",
              "int32_t": "i32", "int64_t": "i64", "double": "f64", "size_t": "usize", "char": "c_char", "void": "void",
-             "phmm_handle": "phmm_handle", "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config", "phmm_sw_parameters": "phmm_sw_parameters"}
+             "phmm_handle": "phmm_handle", "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config", "phmm_sw_parameters": "phmm_sw_parameters",
+             "phmm_realign_config": "phmm_realign_config"}
 RS_SCALARS = {"c_int": "i32", "c_uint": "u32", "u8": "u8", "u32": "u32", "u64": "u64", "i32": "i32", "i64": "i64", "f64": "f64",
               "usize": "usize", "c_char": "c_char", "c_void": "void", "phmm_handle": "phmm_handle",
               "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config",
-              "phmm_sw_parameters": "phmm_sw_parameters"}
+              "phmm_sw_parameters": "phmm_sw_parameters", "phmm_realign_config": "phmm_realign_config"}
 
 
 def _strip_c(text):
@@ -122,6 +123,10 @@ def test_rust_constants_and_struct_mirror_the_header():
     fields_r = re.findall(r"pub (\w+): (\[u8; \d+\]|u8|f64),", re.search(r"pub struct phmm_engine_config \{(.*?)\}", r, re.S).group(1))
     assert [(n, {"uint8_t": "u8", "double": "f64"}[t] if not arr else "[u8; %s]" % arr[1:-1]) for t, n, arr in fields_c] == \
            [(n, t) for n, t in fields_r]
+    # phmm_realign_config: same fields, same order, same widths
+    fc = re.findall(r"^\s+(phmm_sw_parameters|int32_t|uint32_t|double)\s+(\w+);", re.search(r"typedef struct phmm_realign_config \{(.*?)\}", h, re.S).group(1), re.M)
+    fr = re.findall(r"pub (\w+): (\w+),", re.search(r"pub struct phmm_realign_config \{(.*?)\}", r, re.S).group(1))
+    assert [(n, {"phmm_sw_parameters": "phmm_sw_parameters", "int32_t": "i32", "uint32_t": "u32", "double": "f64"}[t]) for t, n in fc] == fr and len(fr) == 4
 
 
 def test_every_export_is_callable_from_plain_c99():
@@ -194,7 +199,9 @@ def test_the_safe_wrapper_calls_what_the_ffi_declares():
         n = len([a for a in args if a.strip()])
         assert n == arity[name], (name, n, arity[name])
         calls += 1
-    assert calls >= 6
+    assert calls >= 8
+    for name in ("phmm_compute", "phmm_realign_reads", "phmm_region_submit", "phmm_wait", "phmm_calculate_cigar"):
+        assert re.search(r"\b%s\(" % name, backend), name
     for o, c in ("()", "[]", "{}"):
         assert backend.count(o) == backend.count(c), (o, c)
 
@@ -207,7 +214,12 @@ def test_patches_apply_to_the_reference_tree():
     touched = set(re.findall(r"^diff --git a/(\S+)", open(PATCH).read(), flags=re.M))
     assert {"src/pair_hmm/pair_hmm.rs", "src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs", "src/cli.rs",
             "src/assembly/assembly_based_caller_utils.rs", "src/smith_waterman/smith_waterman_aligner.rs",
-            "src/pair_hmm/hip_ffi.rs", "src/pair_hmm/hip_backend.rs", "src/pair_hmm/mod.rs", "build.rs", "Cargo.toml"} <= touched
+            "src/pair_hmm/hip_ffi.rs", "src/pair_hmm/hip_backend.rs", "src/pair_hmm/mod.rs", "build.rs", "Cargo.toml",
+            # round 3: the call sites of the whole per-region path (compute_read_likelihoods ...engine.rs:195-242,
+            # realign_reads_to_their_best_haplotype assembly_based_caller_utils.rs:208-246 with its caller
+            # haplotype_caller_engine.rs:1345-1355, create_read_aligned_to_ref's tail, calculate_cigar cigar_utils.rs:358-457)
+            "src/haplotype/haplotype_caller_engine.rs", "src/model/allele_likelihoods.rs", "src/reads/alignment_utils.rs",
+            "src/reads/cigar_utils.rs"} <= touched
     assert open(PATCH).read().count('Arg::new("pairhmm-backend")') == 3   # one per subcommand that has --disable-avx
     # second patch: on a copy of the touched files with the first one applied
     with tempfile.TemporaryDirectory() as d:
@@ -236,3 +248,24 @@ def test_patches_apply_to_the_reference_tree():
         for f in touched:
             if f.endswith(".rs"):
                 assert surplus(os.path.join(d, f)) == surplus(os.path.join(REFERENCE, f)), f
+
+
+def test_the_patch_binds_every_call_site_of_the_path():
+    """What the hunks must contain (textual: no Rust toolchain here): the engine-level call and the realignment are routed
+    to the device under AVXMode::Hip, the realignment picks up what the engine-level call left for it, and calculate_cigar
+    has its device arm; every cfg(feature = "hip") statement guard is a block (attributes on `if` expressions do not compile)."""
+    patch = open(PATCH).read()
+    def hunk(path):
+        return patch.split("diff --git a/%s b/%s" % (path, path), 1)[1].split("\ndiff --git", 1)[0]
+    eng = hunk("src/pair_hmm/pair_hmm_likelihood_calculation_engine.rs")
+    assert "fn compute_read_likelihoods_hip" in eng and "hip_backend::region_compute(" in eng and "hip_backend::stash_realignment(" in eng
+    assert "remove_poorly_modeled_evidence(s, removed)" in eng and "fn remove_poorly_modeled_evidence" in hunk("src/model/allele_likelihoods.rs")
+    asm = hunk("src/assembly/assembly_based_caller_utils.rs")
+    assert "fn realign_reads_to_their_best_haplotype_hip" in asm and "hip_backend::take_realignment(" in asm and "hip_backend::realign_reads(" in asm
+    assert "AlignmentUtils::apply_realignment(" in asm and "pub fn apply_realignment" in hunk("src/reads/alignment_utils.rs")
+    assert 'args.get_one::<String>("pairhmm-backend")' in hunk("src/haplotype/haplotype_caller_engine.rs")
+    assert "hip_backend::calculate_cigars(" in hunk("src/reads/cigar_utils.rs")
+    added = [l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++")]
+    for i, l in enumerate(added[:-1]):
+        if l.strip() == '#[cfg(feature = "hip")]':
+            assert not added[i + 1].strip().startswith("if "), added[i + 1]

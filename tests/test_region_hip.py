@@ -1,0 +1,286 @@
+"""phmm_region_compute / phmm_region_submit on the MI355X: the whole per-region path in one enqueue -- pre-step, PairHMM,
+normalisation + disqualification, best alleles, Smith-Waterman to the best haplotype, projection onto the reference --
+EQUAL, field by field, to phmm_engine_compute followed by phmm_realign_reads (the two calls it fuses), and to the oracle
+pipeline built from the pieces the reference's own tests pin (tests/test_engine_oracle.py, test_best_alleles_oracle.py,
+test_sw_oracle.py, test_cigar_oracle.py).  Reference: src/haplotype/haplotype_caller_engine.rs:1311-1357."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from lorikeet_amd import _lib, realign, region, synthetic
+from lorikeet_amd.batch import Read, RegionBatch
+from lorikeet_amd.engine import HipPairHMMEngine, PhmmError
+from oracle import oracle
+
+from project_scenarios import oracle_read as _oracle_read, scenario as _scenario
+
+pytestmark = pytest.mark.gpu
+MODELS = ["none", "hostile", "aggressive", "conservative"]
+
+
+def _cfg(pcr=3, symmetric=True, dynamic=False, gcp=10, cap=-4.5, disable_cap=False, bq=18, scale=1.0, err=0.02):
+    c = _lib.EngineConfig()
+    c.constant_gcp, c.pcr_error_model, c.base_quality_score_threshold = gcp, pcr, bq
+    c.dynamic_read_disqualification, c.symmetrically_normalize_alleles_to_reference = int(dynamic), int(symmetric)
+    c.disable_cap_read_qualities_to_mapq = int(disable_cap)
+    c.log10_global_read_mismapping_rate, c.read_disqualification_scale, c.expected_error_rate_per_base = cap, scale, err
+    return c
+
+
+def _engine_compute(eng, cfg, b, mapq, ref_hap):
+    p = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+    out, keep = np.full(b.n_out, np.nan), np.zeros(b.n_reads, np.uint8)
+    mq, rr = np.ascontiguousarray(mapq, np.uint8), np.ascontiguousarray(ref_hap, np.int32)
+    code = eng.lib.phmm_engine_compute(eng._h, C.byref(cfg), b.n_regions, p(b.region_read_off, _lib.u32p), p(b.region_hap_off, _lib.u32p),
+                                       p(b.read_off, _lib.u32p), p(b.read_bases, _lib.u8p), p(b.base_q, _lib.u8p), p(b.ins_q, _lib.u8p),
+                                       p(b.del_q, _lib.u8p), p(mq, _lib.u8p), p(b.hap_off, _lib.u32p), p(b.hap_bases, _lib.u8p),
+                                       p(rr, C.POINTER(C.c_int32)), p(b.out_off, _lib.u64p), p(out, _lib.f64p), p(keep, _lib.u8p))
+    if code != _lib.PHMM_OK:
+        raise PhmmError(code, eng.last_error())
+    return out, keep
+
+
+def _same(got, out, keep, best, proj, exact=True):
+    if exact:
+        assert np.array_equal(got.likelihoods, out)
+    else:
+        assert np.max(np.abs(got.likelihoods - out)) < 1e-11
+    assert np.array_equal(got.keep, keep.astype(bool))
+    assert np.array_equal(got.best.allele_index, best.allele_index)
+    if exact:
+        assert np.array_equal(got.best.likelihood, best.likelihood) and np.array_equal(got.best.confidence, best.confidence, equal_nan=True)
+    assert np.array_equal(got.reads.status, proj.status) and np.array_equal(got.reads.new_pos, proj.new_pos)
+    for r in range(len(proj.cigars)):
+        assert np.array_equal(got.reads.cigars[r], proj.cigars[r]), r
+
+
+def _priorities(b, hap_cigars, ref_hap):
+    is_ref = np.zeros(b.n_haps, np.int32)
+    for g in range(b.n_regions):
+        is_ref[int(b.region_hap_off[g]) + ref_hap[g]] = 1
+    return realign.haplotype_alignment_tiebreaking_priority(is_ref, [len(c) for c in hap_cigars])
+
+
+def _noisy_quals(b, seed):
+    """Scenario reads come with flat Q30 / Q45: give them the spread the pre-step reacts to."""
+    rng = np.random.default_rng(seed)
+    b.base_q[:] = rng.choice([37, 32, 27, 22, 12, 6, 2], len(b.base_q), p=[.5, .15, .1, .1, .08, .05, .02])
+    b.ins_q[:] = rng.integers(20, 46, len(b.ins_q))
+    b.del_q[:] = rng.integers(20, 46, len(b.del_q))
+    return rng.choice([60, 60, 40, 25, 10], b.n_reads).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed,pcr,symmetric,dynamic,low", [(1, 3, True, False, False), (2, 0, False, True, False), (3, 1, True, True, True),
+                                                             (4, 2, False, False, True), (5, 3, True, False, False)])
+def test_region_call_equals_the_two_calls_it_fuses(hip_engine, seed, pcr, symmetric, dynamic, low):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(seed, n_regions=7, low_complexity=low)
+    mapq = _noisy_quals(b, seed)
+    cfg = _cfg(pcr=pcr, symmetric=symmetric, dynamic=dynamic)
+    pri = _priorities(b, hap_cigars, ref_hap)
+    out, keep = _engine_compute(hip_engine, cfg, b, mapq, ref_hap)
+    best, proj = realign.realign_reads(hip_engine, b, out, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri, keep=keep)
+    got = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri)
+    _same(got, out, keep, best, proj)
+    assert (got.reads.status == 0).sum() > b.n_reads // 3
+    # the same through the shared queue
+    got2 = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri, shared=True)
+    _same(got2, out, keep, best, proj)
+
+
+def _oracle_pipeline(cfg, b, mapq, ref_hap, pri):
+    """engine.rs:195-242 + allele_likelihoods.rs:457-554 with the oracle's pieces -> (normalised [read][hap] flat, keep, best)."""
+    out, keep, best = np.zeros(b.n_out), np.zeros(b.n_reads, bool), np.full(b.n_reads, -1, np.int32)
+    for g in range(b.n_regions):
+        r0, r1, h0, h1 = (int(x) for x in (b.region_read_off[g], b.region_read_off[g + 1], b.region_hap_off[g], b.region_hap_off[g + 1]))
+        reads, thr = [], []
+        for r in range(r0, r1):
+            s, e = int(b.read_off[r]), int(b.read_off[r + 1])
+            q, i, d = oracle.modify_read_qualities(MODELS[cfg.pcr_error_model], b.read_bases[s:e], int(mapq[r]), b.base_q[s:e], b.ins_q[s:e], b.del_q[s:e],
+                                                   cfg.base_quality_score_threshold, bool(cfg.disable_cap_read_qualities_to_mapq))
+            reads.append(Read(b.read_bases[s:e], q, i, d, np.full(e - s, cfg.constant_gcp, np.uint8)))
+            thr.append(oracle.read_disqualification_threshold(b.base_q[s:e], bool(cfg.dynamic_read_disqualification), cfg.read_disqualification_scale,
+                                                              cfg.expected_error_rate_per_base))
+        haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(h0, h1)]
+        rb = RegionBatch.from_regions([(reads, haps)])
+        raw = oracle.compute_batch(rb.as_dict(), n_threads=4).reshape(r1 - r0, h1 - h0)
+        norm = oracle.normalize_likelihoods(raw.T.copy(), cfg.log10_global_read_mismapping_rate, bool(cfg.symmetrically_normalize_alleles_to_reference), ref_hap[g])
+        _, kp, _ = oracle.filter_poorly_modeled_evidence(norm.copy(), thr)
+        out[int(b.out_off[g]):int(b.out_off[g]) + norm.size] = norm.T.reshape(-1)
+        keep[r0:r1] = kp
+        wb, _, _ = oracle.best_alleles(norm, pri[h0:h1], 0.2)
+        best[r0:r1] = np.where(kp, wb, -1)
+    return out, keep, best
+
+
+@pytest.mark.parametrize("seed,low", [(21, False), (22, True)])
+def test_region_call_equals_the_oracle_pipeline(hip_engine, seed, low):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(seed, n_regions=5, low_complexity=low)
+    mapq = _noisy_quals(b, seed)
+    cfg = _cfg(pcr=3, dynamic=True)
+    pri = _priorities(b, hap_cigars, ref_hap)
+    got = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri)
+    out, keep, best = _oracle_pipeline(cfg, b, mapq, ref_hap, pri)
+    assert np.max(np.abs(got.likelihoods - out)) < 1e-9
+    assert np.array_equal(got.keep, keep) and np.array_equal(got.best.allele_index, best)
+    reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+    n_ok = 0
+    for r in range(b.n_reads):
+        st, pos, cig = _oracle_read(b, r, reg[r], best[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        assert got.reads.status[r] == st, (r, got.reads.status[r], st)
+        if st == 0:
+            assert got.reads.new_pos[r] == pos and oracle.cigar_to_string(got.reads.cigars[r]) == cig, r
+            n_ok += 1
+    assert n_ok > b.n_reads // 3 and (~keep).sum() >= 0
+
+
+def test_soft_clipped_reads_are_aligned_without_their_clips(hip_engine):
+    """modify_soft_clipped_bases: the PairHMM sees the whole read, the aligner the read minus its soft clips
+    (alignment_utils.rs:47-50) -- the same as the two separate calls on the two versions of the reads."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, _ = _scenario(31, n_regions=5)
+    rng = np.random.default_rng(31)
+    regions_full, clips, orig = [], [], []
+    for g in range(b.n_regions):
+        reads = []
+        for r in range(int(b.region_read_off[g]), int(b.region_read_off[g + 1])):
+            core = bytes(b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])])
+            cl, cr = (int(rng.integers(0, 9)) * int(rng.random() < 0.5) for _ in range(2))
+            full = bytes(rng.choice(list(b"ACGT"), cl).astype(np.uint8)) + core + bytes(rng.choice(list(b"ACGT"), cr).astype(np.uint8))
+            n = len(full)
+            reads.append(Read(full, np.full(n, 30, np.uint8), np.full(n, 45, np.uint8), np.full(n, 45, np.uint8), np.full(n, 10, np.uint8)))
+            clips.append((cl, cr))
+            orig.append(oracle.parse_cigar(("%dS" % cl if cl else "") + "%dM" % len(core) + ("%dS" % cr if cr else "")))
+        haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(int(b.region_hap_off[g]), int(b.region_hap_off[g + 1]))]
+        regions_full.append((reads, haps))
+    bf = RegionBatch.from_regions(regions_full)
+    mapq = np.full(bf.n_reads, 60, np.uint8)
+    cfg = _cfg(pcr=0)
+    out, keep = _engine_compute(hip_engine, cfg, bf, mapq, ref_hap)                       # the likelihoods of the WHOLE reads
+    best, proj = realign.realign_reads(hip_engine, b, out, hap_cigars, hap_starts, ref_hap, ref_start, orig, keep=keep)  # b: the clipped reads
+    got = region.region_compute(hip_engine, cfg, bf, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig, read_soft_clip=np.array(clips, np.uint32))
+    _same(got, out, keep, best, proj)
+    assert sum(1 for c in clips if c != (0, 0)) > 5
+
+
+def test_single_allele_regions_are_not_realigned_when_asked(hip_engine):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(41, n_regions=4)
+    # cut region 1 and 3 down to their reference haplotype
+    regions, hc, hs = [], [], []
+    for g in range(b.n_regions):
+        reads = [Read(b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])], *(x[int(b.read_off[r]):int(b.read_off[r + 1])] for x in (b.base_q, b.ins_q, b.del_q, b.gcp)))
+                 for r in range(int(b.region_read_off[g]), int(b.region_read_off[g + 1]))]
+        a0, a1 = int(b.region_hap_off[g]), int(b.region_hap_off[g + 1])
+        if g % 2:
+            a1 = a0 + 1
+        regions.append((reads, [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(a0, a1)]))
+        hc += hap_cigars[a0:a1]
+        hs += hap_starts[a0:a1]
+    b2 = RegionBatch.from_regions(regions)
+    mapq = np.full(b2.n_reads, 60, np.uint8)
+    cfg = _cfg()
+    full = region.region_compute(hip_engine, cfg, b2, mapq, hc, hs, ref_hap, ref_start, orig_cigars)
+    skip = region.region_compute(hip_engine, cfg, b2, mapq, hc, hs, ref_hap, ref_start, orig_cigars, rcfg=region.realign_config(skip_single_allele=True))
+    reg = np.repeat(np.arange(b2.n_regions), np.diff(b2.region_read_off.astype(np.int64)))
+    single = (reg % 2) == 1
+    assert np.array_equal(full.likelihoods, skip.likelihoods) and np.array_equal(full.best.allele_index, skip.best.allele_index)
+    assert np.all(skip.reads.status[single] == _lib.PHMM_PROJECT_UNCHANGED) and np.any(full.reads.status[single] == 0)
+    assert np.array_equal(full.reads.status[~single], skip.reads.status[~single])
+    for r in np.flatnonzero(~single):
+        assert np.array_equal(full.reads.cigars[r], skip.reads.cigars[r])
+
+
+def _uniform_extras(b, H):
+    hap_cigars = [oracle.parse_cigar("%dM" % H)] * b.n_haps
+    orig = [oracle.parse_cigar("%dM" % (int(b.read_off[r + 1]) - int(b.read_off[r]))) for r in range(b.n_reads)]
+    return hap_cigars, [0] * b.n_haps, [0] * b.n_regions, [1000 * (g + 1) for g in range(b.n_regions)], orig
+
+
+def test_large_call_is_pipelined_transparently(hip_engine):
+    """96 regions of 128 x 8 (1.8 MB per array): chunks through the three slots, equal to the one-shot path."""
+    b = synthetic.make_regions(96, 128, 8, 300, [100, 150, 250], seed=5)
+    hap_cigars, hs, ref_hap, ref_start, orig = _uniform_extras(b, 300)
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    cfg = _cfg()
+    with hip_engine.switches(no_pipeline=1):
+        one = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hs, ref_hap, ref_start, orig)
+    got = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hs, ref_hap, ref_start, orig)
+    _same(got, one.likelihoods, one.keep, one.best, one.reads, exact=False)
+    out, keep = _engine_compute(hip_engine, cfg, b, mapq, ref_hap)
+    best, proj = realign.realign_reads(hip_engine, b, out, hap_cigars, hs, ref_hap, ref_start, orig, keep=keep)
+    _same(got, out, keep, best, proj, exact=False)
+    assert (got.reads.status == 0).sum() > b.n_reads * 0.7
+
+
+def test_concurrent_workers_share_one_handle(hip_engine):
+    """The reference's pattern: every worker calls with one region; the shared handle computes the waiting workers'
+    regions together (phmm_region_submit / phmm_wait) -- results equal to a lone caller's."""
+    T, per = 8, 6
+    shared = HipPairHMMEngine(0)
+    jobs = []
+    for t in range(T):
+        for k in range(per):
+            b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(500 + 10 * t + k, n_regions=1 + (k % 3))
+            jobs.append((t, b, _noisy_quals(b, t * 100 + k), hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars))
+    cfg = _cfg(pcr=3)
+    want = [region.region_compute(hip_engine, cfg, j[1], *j[2:]) for j in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def worker(t):
+        try:
+            for i, j in enumerate(jobs):
+                if j[0] == t:
+                    got[i] = region.region_compute(shared, cfg, j[1], *j[2:], shared=True)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for g, w in zip(got, want):
+        _same(g, w.likelihoods, w.keep, w.best, w.reads, exact=False)
+    flushes, subs = shared.submit_stats()
+    assert subs == len(jobs) and flushes <= subs
+    shared.close()
+
+
+def test_alignments_that_outgrow_the_library_slots_are_redone(hip_engine):
+    """A read that needs more than 24 CIGAR elements against its haplotype: the call runs that batch again with larger slots."""
+    rng = np.random.default_rng(7)
+    hap = bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    read = bytearray()
+    for k in range(0, 660, 44):   # 15 segments, a 3-base deletion between each pair: 29 elements
+        read += hap[k:k + 41]
+    reads = [Read(bytes(read), np.full(len(read), 30, np.uint8), np.full(len(read), 45, np.uint8), np.full(len(read), 45, np.uint8), np.full(len(read), 10, np.uint8))]
+    b = RegionBatch.from_regions([(reads, [hap])])
+    extras = ([oracle.parse_cigar("700M")], [0], [0], [5000], [oracle.parse_cigar("%dM" % len(read))])
+    cfg = _cfg(pcr=0, cap=-1000.0, dynamic=True, err=1.0)  # (a threshold that keeps a read with fourteen deletions)
+    got = region.region_compute(hip_engine, cfg, b, np.array([60], np.uint8), *extras, capacity=64)
+    assert got.keep[0]
+    st, pos, cig = _oracle_read(b, 0, 0, 0, *extras)
+    assert st == 0 and got.reads.status[0] == 0 and got.reads.new_pos[0] == pos and oracle.cigar_to_string(got.reads.cigars[0]) == cig
+    assert cig.count("D") >= 13
+
+
+def test_argument_errors(hip_engine):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(61, n_regions=2)
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    with pytest.raises(PhmmError) as e:
+        region.region_compute(hip_engine, _cfg(pcr=7), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "PCR" in str(e.value)
+    with pytest.raises(PhmmError) as e:
+        region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, [-1, 0], ref_start, orig_cigars)
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "reference haplotype" in str(e.value)
+    with pytest.raises(PhmmError) as e:
+        region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars,
+                              read_soft_clip=np.full((b.n_reads, 2), 500, np.uint32))
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "soft clips" in str(e.value)
+    with pytest.raises(PhmmError) as e:
+        region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, shared=True,
+                              rcfg=region.realign_config(overhang_strategy=9))
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG
+    # too small output slots: reported with the sizes, the mirror retries (capacity=1 first)
+    got = region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, capacity=1)
+    want = region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+    _same(got, want.likelihoods, want.keep, want.best, want.reads)

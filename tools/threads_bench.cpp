@@ -5,6 +5,9 @@
 //   shared  all threads share one handle and call phmm_submit + phmm_wait (cross-thread batching)
 //   pipeline (TB_MODE=pipeline only)  own handles; per call phmm_compute and then phmm_realign_reads with its likelihoods
 //   realign  (TB_MODE=realign only)   own handles; phmm_realign_reads alone, on likelihoods computed beforehand
+//   fused    (TB_MODE=fused only)     own handles; phmm_region_compute: pre-step, PairHMM, post-step, best alleles, alignments,
+//                                     projection in ONE call -- the likelihoods never leave the device in between
+//   gshared  (TB_MODE=gshared only)   one shared handle; phmm_region_submit + phmm_wait (the fused call, batched across threads)
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
 // env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>
 #include <atomic>
@@ -21,7 +24,7 @@
 struct Region {
     std::vector<uint32_t> rro, rho, ro, ho;
     std::vector<uint64_t> oo;
-    std::vector<uint8_t> bases, q, iq, dq, gcp, haps;
+    std::vector<uint8_t> bases, q, iq, dq, gcp, haps, mapq, keep;
     std::vector<double> out;
     uint64_t cells = 0;
     // what phmm_realign_reads takes besides (mode "pipeline"): priorities, reference haplotype / start per region, the
@@ -98,6 +101,8 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_c
     g.best.assign(n_reads, 0);
     g.lk.assign(n_reads, 0.0);
     g.conf.assign(n_reads, 0.0);
+    g.mapq.assign(n_reads, 60);
+    g.keep.assign(n_reads, 0);
     return g;
 }
 
@@ -132,6 +137,26 @@ static int call_realign(phmm_handle *h, Region &g) {
                               g.n_cig.data(), g.pos.data(), g.status.data(), g.best.data(), g.lk.data(), g.conf.data());
 }
 
+// the whole per-region path in one call (the engine-level pre- and post-step included)
+static const phmm_engine_config kCfg{10, 3, 18, 0, 1, 0, {0, 0}, -4.5, 1.0, 0.02};
+static const phmm_realign_config kRcfg{{10, -15, -30, -5}, PHMM_SW_SOFTCLIP, 0u, 0.2};
+static int call_fused(phmm_handle *h, Region &g) {
+    return phmm_region_compute(h, &kCfg, &kRcfg, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(),
+                               g.iq.data(), g.dq.data(), g.mapq.data(), nullptr, g.ho.data(), g.haps.data(), g.ref_hap.data(), g.oo.data(), g.pri.data(),
+                               g.rstart.data(), g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(), g.out_cig_off.data(),
+                               g.out.data(), g.keep.data(), g.best.data(), g.lk.data(), g.conf.data(), g.cig.data(), g.n_cig.data(), g.pos.data(),
+                               g.status.data());
+}
+static int call_fused_shared(phmm_handle *h, Region &g) {
+    uint64_t t = 0;
+    int st = phmm_region_submit(h, &kCfg, &kRcfg, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(),
+                                g.iq.data(), g.dq.data(), g.mapq.data(), nullptr, g.ho.data(), g.haps.data(), g.ref_hap.data(), g.oo.data(),
+                                g.pri.data(), g.rstart.data(), g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(),
+                                g.out_cig_off.data(), g.out.data(), g.keep.data(), g.best.data(), g.lk.data(), g.conf.data(), g.cig.data(),
+                                g.n_cig.data(), g.pos.data(), g.status.data(), &t);
+    return st ? st : phmm_wait(h, t);
+}
+
 int main(int argc, char **argv) {
     const double dur = argc > 1 ? atof(argv[1]) : 1.0;
     const int nr = argc > 5 ? atoi(argv[2]) : 128, nh = argc > 5 ? atoi(argv[3]) : 8, R = argc > 5 ? atoi(argv[4]) : 150,
@@ -151,11 +176,12 @@ int main(int argc, char **argv) {
         }
     }
     const char *only = getenv("TB_MODE");  // "own", "shared" or "pipeline": just that one (pipeline only when asked for)
-    for (int mode = 0; mode < 4; ++mode) {
-        if (only ? only[0] != "ospr"[mode] : mode >= 2) continue;
+    for (int mode = 0; mode < 6; ++mode) {
+        if (only ? only[0] != "osprfg"[mode] : mode >= 2) continue;
+        const bool one_handle = mode == 1 || mode == 5;
         for (int T : Ts) {
             std::vector<phmm_handle *> hs;
-            for (int i = 0; i < (mode != 1 ? T : 1); ++i) {
+            for (int i = 0; i < (!one_handle ? T : 1); ++i) {
                 hs.push_back(phmm_create(0, getenv("TB_FLAGS") ? (unsigned)atoi(getenv("TB_FLAGS")) : 0u));
                 if (!hs.back()) {
                     fprintf(stderr, "phmm_create: %s\n", phmm_last_error(nullptr));
@@ -172,8 +198,8 @@ int main(int argc, char **argv) {
             std::vector<std::thread> th;
             for (int t = 0; t < T; ++t)
                 th.emplace_back([&, t] {
-                    phmm_handle *h = hs[mode != 1 ? t : 0];
-                    auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : call_realign;
+                    phmm_handle *h = hs[!one_handle ? t : 0];
+                    auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : mode == 3 ? call_realign : mode == 4 ? call_fused : call_fused_shared;
                     for (int k = 0; k < 4; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
                         if ((mode == 3 && call_own(h, regs[t][k])) || call(h, regs[t][k])) failed = 1;
                     while (!go.load()) std::this_thread::yield();
@@ -189,22 +215,22 @@ int main(int argc, char **argv) {
                 });
             std::this_thread::sleep_for(std::chrono::milliseconds(200));
             uint64_t f0 = 0, s0 = 0, f1 = 0, s1 = 0;
-            if (mode == 1) phmm_submit_stats(hs[0], &f0, &s0);
+            if (one_handle) phmm_submit_stats(hs[0], &f0, &s0);
             const auto t0 = std::chrono::steady_clock::now();
             go = true;
             std::this_thread::sleep_for(std::chrono::duration<double>(dur));
             stop = true;
             for (auto &x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (mode == 1) phmm_submit_stats(hs[0], &f1, &s1);
+            if (one_handle) phmm_submit_stats(hs[0], &f1, &s1);
             if (failed) {
                 fprintf(stderr, "a call failed: %s\n", phmm_last_error(hs[0]));
                 return 1;
             }
             const double rate = n_calls * per_call / dt;
-            printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : "realign", T,
+            printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : mode == 3 ? "realign" : mode == 4 ? "fused" : "gshared", T,
                    rate, rate * regs[0][0].cells / per_call / 1e9, dt * T / (double)n_calls * 1e6);
-            if (mode == 1) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
+            if (one_handle) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
             printf("\n");
             fflush(stdout);
             for (auto *h : hs) phmm_destroy(h);
