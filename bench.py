@@ -504,7 +504,16 @@ def main():
                 # projection onto the reference), as the reference's region loop goes on
                 "likelihoods_then_realignment_one_region_per_call_1_thread": point("pipeline", 1, 1),
                 "likelihoods_then_realignment_one_region_per_call_8_threads": point("pipeline", 8, 1),
-                "likelihoods_then_realignment_eight_regions_per_call_4_threads": point("pipeline", 4, 8)}
+                "likelihoods_then_realignment_eight_regions_per_call_4_threads": point("pipeline", 4, 8),
+                # ... and as ONE call (round 3): phmm_region_compute / phmm_region_submit -- pre-step, PairHMM, exact pass,
+                # post-step, best alleles, Smith-Waterman, projection in one enqueue, the likelihood matrix never leaving
+                # the device (the engine-level pre- and post-step are work the two-call rows above do not do)
+                "region_call_one_region_per_call_1_thread": point("fused", 1, 1),
+                "region_call_one_region_per_call_8_threads_own_handles": point("fused", 8, 1),
+                "region_call_one_region_per_call_8_threads_shared_handle": point("gshared", 8, 1),
+                "region_call_one_region_per_call_32_threads_shared_handle": point("gshared", 32, 1),
+                "region_call_eight_regions_per_call_4_threads_own_handles": point("fused", 4, 8),
+                "region_call_64_regions_per_call_1_thread": point("fused", 1, 64)}
 
     def ragged():
         """Real regions span 3 x 2 ... 5 000 x 128: the planner on a long-tailed mix, resident and through host buffers."""

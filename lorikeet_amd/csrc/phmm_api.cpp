@@ -287,6 +287,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
         env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
         env("PHMM_SUBMIT_LANES", w.submit_lanes);
+        env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
         env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
         env("PHMM_SW_CHUNKS", w.sw_chunks);
         env("PHMM_SW_LANES", w.sw_lanes);
@@ -1951,6 +1952,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "no_rescue") w.no_rescue = value != 0;
     else if (n == "no_xcd_interleave") w.no_xcd_interleave = value != 0;
     else if (n == "trace") w.trace = value != 0;
+    else if (n == "submit_gather_us") w.submit_gather_us = value > 0 ? value : 0;
     else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
     else if (n == "sw_transpose") w.sw_transpose = value < 0 ? -1 : value > 0 ? 1 : 0;

@@ -256,7 +256,10 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
     int status = CIGAR_UNCHANGED;
     int64_t new_pos = 0;
     uint32_t n_out = 0;
-    uint32_t *ws = p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity;
+    // (a small launch keeps the lanes' builders in LDS: every builder operation is a dependent memory access, and a
+    // region per call has too few reads to hide HBM latency behind other lanes)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
+    uint32_t *ws = p.workspace ? p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity;
     Builder A, B, T;
     uint32_t *rtl = ws + 3 * (size_t)p.capacity;
 
@@ -489,7 +492,15 @@ hipError_t launch_calculate_cigar(const CalcParams &p, hipStream_t stream) {
 
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream) {
     if (p.n_reads <= p.r_begin) return hipSuccess;
-    hipLaunchKernelGGL(phmm_project_kernel, dim3((p.n_reads - p.r_begin + 63) / 64), dim3(64), 0, stream, p);
+    const uint32_t n = p.n_reads - p.r_begin;
+    const size_t lds_per_lane = 4ull * p.capacity * 4;
+    if (n <= 4096 && 32 * lds_per_lane <= 64 * 1024) {  // workspace in LDS, half a wave per block (no attribute needed up to 64 KB)
+        ProjectParams q = p;
+        q.workspace = nullptr;
+        hipLaunchKernelGGL(phmm_project_kernel, dim3((n + 31) / 32), dim3(32), 32 * lds_per_lane, stream, q);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(phmm_project_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -142,8 +142,16 @@ __device__ int tandem_repeat_length(const uint8_t *s, int n, int offset) {
 
 }  // namespace
 
+typedef uint32_t prep_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void phmm_prep_reads(const PrepParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t prep_blocks = gridDim.x - (p.stage_n16 + 255) / 256;
+    if (blockIdx.x >= prep_blocks) {  // the copy of the staged inputs, side by side with the pre-step
+        const uint32_t i = (blockIdx.x - prep_blocks) * 256u + threadIdx.x;
+        if (i < p.stage_n16)
+            reinterpret_cast<prep_u32x4 *>(p.stage_dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const prep_u32x4 *>(p.stage_src) + i);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a small batch spreads every read over several waves (a region per call: 128 reads would occupy 128 of the chip's
@@ -337,15 +345,134 @@ __global__ __launch_bounds__(256) void phmm_best_alleles_kernel(const BestParams
     best_allele_of(p, r, lo, !p.keep || p.keep[r], true);
 }
 
-// Both steps for the same read in one launch (phmm_region_compute): the row the post-step has just normalised in device
-// memory is the row the best-allele search reads -- nothing leaves the device in between.
+// The two steps for a read with at most RH alleles, its row held in registers: ONE round trip to memory for the values
+// (and one for the priorities) instead of one per pass and allele -- a thread per read is latency, not bandwidth, and a
+// region per call (the reference's pattern) has only a few hundred of them.  Statement for statement post_read followed by
+// best_allele_of; every loop runs over compile-time indices with `a < nh` guards.
+template <int RH>
+__device__ __forceinline__ void post_best_in_registers(const PostBestParams &p, const uint32_t r, const uint32_t g, const uint32_t nh) {
+    const PostParams &po = p.post;
+    const BestParams &bp = p.best;
+    if (r == 0 && po.status_out) *po.status_out = *po.status_in;
+    const uint32_t h0 = po.region_hap_off[g];
+    const uint64_t at = po.out_off[g] + (uint64_t)(r - po.region_read_off[g]) * nh;
+    double *row = po.out + at;
+    const int ref = po.region_ref_hap ? po.region_ref_hap[g] : -1;
+    double v[RH];
+    int32_t pri[RH];
+#pragma unroll
+    for (int a = 0; a < RH; ++a) {
+        v[a] = (uint32_t)a < nh ? row[a] : -INFINITY;
+        pri[a] = bp.priority && (uint32_t)a < nh ? bp.priority[h0 + a] : 0;
+    }
+    const double threshold_r = po.threshold[r];
+    // ---- post_read ----
+    double best_all = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < RH; ++a)
+        if ((uint32_t)a < nh) best_all = v[a] > best_all ? v[a] : best_all;
+    if (nh > 1 && po.max_likelihood_difference_cap != -INFINITY) {
+        const bool can_be_ref = po.symmetric != 0;
+        const uint32_t first = (can_be_ref || ref != 0) ? 0u : 1u;
+        double best = first == 0 ? v[0] : v[1];
+#pragma unroll
+        for (int a = 1; a < RH; ++a) {
+            if ((uint32_t)a < first + 1 || (uint32_t)a >= nh) continue;
+            if (!can_be_ref && ref == a) continue;
+            best = v[a] > best ? v[a] : best;
+        }
+        const double worst = best + po.max_likelihood_difference_cap;
+#pragma unroll
+        for (int a = 0; a < RH; ++a)
+            if ((uint32_t)a < nh) {
+                const bool raise = v[a] < worst;
+                v[a] = raise ? worst : v[a];
+                if (raise || po.out_final) row[a] = v[a];
+                if (po.out_final) po.out_final[at + a] = v[a];
+            }
+        best_all = best_all > worst ? best_all : worst;
+    } else if (po.out_final) {
+#pragma unroll
+        for (int a = 0; a < RH; ++a)
+            if ((uint32_t)a < nh) po.out_final[at + a] = v[a];
+    }
+    const uint8_t keep = (best_all < threshold_r) ? 0 : 1;
+    po.keep[r] = keep;
+    if (p.keep_final) p.keep_final[r] = keep;
+    // ---- best_allele_of ----
+    int32_t best_out = -1;
+    double lk_out = -INFINITY, conf_out = (-INFINITY) - (-INFINITY);
+    if (nh && keep) {
+        uint32_t best = 0, second = 0;
+        double best_lk = v[0], second_lk = -INFINITY;
+        int32_t best_pri = pri[0], second_pri = pri[0];  // the priorities of `best` / `second`, carried along
+#pragma unroll
+        for (int a = 1; a < RH; ++a) {
+            if ((uint32_t)a >= nh) continue;
+            const double c = v[a];
+            if (c > best_lk) {
+                second = best;
+                second_lk = best_lk;
+                second_pri = best_pri;
+                best = a;
+                best_lk = c;
+                best_pri = pri[a];
+            } else if (c > second_lk) {
+                second = a;
+                second_lk = c;
+                second_pri = pri[a];
+            }
+        }
+        double best_val = best_lk, second_val = second_lk;  // v[best], v[second] (second_val is only read when second != best)
+        if (bp.priority && (best_lk - second_lk) < bp.threshold) {
+            const double top = best_lk;
+#pragma unroll
+            for (int a = 0; a < RH; ++a) {
+                if ((uint32_t)a >= nh) continue;
+                const double c = v[a];
+                if ((uint32_t)a == best || (top - c) > bp.threshold) continue;
+                const int32_t cp = pri[a];
+                if (cp > best_pri) {
+                    second = best;
+                    second_pri = best_pri;
+                    second_val = best_val;
+                    best = a;
+                    best_pri = cp;
+                    best_val = c;
+                } else if (cp > second_pri) {
+                    second = a;
+                    second_pri = cp;
+                    second_val = c;
+                }
+            }
+        }
+        best_lk = best_val;
+        second_lk = second != best ? second_val : -INFINITY;
+        best_out = (int32_t)best;
+        lk_out = best_lk;
+        const double d = best_lk - second_lk;
+        conf_out = fabs(d) < 2.220446049250313e-16 ? 0.0 : d;
+    }
+    bp.best_allele[r] = best_out;
+    bp.likelihood[r] = lk_out;
+    bp.confidence[r] = conf_out;
+    const bool aligned = !(p.skip_single_allele && nh == 1);
+    if (bp.ref_index) bp.ref_index[r] = best_out >= 0 && aligned ? h0 + (uint32_t)best_out : SW_NO_REFERENCE;
+}
+
+// Both steps for the same read in one launch (phmm_region_compute): the row the post-step has just normalised is the row
+// the best-allele search reads -- nothing leaves the device in between.
 __global__ __launch_bounds__(256) void phmm_post_best_reads(const PostBestParams p) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.post.n_reads) return;
-    const uint8_t keep = post_read(p.post, r, true);
-    if (p.keep_final) p.keep_final[r] = keep;
     const uint32_t g = p.post.read_region[r];
     const uint32_t nh = p.post.region_hap_off[g + 1] - p.post.region_hap_off[g];
+    if (nh <= 16) {
+        post_best_in_registers<16>(p, r, g, nh);
+        return;
+    }
+    const uint8_t keep = post_read(p.post, r, true);
+    if (p.keep_final) p.keep_final[r] = keep;
     best_allele_of(p.best, r, g, keep != 0, !(p.skip_single_allele && nh == 1));
 }
 
@@ -371,7 +498,7 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     const size_t waves = (size_t)p.n_reads * p.waves_per_read;
-    hipLaunchKernelGGL(phmm_prep_reads, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds, stream, p);
+    hipLaunchKernelGGL(phmm_prep_reads, dim3((unsigned)((waves + wpb - 1) / wpb + (p.stage_n16 + 255) / 256)), dim3(64 * wpb), lds, stream, p);
     return hipGetLastError();
 }
 

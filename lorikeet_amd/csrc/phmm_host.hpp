@@ -35,6 +35,7 @@ struct Switches {
     int no_xcd_interleave = 0;  // PHMM_NO_XCD_INTERLEAVE: haplotype groups of a run adjacent in the launch instead of 8 blocks apart
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
+    int submit_gather_us = 40;  // PHMM_SUBMIT_GATHER_US: how long the leader of a flush lets submissions that are on their way arrive (0 = never)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
     int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)

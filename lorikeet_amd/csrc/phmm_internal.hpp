@@ -123,6 +123,12 @@ struct PrepParams {
     uint32_t default_indel_qual, constant_gcp, base_quality_score_threshold, disable_cap_to_mapq,
         dynamic_disqualification;
     double read_disqualification_scale, expected_error_rate_per_base;
+    // small calls (phmm_region_compute): the pre-step reads its inputs straight from the caller's pinned mirror while
+    // further blocks of the SAME launch copy the staged block to the device for the kernels behind it (one launch and
+    // one PCIe round trip less than stage-in kernel + pre-step); stage_n16 == 0: nothing to copy
+    const void *stage_src;
+    void *stage_dst;
+    uint32_t stage_n16;    // 16-byte units
 };
 struct PostParams {
     uint32_t n_reads;

@@ -278,10 +278,10 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     }
     char *const res_base = mirror ? mirror : A.dev;  // what only the caller reads
     bool good;
-    if (mirror) {
+    if (mirror) {  // (the inputs are fetched by blocks of the pre-step's launch, below)
         memset(A.host + L.res, 0, 256);
         batch_set_status(b, (uint32_t *)(A.dev + L.status_in));
-        good = ok(h, launch_stage_in(mirror, A.dev, L.in_end, S), "phmm_stage_in_kernel");
+        good = true;
     } else {
         batch_set_status(b, (uint32_t *)(A.dev + L.res));
         good = ok(h, hipMemcpyAsync(A.dev, A.host, L.in_end, hipMemcpyHostToDevice, S), "H2D batch") &&
@@ -291,12 +291,17 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     if (good && nr) {
         PrepParams pp{};
         pp.n_reads = nr;
-        pp.read_off = V.d_read_off;
-        pp.read_bases = (const uint8_t *)(A.dev + L.bases);
-        pp.base_q = (const uint8_t *)(A.dev + L.q0);
-        pp.ins_q = a.ins_q ? (const uint8_t *)(A.dev + L.i0) : nullptr;
-        pp.del_q = a.del_q ? (const uint8_t *)(A.dev + L.d0) : nullptr;
-        pp.mapq = (const uint8_t *)(A.dev + L.mapq);
+        // a small call: the pre-step reads the pinned mirror itself, and its launch carries the copy of everything staged
+        char *const in_base = mirror ? mirror : A.dev;
+        pp.read_off = mirror ? (const uint32_t *)(mirror + ((const char *)V.d_read_off - A.dev)) : V.d_read_off;
+        pp.read_bases = (const uint8_t *)(in_base + L.bases);
+        pp.base_q = (const uint8_t *)(in_base + L.q0);
+        pp.ins_q = a.ins_q ? (const uint8_t *)(in_base + L.i0) : nullptr;
+        pp.del_q = a.del_q ? (const uint8_t *)(in_base + L.d0) : nullptr;
+        pp.mapq = (const uint8_t *)(in_base + L.mapq);
+        pp.stage_src = mirror;
+        pp.stage_dst = A.dev;
+        pp.stage_n16 = mirror ? (uint32_t)((L.in_end + 15) / 16) : 0u;
         pp.pcr_cache = a.cfg.pcr_error_model ? h->d_pcr_cache + 128 * a.cfg.pcr_error_model : nullptr;
         pp.out_q = (uint8_t *)(A.dev + L.q);
         pp.out_ins = (uint8_t *)(A.dev + L.i);

@@ -60,6 +60,9 @@ struct Combiner {
     static constexpr size_t kMaxParts = 256;
     std::mutex mu;
     std::condition_variable cv;
+    std::condition_variable gather_cv;  // the one leader that is letting submissions arrive (below) sleeps here; phmm_submit wakes it
+    bool gathering = false;
+    int gather_us = 40;
     std::deque<uint64_t> queue;  // tickets nobody has picked up yet, in submission order
     std::unordered_map<uint64_t, Submission> live;  // until phmm_wait returns them (element addresses are stable)
     uint64_t next_ticket = 1;
@@ -97,6 +100,7 @@ void combiner_destroy(Combiner *c) {
 
 void combiner_set_switches(Combiner *c, const Switches &sw) {
     std::lock_guard<std::mutex> lk(c->mu);
+    c->gather_us = sw.submit_gather_us;
     for (int l = 0; l < Combiner::kMaxLanes; ++l)
         if (c->lane[l]) c->lane[l]->sw = sw;
 }
@@ -295,6 +299,7 @@ int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
         Combiner *c = new Combiner();
         c->n_lanes = std::min(std::max(h->sw.submit_lanes, 1), (int)Combiner::kMaxLanes);
         c->trace = h->sw.trace != 0;
+        c->gather_us = h->sw.submit_gather_us;
         h->comb = c;
     });
     Combiner *c = h->comb;
@@ -309,6 +314,7 @@ int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
     c->live.emplace(t, std::move(s));
     c->queue.push_back(t);
     *ticket = t;
+    if (c->gathering) c->gather_cv.notify_one();
     return PHMM_OK;
 }
 
@@ -459,12 +465,33 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
             return st;
         }
         int lane = -1;
-        if (me->state == Submission::QUEUED)
+        if (me->state == Submission::QUEUED && !c->gathering)
             for (int l = 0; l < c->n_lanes && lane < 0; ++l)
                 if (!c->lane_busy[l]) lane = l;
-        if (lane < 0) {  // my region is in somebody's flush, or every lane is taken: the finishing leader wakes me
+        if (lane < 0) {  // my region is in somebody's flush (or about to be), or every lane is taken: the finishing leader wakes me
             c->cv.wait(lk);
             continue;
+        }
+        // Under load the workers a finished flush has just released re-submit within microseconds of each other; the first
+        // of them to get here would lead a flush of one or two regions and leave the others to wait for the next free lane
+        // (32 workers, 4 lanes: 5.3 regions per flush where 8 are outstanding per lane).  So a leader that sees more work
+        // outstanding than is queued lets it arrive: until the queue holds an equal share of everything outstanding, for
+        // as long as submissions keep coming (15 us without one ends it), at most gather_us.  A lone caller, or as many
+        // workers as lanes, never waits: their share is one region.
+        {
+            const size_t share = (c->live.size() + (size_t)c->n_lanes - 1) / (size_t)c->n_lanes;
+            if (c->gather_us > 0 && share > 1 && c->queue.size() < share) {
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(c->gather_us);
+                c->gathering = true;
+                for (;;) {
+                    const size_t before = c->queue.size();
+                    const auto t_now = std::chrono::steady_clock::now();
+                    if (before >= share || t_now >= t_end) break;
+                    c->gather_cv.wait_until(lk, std::min(t_end, t_now + std::chrono::microseconds(15)));
+                    if (c->queue.size() == before) break;  // nobody came
+                }
+                c->gathering = false;
+            }
         }
         // Lead one flush: everything queued so far, in order, while it fits one staging pass.  (Measured and dropped:
         // polling instead of sleeping, and a leader that keeps the lane for further flushes -- neither changes the
@@ -480,6 +507,7 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
             c->queue.pop_front();
         }
         c->lane_busy[lane] = true;
+        if (!c->queue.empty()) c->cv.notify_all();  // (what did not fit this flush may find another free lane)
         {
             // A combined flush means the handle is under load: plan it for the share of the chip it will get (the lanes
             // computing right now, this one included) rather than for an empty chip -- 16 threads 53-60 k -> 59-68 k

@@ -92,8 +92,17 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
 #define PHMM_SW_EU 5
 #endif
 // SW_L lanes per alignment (8 / 16 / 32 / 64: 8 ... 1 alignments per wave), K columns per lane
+// Registers: the allocator's own choice.  An occupancy target (amdgpu_waves_per_eu: 4 waves per SIMD up to K = 19, 5 up to
+// K = 12) was worth 2-4 % on the 8 x 19 instance and cost 20-40 spilled VGPRs and 90-150 bytes of scratch per lane in the
+// set-up and backtrack code of a dozen instances (PHMM_SW_FORCE_OCCUPANCY builds it back in for A/B runs); since the sweep
+// updates the row above in place (one register set instead of two) no instance needs scratch.
+#ifdef PHMM_SW_FORCE_OCCUPANCY
+#define PHMM_SW_OCCUPANCY(K) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : K <= PHMM_SW_K4 ? 4 : K <= 26 ? 3 : 2)))
+#else
+#define PHMM_SW_OCCUPANCY(K)
+#endif
 template <int SW_L, int K, bool TR = false>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(K <= 12 ? PHMM_SW_EU : K <= PHMM_SW_K4 ? 4 : K <= 26 ? 3 : 2)))
+__global__ __launch_bounds__(WAVE) PHMM_SW_OCCUPANCY(K)
 void phmm_sw_align_kernel(const SwParams p) {
     // TR: the sweep runs along the ALTERNATE sequence and the lanes share out the reference's rows (K rows per lane) --
     // the same cells in another order.  For a small call of reads against longer haplotypes that is fewer steps of more
@@ -196,13 +205,16 @@ void phmm_sw_align_kernel(const SwParams p) {
         for (int s = 0; s < n_strips; ++s) {
             const bool strip_on = dp && s < my_strips;
             const int j0 = s * strip_cols + l * K;  // columns j0+1 .. j0+K
-            // the row above lives in one of two register sets that swap roles every step (no copies at the loop's back edge)
-            int32_t up_a[K], up_b[K], bgv[K], bb[K];
+            // the row above, updated in place: a cell's diagonal term for its right neighbour is taken (one add, the same add
+            // the neighbour needs anyway) before the cell overwrites its own entry, so one register set suffices
+            int32_t up[K], bgv[K];
+            uint32_t bb4[(K + 3) / 4] = {};              // the lane's bases, four to a register (compared through a byte select)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = j0 + k + 1;
-                bb[k] = (strip_on && j <= nl) ? (int32_t)seq_l[j - 1] : 0x1000;
-                up_a[k] = up_b[k] = row0(j);             // (a lane's first row may fall on either set)
+                // (columns beyond the sequence compute values nobody reads: whatever they compare with)
+                bb4[k / 4] |= ((strip_on && j <= nl) ? (uint32_t)seq_l[j - 1] : 0u) << (8 * (k % 4));
+                up[k] = row0(j);
                 bgv[k] = SW_LOW_INIT | TAG_S;
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
@@ -211,13 +223,13 @@ void phmm_sw_align_kernel(const SwParams p) {
             uint32_t *bt = slab + (size_t)s * strip_stride + lane;
             // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
             int32_t a_next = (int32_t)seq_s[max(-l, 0)];
-            const bool first_strip = s == 0;
+            const bool first_strip = TR ? true : s == 0;  // (the sweep along the alternate has one strip)
             // RAMP: the first SW_L - 1 steps, while lanes are still waiting for their first row -- a lane computes only
             // inside its matrix.  After that every lane computes every step, predicate-free (8 % of the kernel): rows
             // beyond the alignment's last (other alignments of the wave are longer) and strips it does not have produce
             // values nobody reads -- their flag stores land in the slab's unused part -- and only what leaves the lane's
             // registers for LDS or the best-cell bookkeeping asks `live`.
-            auto step = [&](auto ramp_c, const int t, const int32_t (&up)[K], int32_t (&out)[K]) {
+            auto step = [&](auto ramp_c, const int t) {
                 constexpr bool RAMP = decltype(ramp_c)::value;
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
@@ -234,11 +246,12 @@ void phmm_sw_align_kernel(const SwParams p) {
                         h_bg = e_bgh[min(i, ns)];
                     }
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
+                    auto score = [&](int k) { return (uint32_t)a_base == ((bb4[k / 4] >> (8 * (k % 4))) & 0xffu) ? x_match : x_mismatch; };
+                    int32_t step_diag = diag + score(0);                                           // :194-199 (tag: diagonal)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const int32_t d = k ? up[k - 1] : diag;
-                        const int32_t step_diag = d + (a_base == bb[k] ? x_match : x_mismatch);   // :194-199 (tag: diagonal)
                         const int32_t pv = up[k] + x_open_s;                                       // :207-218
+                        const int32_t next_diag = k + 1 < K ? up[k] + score(k + 1) : 0;           // (before up[k] becomes this row's value)
                         const int32_t ev = bgv[k] + x_extend;
                         acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(ev - pv), 31);  // 1: pv > ev, the gap opens here
                         bgv[k] = max(pv, ev);
@@ -249,7 +262,8 @@ void phmm_sw_align_kernel(const SwParams p) {
                         // priority: diagonal, then right (horizontal), then down (:250-266) -- the tags break the ties
                         const int32_t cx = max(step_diag, max(h_bg, bgv[k]));
                         acc_c[k / 16] = __builtin_amdgcn_alignbit((uint32_t)cx, acc_c[k / 16], 2);
-                        left = out[k] = cx & ~3;
+                        left = up[k] = cx & ~3;
+                        step_diag = next_diag;
                     }
                     // (streaming stores: 0.6 bytes per cell that nobody reads before the backtrack -- the flags are a quarter of
                     // the kernel's time, in proportion to their volume)
@@ -267,14 +281,14 @@ void phmm_sw_align_kernel(const SwParams p) {
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
-                    if (live && l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
+                    if (!TR && live && l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
                         e_sw[i] = left;
                         e_bgh[i] = h_bg;
                     }
                     if (live && s == sm && l == lm) {
-                        int32_t v = out[0];
+                        int32_t v = up[0];
 #pragma unroll
-                        for (int k = 1; k < K; ++k) v = (k == km) ? out[k] : v;
+                        for (int k = 1; k < K; ++k) v = (k == km) ? up[k] : v;
                         if constexpr (TR) {
                             bottom[i] = v;               // the last row, column by column
                         } else if (v >= lc_score) {
@@ -286,12 +300,12 @@ void phmm_sw_align_kernel(const SwParams p) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             if constexpr (TR) {          // the last column: this lane's rows, top down (`>=`, as above)
-                                if (j0 + k + 1 <= nl && out[k] >= lc_score) {
-                                    lc_score = out[k];
+                                if (j0 + k + 1 <= nl && up[k] >= lc_score) {
+                                    lc_score = up[k];
                                     lc_row = j0 + k + 1;
                                 }
                             } else if (j0 + k + 1 <= nl) {
-                                bottom[j0 + k + 1] = out[k];
+                                bottom[j0 + k + 1] = up[k];
                             }
                         }
                     }
@@ -301,14 +315,14 @@ void phmm_sw_align_kernel(const SwParams p) {
             // three columns: 50 lanes); rounded up to even (the extra step is nobody's row)
             const int lanes_in_use = min(SW_L, (m_max - s * strip_cols + K - 1) / K);
             const int steps = (n_max + lanes_in_use) & ~1;
-            constexpr int RAMP_STEPS = SW_L & ~1;       // (even: the register sets swap roles every step)
+            constexpr int RAMP_STEPS = SW_L & ~1;       // (even: the loops take two steps at a time)
             for (int t = 0; t < min(RAMP_STEPS, steps); t += 2) {
-                step(std::true_type{}, t, up_a, up_b);
-                step(std::true_type{}, t + 1, up_b, up_a);
+                step(std::true_type{}, t);
+                step(std::true_type{}, t + 1);
             }
             for (int t = RAMP_STEPS; t < steps; t += 2) {
-                step(std::false_type{}, t, up_a, up_b);
-                step(std::false_type{}, t + 1, up_b, up_a);
+                step(std::false_type{}, t);
+                step(std::false_type{}, t + 1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

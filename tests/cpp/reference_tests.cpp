@@ -549,10 +549,12 @@ static void test_region_pipeline_worker_pattern() {
                         ++failed;
                         continue;
                     }
-                    bool same = g.keep == w.keep && g.best == w.best && g.status == w.status && g.pos == w.pos && g.n_cig == w.n_cig && g.cig == w.cig;
+                    bool same = g.keep == w.keep && g.best == w.best && g.status == w.status && g.pos == w.pos && g.n_cig == w.n_cig;
+                    for (size_t r = 0; same && r < g.n_cig.size(); ++r)  // (what lies behind a CIGAR's last element is not defined)
+                        same = std::equal(g.cig.begin() + g.outco[r], g.cig.begin() + g.outco[r] + g.n_cig[r], w.cig.begin() + w.outco[r]);
                     for (size_t i = 0; same && i < g.out.size(); ++i) same = std::fabs(g.out[i] - w.out[i]) <= 1e-12;
-                    for (size_t i = 0; same && i < g.lk.size(); ++i)
-                        same = std::fabs(g.lk[i] - w.lk[i]) <= 1e-12 && (std::fabs(g.conf[i] - w.conf[i]) <= 1e-12 || (std::isnan(g.conf[i]) && std::isnan(w.conf[i])));
+                    auto close = [](double a, double b) { return a == b || (std::isnan(a) && std::isnan(b)) || std::fabs(a - b) <= 1e-12; };  // (-inf / NaN: no best allele)
+                    for (size_t i = 0; same && i < g.lk.size(); ++i) same = close(g.lk[i], w.lk[i]) && close(g.conf[i], w.conf[i]);
                     if (!same) ++mismatches;
                 }
         });
