@@ -28,7 +28,8 @@ namespace {
 #define PHMM_CHAIN32_L 16
 #endif
 constexpr int CL = PHMM_CHAIN32_L;    // lanes per pair
-constexpr int RING = 256;             // ring rows (power of two), shared by the streams; slot RING holds the neutral row
+constexpr int RING = 256;             // ring rows (power of two), shared by the streams
+constexpr int RING_SLOTS = RING + 4 + 1;  // every stream's rows + a guard slot repeating its row 0 (phmm_chain_kernels.hip), then the neutral row
 constexpr int CHAIN_META = CHAIN_MAX_READS + 8;
 constexpr uint32_t X_PAD = 0x100u;    // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;   // read-side code that matches nothing
@@ -43,6 +44,23 @@ static_assert(sizeof(Row32) == 36, "LDS row record (f32)");
 
 __device__ __forceinline__ Row32 lds_row32(const Row32 *rows, int idx) {
     return *reinterpret_cast<const Row32 *>(reinterpret_cast<const unsigned char *>(rows) + __mul24(idx, (int)sizeof(Row32)));
+}
+
+__device__ __forceinline__ Row32 lds_row32_at(uint32_t at, int skip) {  // the record at LDS byte address `at` (+ `skip` records)
+    Row32 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) uint32_t *LdsU32;
+    const LdsU32 w = (LdsU32)(uintptr_t)at + skip * (int)(sizeof(Row32) / 4);
+    uint32_t v[sizeof(Row32) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Row32) / 4); ++i) v[i] = w[i];
+    __builtin_memcpy(&r, v, sizeof r);
+#else
+    (void)at;
+    (void)skip;
+    r = Row32{};
+#endif
+    return r;
 }
 
 // lane n <- lane n-1 inside each group; the group's first lane gets `inject` (0 for M and I): through the DPP `old`
@@ -147,8 +165,8 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
         ho = p.hap_off[h0 + a];
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
-    Row32 *ring = reinterpret_cast<Row32 *>(smem);                     // RING + 1 records
-    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING + 1);    // per stream s at s*(n_sub+1): byte offset of each read
+    Row32 *ring = reinterpret_cast<Row32 *>(smem);                     // RING_SLOTS records
+    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s*(n_sub+1): byte offset of each read
     uint32_t *stot = roff + CHAIN_META;                                // [4] rows of each stream
 
     HapCols<K> hc;
@@ -191,7 +209,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
                 stot[sj] = incl - (sj > 0 ? before : 0u);
             }
         }
-        if (lane == 0) ring[RING] = neutral_row32();
+        if (lane == 0) ring[RING_SLOTS - 1] = neutral_row32();
     }
     lds_wave_sync();
     const int S_max = (int)max(max(stot[0], stot[1]), max(stot[2], stot[3]));
@@ -252,7 +270,9 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
         } else {
             n = neutral_row32();
         }
-        ring[ps * (NM + 1) + (Q & NM)] = n;
+        const int slot = ps * (NM + 2) + (Q & NM);
+        ring[slot] = n;
+        if ((Q & NM) == 0) ring[slot + NM + 1] = n;  // the stream's guard slot
     };
     issue();
     finish(0);
@@ -294,8 +314,10 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     };
 
     int q = LEAD - l;
-    const int my_ring = sid * (NM + 1);
+    const int my_ring = sid * (NM + 2);
+    const uint32_t my_rows = (uint32_t)(uintptr_t)(ring + my_ring);  // (the low half of a flat address into LDS is the LDS address)
     Row32 cA = lds_row32(ring, my_ring + (q & NM)), cB;
+    int q1 = q + 1;
     const int T = (S_max + CL - 1 + 1) & ~1;
     const int phase = (int)((blockIdx.x * 2654435761u) >> 26) & (TPS - 2);
     for (int t0 = 0, t1 = min(T, TPS - phase), tick = 0; t0 < T; t0 = t1, t1 = min(T, t1 + TPS), ++tick) {
@@ -305,19 +327,22 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
             issue();
         }
         for (int t = t0; t < t1; t += 2) {
-            cB = lds_row32(ring, my_ring + ((q + 1) & NM));
+            // rows q + 1 and q + 2 from one address (the guard slot repeats row 0 behind the stream's last row)
+            uint32_t pair_at;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_at) : "v"((uint32_t)(q1 & NM)), "s"((uint32_t)sizeof(Row32)), "v"(my_rows));
+            cB = lds_row32_at(pair_at, 0);
             aM = from_left32(Mp[K - 1], group_head);
             aI = from_left32(Ip[K - 1], group_head);
             aD = from_left_inject32(Dp[K - 1], cA.inj, group_head);
             row_update32<K>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc);
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
-            cA = lds_row32(ring, my_ring + ((q + 2) & NM));
+            cA = lds_row32_at(pair_at, 1);
             bM = from_left32(Mp[K - 1], group_head);
             bI = from_left32(Ip[K - 1], group_head);
             bD = from_left_inject32(Dp[K - 1], cB.inj, group_head);
             row_update32<K>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc);
             if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
-            q += 2;
+            q1 += 2;
         }
     }
 }
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_f32(const ChainPar
 
 // single_k: the K every item of the launch has, or 0 for a mixed launch
 hipError_t PHMM_C32_LAUNCH(int single_k, const ChainParams &cp, hipStream_t stream) {
-    const size_t lds = (size_t)(RING + 1) * sizeof(Row32) + (CHAIN_META + 4) * sizeof(uint32_t);
+    const size_t lds = (size_t)RING_SLOTS * sizeof(Row32) + (CHAIN_META + 4) * sizeof(uint32_t);
 #define PHMM_CASE(KK)                                                                                         \
     if (single_k == KK) {                                                                                     \
         hipLaunchKernelGGL((phmm_forward_chain_f32<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);   \

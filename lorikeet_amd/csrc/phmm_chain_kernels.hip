@@ -43,7 +43,11 @@ constexpr int CL = PHMM_CHAIN_L;     // lanes per pair
 #ifndef PHMM_RING
 #define PHMM_RING 256
 #endif
-constexpr int RING = PHMM_RING;      // ring rows (power of two), shared by the streams; slot RING holds the neutral row
+constexpr int RING = PHMM_RING;      // ring rows (power of two), shared by the streams
+// Every stream's rows are followed by a GUARD slot that repeats its row 0, so the sweep fetches the two rows of a
+// ping-pong pair from ONE address (the second through the immediate offset of the LDS read): 3 instead of 10 address
+// instructions per pair of steps.  Slots: S streams x (RING / S rows + guard), at most RING + 4; then the neutral row.
+constexpr int RING_SLOTS = RING + 4 + 1;
 constexpr int CHAIN_META = CHAIN_MAX_READS + 8;  // per-read offsets of all streams: n_chain + S entries
 constexpr uint32_t X_PAD = 0x100u;   // base code of padding columns (>= H) and read-side code of the SUM row
 constexpr uint32_t X_NONE = 0x102u;  // read-side code that matches nothing
@@ -158,8 +162,8 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
         ho = p.hap_off[h0 + a];
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
-    RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING + 1 records
-    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING + 1);  // per stream s at s*(n_sub+1): byte offset of each read
+    RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING_SLOTS records
+    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s*(n_sub+1): byte offset of each read
     uint32_t *stot = roff + CHAIN_META;                              // [4] rows of each stream
 
     // ---- haplotype columns: real bases, one EDGE column, then padding -------------------------------
@@ -208,7 +212,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
                 stot[sj] = incl - (sj > 0 ? before : 0u);
             }
         }
-        if (lane == 0) ring[RING] = neutral_row();
+        if (lane == 0) ring[RING_SLOTS - 1] = neutral_row();
     }
     lds_wave_sync();
     const int S_max = (int)max(max(stot[0], stot[1]), max(stot[2], stot[3]));  // longest stream (rows)
@@ -273,7 +277,11 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
         } else {
             n = neutral_row();
         }
-        if (producer) ring[ps * (NM + 1) + (Q & NM)] = n;
+        if (producer) {
+            const int slot = ps * (NM + 2) + (Q & NM);
+            ring[slot] = n;
+            if ((Q & NM) == 0) ring[slot + NM + 1] = n;  // the stream's guard slot
+        }
     };
     issue();
     finish(0);
@@ -323,8 +331,11 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
 
     // lane l works on ring position q = t + LEAD - l  (stream position t - l); rows outside the stream are neutral
     int q = LEAD - l;
-    const int my_ring = sid * (NM + 1);  // first slot of this lane's stream (an index, so the LDS address stays 32-bit math)
+    const int my_ring = sid * (NM + 2);  // first slot of this lane's stream (an index, so the LDS address stays 32-bit math)
+    // (LDS byte address of the stream's first slot; q1 = q + 1 is what the loop advances)
+    const uint32_t my_rows = (uint32_t)(uintptr_t)(ring + my_ring);  // (the low half of a flat address into LDS is the LDS address)
     RowConst cA = lds_row(ring, my_ring + (q & NM)), cB;
+    int q1 = q + 1;
     const int T = (S_max + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
     // Outer loop = one producer tick (TPS steps), inner loop = the sweep.  The producer's pending bytes are
     // defined before the inner loop and first used after it, so their loads have a tick to land.
@@ -338,7 +349,12 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
             issue();
         }
         for (int t = t0; t < t1; t += 2) {
-            cB = lds_row(ring, my_ring + ((q + 1) & NM));
+            // rows q + 1 and q + 2 lie next to each other (the guard slot repeats row 0 behind the stream's last row)
+            // (one full-rate v_mad_u32_u24: the compiler turns the 24-bit multiply back into a 32-bit v_mul_lo_u32, a
+            // quarter-rate instruction, plus an add)
+            uint32_t pair_at;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_at) : "v"((uint32_t)(q1 & NM)), "s"((uint32_t)sizeof(RowConst)), "v"(my_rows));
+            cB = lds_row_at(pair_at, 0);
             aM = from_left<CL>(Mp[K - 1], group_head);
             aI = from_left<CL>(Ip[K - 1], group_head);
             aD = from_left_inject(Dp[K - 1], cA.pad1, group_head);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
@@ -346,13 +362,13 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
             // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
             // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
-            cA = lds_row(ring, my_ring + ((q + 2) & NM));
+            cA = lds_row_at(pair_at, 1);
             bM = from_left<CL>(Mp[K - 1], group_head);
             bI = from_left<CL>(Ip[K - 1], group_head);
             bD = from_left_inject(Dp[K - 1], cB.pad1, group_head);
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
             if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
-            q += 2;
+            q1 += 2;
         }
     }
 }
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_k(const ChainParam
 
 // single_k: the K every item of the launch has, or 0 for a mixed launch
 hipError_t PHMM_CHAIN_LAUNCH(int single_k, const ChainParams &cp, hipStream_t stream) {
-    const size_t lds = (size_t)(RING + 1) * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
+    const size_t lds = (size_t)RING_SLOTS * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
 #define PHMM_CASE(KK)                                                                                     \
     if (single_k == KK) {                                                                                 \
         hipLaunchKernelGGL((phmm_forward_chain_k<CL, KK>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp); \

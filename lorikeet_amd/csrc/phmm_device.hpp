@@ -80,6 +80,26 @@ __device__ __forceinline__ RowConst lds_row(const RowConst *rows, int idx) {
                                                __mul24(idx, (int)sizeof(RowConst)));
 }
 
+// The record at LDS byte address `at` (+ `skip` records): nine 64-bit LDS reads off one address register, the record
+// offset in their immediate fields.
+__device__ __forceinline__ RowConst lds_row_at(uint32_t at, int skip) {
+    RowConst r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) unsigned long long *LdsU64;
+    const LdsU64 w = (LdsU64)(uintptr_t)at + skip * (int)(sizeof(RowConst) / 8);
+    unsigned long long v[sizeof(RowConst) / 8];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(RowConst) / 8) - 1; ++i) v[i] = w[i];
+    v[8] = w[8];
+    __builtin_memcpy(&r, v, sizeof r);
+#else
+    (void)at;
+    (void)skip;
+    r = RowConst{};
+#endif
+    return r;
+}
+
 struct LdsView {
     const RowConst *rows;  // index 0 = neutral row, read row r at index r+1
     __device__ __forceinline__ RowConst load(int idx) const { return lds_row(rows, idx); }
