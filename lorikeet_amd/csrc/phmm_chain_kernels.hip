@@ -384,14 +384,17 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
     X(23) X(24) X(25)
 
-template <int CLT>
+// (Round 3: one kernel per RANGE of K -- kChainRange below -- instead of one for all 24 bodies: that one carried 725
+// spilled SGPRs and 12 bytes of scratch per lane and ran a uniform batch 1.5-2 % slower than the body alone.  The
+// planner groups a launch's items by range; launches of different groups go out on parallel streams.)
+template <int CLT, int KLO, int KHI>
 __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams cp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ChainItem it = cp.items[blockIdx.x];
     switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
-#define PHMM_CASE(KK)                        \
-    case KK:                                 \
-        chain_body<CLT, KK>(cp, it, smem);   \
+#define PHMM_CASE(KK)                                                  \
+    case KK:                                                           \
+        if constexpr (KK >= KLO && KK <= KHI) chain_body<CLT, KK>(cp, it, smem); \
         break;
         PHMM_CHAIN_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
@@ -423,8 +426,15 @@ hipError_t PHMM_CHAIN_LAUNCH(int single_k, const ChainParams &cp, hipStream_t st
     }
     PHMM_CHAIN_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
-    hipLaunchKernelGGL((phmm_forward_chain<CL>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);
-    return hipGetLastError();
+    // a mixed launch: single_k = -(range index + 1)
+#define PHMM_RANGE(R, LO, HI)                                                                                       \
+    if (single_k == -(R + 1)) {                                                                                     \
+        hipLaunchKernelGGL((phmm_forward_chain<CL, LO, HI>), dim3(cp.n_items), dim3(WAVE), lds, stream, cp);        \
+        return hipGetLastError();                                                                                   \
+    }
+    PHMM_CHAIN_RANGES(PHMM_RANGE)
+#undef PHMM_RANGE
+    return hipErrorInvalidValue;
 }
 
 #if PHMM_CHAIN_L == 16

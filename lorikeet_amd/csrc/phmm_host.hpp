@@ -33,6 +33,7 @@ struct Switches {
     int force_cnd_select = -1;  // PHMM_FORCE_CND_SELECT
     int no_pipeline = 0;        // PHMM_NO_PIPELINE: host path in one shot whatever the size
     int no_xcd_interleave = 0;  // PHMM_NO_XCD_INTERLEAVE: haplotype groups of a run adjacent in the launch instead of 8 blocks apart
+    int no_fork = 0;            // PHMM_NO_FORK: the chained launches of a batch one after the other on the caller's stream (A/B only)
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int submit_gather_us = 40;  // PHMM_SUBMIT_GATHER_US: how long the leader of a flush lets submissions that are on their way arrive (0 = never)
@@ -55,6 +56,10 @@ struct phmm_handle {
     int slot = 0;
     Arena &A() { return arenas[slot]; }
     hipStream_t S() { return streams[slot]; }
+    // the chained launches of one batch run side by side: the first on the caller's stream, the others here (phmm_batch_launch)
+    static constexpr int kSideStreams = 3;
+    hipStream_t side_streams[kSideStreams] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
     int device = 0;
     unsigned flags = 0;
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr, *d_ratio_mis = nullptr, *d_inv_om = nullptr;

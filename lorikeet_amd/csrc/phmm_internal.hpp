@@ -103,8 +103,12 @@ struct ChainParams {
     uint32_t n_items;
     uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
 };
-// all chained classes of one lanes-per-pair value in ONE launch (every item carries its K and stream count);
-// single_k = the K all items share (the per-K kernel is used), 0 = mixed (the any-K kernel)
+// The K ranges a mixed launch is cut into: one kernel per range holds only that range's bodies (phmm_chain_kernels.hip).
+#define PHMM_CHAIN_RANGES(X) X(0, 2, 9) X(1, 10, 15) X(2, 16, 19) X(3, 20, 25)
+constexpr int kChainRanges = 4;
+constexpr int chain_range_of(int k) { return k <= 9 ? 0 : k <= 15 ? 1 : k <= 19 ? 2 : 3; }
+// all chained classes of one lanes-per-pair value and one K range in ONE launch (every item carries its K and stream
+// count); single_k = the K all items share (the per-K kernel is used), or -(range + 1) for a mixed launch of that range
 hipError_t launch_chain(int L, int single_k, const ChainParams &p, hipStream_t stream);  // L lanes per pair: 16, 32 or 64
 hipError_t launch_chain_f32(int L, int single_k, const ChainParams &p, hipStream_t stream);  // phmm_chain32_kernels.hip, L = 16 | 32
 int chain_max_k();  // largest instantiated K

@@ -272,7 +272,9 @@ def test_ragged_mix_matches_the_oracle(hip_engine):
     assert np.max(np.abs(plan.download() - want)) <= 1e-9
     plan.close()
     plan = hip_engine.plan(full)
-    assert plan.num_launches <= 6, plan.num_launches      # one per lanes-per-pair value (+ per-read classes), not one per <K, streams>
+    # one per lanes-per-pair value and range of K -- four ranges, side by side on parallel streams -- (+ per-read classes),
+    # not one per <K, streams> class (72 in round 1)
+    assert plan.num_launches <= 10, plan.num_launches
     plan.upload()
     plan.launch()
     resident = plan.download()
