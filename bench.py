@@ -858,6 +858,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            # (BENCH_DIST_BACKEND=gloo on a box with fewer devices than ranks only exercises the N > 1 code path: ranks share a
+            # device, and the line says so -- it is not a scaling measurement)
+            "devices_aliased": bool(world > max(torch.cuda.device_count(), 1)),
             "dtype": "f32 first, f64 redo (PMC pass only)" if a.f32_first else "f64", "data": "synthetic",
             "config": {"workload": "config3: the same %d regions (seed %d) at every N, sharded over the %d rank(s) in contiguous "
                                    "cell-balanced ranges (BASELINE.json configs[2]/[3]): %s" % (strong["regions"], strong["seed"], world, shape)

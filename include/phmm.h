@@ -207,8 +207,27 @@ int phmm_batch_status(phmm_batch *b);
 uint64_t phmm_batch_cells(const phmm_batch *b);           /* sum over regions of (sum R)*(sum H)      */
 uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b); /* sum 5R + sum H + 8*Nr*Nh    */
 uint32_t phmm_batch_num_launches(const phmm_batch *b);    /* kernel launches one phmm_batch_launch does */
-/* Name of the kernel shape class doing most cells of this batch, e.g. "phmm_forward<16,19>". */
+/* Name of the kernel doing most cells of this batch as rocprofv3 reports it, e.g. "phmm_forward_chain_k<16,19>". */
 const char *phmm_batch_dominant_kernel(const phmm_batch *b);
+
+/*
+ * The launch plan of a batch WITHOUT a device (host only, like phmm_split_regions): what phmm_batch_create would decide
+ * for these offsets on an engine created with `flags`, `concurrent_callers` flows sharing the chip (1 = alone).  For sizing
+ * shards before any GPU is touched: e.g. that each rank's share of a set still takes the chained kernel with enough work
+ * items (one wave each) to put two waves on every one of the chip's 1 024 SIMDs.
+ */
+typedef struct phmm_plan_info {
+    uint64_t cells;              /* sum over regions of (sum R) x (sum H)                                   */
+    uint64_t chain_cells;        /* ... of which the chained kernels sweep                                  */
+    uint64_t chain_items;        /* their work items: one wave each (a run of reads x one load of haplotypes) */
+    uint32_t n_launches;         /* kernel launches of one phmm_batch_launch                                */
+    uint32_t n_chain_launches;
+    uint32_t min_reads_per_run;  /* shortest run of reads a chained work item holds (0: nothing chains)     */
+    uint32_t reserved;
+    char dominant_kernel[64];
+} phmm_plan_info;
+int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_regions, const uint32_t *region_read_off,
+                       const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off, phmm_plan_info *info);
 
 /*
  * Engine-level call: everything PairHMMLikelihoodCalculationEngine::compute_read_likelihoods does with

@@ -56,6 +56,20 @@ pub struct phmm_sw_parameters {
     pub gap_extend_penalty: i32,
 }
 
+/// `phmm_plan_info`: the launch plan of a batch, computed on the host alone (`phmm_plan_describe`)
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct phmm_plan_info {
+    pub cells: u64,
+    pub chain_cells: u64,
+    pub chain_items: u64,
+    pub n_launches: u32,
+    pub n_chain_launches: u32,
+    pub min_reads_per_run: u32,
+    pub reserved: u32,
+    pub dominant_kernel: [c_char; 64],
+}
+
 /// `flags` of `phmm_realign_config`: a region with exactly one haplotype is not realigned
 /// (src/haplotype/haplotype_caller_engine.rs:1339-1345 returns before it gets there)
 pub const PHMM_REGION_SKIP_SINGLE_ALLELE: c_uint = 1;
@@ -203,6 +217,16 @@ extern "C" {
     pub fn phmm_batch_algorithmic_bytes(b: *const phmm_batch) -> u64;
     pub fn phmm_batch_num_launches(b: *const phmm_batch) -> u32;
     pub fn phmm_batch_dominant_kernel(b: *const phmm_batch) -> *const c_char;
+    pub fn phmm_plan_describe(
+        flags: c_uint,
+        concurrent_callers: u32,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        hap_off: *const u32,
+        info: *mut phmm_plan_info,
+    ) -> c_int;
 
     pub fn phmm_engine_compute(
         h: *mut phmm_handle,

@@ -53,6 +53,13 @@ class RealignConfig(C.Structure):
                 ("informative_threshold", C.c_double)]
 
 
+class PlanInfo(C.Structure):
+    """phmm_plan_info (include/phmm.h)."""
+    _fields_ = [("cells", C.c_uint64), ("chain_cells", C.c_uint64), ("chain_items", C.c_uint64), ("n_launches", C.c_uint32),
+                ("n_chain_launches", C.c_uint32), ("min_reads_per_run", C.c_uint32), ("reserved", C.c_uint32),
+                ("dominant_kernel", C.c_char * 64)]
+
+
 _REGION_ARGS = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p,
                 C.POINTER(C.c_int32), u64p, C.POINTER(C.c_int32), u64p, u32p, u32p, u32p, u32p, u32p, u64p, f64p, u8p,
                 C.POINTER(C.c_int32), f64p, f64p, u32p, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
@@ -83,6 +90,7 @@ SYMBOLS = [
     ("phmm_batch_algorithmic_bytes", C.c_uint64, [C.c_void_p]),
     ("phmm_batch_num_launches", C.c_uint32, [C.c_void_p]),
     ("phmm_batch_dominant_kernel", C.c_char_p, [C.c_void_p]),
+    ("phmm_plan_describe", C.c_int, [C.c_uint, C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, C.POINTER(PlanInfo)]),
     ("phmm_engine_compute", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                       u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_engine_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,

@@ -435,10 +435,11 @@ const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off
 }  // namespace phmm_host
 using namespace phmm_host;
 
+// (`dry`: plan only -- no device is touched, every "device" pointer of the batch stays null: phmm_plan_describe)
 static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off,
                                      const uint32_t *region_hap_off, const uint32_t *read_off,
                                      const uint32_t *hap_off, const uint64_t *out_off, bool use_arena,
-                                     size_t extra_arena_bytes = 0) {
+                                     size_t extra_arena_bytes = 0, bool dry = false) {
     if (!h) return nullptr;
     h->err.clear();
     h->err_code = PHMM_OK;
@@ -450,11 +451,14 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         return nullptr;
     }
     const uint32_t n_reads = region_read_off[n_regions], n_haps = region_hap_off[n_regions];
-    DeviceGuard dg(h->device);
-    if (!dg.ok) {
-        h->err = "hipSetDevice failed";
-        h->err_code = PHMM_ERR_HIP;
-        return nullptr;
+    std::unique_ptr<DeviceGuard> dg;
+    if (!dry) {
+        dg.reset(new DeviceGuard(h->device));
+        if (!dg->ok) {
+            h->err = "hipSetDevice failed";
+            h->err_code = PHMM_ERR_HIP;
+            return nullptr;
+        }
     }
 
     phmm_batch *b = new phmm_batch();
@@ -723,7 +727,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     }
     auto dalloc = [&](size_t bytes, void **mirror) -> void * {
         if (mirror) *mirror = nullptr;
-        if (!ok) return nullptr;
+        if (!ok || dry) return nullptr;
         if (b->arena && align_up(b->arena->used, 256) + bytes <= b->arena->cap) {
             const size_t off = align_up(b->arena->used, 256);
             b->arena->used = off + bytes;
@@ -737,7 +741,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     };
     bool async_pending = false;
     auto up = [&](void *dst, void *mirror, const void *src, size_t bytes) {
-        if (!ok || !bytes) return;
+        if (!ok || !bytes || dry) return;
         if (mirror) {
             memcpy(mirror, src, bytes);
         } else {
@@ -760,7 +764,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     up(b->d_read_off, m_ro, read_off, (size_t)(n_reads + 1) * 4);
     up(b->d_hap_off, m_ho, hap_off, (size_t)(n_haps + 1) * 4);
     up(b->d_out_off, m_oo, out_off, (size_t)(n_regions + 1) * 8);
-    if (!b->arena) {  // persistent batch: own status word (arena mode keeps it next to the results)
+    if (!b->arena && !dry) {  // persistent batch: own status word (arena mode keeps it next to the results)
         b->d_status = (uint32_t *)dalloc(256, nullptr);
         if (ok) ok = hip_ok(h, hipMemsetAsync(b->d_status, 0, 4, h->S()), "memset status");
         // ... and own scratch for the exact pass, which rides behind the forward kernels of every launch (the caller
@@ -869,8 +873,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             threads = std::min<uint64_t>(threads, std::max<uint64_t>(256, kGenericScratchBytes / per_thread / 256 * 256));
             c.generic_blocks = (uint32_t)(threads / 256);
             // scratch can be large: always its own allocation, never the arena
-            if (ok) ok = hip_ok(h, hipMalloc((void **)&c.d_scratch, threads * per_thread), "hipMalloc(generic scratch)");
-            if (ok) b->mallocs.push_back(c.d_scratch);
+            if (ok && !dry) ok = hip_ok(h, hipMalloc((void **)&c.d_scratch, threads * per_thread), "hipMalloc(generic scratch)");
+            if (ok && !dry) b->mallocs.push_back(c.d_scratch);
             void *mirror;
             c.d_pair_first = (uint64_t *)dalloc(c.pair_first.size() * 8, &mirror);
             up(c.d_pair_first, mirror, c.pair_first.data(), c.pair_first.size() * 8);
@@ -2073,6 +2077,39 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
+}
+
+int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_regions, const uint32_t *region_read_off,
+                       const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off, phmm_plan_info *info) {
+    if (!info) return PHMM_ERR_INVALID_ARG;
+    try {
+        memset(info, 0, sizeof *info);
+        std::vector<uint64_t> oo((size_t)n_regions + 1, 0);
+        if (region_read_off && region_hap_off)
+            for (uint32_t g = 0; g < n_regions; ++g)
+                oo[g + 1] = oo[g] + (uint64_t)(region_read_off[g + 1] - region_read_off[g]) * (region_hap_off[g + 1] - region_hap_off[g]);
+        phmm_handle h;  // host-only: carries the flags and the planner's switches, never a device
+        h.flags = flags;
+        h.gpu_sharers = concurrent_callers ? concurrent_callers : 1u;
+        phmm_batch *b = batch_create_impl(&h, n_regions, region_read_off, region_hap_off, read_off, hap_off, oo.data(), false, 0, true);
+        if (!b) return PHMM_ERR_INVALID_ARG;
+        info->cells = b->cells;
+        info->n_launches = phmm_batch_num_launches(b);
+        for (const auto &g : b->chain_groups) {
+            info->n_chain_launches += 1;
+            info->chain_items += g.items.size();
+            uint32_t fewest = 0xffffffffu;
+            for (const ChainItem &it : g.items) fewest = std::min(fewest, it.read_end - it.read_begin);
+            info->min_reads_per_run = info->min_reads_per_run ? std::min(info->min_reads_per_run, fewest) : fewest;
+        }
+        for (const auto &c : b->classes)
+            if (c.chain) info->chain_cells += c.cells;
+        snprintf(info->dominant_kernel, sizeof info->dominant_kernel, "%s", b->dominant.c_str());
+        delete b;
+        return PHMM_OK;
+    } catch (...) {
+        return PHMM_ERR_NO_MEMORY;
+    }
 }
 
 uint64_t phmm_batch_cells(const phmm_batch *b) { return b ? b->cells : 0; }

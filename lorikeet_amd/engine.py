@@ -192,6 +192,18 @@ class HipPairHMMEngine:
             pass
 
 
+def plan_describe(batch: RegionBatch, flags=0, concurrent_callers=1):
+    """phmm_plan_describe: the launch plan of `batch` without touching a device (host only) -> _lib.PlanInfo."""
+    lib = _lib.load()
+    info = _lib.PlanInfo()
+    code = lib.phmm_plan_describe(int(flags), int(concurrent_callers), batch.n_regions, _p(batch.region_read_off, _lib.u32p),
+                                  _p(batch.region_hap_off, _lib.u32p), _p(batch.read_off, _lib.u32p), _p(batch.hap_off, _lib.u32p),
+                                  C.byref(info))
+    if code != _lib.PHMM_OK:
+        raise PhmmError(code, "phmm_plan_describe: invalid argument")
+    return info
+
+
 def assign_regions(batch: RegionBatch, n_parts):
     """phmm_assign_regions: greedy longest-processing-time assignment of whole regions to `n_parts` engines by
     cells(region).  Host only -- works without a device.  Returns uint32[n_regions]."""

@@ -26,11 +26,12 @@ REFERENCE = "/root/reference"
 C_SCALARS = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64",
              "int32_t": "i32", "int64_t": "i64", "double": "f64", "size_t": "usize", "char": "c_char", "void": "void",
              "phmm_handle": "phmm_handle", "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config", "phmm_sw_parameters": "phmm_sw_parameters",
-             "phmm_realign_config": "phmm_realign_config"}
+             "phmm_realign_config": "phmm_realign_config", "phmm_plan_info": "phmm_plan_info"}
 RS_SCALARS = {"c_int": "i32", "c_uint": "u32", "u8": "u8", "u32": "u32", "u64": "u64", "i32": "i32", "i64": "i64", "f64": "f64",
               "usize": "usize", "c_char": "c_char", "c_void": "void", "phmm_handle": "phmm_handle",
               "phmm_batch": "phmm_batch", "phmm_engine_config": "phmm_engine_config",
-              "phmm_sw_parameters": "phmm_sw_parameters", "phmm_realign_config": "phmm_realign_config"}
+              "phmm_sw_parameters": "phmm_sw_parameters", "phmm_realign_config": "phmm_realign_config",
+              "phmm_plan_info": "phmm_plan_info"}
 
 
 def _strip_c(text):

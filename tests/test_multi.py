@@ -1,5 +1,8 @@
-"""phmm_compute_multi: one process, several engines (one per device on a multi-GPU node; several on the one device of the
-test box), whole regions sharded by cells with greedy LPT and nothing exchanged between them."""
+"""phmm_compute_multi: one process, several engines, whole regions sharded by cells (contiguous ranges, greedy LPT for
+heavy-tailed sets) and nothing exchanged between them.  On a node with several GPUs the engines sit on
+DISTINCT devices (`_engines`); on a one-GPU box the same tests exercise the sharding and staging logic with several
+engines on that device -- they say nothing about several devices, and `test_one_engine_per_device` is skipped there
+rather than aliased."""
 import numpy as np
 import pytest
 
@@ -13,8 +16,37 @@ from test_sharding import _ragged_batch
 pytestmark = pytest.mark.gpu
 
 
+def _device_count():
+    return int(_lib.load().phmm_device_count())
+
+
+def _engines(n):
+    """n engines: on distinct devices where the node has that many, else as many devices as there are, round robin."""
+    nd = max(_device_count(), 1)
+    return [HipPairHMMEngine(i % nd) for i in range(n)]
+
+
+def test_one_engine_per_device():
+    """BASELINE.json configs[3] inside ONE process: the engines of phmm_compute_multi on distinct devices (each with its own
+    host thread pinned to the CPUs local to its GPU).  Skipped -- not aliased onto one device -- on a one-GPU box."""
+    nd = _device_count()
+    if nd < 2:
+        pytest.skip("one HIP device visible: nothing to shard across")
+    engines = [HipPairHMMEngine(d) for d in range(min(nd, 8))]
+    for b in (synthetic.config3(64 * len(engines), seed=21),
+              RegionBatch.concat([synthetic.make_regions(1, 1200, 8, 300, 150, seed=5), synthetic.config2(3 * len(engines), seed=6)])):
+        before = [e.stat("staged_bytes") for e in engines]
+        got = compute_multi(engines, b)
+        staged = [e.stat("staged_bytes") - x for e, x in zip(engines, before)]
+        assert all(x > 0 for x in staged) and sum(staged) == 5 * int(b.read_off[-1]) + int(b.hap_off[-1]), staged
+        assert np.max(np.abs(got - engines[0].compute(b))) <= 1e-12      # every device computes what device 0 computes
+        assert np.max(np.abs(got - engines[-1].compute(b))) <= 1e-12
+    for e in engines:
+        e.close()
+
+
 def test_several_engines_one_call():
-    engines = [HipPairHMMEngine(0) for _ in range(3)]
+    engines = _engines(3)
     ragged = _ragged_batch()            # regions without reads, 1-4 haplotypes, very different cell counts
     want = oracle.compute_batch(ragged.as_dict(), n_threads=4)
     got = compute_multi(engines, ragged)
@@ -30,7 +62,7 @@ def test_several_engines_one_call():
 
 
 def test_errors_of_a_share_reach_the_caller():
-    engines = [HipPairHMMEngine(0) for _ in range(2)]
+    engines = _engines(2)
     hap = np.full(40, ord("A"), np.uint8)
     n = 8
     weird = ([Read(hap[:n].copy(), np.full(n, 93), np.zeros(n, int), np.zeros(n, int), np.full(n, 10))], [hap])
@@ -55,7 +87,7 @@ def test_no_payload_byte_is_copied_more_than_once():
     """phmm_compute_multi used to gather every engine's share on the calling thread and then copy it again
     into the pinned mirror.  Now every engine stages straight from the caller's arrays: the engines' staging counters add
     up to exactly the payload (5 bytes per read base + 1 per haplotype base), in both assignment modes."""
-    engines = [HipPairHMMEngine(0) for _ in range(3)]
+    engines = _engines(3)
     uniform = synthetic.config3(90, seed=12)                    # contiguous cell-balanced ranges, chunked per engine
     heavy = RegionBatch.concat([synthetic.make_regions(1, 1200, 8, 300, 150, seed=5), synthetic.config2(6, seed=6),
                                 synthetic.make_regions(12, 10, 2, 80, 40, seed=7)])   # one region dominates: LPT lists

@@ -139,3 +139,26 @@ def test_strong_scaling_shards_cover_the_fixed_set_exactly_once():
         whole = RegionBatch.concat(parts)
         for f in RegionBatch.FIELDS:
             assert np.array_equal(getattr(whole, f), getattr(full, f)), f
+
+
+def test_every_rank_of_an_8_gpu_node_still_fills_its_chip():
+    """VERDICT r2, multi-GPU readiness: no 8-GPU node exists to measure on, so the plan is checked where it can be -- on the
+    host.  Rank r's share of BASELINE.json configs[3] at N = 8 (1 250 of the 10 000 regions) and of configs[4] (32 of the
+    256 stress regions, 512 x 64, H = 400) must still take the chained kernel for every cell, with enough work items (one
+    wave each) to put two waves on each of the chip's 1 024 SIMDs several times over, and runs of at least four reads
+    (shorter runs pay the lane pipeline's fill too often).  phmm_plan_describe: the planner without a device."""
+    from lorikeet_amd.engine import plan_describe
+    for name, world in (("config3", 8), ("config5", 8), ("config3", 4), ("config5", 2)):
+        cells = synthetic.config_cells(name)
+        bounds = sharding.split_contiguous(cells, world)
+        for rank in (0, world - 1):
+            shard = synthetic.config(name, only=(bounds[rank], bounds[rank + 1]))
+            info = plan_describe(shard)
+            assert info.cells == int(cells[bounds[rank]:bounds[rank + 1]].sum())
+            assert info.chain_cells == info.cells, (name, world, rank)                  # nothing falls back to the per-read kernel
+            assert info.chain_items >= 4 * 2 * 1024, (name, world, rank, info.chain_items)  # >= 4 rounds of 2 waves per SIMD
+            assert info.min_reads_per_run >= 4 and info.n_chain_launches == 1
+            assert info.dominant_kernel.decode().startswith("phmm_forward_chain_k<16,"), info.dominant_kernel
+    # the whole set on one GPU is the N = 1 row of the same experiment
+    one = plan_describe(synthetic.config("config5"))
+    assert one.chain_cells == one.cells == int(synthetic.config_cells("config5").sum())
