@@ -461,7 +461,17 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         }
     }
 
-    phmm_batch *b = new phmm_batch();
+    // (owned until the plan is complete: an exception on the way -- a host allocation -- releases it and what it holds)
+    struct BatchDeleter {
+        bool dry;
+        void operator()(phmm_batch *x) const {
+            if (!dry)
+                for (void *m : x->mallocs) (void)hipFree(m);
+            delete x;
+        }
+    };
+    std::unique_ptr<phmm_batch, BatchDeleter> owner(new phmm_batch(), BatchDeleter{dry});
+    phmm_batch *b = owner.get();
     b->h = h;
     b->n_regions = n_regions;
     b->n_reads = n_reads;
@@ -716,10 +726,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             const size_t cap = std::max<size_t>(need + need / 2, 1 << 20);
             ok = hip_ok(h, hipMalloc((void **)&A.dev, cap), "hipMalloc(arena)") &&
                  hip_ok(h, hipHostMalloc((void **)&A.host, cap, hipHostMallocDefault), "hipHostMalloc(arena)");
-            if (!ok) {
-                delete b;
-                return nullptr;
-            }
+            if (!ok) return nullptr;
             A.cap = cap;
         }
         A.used = 0;
@@ -1003,11 +1010,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     }
     // host staging vectors die at return: finish the async copies first (arena mode copied into the mirror)
     if (ok && async_pending) ok = hip_ok(h, hipStreamSynchronize(h->S()), "sync(meta)");
-    if (!ok) {
-        phmm_batch_destroy(b);
-        return nullptr;
-    }
-    return b;
+    if (!ok) return nullptr;
+    return owner.release();
 }
 
 extern "C" {
@@ -1457,11 +1461,11 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
             if (!ensure_arena_rescue(h, A, b->max_h, &nb) || launch_rescue_pass(b, A.rescue, nb, true, S) != PHMM_OK ||
                 !hip_ok(h, hipStreamSynchronize(S), "sync(rescue)") || (!p->zero_copy && !fetch())) {
                 st = PHMM_ERR_HIP;
-            } else if (p->zero_copy) {
+            } else {
+                // (from the values on every path: phmm_rescue only ORs into the device word, so a bit a fast kernel raised
+                // for a pair the exact pass has since replaced would survive there)
                 bits = 0;
                 each_result([&](double x) { bits |= status_bits(x); });
-            } else {
-                bits = *(const uint32_t *)hs;
             }
         }
         if (st == PHMM_OK) {

@@ -181,6 +181,14 @@ int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t
         std::vector<int> status(n_handles, PHMM_OK);
         std::vector<std::string> errs(n_handles);
         std::vector<std::thread> workers;
+        workers.reserve(n_handles);
+        struct JoinAll {  // if starting a thread throws, the ones already running are joined before the exception travels on
+            std::vector<std::thread> &w;
+            ~JoinAll() {
+                for (auto &t : w)
+                    if (t.joinable()) t.join();
+            }
+        } join_all{workers};
         for (uint32_t k = 0; k < n_handles; ++k) {
             if (contiguous ? first[k] == first[k + 1] : lists[k].empty()) continue;
             workers.emplace_back([&, k] {
@@ -203,7 +211,8 @@ int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t
                 }
             });
         }
-        for (auto &w : workers) w.join();
+        for (auto &w : workers)
+            if (w.joinable()) w.join();
         for (uint32_t k = 0; k < n_handles; ++k)
             if (status[k] != PHMM_OK) {
                 h0->err = errs[k];

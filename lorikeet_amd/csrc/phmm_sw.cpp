@@ -302,10 +302,10 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             !PJ->out_cigar_off || !PJ->n_out_cigar || !PJ->new_pos || !PJ->status)
             return fail(h, who + ": null array");
         if (PJ->hap_cigar_off[0] != 0 || PJ->orig_cigar_off[0] != 0 || PJ->out_cigar_off[0] != 0) return fail(h, who + ": offset arrays must start at 0");
-        for (uint32_t g = 0; g < B.n_regions; ++g)
-            if (B.region_read_off[g + 1] > B.region_read_off[g] &&
+        for (uint32_t g = 0; g < B.n_regions; ++g)  // (a region without haplotypes has no best alleles: its reads stay as they are)
+            if (B.region_read_off[g + 1] > B.region_read_off[g] && B.region_hap_off[g + 1] > B.region_hap_off[g] &&
                 (PJ->region_ref_hap[g] < 0 || (uint32_t)PJ->region_ref_hap[g] >= B.region_hap_off[g + 1] - B.region_hap_off[g]))
-                return fail(h, who + ": every region with reads needs its reference haplotype (region_ref_hap inside the region)");
+                return fail(h, who + ": every region with reads and haplotypes needs its reference haplotype (region_ref_hap inside the region)");
         for (uint32_t a = 0; a < B.n_haps; ++a)
             if (PJ->hap_cigar_off[a + 1] < PJ->hap_cigar_off[a]) return fail(h, who + ": offsets not monotonic");
         for (uint32_t r = 0; r < B.n_reads; ++r)
@@ -317,18 +317,25 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     if (!n_refs) return fail(h, who + ": no reference sequences");
     uint32_t max_ref = 0, max_alt = 0;
+    // The reference asserts / panics on empty input (smith_waterman_aligner.rs:65-68, :132-134) -- for the sequences it
+    // actually aligns: a reference no alignment names, or the read of a skipped alignment, may be empty.  Where the device
+    // chooses the reference (the best allele) the kernel raises the condition for the alignments it meets (SW_STATUS_EMPTY).
+    const char *const empty_msg = ": non-empty sequences are required for the Smith-Waterman calculation";
     for (uint32_t r = 0; r < n_refs; ++r) {
         if (ref_off[r + 1] < ref_off[r]) return fail(h, who + ": offsets not monotonic");
-        // the reference asserts / panics on empty input (smith_waterman_aligner.rs:65-68, :132-134)
-        if (ref_off[r + 1] == ref_off[r]) return fail(h, who + ": non-empty sequences are required for the Smith-Waterman calculation");
+        if (ref_off[r + 1] == ref_off[r] && !J.ref_index && !J.best) return fail(h, who + empty_msg);
         max_ref = std::max(max_ref, ref_off[r + 1] - ref_off[r]);
     }
+    if (!max_ref) return fail(h, who + empty_msg);
     for (uint32_t a = 0; a < n_alignments; ++a) {
         if (alt_off[a + 1] < alt_off[a] || cigar_off[a + 1] < cigar_off[a]) return fail(h, who + ": offsets not monotonic");
-        if (alt_off[a + 1] == alt_off[a]) return fail(h, who + ": non-empty sequences are required for the Smith-Waterman calculation");
-        max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
         if (J.ref_index && J.ref_index[a] != SW_NO_REFERENCE && J.ref_index[a] >= n_refs) return fail(h, who + ": reference index out of range");
+        const bool skipped = J.ref_index && J.ref_index[a] == SW_NO_REFERENCE;
+        if (!skipped && !J.best && (alt_off[a + 1] == alt_off[a] || (J.ref_index && ref_off[J.ref_index[a] + 1] == ref_off[J.ref_index[a]])))
+            return fail(h, who + empty_msg);
+        max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
     }
+    if (!max_alt) max_alt = 1;  // (only skipped alignments: nothing will be swept)
     {
         // the kernel carries scores times four with a two-bit tag and leaves out the reference's clamp at -1e8
         // (MATRIX_MIN_CUTOFF): both are exact as long as no score can get near that clamp
@@ -437,10 +444,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             W.ws_bytes = ws_bytes;
         }
     }
-    for (int c = 0; c < n_chunks; ++c)
-        if (!W.ev_in[c] && (!ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate") ||
-                            !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate") ||
-                            !ok(h, hipEventCreate(&W.ev_k0[c]), "hipEventCreate") || !ok(h, hipEventCreate(&W.ev_k1[c]), "hipEventCreate")))
+    for (int c = 0; c < n_chunks; ++c)  // (each event under its own check: a failure half way must not leave the piece with null events for good)
+        if ((!W.ev_in[c] && !ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate")) ||
+            (!W.ev_out[c] && !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate")) ||
+            (!W.ev_k0[c] && !ok(h, hipEventCreate(&W.ev_k0[c]), "hipEventCreate")) ||
+            (!W.ev_k1[c] && !ok(h, hipEventCreate(&W.ev_k1[c]), "hipEventCreate")))
             return PHMM_ERR_HIP;
     SwParams p{};
     p.ref_off = (const uint32_t *)(W.dev + o_ro);
@@ -684,6 +692,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0], [1] conditions; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
     W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;
+    if (st[SW_STATUS_EMPTY]) return fail(h, who + empty_msg);  // (an alignment the device met had an empty sequence)
     if (st[SW_STATUS_CAPACITY]) {
         if (on_device) {  // an alignment outgrew the library's own slots: tell the caller how large the largest is (it runs again)
             std::vector<uint32_t> n_cig_host(n_alignments);

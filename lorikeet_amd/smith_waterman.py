@@ -89,7 +89,10 @@ class SmithWatermanAligner:
         ref_index None = one reference per alternate; an index of -1 skips the alignment (None in the result)."""
         refs = [_u8(r) for r in references]
         alts = [_u8(a) for a in alternates]
-        for r in refs + alts:  # smith_waterman_aligner.rs:65-68
+        # smith_waterman_aligner.rs:65-68 asserts on what it aligns: a reference no alignment names, or the read of a
+        # skipped alignment, may be empty
+        used = set(range(len(refs))) if ref_index is None else {int(i) for i in ref_index if int(i) >= 0}
+        for r in [refs[i] for i in sorted(used) if i < len(refs)] + [a for k, a in enumerate(alts) if ref_index is None or int(ref_index[k]) >= 0]:
             if len(r) == 0:
                 raise AssertionError("non-empty sequences are required for the Smith-Waterman calculation")
         st = OverhangStrategy.NAMES[overhang_strategy] if isinstance(overhang_strategy, str) else int(overhang_strategy)
@@ -101,7 +104,7 @@ class SmithWatermanAligner:
             idx = np.where(np.asarray(ref_index, np.int64) < 0, _lib.PHMM_SW_NO_REFERENCE, np.asarray(ref_index, np.int64)).astype(np.uint32)
         ref_off = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint32)
         alt_off = np.concatenate([[0], np.cumsum([len(a) for a in alts])]).astype(np.uint32)
-        rb, ab = np.ascontiguousarray(np.concatenate(refs)), np.ascontiguousarray(np.concatenate(alts))
+        rb, ab = np.ascontiguousarray(np.concatenate(refs + [np.zeros(1, np.uint8)])), np.ascontiguousarray(np.concatenate(alts + [np.zeros(1, np.uint8)]))
         cap = np.full(n, 24 if capacity is None else int(capacity), np.int64)
         prm = parameters.as_struct()
         eng = self.engine

@@ -37,8 +37,8 @@ def test_reference_tests_in_cpp_pass_on_the_gpu():
     r = subprocess.run([EXE, os.path.join(GOLDEN, "pairhmm-testdata.txt")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "16 tests, 0 failed" in r.stdout
+    assert "17 tests, 0 failed" in r.stdout
     for name in ("test_likelihoods_avx", "make_basic_likelihood_tests", "test_compute_likelihoods",
-                 "make_haplotype_indexing_provider", "make_big_read_hmm_provider", "rayon_worker_pattern",
+                 "make_haplotype_indexing_provider", "make_big_read_hmm_provider", "rayon_worker_pattern", "region_pipeline_worker_pattern",
                  "smith_waterman_asserted_cases", "test_for_identical_alignments_with_differing_flank_lengths", "test_best_alleles", "make_read_aligned_to_ref_data", "make_test_compute_cigar_data"):
         assert "PASS " + name in r.stdout

@@ -28,7 +28,7 @@ def test_f32_first_on_synthetic_regions(engines):
     e64, e32 = engines
     b = synthetic.config2(600, seed=31)
     plan = e32.plan(b)
-    assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<16,"), plan.dominant_kernel
+    assert __import__("re").match(r"phmm_forward_chain_f32(_any)?<16[,>]", plan.dominant_kernel), plan.dominant_kernel
     plan.close()
     r64, r32 = e64.compute(b), e32.compute(b)
     assert np.all(r32 <= 0.0) and not np.isnan(r32).any()
@@ -42,7 +42,7 @@ def test_f32_first_on_synthetic_regions(engines):
     # haplotypes of 600 columns: 32 lanes per pair
     long_haps = synthetic.make_regions(400, 64, 8, 600, 150, seed=36)
     plan = e32.plan(long_haps)
-    assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<32,"), plan.dominant_kernel
+    assert __import__("re").match(r"phmm_forward_chain_f32(_any)?<32[,>]", plan.dominant_kernel), plan.dominant_kernel
     plan.close()
     r32 = e32.compute(long_haps)
     assert np.max(np.abs(r32 - e64.compute(long_haps))) <= TOL_F32
@@ -63,7 +63,7 @@ def test_f32_first_known_answer_vectors(engines, kat_rows):
         eng = HipPairHMMEngine(0, f32_first=True)
         with eng.switches(force_chain=5, force_L=int(lanes), force_streams=int(streams)):
             plan = eng.plan(kb)
-            assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<%s," % lanes), plan.dominant_kernel
+            assert __import__("re").match(r"phmm_forward_chain_f32(_any)?<%s[,>]" % lanes, plan.dominant_kernel), plan.dominant_kernel
             plan.close()
             got = eng.compute(kb)
         eng.close()
@@ -99,7 +99,7 @@ def test_what_f32_cannot_be_trusted_with_is_redone_in_f64(engines):
         regs.append((reads, haps))
     b = RegionBatch.from_regions(regs)
     plan = e32.plan(b)
-    assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<16,"), plan.dominant_kernel
+    assert __import__("re").match(r"phmm_forward_chain_f32(_any)?<16[,>]", plan.dominant_kernel), plan.dominant_kernel
     plan.close()
     r64, r32 = e64.compute(b), e32.compute(b)
     with e64.switches(force_chain=0):                   # the f64 per-read kernel: what the redo pass runs

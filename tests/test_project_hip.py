@@ -199,3 +199,30 @@ def test_small_calls_store_results_into_the_mirror_or_copy_them_same_answer(hip_
     for r in range(b.n_reads):
         st, pos, cig = _oracle_read(b, r, reg[r], b0.allele_index[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
         assert g0.status[r] == st and (st != 0 or (g0.new_pos[r] == pos and oracle.cigar_to_string(g0.cigars[r]) == cig)), r
+
+
+def test_a_region_without_haplotypes_leaves_its_reads_unchanged(hip_engine):
+    """a region with reads but no haplotypes (nothing assembled) has no best alleles; phmm_realign_reads and
+    phmm_region_compute leave its reads as they are instead of refusing the whole call for its missing reference haplotype."""
+    from lorikeet_amd import _lib, region
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(91, n_regions=3)
+    regions = []
+    for g in range(3):
+        reads = [_read(bytes(b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])])) for r in range(int(b.region_read_off[g]), int(b.region_read_off[g + 1]))]
+        haps = [] if g == 1 else [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(int(b.region_hap_off[g]), int(b.region_hap_off[g + 1]))]
+        regions.append((reads, haps))
+    keep_h = [a for g in (0, 2) for a in range(int(b.region_hap_off[g]), int(b.region_hap_off[g + 1]))]
+    b2 = RegionBatch.from_regions(regions)
+    hc, hs = [hap_cigars[a] for a in keep_h], [hap_starts[a] for a in keep_h]
+    rh = [ref_hap[0], -1, ref_hap[2]]
+    lk = hip_engine.compute(b2)
+    best, got = realign.realign_reads(hip_engine, b2, lk, hc, hs, rh, ref_start, orig_cigars)
+    mid = slice(int(b2.region_read_off[1]), int(b2.region_read_off[2]))
+    assert np.all(best.allele_index[mid] == -1) and np.all(got.status[mid] == _lib.PHMM_PROJECT_UNCHANGED)
+    assert np.any(got.status[:mid.start] == 0) and np.any(got.status[mid.stop:] == 0)
+    cfg = _lib.EngineConfig()
+    cfg.constant_gcp, cfg.base_quality_score_threshold, cfg.symmetrically_normalize_alleles_to_reference = 10, 18, 1
+    cfg.log10_global_read_mismapping_rate, cfg.read_disqualification_scale, cfg.expected_error_rate_per_base = -4.5, 1.0, 0.02
+    fused = region.region_compute(hip_engine, cfg, b2, np.full(b2.n_reads, 60, np.uint8), hc, hs, rh, ref_start, orig_cigars)
+    assert np.all(fused.best.allele_index[mid] == -1) and np.all(fused.reads.status[mid] == _lib.PHMM_PROJECT_UNCHANGED)
+    assert np.any(fused.reads.status[:mid.start] == 0)

@@ -247,3 +247,18 @@ def test_small_calls_sweep_along_the_alternate_sequence_same_alignments(hip_engi
     finally:
         hip_engine.set_switch("sw_transpose", -1)
         hip_engine.set_switch("sw_lanes", 0)
+
+
+def test_only_sequences_that_are_aligned_must_be_non_empty(hip_engine):
+    """the reference asserts on the sequences it aligns (smith_waterman_aligner.rs:65-68), not on a haplotype no
+    read is aligned to, nor on the read of a skipped alignment."""
+    al = SmithWatermanAligner(hip_engine)
+    refs = [b"ACGTACGTTTGACCA", b"", b"TTGACCAGGA"]
+    alts = [b"ACGTTTGA", b"", b"GACCAG", b"CCAGG"]
+    got = al.align_indexed(refs, alts, [0, -1, 2, 2], NEW_SW_PARAMETERS, "SoftClip")
+    assert got[1] is None
+    for k, r in ((0, 0), (2, 2), (3, 2)):
+        cig, off = oracle.sw_align(refs[r], alts[k], [200, -150, -260, -11], "SoftClip")
+        assert got[k].alignment_offset == off and np.array_equal(got[k].elements, cig)
+    with pytest.raises(AssertionError, match="non-empty"):
+        al.align_indexed(refs, alts, [0, -1, 1, 2], NEW_SW_PARAMETERS, "SoftClip")   # the empty reference IS used

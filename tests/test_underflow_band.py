@@ -98,7 +98,7 @@ def test_underflow_band_f32_first(band):
     for sw in ({"force_L": 16, "force_chain": 6}, {"force_L": 32, "force_chain": 6}):
         with eng.switches(**sw):
             plan = eng.plan(b)
-            assert plan.dominant_kernel.startswith("phmm_forward_chain_f32<"), plan.dominant_kernel
+            assert plan.dominant_kernel.startswith("phmm_forward_chain_f32"), plan.dominant_kernel
             plan.close()
             _check(eng.compute(b), want)   # everything down here is far below f32's range: f64 redo, then the exact pass
     eng.close()
