@@ -1,0 +1,12 @@
+#!/bin/bash
+# gpurun recipe 4: random batches of every kind against the oracle (PairHMM through every kernel selection, the
+# engine-level call, Smith-Waterman, the projection).  usage (on the GPU box): bash tools/run/soak.sh <round> [seconds each]
+R=${1:-r03}; S=${2:-150}
+cd "$(dirname "$0")/../.."
+{
+timeout $((S * 2 + 100)) python tools/soak.py $S 71 2>&1 | tail -1
+timeout $((S * 2 + 100)) python tools/soak_engine.py $S 72 2>&1 | tail -1
+timeout $((S * 2 + 100)) python tools/soak_sw.py $S 73 2>&1 | tail -1
+timeout $((S * 2 + 100)) python tools/soak_project.py $S 74 2>&1 | tail -1
+} > gpurun_out/${R}_soak_parity.txt 2>&1
+cat gpurun_out/${R}_soak_parity.txt
