@@ -296,11 +296,15 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
  * reference's, so CIGAR and offset EQUAL the reference's scalar arm (which its own tests assert equal to the vector
  * arm, tests/smith_waterman_aligner_unit_tests.rs:999-1103).
  *
- *   ref_off / alt_off [n+1]   byte offsets of each pair's reference / alternate sequence; both must be non-empty
- *                             (the reference asserts, :65-68); about 8 000 bases each fit the LDS staging
- *   params                    gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend);
- *                             max |weight| x (longest ref + longest alt + 2) must stay below 1e8 (the range in which
- *                             the reference's clamp at -1e8, :31, cannot act), otherwise PHMM_ERR_INVALID_ARG
+ *   ref_off / alt_off [n+1]   byte offsets of each pair's reference / alternate sequence; what is aligned must be non-empty
+ *                             (the reference asserts, :65-68).  Any lengths: up to ~8 000 bases everything of an alignment
+ *                             lives in LDS, beyond that its bottom row and strip edges move to device memory (the two
+ *                             sequences themselves must fit LDS together: ~80 000 bases each)
+ *   params                    gkl::smithwaterman::Parameters::new(match, mismatch, gap open, gap extend).  While
+ *                             max |weight| x (longest ref + longest alt + 2) stays below 1e8 -- the range in which the
+ *                             reference's clamp at -1e8 (:31) cannot act -- scores travel times four with the winning
+ *                             candidate in their low bits; beyond that a wide instance carries them as they are and applies
+ *                             the clamp; from 1e9 on, where the reference's own 32-bit sums overflow, PHMM_ERR_INVALID_ARG
  *   overhang_strategy         PHMM_SW_* below == gkl::smithwaterman::OverhangStrategy
  *   cigar_off [n+1]           element offsets into `cigar`: alignment a may use cigar_off[a+1] - cigar_off[a] elements
  *                             (ref_len + alt_len + 3 always suffices; real CIGARs have a handful)

@@ -365,6 +365,7 @@ void phmm_destroy(phmm_handle *h) {
     if (h->swork.host) (void)hipHostFree(h->swork.host);
     if (h->swork.slab) (void)hipFree(h->swork.slab);
     if (h->swork.ws) (void)hipFree(h->swork.ws);
+    if (h->swork.ext) (void)hipFree(h->swork.ext);
     for (int c = 0; c < phmm_handle::SwWork::kMaxChunks; ++c)
         for (hipEvent_t e : {h->swork.ev_in[c], h->swork.ev_out[c], h->swork.ev_k0[c], h->swork.ev_k1[c]})
             if (e) (void)hipEventDestroy(e);

@@ -75,6 +75,8 @@ struct phmm_handle {
         size_t slab_bytes = 0;
         uint32_t *ws = nullptr;  // the projection's builders (phmm_realign_reads)
         size_t ws_bytes = 0;
+        unsigned char *ext = nullptr;  // bottom rows / strip edges of alignments too long for LDS (SwGeometry::ext_stride)
+        size_t ext_bytes = 0;
         static constexpr int kMaxChunks = 8;      // pieces of one call: piece c+1 is staged and copied while piece c computes
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
@@ -174,9 +176,14 @@ size_t zero_copy_out_bytes();  // results up to this size are stored into the pi
 struct SwGeometry {
     int L = 0, K = 0, per_cu = 0;
     bool transposed = false;
+    bool wide = false;  // weights beyond the scaled kernels' range: the un-scaled instance with the reference's clamp
     size_t strips = 0, lds_ref = 0, lds_alt = 0, lds_group = 0, gpb = 0, lds = 0, flag_words = 0, slab_stride = 0, max_workers = 0;
+    size_t ext_stride = 0;  // > 0: the bottom row and strip edges of a block live in device memory (sequences beyond ~8 000 bases)
 };
-int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt, SwGeometry *G);
+// (`params`: the weights decide between the scaled kernels and the wide instance, or refuse what overflows 32 bits in the
+// reference as well)
+int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt,
+            const phmm_sw_parameters *params, SwGeometry *G);
 
 // The caller's arrays of one phmm_region_compute call (include/phmm.h), or of one chunk / one combined flush of it.
 struct RegionArgs {

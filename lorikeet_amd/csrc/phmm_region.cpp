@@ -255,14 +255,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     size_t workers = 0;
     uint32_t pj_capacity = 0;
     if (align) {
-        const phmm_sw_parameters &sp = a.rcfg.sw_parameters;
-        const int64_t big = std::max(std::max(std::llabs((long long)sp.match_value), std::llabs((long long)sp.mismatch_penalty)),
-                                     std::max(std::llabs((long long)sp.gap_open_penalty), std::llabs((long long)sp.gap_extend_penalty)));
-        if (big * ((int64_t)V.max_h + std::max<uint32_t>(max_r, 1) + 2) >= 100000000) {
-            h->err = who + ": parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e8)";
-            return bail(PHMM_ERR_INVALID_ARG);
-        }
-        st = sw_plan(h, who, nr, V.max_h, std::max<uint32_t>(max_r, 1), &G);
+        st = sw_plan(h, who, nr, V.max_h, std::max<uint32_t>(max_r, 1), &a.rcfg.sw_parameters, &G);
         if (st != PHMM_OK) return bail(st);
         workers = std::min<size_t>(G.max_workers, ((size_t)nr + G.gpb - 1) / G.gpb);
         pj_capacity = 4 * (sw_capacity + max_hap_cigar + 2) + 8;  // the lanes' builders: see phmm_cigar.cpp
@@ -440,9 +433,13 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         sp.lds_alt_bytes = (uint32_t)G.lds_alt;
         sp.lds_group_bytes = (uint32_t)G.lds_group;
         sp.groups_per_block = (uint32_t)G.gpb;
+        if (G.ext_stride) {  // (reads and haplotypes never get there; the aligner's own entry points handle such lengths)
+            h->err = who + ": sequences too long for the per-region pipeline (about 8 000 bases each)";
+            return bail(PHMM_ERR_INVALID_ARG);
+        }
         // (chunks of one call follow each other through the handle's one slab and workspace)
         if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
-        good = good && ok(h, launch_sw(G.L, G.K, G.transposed, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
+        good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.wide, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
     } else if (good && nr) {  // nothing was aligned: the kernels behind the aligner still find defined alignments
         good = ok(h, hipMemsetAsync(A.dev + L.nsw, 0, 4ull * nr, S), "memset") && ok(h, hipMemsetAsync(A.dev + L.swo, 0, 4ull * nr, S), "memset");
     }

@@ -189,7 +189,23 @@ bool grow_staging(phmm_handle *h, size_t total) {
 namespace phmm_host {
 
 // Worker geometry of one batch of alignments (shared by sw_run and the per-region pipeline, phmm_region.cpp).
-int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt, SwGeometry *G) {
+int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint32_t max_ref, uint32_t max_alt,
+            const phmm_sw_parameters *params, SwGeometry *G) {
+    // The scaled kernels carry scores times four with a two-bit tag and leave out the reference's clamp at -1e8
+    // (MATRIX_MIN_CUTOFF): exact as long as no score can get near that clamp.  Beyond that the wide instance takes over
+    // (scores as they are, the reference's comparisons and its clamp) -- up to where the reference's own 32-bit sums
+    // (low_init_value = i32::MIN / 2 plus one gap extension per row, :137, :203) would overflow, which it does not survive
+    // either (a panic in debug builds, wrapped values in release builds).
+    bool wide = false;
+    {
+        const int64_t big = std::max(std::max(std::llabs((long long)params->match_value), std::llabs((long long)params->mismatch_penalty)),
+                                     std::max(std::llabs((long long)params->gap_open_penalty), std::llabs((long long)params->gap_extend_penalty)));
+        const int64_t reach = big * ((int64_t)max_ref + max_alt + 2);
+        if (reach >= 1000000000)
+            return fail(h, who + ": parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e9: "
+                                 "beyond that the reference's own 32-bit arithmetic overflows)");
+        wide = reach >= 100000000;
+    }
     // ---- geometry ---------------------------------------------------------------------------------------------
     // L lanes per alignment, K columns per lane, so that one strip of L x K columns covers the longest alternate sequence
     // (more than 512 columns take several strips of 512).  Throughput wants few lanes per alignment -- eight alignments
@@ -197,7 +213,7 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     // a call that cannot fill the chip anyway (a round of the persistent blocks is 32 768 alignments at eight lanes) gets
     // 16, 32 or 64 lanes per alignment, i.e. more waves with less work each (one region of 128 reads: 305 us at 8 lanes,
     // 220 at 16).
-    const int force_L = h->sw.sw_lanes;
+    const int force_L = wide ? 16 : h->sw.sw_lanes;
     // (64 lanes up to 2 048 alignments where the sweep along the alternate applies, below: 16 regions of 128 reads 248 -> 228 us)
     const uint32_t most_at_64 = h->sw.sw_transpose != 0 && max_ref > max_alt && max_ref <= 512 ? 2048 : 1024;
     int L = force_L ? force_L : max_alt <= 8 * 20 && n_alignments >= 32768 ? 8 : max_alt > 512 || n_alignments > 4096 ? 16 : n_alignments > most_at_64 ? 32 : 64;
@@ -206,12 +222,13 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     int K = ks[nks - 1];
     for (int i = nks - 1; i >= 0; --i)
         if ((size_t)ks[i] * L >= max_alt) K = ks[i];
+    if (wide) K = 16;  // (the one wide instance)
     // A small call whose references are longer than its alternates (reads against their haplotypes) sweeps along the
     // ALTERNATE instead, the reference's rows shared out over the 64 lanes: fewer steps of more cells each, and a step's
     // fixed cost (~50 instructions next to 16 per cell) is what a lone wave per SIMD feels -- 150 x 300: 350 steps of
     // three cells against 210 of five.  One strip only.
     bool transposed = false;
-    if (L == 64 && h->sw.sw_transpose != 0 && max_ref <= 64u * (uint32_t)kSwK64T[kNumSwK64T - 1]) {
+    if (!wide && L == 64 && h->sw.sw_transpose != 0 && max_ref <= 64u * (uint32_t)kSwK64T[kNumSwK64T - 1]) {
         int KT = kSwK64T[kNumSwK64T - 1];
         for (int i = kNumSwK64T - 1; i >= 0; --i)
             if ((size_t)kSwK64T[i] * 64 >= max_ref) KT = kSwK64T[i];
@@ -229,17 +246,24 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
     // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
     const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
-    const size_t lds = gpb * lds_group;
-    if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 8 000 bases each)");
+    size_t lds = gpb * lds_group, ext_stride = 0;
+    if (lds > 160 * 1024) {
+        // Beyond ~8 000 bases the bottom row and the strip edges (4 and 8 bytes per base) no longer fit next to the sequences:
+        // they move to device memory, one slice per block -- slower per step, but the reference aligns any lengths
+        // (smith_waterman_aligner.rs:47-107) and so does this.  The sequences themselves stay in LDS (up to ~80 000 bases each).
+        lds = lds_ref + lds_alt;
+        ext_stride = (4ull * (max_alt + 1) + 8ull * (max_ref + 1) + 255) / 256 * 256;
+        if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 80 000 bases each)");
+    }
     // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
     // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
     int per_cu;
     {
-        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)lds;
+        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)wide << 46 | (uint64_t)lds;
         auto it = h->swork.blocks_per_cu.find(key);
         if (it == h->swork.blocks_per_cu.end()) {
             if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
-            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed)).first;
+            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed, wide)).first;
         }
         per_cu = it->second;
     }
@@ -255,6 +279,7 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     G->L = L;
     G->K = K;
     G->transposed = transposed;
+    G->wide = wide;
     G->strips = strips;
     G->lds_ref = lds_ref;
     G->lds_alt = lds_alt;
@@ -265,6 +290,7 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     G->flag_words = flag_words;
     G->slab_stride = slab_stride;
     G->max_workers = max_workers;
+    G->ext_stride = ext_stride;
     return PHMM_OK;
 }
 
@@ -336,14 +362,6 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
     }
     if (!max_alt) max_alt = 1;  // (only skipped alignments: nothing will be swept)
-    {
-        // the kernel carries scores times four with a two-bit tag and leaves out the reference's clamp at -1e8
-        // (MATRIX_MIN_CUTOFF): both are exact as long as no score can get near that clamp
-        const int64_t big = std::max(std::max(std::llabs((long long)params->match_value), std::llabs((long long)params->mismatch_penalty)),
-                                     std::max(std::llabs((long long)params->gap_open_penalty), std::llabs((long long)params->gap_extend_penalty)));
-        if (big * ((int64_t)max_ref + max_alt + 2) >= 100000000)
-            return fail(h, who + ": parameters too large for these sequence lengths (|weight| x (ref + alt) must stay below 1e8)");
-    }
     const size_t rb = ref_off[n_refs], ab = alt_off[n_alignments];
     const uint64_t n_cig = cigar_off[n_alignments];
     if (!J.ref_bases || !J.alt_bases || (n_cig && !J.cigar && !on_device)) return fail(h, who + ": null array");
@@ -353,7 +371,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     // ---- geometry (sw_plan above) ------------------------------------------------------------------------------
     phmm_host::SwGeometry G;
     {
-        const int gst = phmm_host::sw_plan(h, who, n_alignments, max_ref, max_alt, &G);
+        const int gst = phmm_host::sw_plan(h, who, n_alignments, max_ref, max_alt, params, &G);
         if (gst != PHMM_OK) return gst;
     }
     const int L = G.L, K = G.K;
@@ -384,6 +402,17 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks; ++c) most = std::max<size_t>(most, cut[c + 1] - cut[c]);
     const size_t slab_bytes = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * slab_stride * 4;
     phmm_handle::SwWork &W = h->swork;
+    if (G.ext_stride) {  // (giant sequences only)
+        const size_t need = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * G.ext_stride;
+        if (W.ext_bytes < need) {
+            for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(h->streams[i]);
+            if (W.ext) (void)hipFree(W.ext);
+            W.ext = nullptr;
+            W.ext_bytes = 0;
+            if (!ok(h, hipMalloc((void **)&W.ext, need), "hipMalloc(sw rows)")) return PHMM_ERR_HIP;
+            W.ext_bytes = need;
+        }
+    }
     // one piece: everything in order on one stream, one copy each way, one wait (a region per call is the reference's pattern)
     const bool one_piece = n_chunks == 1;
     hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
@@ -475,6 +504,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     p.lds_alt_bytes = (uint32_t)lds_alt;
     p.lds_group_bytes = (uint32_t)lds_group;
     p.groups_per_block = (uint32_t)gpb;
+    p.ext = G.ext_stride ? W.ext : nullptr;
+    p.ext_stride = G.ext_stride;
     // the offset arrays, the status word, the index and the best-allele inputs travel with the first piece -- and, when
     // the references are shared (reads -> their haplotypes), all the references
     memset(W.host, 0, 256);
@@ -591,7 +622,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         p.n_alignments = a1;
         const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
         (void)hipEventRecord(W.ev_k0[c], S);
-        good = ok(h, launch_sw(L, K, transposed, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        good = ok(h, launch_sw(L, K, transposed, G.wide, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
         if (good && PJ) {  // ... and the piece's alignments projected onto the reference, where they lie
             pp.r_begin = a0;
             pp.n_reads = a1;

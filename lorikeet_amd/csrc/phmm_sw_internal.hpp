@@ -35,10 +35,13 @@ struct SwParams {
     uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
     uint32_t lds_group_bytes;              // LDS of one alignment
     uint32_t groups_per_block;             // alignments a block works on side by side: 64 / L, or 1 for very long sequences
+    unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of
+    size_t ext_stride;                     // block b live at ext + b * ext_stride (device memory), LDS holds the two sequences only
 };
 // L lanes per alignment (8 / 16 / 32 / 64), K columns per lane (one of kSwK<L>), 64 / L alignments per block
-hipError_t launch_sw(int L, int K, bool transposed, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed);  // what a CU holds at once (registers, LDS); 0 on failure
+// `wide`: the instance for weights beyond the x4 range (scores as they are, the reference's comparisons and clamp): L = K = 16
+hipError_t launch_sw(int L, int K, bool transposed, bool wide, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, bool wide);  // what a CU holds at once (registers, LDS); 0 on failure
 extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[], kSwK64T[];  // (T: rows per lane of the sweep along the alternate)
 extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64, kNumSwK64T;
 

@@ -101,7 +101,10 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
 #else
 #define PHMM_SW_OCCUPANCY(K)
 #endif
-template <int SW_L, int K, bool TR = false>
+// WIDE: weights so large that four times a score no longer fits 32 bits, or that the reference's clamp at -1e8
+// (MATRIX_MIN_CUTOFF, :31) can act: scores are carried as they are, the winning candidate is found by the reference's own
+// comparisons (:250-266) and the clamp is applied -- six more instructions per cell, one instance (16 lanes x 16 columns).
+template <int SW_L, int K, bool TR = false, bool WIDE = false>
 __global__ __launch_bounds__(WAVE) PHMM_SW_OCCUPANCY(K)
 void phmm_sw_align_kernel(const SwParams p) {
     // TR: the sweep runs along the ALTERNATE sequence and the lanes share out the reference's rows (K rows per lane) --
@@ -117,7 +120,8 @@ void phmm_sw_align_kernel(const SwParams p) {
     unsigned char *gbase = smem + (size_t)(g < (int)gpb ? g : 0) * p.lds_group_bytes;
     uint8_t *s_ref = gbase;
     uint8_t *s_alt = s_ref + p.lds_ref_bytes;
-    int32_t *bottom = reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
+    // (sequences of tens of thousands of bases: the per-row / per-column arrays live in device memory, one slice per block)
+    int32_t *bottom = p.ext ? reinterpret_cast<int32_t *>(p.ext + (size_t)blockIdx.x * p.ext_stride) : reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     // backtrack flags of this block, [strip][step][dword][lane]
@@ -127,12 +131,13 @@ void phmm_sw_align_kernel(const SwParams p) {
     constexpr bool LAST_PACKED = REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
     uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
     // scores times four; the low two bits name the candidate
-    int32_t x_match = 4 * p.w_match + TAG_DIAG, x_mismatch = 4 * p.w_mismatch + TAG_DIAG;
+    constexpr int32_t SC = WIDE ? 1 : 4, TG = WIDE ? 0 : 1;  // scale of the scores; whether their low two bits carry the candidate
+    int32_t x_match = SC * p.w_match + TG * TAG_DIAG, x_mismatch = SC * p.w_mismatch + TG * TAG_DIAG;
     asm volatile("" : "+s"(x_match), "+s"(x_mismatch));  // opaque: or the compiler selects between the raw weights and scales per cell
     // the gap that runs along the sweep is kept per lane position in registers, the one across it travels through the
     // step and on to the next lane: vertical (tag: down) and horizontal (tag: right), or the other way round
     constexpr int32_t TAG_S = TR ? TAG_RIGHT : TAG_DOWN, TAG_L = TR ? TAG_DOWN : TAG_RIGHT;
-    const int32_t x_open = 4 * p.w_open, x_open_s = 4 * p.w_open + TAG_S, x_open_l = 4 * p.w_open + TAG_L, x_extend = 4 * p.w_extend;
+    const int32_t x_open = SC * p.w_open, x_open_s = SC * p.w_open + TG * TAG_S, x_open_l = SC * p.w_open + TG * TAG_L, x_extend = SC * p.w_extend;
     const bool edge_gaps = p.strategy == PHMM_SW_STRATEGY_INDEL || p.strategy == PHMM_SW_STRATEGY_LEADING_INDEL;  // :145
     const int strip_cols = SW_L * K;
     const size_t strip_stride = (size_t)(p.max_ref + SW_L) * NW * WAVE;  // flag dwords of one strip
@@ -215,7 +220,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 // (columns beyond the sequence compute values nobody reads: whatever they compare with)
                 bb4[k / 4] |= ((strip_on && j <= nl) ? (uint32_t)seq_l[j - 1] : 0u) << (8 * (k % 4));
                 up[k] = row0(j);
-                bgv[k] = SW_LOW_INIT | TAG_S;
+                bgv[k] = SW_LOW_INIT | (TG * TAG_S);
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
@@ -240,7 +245,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 if (active) {
                     if (first_strip) {                   // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
                         left = l == 0 ? (edge_gaps ? x_open + (i - 1) * x_extend : 0) : left;
-                        h_bg = l == 0 ? (SW_LOW_INIT | TAG_L) : h_bg;
+                        h_bg = l == 0 ? (SW_LOW_INIT | (TG * TAG_L)) : h_bg;
                     } else if (l == 0) {                 // the right edge of the previous strip
                         left = e_sw[min(i, ns)];
                         h_bg = e_bgh[min(i, ns)];
@@ -260,9 +265,17 @@ void phmm_sw_align_kernel(const SwParams p) {
                         acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(eh - ph), 31);
                         h_bg = max(ph, eh);
                         // priority: diagonal, then right (horizontal), then down (:250-266) -- the tags break the ties
-                        const int32_t cx = max(step_diag, max(h_bg, bgv[k]));
-                        acc_c[k / 16] = __builtin_amdgcn_alignbit((uint32_t)cx, acc_c[k / 16], 2);
-                        left = up[k] = cx & ~3;
+                        if constexpr (!WIDE) {
+                            const int32_t cx = max(step_diag, max(h_bg, bgv[k]));
+                            acc_c[k / 16] = __builtin_amdgcn_alignbit((uint32_t)cx, acc_c[k / 16], 2);
+                            left = up[k] = cx & ~3;
+                        } else {  // the reference's comparisons, then its clamp
+                            const int32_t g_h = TR ? bgv[k] : h_bg, g_v = TR ? h_bg : bgv[k];  // the horizontal / vertical gap candidates
+                            const int32_t gap = max(g_h, g_v);
+                            const uint32_t tag = step_diag >= gap ? (uint32_t)TAG_DIAG : g_h >= g_v ? (uint32_t)TAG_RIGHT : (uint32_t)TAG_DOWN;
+                            acc_c[k / 16] = __builtin_amdgcn_alignbit(tag, acc_c[k / 16], 2);
+                            left = up[k] = max(max(step_diag, gap), -100000000);
+                        }
                         step_diag = next_diag;
                     }
                     // (streaming stores: 0.6 bytes per cell that nobody reads before the backtrack -- the flags are a quarter of
@@ -513,7 +526,16 @@ const int kSwK64T[] = {2, 3, 4, 5, 6, 8};
 const int kNumSwK64T = sizeof(kSwK64T) / sizeof(int);
 
 // blocks (of one wave) of this instance a CU holds at once, by registers and LDS
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed) {
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, bool wide) {
+    if (wide) {
+        auto kern = phmm_sw_align_kernel<16, 16, false, true>;
+        if (lds_bytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return 0;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;
+        return nb;
+    }
 #define PHMM_CASE_T(LL, KK, TT)                                                                                    \
     if (L == LL && K == KK && transposed == TT) {                                                                  \
         auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \
@@ -535,8 +557,18 @@ int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed) {
     return 0;
 }
 
-hipError_t launch_sw(int L, int K, bool transposed, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_sw(int L, int K, bool transposed, bool wide, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
     if (p.n_alignments <= p.a_begin) return hipSuccess;
+    if (wide) {  // one instance: 16 lanes x 16 columns (any lengths through strips)
+        if (L != 16 || K != 16 || transposed) return hipErrorInvalidValue;
+        auto kern = phmm_sw_align_kernel<16, 16, false, true>;
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);
+        return hipGetLastError();
+    }
 #define PHMM_CASE_T(LL, KK, TT)                                                                                    \
     if (L == LL && K == KK && transposed == TT) {                                                                  \
         auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \

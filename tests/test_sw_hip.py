@@ -105,8 +105,17 @@ def test_long_sequences_one_alignment_per_wave(aligner):
     for strategy in ("SoftClip", "InDel"):
         for g, (r, a) in zip(aligner.align_batch(pairs, NEW_SW_PARAMETERS, strategy, capacity=64), pairs):
             _same(g, r, a, NEW_SW_PARAMETERS, strategy)
+    # ... and beyond ~8 000 bases, where the bottom row and the strip edges no longer fit LDS next to the sequences and move
+    # to device memory: the reference aligns any lengths (smith_waterman_aligner.rs:47-107), so does the library
+    # (20 000 x 20 000 used to be refused).  One pair, every strip of it.
+    big_ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, 20000))
+    big_alt = _mutate(rng, big_ref[300:19800], 0.004, 0.001) + bytes(alpha[int(x)] for x in rng.integers(0, 4, 200))
+    for strategy, prm in (("SoftClip", ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), ("InDel", NEW_SW_PARAMETERS)):
+        g = aligner.align_batch([(big_ref, big_alt)], prm, strategy, capacity=4096)[0]
+        _same(g, big_ref, big_alt, prm, strategy)
+        assert len(g.elements) > 20
     with pytest.raises(PhmmError, match="too long"):
-        aligner.align(b"A" * 20000, b"C" * 20000, NEW_SW_PARAMETERS, "InDel")
+        aligner.align(b"A" * 200000, b"C" * 1000, NEW_SW_PARAMETERS, "InDel")
 
 
 def test_capacity_is_reported_not_overrun(hip_engine):
@@ -204,11 +213,26 @@ def test_pipelined_pieces_equal_one_piece(hip_engine, aligner):
         hip_engine.set_switch("sw_lanes", 0)
 
 
-def test_parameters_beyond_the_exact_range_are_refused(aligner):
+def test_weights_of_a_million_take_the_wide_instance_with_the_reference_clamp(aligner):
     """Scores travel times four with a tag in the low bits and without the reference's clamp at -1e8: exact while
-    |weight| x (ref + alt) < 1e8, refused beyond (nobody aligns with weights of a million)."""
+    |weight| x (ref + alt) < 1e8.  Beyond that (used to be refused) the wide instance carries the scores as they
+    are, picks the candidate by the reference's own comparisons and applies its clamp -- equal to the oracle, also where the
+    clamp acts.  Where the reference's own 32-bit sums overflow (|weight| x (ref + alt) >= 1e9) the call is refused."""
+    rng = np.random.default_rng(31)
+    alpha = b"ACGT"
+    pairs = []
+    for _ in range(24):
+        ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(40, 260))))
+        alt = _mutate(rng, ref[int(rng.integers(0, 20)):len(ref) - int(rng.integers(0, 20))], 0.05, 0.03) if rng.random() < 0.7 else \
+            bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(30, 200))))
+        pairs.append((ref, alt or b"A"))
+    for prm in (Parameters(1000000, -1000000, -2000000, -500000), Parameters(700000, -1500000, -900000, -300000),
+                Parameters(3, -2000000, -1900000, -1000000)):   # the last: unrelated pairs run into the clamp at -1e8
+        for strategy in ("SoftClip", "InDel", "LeadingInDel", "Ignore"):
+            for g, (r, a) in zip(aligner.align_batch(pairs, prm, strategy, capacity=64), pairs):
+                _same(g, r, a, prm, strategy)
     with pytest.raises(PhmmError, match="parameters too large"):
-        aligner.align(b"ACGT" * 50, b"ACGT" * 40, Parameters(1000000, -1000000, -2000000, -500000), "SoftClip")
+        aligner.align(b"ACGT" * 200, b"ACGT" * 200, Parameters(1000000, -1000000, -2000000, -500000), "SoftClip")
 
 
 def test_small_calls_sweep_along_the_alternate_sequence_same_alignments(hip_engine, aligner):
