@@ -271,23 +271,7 @@ class Resident:
         self.plan.close()
 
 
-_ROCTX = None
-
-
-def roctx(resume):
-    """Under `rocprofv3 --selected-regions` (tools/profile.sh sets PHMM_ROCTX=1) only what lies between
-    roctxProfilerResume(0) and roctxProfilerPause(0) is collected: the TIMED launches of the main loop -- no warm-up
-    dispatch in the summary, so its average duration is the steady state the bench line reports."""
-    global _ROCTX
-    if os.environ.get("PHMM_ROCTX") != "1":
-        return
-    if _ROCTX is None:
-        import ctypes
-        _ROCTX = ctypes.CDLL("librocprofiler-sdk-roctx.so")
-    (_ROCTX.roctxProfilerResume if resume else _ROCTX.roctxProfilerPause)(0)
-
-
-def timed_launches(D, res, stream, steps, warmup, flush=None, traced=False):
+def timed_launches(D, res, stream, steps, warmup, flush=None):
     """`steps` launches bracketed by barrier + synchronize on both sides; returns (max-over-ranks seconds, per-launch ms
     from HIP events on the launch stream)."""
     torch = D.torch
@@ -296,8 +280,6 @@ def timed_launches(D, res, stream, steps, warmup, flush=None, traced=False):
         for _ in range(warmup):
             res.plan.launch(sh)
         D.barrier()
-        if traced:
-            roctx(True)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         ev[0].record(stream)
@@ -308,8 +290,6 @@ def timed_launches(D, res, stream, steps, warmup, flush=None, traced=False):
             ev[i + 1].record(stream)
         D.barrier()
         elapsed = time.perf_counter() - t0
-        if traced:
-            roctx(False)
     res.plan.status()  # raises if any likelihood came out > 0
     return D.max(elapsed), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
@@ -440,8 +420,7 @@ def main():
     sh = stream.cuda_stream
 
     flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if a.flush_caches else None
-    roctx(False)  # (everything up to the timed loop stays out of a --selected-regions profile)
-    elapsed, kern_ms = timed_launches(D, res, stream, a.steps, a.warmup, flush, traced=True)
+    elapsed, kern_ms = timed_launches(D, res, stream, a.steps, a.warmup, flush)
     cells_total = plan.cells * world  # identical shapes on every rank
     regions_total = regions * world
     per_rank_cells = None
@@ -612,54 +591,44 @@ def main():
         r.close()
         return row
 
-    def smith_waterman():
-        """SURVEY 8 row f4: every read of the batch's regions (up to 1 024) realigned to the first haplotype of its
-        region (the shape of realign_reads_to_their_best_haplotype, src/assembly/assembly_based_caller_utils.rs:208-246:
-        SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), host buffers, PCIe included."""
+    def sw_measure(ref_off, ref, alt_off, alt, weights, strategy, cap, sample):
+        """One phmm_sw_align call over host buffers, timed (three repeats), with the kernel's own HIP-event time, and the
+        oracle (the reference's scalar arm in C) beside it on the first `sample` alignments."""
         import ctypes as C
         import numpy as np
         from concurrent.futures import ThreadPoolExecutor
         from lorikeet_amd import _lib
         from oracle import oracle
-        sub = batch.region_slice(0, min(1024, batch.n_regions))
-        n = sub.n_reads
-        alt_off, alt = sub.read_off, sub.read_bases
-        reg_of_read = np.repeat(np.arange(sub.n_regions), np.diff(sub.region_read_off.astype(np.int64)))
-        first_hap = sub.region_hap_off[:-1].astype(np.int64)[reg_of_read]
-        h0, h1 = sub.hap_off.astype(np.int64)[first_hap], sub.hap_off.astype(np.int64)[first_hap + 1]
-        ref_off = np.concatenate([[0], np.cumsum(h1 - h0)]).astype(np.uint32)
-        ref = np.concatenate([sub.hap_bases[a:b] for a, b in zip(h0, h1)])
-        cells = int(np.sum((h1 - h0) * np.diff(alt_off.astype(np.int64))))
-        cap = 16
+        n = len(ref_off) - 1
+        rl, al = np.diff(ref_off.astype(np.int64)), np.diff(alt_off.astype(np.int64))
+        cells = int(np.sum(rl * al))
         cig_off = (np.arange(n + 1, dtype=np.uint64) * cap)
         cigar = np.zeros(n * cap, np.uint32)
         n_cig = np.zeros(n, np.uint32)
         off = np.zeros(n, np.int32)
-        prm = _lib.SwParameters(10, -15, -30, -5)
+        prm = _lib.SwParameters(*weights)
         pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
         args = (eng._h, n, pp(ref_off, _lib.u32p), pp(ref, _lib.u8p), pp(alt_off, _lib.u32p), pp(alt, _lib.u8p), C.byref(prm),
-                _lib.PHMM_SW_SOFTCLIP, pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p), pp(off, C.POINTER(C.c_int32)))
+                strategy, pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p), pp(off, C.POINTER(C.c_int32)))
         assert eng.lib.phmm_sw_align(*args) == 0, eng.last_error()
         t = time.perf_counter()
         for _ in range(3):
             assert eng.lib.phmm_sw_align(*args) == 0
         dt = (time.perf_counter() - t) / 3
         kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernels of the last call
-        pe, pwhy = pmc_entry("smith_waterman", int(n), "phmm_sw_align_kernel", "i32")
-        bt_bytes = eng.stat("sw_backtrack_bytes")
-        # oracle (the reference's scalar arm in C) on a sample: equality, and the CPU rate beside it
-        k = min(n, 4096)
+        flag_bytes = eng.stat("sw_backtrack_bytes")
+        k = min(n, sample)
         L = oracle.lib()
         cores = usable_cores()
         o_cig, o_n, o_off = np.zeros(k * cap, np.uint32), np.zeros(k, np.uint32), np.zeros(k, np.int32)
+        oracle_strategy = {_lib.PHMM_SW_SOFTCLIP: 0, _lib.PHMM_SW_INDEL: 1, _lib.PHMM_SW_LEADING_INDEL: 2, _lib.PHMM_SW_IGNORE: 3}[strategy]
 
         def chunk(lo, hi):
             for a in range(lo, hi):
-                tmp = np.zeros(int(ref_off[a + 1] - ref_off[a]) + int(alt_off[a + 1] - alt_off[a]) + 3, np.uint32)
+                tmp = np.zeros(int(rl[a] + al[a]) + 3, np.uint32)
                 o = C.c_int32(0)
-                m = L.oracle_sw_align(pp(ref[int(ref_off[a]):], _lib.u8p), int(ref_off[a + 1] - ref_off[a]),
-                                      pp(alt[int(alt_off[a]):], _lib.u8p), int(alt_off[a + 1] - alt_off[a]), 10, -15, -30, -5, 0,
-                                      pp(tmp, _lib.u32p), C.byref(o))
+                m = L.oracle_sw_align(pp(ref[int(ref_off[a]):], _lib.u8p), int(rl[a]), pp(alt[int(alt_off[a]):], _lib.u8p), int(al[a]),
+                                      *weights, oracle_strategy, pp(tmp, _lib.u32p), C.byref(o))
                 o_n[a], o_off[a] = m, o.value
                 o_cig[a * cap:a * cap + min(m, cap)] = tmp[:min(m, cap)]
         tc = time.perf_counter()
@@ -668,37 +637,114 @@ def main():
         tc = time.perf_counter() - tc
         same = bool(np.array_equal(o_n, n_cig[:k]) and np.array_equal(o_off, off[:k]) and
                     all(np.array_equal(o_cig[a * cap:a * cap + min(int(o_n[a]), cap)], cigar[a * cap:a * cap + min(int(o_n[a]), cap)]) for a in range(k)))
-        cells_k = int(np.sum((h1 - h0)[:k] * np.diff(alt_off.astype(np.int64))[:k]))
-        return {"call": "phmm_sw_align: reads -> first haplotype of their region, SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS "
-                        "(10,-15,-30,-5); host buffers, PCIe and CIGAR assembly included",
-                "alignments": int(n), "cells": cells, "ms_per_call": round(dt * 1e3, 3),
+        # what no implementation can avoid moving: both sequences in, the CIGAR and the offset out
+        compulsory = int(rl.sum() + al.sum() + 4 * int(np.minimum(n_cig, cap).sum()) + 8 * n)
+        return {"alignments": int(n), "cells": cells, "ms_per_call": round(dt * 1e3, 3),
                 "alignments_per_s": round(n / dt, 1), "gcups_i32": round(cells / dt / 1e9, 1),
-                "single_element_cigars": int(np.sum(n_cig == 1)),
+                "single_element_cigars": int(np.sum(n_cig == 1)), "cigar_elements_mean": round(float(n_cig.mean()), 2),
                 "equal_to_oracle_on_sample": same, "sample": int(k),
                 "kernel": {"ms": round(kern_s * 1e3, 3), "gcups_i32": round(cells / max(kern_s, 1e-9) / 1e9, 1),
                            "shader_clock_mhz": int(eng.stat("sw_clock_mhz")),
                            "note": "the phmm_sw_align_kernel<L,K> launches of the last call (HIP events in the library, phmm_get_stat)"},
-                "roofline": {"bound": "hbm", "achieved": round(bt_bytes / max(kern_s, 1e-9) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(bt_bytes / max(kern_s, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
-                             "algorithmic_bytes_per_launch": int(bt_bytes),
-                             "traffic": pe["hbm_bytes_per_launch"] if pe else None,
-                             "note": "the backtrack flags (4 bits per cell, K/8 dwords per lane and step) are the traffic "
-                                     "that scales with the cells; the bound that binds is VALU issue, see valu_int32"
-                                     + ("" if pe else "; traffic: " + pwhy)},
-                # the cell is 16 instructions: 9 that issue every 2.55 clocks per wave64 (add, and, cndmask) and 7 that issue
-                # every 4.3-4.8 (max, max3, alignbit, compare) -- tools/ubench/rates.hip; the cell body alone, no memory, no
-                # branches, runs at 56-61 clocks per wave-level cell (tools/ubench/sw_cell.hip): that is `peak`
-                "valu_int32": ({"valu_insts_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
-                                "achieved": round(cells / max(kern_s, 1e-9) / 1e9, 1), "peak": SW_CELL_CEILING_GCUPS,
-                                "unit": "GCUPS-i32", "frac": round(cells / max(kern_s, 1e-9) / 1e9 / SW_CELL_CEILING_GCUPS, 4),
-                                "lane_ops_per_s": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2),
-                                "note": "peak = what the 16-instruction cell body alone sustains on the whole chip at four waves per "
-                                        "SIMD (tools/ubench/sw_cell.hip, profiles/r02_ubench_sw_cell.txt: 61 clocks per wave-level "
-                                        "cell at 2.4 GHz; nine of the instructions issue every 2.55 clocks, seven every 4.3-4.8: "
-                                        "profiles/r02_ubench_rates.txt); valu_insts_per_cell = SQ_INSTS_VALU of the call "
-                                        "(profiles/pmc_traffic.json, same kernel sources) x 64 lanes / cells"} if pe else None),
-                "cpu_oracle": {"gcups_i32": round(cells_k / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1), "cores": cores,
-                               "kind": "port", "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}
+                "cpu_oracle": {"gcups_i32": round(int(np.sum(rl[:k] * al[:k])) / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1),
+                               "cores": cores, "kind": "port",
+                               "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}, \
+            kern_s, flag_bytes, compulsory
+
+    def smith_waterman():
+        """SURVEY 8 row f4: every read of the batch's regions (up to 1 024) realigned to the first haplotype of its
+        region (the shape of realign_reads_to_their_best_haplotype, src/assembly/assembly_based_caller_utils.rs:208-246:
+        SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS), host buffers, PCIe included."""
+        import numpy as np
+        from lorikeet_amd import _lib
+        sub = batch.region_slice(0, min(1024, batch.n_regions))
+        n = sub.n_reads
+        alt_off, alt = sub.read_off, sub.read_bases
+        reg_of_read = np.repeat(np.arange(sub.n_regions), np.diff(sub.region_read_off.astype(np.int64)))
+        first_hap = sub.region_hap_off[:-1].astype(np.int64)[reg_of_read]
+        h0, h1 = sub.hap_off.astype(np.int64)[first_hap], sub.hap_off.astype(np.int64)[first_hap + 1]
+        ref_off = np.concatenate([[0], np.cumsum(h1 - h0)]).astype(np.uint32)
+        ref = np.concatenate([sub.hap_bases[a:b] for a, b in zip(h0, h1)])
+        row, kern_s, flag_bytes, compulsory = sw_measure(ref_off, ref, alt_off, alt, (10, -15, -30, -5), _lib.PHMM_SW_SOFTCLIP, 16, 4096)
+        cells = row["cells"]
+        pe, pwhy = pmc_entry("smith_waterman", int(n), "phmm_sw_align_kernel", "i32")
+        row = {"call": "phmm_sw_align: reads -> first haplotype of their region, SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS "
+                       "(10,-15,-30,-5); host buffers, PCIe and CIGAR assembly included", **row}
+        row["roofline"] = {"bound": "hbm", "achieved": round(compulsory / max(kern_s, 1e-9) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(compulsory / max(kern_s, 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
+                           "algorithmic_bytes_per_launch": compulsory,
+                           "traffic": pe["hbm_bytes_per_launch"] if pe else None,
+                           "backtrack_flag_bytes_per_launch": int(flag_bytes),
+                           "note": "algorithmic bytes = what any implementation must move: both sequences in, CIGAR elements and "
+                                   "offset out.  The backtrack flags (4 bits per cell, written once, the cells on the backtrack "
+                                   "path read once) are this implementation's choice and are what `traffic` mostly is; neither "
+                                   "comes near HBM: the bound that binds is VALU issue, see valu_int32"
+                                   + ("" if pe else "; traffic: " + pwhy)}
+        # the cell is 16 instructions: 9 that issue every 2.55 clocks per wave64 (add, and, cndmask) and 7 that issue
+        # every 4.3-4.8 (max, max3, alignbit, compare) -- tools/ubench/rates.hip; the cell body alone, no memory, no
+        # branches, runs at 56-61 clocks per wave-level cell (tools/ubench/sw_cell.hip): that is `peak`
+        row["valu_int32"] = ({"valu_insts_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
+                              "achieved": round(cells / max(kern_s, 1e-9) / 1e9, 1), "peak": SW_CELL_CEILING_GCUPS,
+                              "unit": "GCUPS-i32", "frac": round(cells / max(kern_s, 1e-9) / 1e9 / SW_CELL_CEILING_GCUPS, 4),
+                              "lane_ops_per_s": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2),
+                              "note": "peak = what the 16-instruction cell body alone sustains on the whole chip at four waves per "
+                                      "SIMD (tools/ubench/sw_cell.hip, profiles/r02_ubench_sw_cell.txt: 61 clocks per wave-level "
+                                      "cell at 2.4 GHz; nine of the instructions issue every 2.55 clocks, seven every 4.3-4.8: "
+                                      "profiles/r02_ubench_rates.txt); valu_insts_per_cell = SQ_INSTS_VALU of the call "
+                                      "(profiles/pmc_traffic.json, same kernel sources) x 64 lanes / cells"} if pe else None)
+        row["indel_rich"] = optional(sw_indel_rich)
+        return row
+
+    def sw_indel_rich():
+        """The same call on alignments that are NOT one match run: (a) 16 384 reads of 150 bases carrying 2-5 % indels and
+        1 % mismatches against the 300-base window they come from (SoftClip, ALIGNMENT_TO_BEST_HAPLOTYPE parameters);
+        (b) 2 048 haplotypes of ~400 bases with 1-3 indels of 1-12 bases and a few SNPs against their 400-base reference
+        (InDel, NEW_SW_PARAMETERS 200,-150,-260,-11: the shape of calculate_cigar, reads/cigar_builder + haplotype.rs)."""
+        import numpy as np
+        from lorikeet_amd import _lib
+        rng = np.random.default_rng(77)
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+
+        def mutate(src, indel_rate, snp_rate):
+            out, i = [], 0
+            while i < len(src):
+                u = rng.random()
+                if u < indel_rate / 2:
+                    out.append(acgt[rng.integers(0, 4, int(rng.integers(1, 4)))])     # insertion of 1-3 bases
+                elif u < indel_rate:
+                    i += int(rng.integers(1, 4))                                       # deletion of 1-3 bases
+                    continue
+                out.append(src[i:i + 1] if rng.random() >= snp_rate else acgt[rng.integers(0, 4, 1)])
+                i += 1
+            return np.concatenate(out) if out else src[:1]
+
+        def pairs(n, ref_len, make_alt):
+            refs = [acgt[rng.integers(0, 4, ref_len)] for _ in range(n)]
+            alts = [make_alt(r) for r in refs]
+            ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint32)
+            ao = np.concatenate([[0], np.cumsum([len(a) for a in alts])]).astype(np.uint32)
+            return ro, np.concatenate(refs), ao, np.concatenate(alts)
+
+        def read_of(r):
+            s = int(rng.integers(0, len(r) - 160))
+            return mutate(r[s:s + 150], float(rng.uniform(0.02, 0.05)), 0.01)
+
+        def hap_of(r):
+            h = r.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                at, ln = int(rng.integers(20, len(h) - 40)), int(rng.integers(1, 13))
+                h = np.concatenate([h[:at], acgt[rng.integers(0, 4, ln)], h[at:]]) if rng.random() < 0.5 else np.concatenate([h[:at], h[at + ln:]])
+            snp = rng.integers(0, len(h), 3)
+            h[snp] = acgt[rng.integers(0, 4, 3)]
+            return h
+        out = {}
+        for name, (data, weights, strategy, cap) in {
+                "reads_150_with_2_to_5_percent_indels": (pairs(16384, 300, read_of), (10, -15, -30, -5), _lib.PHMM_SW_SOFTCLIP, 48),
+                "haplotype_to_reference_400x400": (pairs(2048, 400, hap_of), (200, -150, -260, -11), _lib.PHMM_SW_INDEL, 32)}.items():
+            row, kern_s, flag_bytes, compulsory = sw_measure(*data, weights, strategy, cap, 2048)
+            row["weights"] = list(weights)
+            out[name] = row
+        return out
 
     def realign(likelihoods):
         """The step behind the likelihoods (assembly_based_caller_utils.rs:208-246): best allele per read with the

@@ -29,7 +29,7 @@
  *     as PHMM_ERR_POSITIVE_RESULT.
  * Results agree with the reference's scalar f64 path to ~1e-13 absolute in log10 (FMA contraction,
  * exact rescalings of the DP state and the order of the final row sum are the only differences,
- * DESIGN.md section 4); the reference's own gate is 1e-5 abs.  Pairs whose log10 likelihood is below -600 --
+ * NOTEBOOK.md §4); the reference's own gate is 1e-5 abs.  Pairs whose log10 likelihood is below -600 --
  * where the reference's 2^1020-scaled sums approach the denormal range and every rounding shows -- are recomputed
  * in the reference's own operation order, so the underflow band (down to and including the point where the result
  * turns to -inf, ~1e-628) agrees with the scalar arm as well.
@@ -486,7 +486,7 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
                          const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *status);
 
 /*
- * Developer switches and counters (tests, A/B measurements; never needed in production).
+ * Developer switches and counters (tests, A/B measurements; never needed in production, NOTEBOOK.md §11).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
  * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy"; value -1 / 0 = back to the

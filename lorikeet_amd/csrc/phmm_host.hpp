@@ -177,6 +177,7 @@ struct SwGeometry {
     int L = 0, K = 0, per_cu = 0;
     bool transposed = false;
     bool wide = false;  // weights beyond the scaled kernels' range: the un-scaled instance with the reference's clamp
+    int variant = 0;    // phmm::SW_WIDE | phmm::SW_EXT: which special instance, 0 = the ordinary ones
     size_t strips = 0, lds_ref = 0, lds_alt = 0, lds_group = 0, gpb = 0, lds = 0, flag_words = 0, slab_stride = 0, max_workers = 0;
     size_t ext_stride = 0;  // > 0: the bottom row and strip edges of a block live in device memory (sequences beyond ~8 000 bases)
 };

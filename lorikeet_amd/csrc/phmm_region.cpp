@@ -439,7 +439,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         // (chunks of one call follow each other through the handle's one slab and workspace)
         if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
-        good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.wide, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
+        good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
     } else if (good && nr) {  // nothing was aligned: the kernels behind the aligner still find defined alignments
         good = ok(h, hipMemsetAsync(A.dev + L.nsw, 0, 4ull * nr, S), "memset") && ok(h, hipMemsetAsync(A.dev + L.swo, 0, 4ull * nr, S), "memset");
     }

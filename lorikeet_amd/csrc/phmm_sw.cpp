@@ -239,31 +239,42 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
             K = KT;
         }
     }
-    const size_t strip_cols = (size_t)L * K;
-    const size_t strips = transposed ? 1 : (max_alt + strip_cols - 1) / strip_cols;
+    size_t strip_cols, strips, lds_group, gpb, lds, ext_stride = 0;
     const size_t lds_ref = (max_ref + 15) / 16 * 16, lds_alt = (max_alt + 15) / 16 * 16;
-    // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
-    const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
-    // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
-    const size_t gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
-    size_t lds = gpb * lds_group, ext_stride = 0;
+    auto layout = [&]() {
+        strip_cols = (size_t)L * K;
+        strips = transposed ? 1 : (max_alt + strip_cols - 1) / strip_cols;
+        // per alignment: the two sequences, the bottom row, and (several strips only) the strip edge, two i32 per row
+        lds_group = (lds_ref + lds_alt + 4ull * (max_alt + 1) + (strips > 1 ? 8ull * (max_ref + 1) : 0) + 15) / 16 * 16;
+        // 64 / L alignments share a wave; sequences so long that they do not fit a block's LDS together get the wave to themselves
+        gpb = (64 / L) * lds_group <= 160 * 1024 ? 64 / L : 1;
+        lds = gpb * lds_group;
+    };
+    layout();
     if (lds > 160 * 1024) {
         // Beyond ~8 000 bases the bottom row and the strip edges (4 and 8 bytes per base) no longer fit next to the sequences:
         // they move to device memory, one slice per block -- slower per step, but the reference aligns any lengths
         // (smith_waterman_aligner.rs:47-107) and so does this.  The sequences themselves stay in LDS (up to ~80 000 bases each).
+        // One instance does it: 16 lanes x 32 columns (16 x 16 for wide weights), one alignment per block.
+        L = 16;
+        K = wide ? 16 : 32;
+        transposed = false;
+        layout();
+        gpb = 1;
         lds = lds_ref + lds_alt;
         ext_stride = (4ull * (max_alt + 1) + 8ull * (max_ref + 1) + 255) / 256 * 256;
         if (lds > 160 * 1024) return fail(h, who + ": sequences too long for the LDS staging (about 80 000 bases each)");
     }
+    const int variant = (wide ? phmm::SW_WIDE : 0) | (ext_stride ? phmm::SW_EXT : 0);
     // persistent blocks (one wave each, `gpb` alignments at a time): exactly what the chip holds at once -- more would
     // queue behind the first ones and leave the last round ragged -- capped by the work and by 6 GB of backtrack storage
     int per_cu;
     {
-        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)wide << 46 | (uint64_t)lds;
+        const uint64_t key = (uint64_t)L << 56 | (uint64_t)K << 48 | (uint64_t)transposed << 47 | (uint64_t)variant << 45 | (uint64_t)lds;
         auto it = h->swork.blocks_per_cu.find(key);
         if (it == h->swork.blocks_per_cu.end()) {
             if (h->swork.blocks_per_cu.size() >= 4096) h->swork.blocks_per_cu.clear();  // (LDS sizes follow the longest sequences of a call)
-            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed, wide)).first;
+            it = h->swork.blocks_per_cu.emplace(key, sw_blocks_per_cu(L, K, lds, transposed, variant)).first;
         }
         per_cu = it->second;
     }
@@ -271,7 +282,7 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
         h->err = who + ": the kernel does not fit a compute unit";
         return h->err_code = PHMM_ERR_INTERNAL;
     }
-    if (h->sw.sw_waves_per_cu > 0) per_cu = std::min(per_cu, h->sw.sw_waves_per_cu);
+    if (h->sw.sw_waves_per_cu > 0) per_cu = h->sw.sw_waves_per_cu;  // (developer switch: more than the chip holds simply queue)
     // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
     const size_t flag_words = (size_t)sw_flag_words(K);
     const size_t slab_stride = strips * (size_t)((transposed ? std::max(max_ref, max_alt) : max_ref) + L) * flag_words * 64;
@@ -280,6 +291,7 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
     G->K = K;
     G->transposed = transposed;
     G->wide = wide;
+    G->variant = variant;
     G->strips = strips;
     G->lds_ref = lds_ref;
     G->lds_alt = lds_alt;
@@ -398,6 +410,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             cut[c] = (uint32_t)std::min<uint64_t>(n_alignments, (uint64_t)c * rounds_per_chunk * max_workers * gpb);
     }
     cut[n_chunks] = n_alignments;
+    if (h->sw.trace)
+        fprintf(stderr, "%s: %u alignments, <%d,%d>%s%s, %d blocks per CU, %zu workers, %zu rounds in %d pieces\n", J.who, n_alignments, L, K,
+                transposed ? " transposed" : "", G.wide ? " wide" : "", G.per_cu, max_workers, rounds, n_chunks);
     size_t most = 0;
     for (int c = 0; c < n_chunks; ++c) most = std::max<size_t>(most, cut[c + 1] - cut[c]);
     const size_t slab_bytes = std::min<size_t>(max_workers, (most + gpb - 1) / gpb) * slab_stride * 4;
@@ -622,7 +637,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         p.n_alignments = a1;
         const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
         (void)hipEventRecord(W.ev_k0[c], S);
-        good = ok(h, launch_sw(L, K, transposed, G.wide, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        good = ok(h, launch_sw(L, K, transposed, G.variant, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
         if (good && PJ) {  // ... and the piece's alignments projected onto the reference, where they lie
             pp.r_begin = a0;
             pp.n_reads = a1;
@@ -641,7 +656,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                                              : (uint64_t)((cols + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * flag_words * 4ull;
     }
     // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
-    // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, DESIGN.md
+    // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, NOTEBOOK.md
     // section 9), and is unpacked into the caller's arrays while the later pieces compute.
     hipStream_t S_out = one_piece ? S : h->streams[2];
     auto unpack = [&](int c) {

@@ -40,8 +40,9 @@ struct SwParams {
 };
 // L lanes per alignment (8 / 16 / 32 / 64), K columns per lane (one of kSwK<L>), 64 / L alignments per block
 // `wide`: the instance for weights beyond the x4 range (scores as they are, the reference's comparisons and clamp): L = K = 16
-hipError_t launch_sw(int L, int K, bool transposed, bool wide, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, bool wide);  // what a CU holds at once (registers, LDS); 0 on failure
+enum : int { SW_PLAIN = 0, SW_WIDE = 1, SW_EXT = 2 };  // kernel variants (bit mask): un-scaled scores with the reference's clamp; rows in device memory
+hipError_t launch_sw(int L, int K, bool transposed, int variant, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int variant);  // what a CU holds at once (registers, LDS); 0 on failure
 extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[], kSwK64T[];  // (T: rows per lane of the sweep along the alternate)
 extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64, kNumSwK64T;
 

@@ -85,6 +85,18 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
     return a.order < b.order;
 }
 
+// NW dwords of backtrack flags, one streaming store (global_store_dword / x2 / x3 / x4; four-byte alignment is all they need)
+template <int NW, typename V>
+__device__ __forceinline__ void store_flags(uint32_t *at, const V &v) {
+    if constexpr (NW == 1) {
+        const uint32_t one = v[0];
+        asm volatile("global_store_dword %0, %1, off nt" ::"v"(at), "v"(one) : "memory");
+    }
+    else if constexpr (NW == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+    else if constexpr (NW == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+}
+
 #ifndef PHMM_SW_K4
 #define PHMM_SW_K4 19
 #endif
@@ -104,7 +116,11 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
 // WIDE: weights so large that four times a score no longer fits 32 bits, or that the reference's clamp at -1e8
 // (MATRIX_MIN_CUTOFF, :31) can act: scores are carried as they are, the winning candidate is found by the reference's own
 // comparisons (:250-266) and the clamp is applied -- six more instructions per cell, one instance (16 lanes x 16 columns).
-template <int SW_L, int K, bool TR = false, bool WIDE = false>
+// EXT: sequences of tens of thousands of bases -- the per-row / per-column arrays (bottom row, strip edges) live in device
+// memory, one slice per block, LDS holds the two sequences only.  An instance of its own (16 lanes x 32 columns, and the
+// wide one): loads from device memory inside the sweep make the compiler wait for ALL outstanding memory operations of a
+// step -- the flag stores included -- which cost the ordinary instances 5-8 % while the two shared one body.
+template <int SW_L, int K, bool TR = false, bool WIDE = false, bool EXT = false>
 __global__ __launch_bounds__(WAVE) PHMM_SW_OCCUPANCY(K)
 void phmm_sw_align_kernel(const SwParams p) {
     // TR: the sweep runs along the ALTERNATE sequence and the lanes share out the reference's rows (K rows per lane) --
@@ -120,8 +136,9 @@ void phmm_sw_align_kernel(const SwParams p) {
     unsigned char *gbase = smem + (size_t)(g < (int)gpb ? g : 0) * p.lds_group_bytes;
     uint8_t *s_ref = gbase;
     uint8_t *s_alt = s_ref + p.lds_ref_bytes;
-    // (sequences of tens of thousands of bases: the per-row / per-column arrays live in device memory, one slice per block)
-    int32_t *bottom = p.ext ? reinterpret_cast<int32_t *>(p.ext + (size_t)blockIdx.x * p.ext_stride) : reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
+    int32_t *bottom;
+    if constexpr (EXT) bottom = reinterpret_cast<int32_t *>(p.ext + (size_t)blockIdx.x * p.ext_stride);
+    else bottom = reinterpret_cast<int32_t *>(s_alt + p.lds_alt_bytes);
     int32_t *e_sw = bottom + (p.max_alt + 1);
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     // backtrack flags of this block, [strip][step][dword][lane]
@@ -177,15 +194,36 @@ void phmm_sw_align_kernel(const SwParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- exact substring: SoftClip / Ignore only (:72-81), the LAST occurrence (alignment_utils.rs:717-735) ----
+        // Every lane of the group screens one candidate offset by its first eight bases (two dword compares; a random offset
+        // passes once in 65 536); what passes -- normally only the offset the read really comes from -- is verified by the
+        // whole group together, every lane a share of the dwords.  (One lane comparing byte after byte held its wave for the
+        // length of the read at every true offset: an eighth of the kernel's time.)
         int found = -1;
         if (p.strategy == PHMM_SW_STRATEGY_SOFTCLIP || p.strategy == PHMM_SW_STRATEGY_IGNORE) {
+            const uint32_t *ref_w = reinterpret_cast<const uint32_t *>(s_ref), *alt_w = reinterpret_cast<const uint32_t *>(s_alt);
+            // do alt[q .. q + 4) and ref[r + q .. r + q + 4) differ (bytes from m on do not count)?  q is a multiple of four
+            auto differ = [&](int r, int q) {
+                const int at = r + q;
+                const uint32_t x = __builtin_amdgcn_alignbyte(ref_w[(at >> 2) + 1], ref_w[at >> 2], (uint32_t)at & 3u) ^ alt_w[q >> 2];
+                const int left_over = m - q;  // >= 1
+                return (left_over >= 4 ? x : x & ((1u << (8 * left_over)) - 1u)) != 0u;
+            };
             int r0 = valid ? n - m : -1;
             while (__any(found < 0 && r0 >= 0)) {
                 const int r = r0 - l;
-                bool ok = found < 0 && r0 >= 0 && r >= 0;
-                for (int q = 0; ok && q < m; ++q) ok = s_ref[r + q] == s_alt[q];
-                const uint64_t hit = (__ballot(ok) >> (lane & GMASK)) & LMASK;
-                if (hit && found < 0) found = r0 - (__ffsll((long long)hit) - 1);
+                bool cand = found < 0 && r0 >= 0 && r >= 0;
+                if (cand) cand = !differ(r, 0) && (m <= 4 || !differ(r, 4));
+                uint64_t cmask = (__ballot(cand) >> (lane & GMASK)) & LMASK;  // the group's candidates, highest offset in the lowest bit
+                while (__any(cmask != 0ull && found < 0)) {
+                    const bool on = cmask != 0ull && found < 0;
+                    const int rc = r0 - (on ? __ffsll((long long)cmask) - 1 : 0);
+                    bool bad = false;
+                    if (on)
+                        for (int q = 8 + 4 * l; q < m; q += 4 * SW_L) bad |= differ(rc, q);
+                    const bool any_bad = ((__ballot(bad) >> (lane & GMASK)) & LMASK) != 0ull;
+                    if (on && !any_bad) found = rc;
+                    cmask &= cmask - 1ull;  // next candidate
+                }
                 r0 -= SW_L;
             }
         }
@@ -213,19 +251,24 @@ void phmm_sw_align_kernel(const SwParams p) {
             // the row above, updated in place: a cell's diagonal term for its right neighbour is taken (one add, the same add
             // the neighbour needs anyway) before the cell overwrites its own entry, so one register set suffices
             int32_t up[K], bgv[K];
-            uint32_t bb4[(K + 3) / 4] = {};              // the lane's bases, four to a register (compared through a byte select)
+            // the lane's bases: one register each while registers allow (two waves per SIMD leave 256), four to a register
+            // beyond that (compared through a byte select: 8 % slower, measured on the 8 x 19 instance)
+            constexpr bool PACKED = K > 24;
+            uint32_t bb4[PACKED ? (K + 3) / 4 : 1] = {}, bb1[PACKED ? 1 : K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = j0 + k + 1;
                 // (columns beyond the sequence compute values nobody reads: whatever they compare with)
-                bb4[k / 4] |= ((strip_on && j <= nl) ? (uint32_t)seq_l[j - 1] : 0u) << (8 * (k % 4));
+                const uint32_t base_k = (strip_on && j <= nl) ? (uint32_t)seq_l[j - 1] : 0u;
+                if constexpr (PACKED) bb4[k / 4] |= base_k << (8 * (k % 4));
+                else bb1[k] = base_k;
                 up[k] = row0(j);
                 bgv[k] = SW_LOW_INIT | (TG * TAG_S);
             }
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
             uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
-            uint32_t *bt = slab + (size_t)s * strip_stride + lane;
+            uint32_t *bt = slab + (size_t)s * strip_stride + (size_t)lane * NW;
             // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
             int32_t a_next = (int32_t)seq_s[max(-l, 0)];
             const bool first_strip = TR ? true : s == 0;  // (the sweep along the alternate has one strip)
@@ -234,8 +277,18 @@ void phmm_sw_align_kernel(const SwParams p) {
             // beyond the alignment's last (other alignments of the wave are longer) and strips it does not have produce
             // values nobody reads -- their flag stores land in the slab's unused part -- and only what leaves the lane's
             // registers for LDS or the best-cell bookkeeping asks `live`.
-            auto step = [&](auto ramp_c, const int t) {
-                constexpr bool RAMP = decltype(ramp_c)::value;
+            // LEAN: every alignment of the wave has ONE strip (the usual case) -- the steady-state step then has no branch but the
+            // rare last-row one: no strip edges, and the last column's cell is taken with masks instead of under a condition.
+            // (The general step has 19 branches and 47 scalar instructions next to its 345 vector ones, and a lone taken
+            // branch costs a wave more than the cells between two of them.)
+            uint32_t kmask[K];                           // all ones for the lane's cell in the last column (row: TR), else zero
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                kmask[k] = k == km ? ~0u : 0u;
+                asm volatile("" : "+v"(kmask[k]));       // (vector registers: as conditions they would be 2 K scalar registers, spilled)
+            }
+            auto step = [&](auto ramp_c, auto lean_c, const int t) {
+                constexpr bool RAMP = decltype(ramp_c)::value, LEAN = decltype(lean_c)::value;
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
                 const bool live = strip_on && i >= 1 && i <= ns;
@@ -243,7 +296,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 const int32_t a_base = a_next;
                 a_next = (int32_t)seq_s[max(i, 0)];      // row i + 1 (the LDS area is padded: bytes beyond the sequence are harmless)
                 if (active) {
-                    if (first_strip) {                   // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
+                    if (LEAN || first_strip) {           // column 0: gap penalties (:161-168) or zeros; no horizontal gap yet
                         left = l == 0 ? (edge_gaps ? x_open + (i - 1) * x_extend : 0) : left;
                         h_bg = l == 0 ? (SW_LOW_INIT | (TG * TAG_L)) : h_bg;
                     } else if (l == 0) {                 // the right edge of the previous strip
@@ -251,7 +304,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                         h_bg = e_bgh[min(i, ns)];
                     }
                     const int32_t diag_next = left;      // sw[i][j0]: the diagonal of this lane's first column, next row
-                    auto score = [&](int k) { return (uint32_t)a_base == ((bb4[k / 4] >> (8 * (k % 4))) & 0xffu) ? x_match : x_mismatch; };
+                    auto score = [&](int k) {
+                        if constexpr (PACKED) return (uint32_t)a_base == ((bb4[k / 4] >> (8 * (k % 4))) & 0xffu) ? x_match : x_mismatch;
+                        else return (uint32_t)a_base == bb1[k] ? x_match : x_mismatch;
+                    };
                     int32_t step_diag = diag + score(0);                                           // :194-199 (tag: diagonal)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -280,33 +336,53 @@ void phmm_sw_align_kernel(const SwParams p) {
                     }
                     // (streaming stores: 0.6 bytes per cell that nobody reads before the backtrack -- the flags are a quarter of
                     // the kernel's time, in proportion to their volume)
+                    // one store per lane and step: the lane's NW dwords lie next to each other ([strip][step][lane][dword]), a
+                    // wave's store covers NW x 256 contiguous bytes.  (Three dword stores per step, 256 bytes apart, cost the
+                    // kernel a fifth of its time: a vector-memory instruction holds up its wave's issue for ~100 clocks.)
                     uint32_t *row_bt = bt + (size_t)t * NW * WAVE;
+                    typedef uint32_t flag_vec __attribute__((ext_vector_type(NW)));
+                    flag_vec fv;
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh) {
                         if (LAST_PACKED && hh == NH - 1) {
                             constexpr uint32_t LO = REM >= 16 ? ~0u : (1u << (2 * (REM & 15))) - 1u;
-                            __builtin_nontemporal_store((acc_c[hh] & ~(~0u >> (2 * (REM & 15)))) | (acc_e[hh] & LO), row_bt + (2 * hh) * WAVE);
+                            fv[2 * hh] = (acc_c[hh] & ~(~0u >> (2 * (REM & 15)))) | (acc_e[hh] & LO);
                         } else {
-                            __builtin_nontemporal_store(acc_c[hh], row_bt + (2 * hh) * WAVE);
-                            __builtin_nontemporal_store(acc_e[hh], row_bt + (2 * hh + 1) * WAVE);
+                            fv[2 * hh] = acc_c[hh];
+                            fv[2 * hh + 1] = acc_e[hh];
                         }
                     }
+                    store_flags<NW>(row_bt, fv);
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
-                    if (!TR && live && l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
+                    if (!LEAN && !TR && live && l == SW_L - 1 && s + 1 < my_strips) {  // leaves the strip: the next one picks it up at this row
                         e_sw[i] = left;
                         e_bgh[i] = h_bg;
                     }
-                    if (live && s == sm && l == lm) {
-                        int32_t v = up[0];
+                    if constexpr (LEAN) {
+                        int32_t v = 0;
 #pragma unroll
-                        for (int k = 1; k < K; ++k) v = (k == km) ? up[k] : v;
+                        for (int k = 0; k < K; ++k) v |= up[k] & (int32_t)kmask[k];
+                        const bool mine = live && l == lm;
                         if constexpr (TR) {
-                            bottom[i] = v;               // the last row, column by column
-                        } else if (v >= lc_score) {
-                            lc_score = v;
-                            lc_row = i;
+                            bottom[mine ? i : 0] = v;    // the last row, column by column (entry 0 is nobody's)
+                        } else {
+                            const bool take = mine && v >= lc_score;
+                            lc_score = take ? v : lc_score;
+                            lc_row = take ? i : lc_row;
+                        }
+                    } else {
+                        if (live && s == sm && l == lm) {
+                            int32_t v = 0;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) v |= up[k] & (int32_t)kmask[k];
+                            if constexpr (TR) {
+                                bottom[i] = v;               // the last row, column by column
+                            } else if (v >= lc_score) {
+                                lc_score = v;
+                                lc_row = i;
+                            }
                         }
                     }
                     if (live && i == ns) {
@@ -330,12 +406,19 @@ void phmm_sw_align_kernel(const SwParams p) {
             const int steps = (n_max + lanes_in_use) & ~1;
             constexpr int RAMP_STEPS = SW_L & ~1;       // (even: the loops take two steps at a time)
             for (int t = 0; t < min(RAMP_STEPS, steps); t += 2) {
-                step(std::true_type{}, t);
-                step(std::true_type{}, t + 1);
+                step(std::true_type{}, std::false_type{}, t);
+                step(std::true_type{}, std::false_type{}, t + 1);
             }
-            for (int t = RAMP_STEPS; t < steps; t += 2) {
-                step(std::false_type{}, t);
-                step(std::false_type{}, t + 1);
+            if (n_strips == 1) {
+                for (int t = RAMP_STEPS; t < steps; t += 2) {
+                    step(std::false_type{}, std::true_type{}, t);
+                    step(std::false_type{}, std::true_type{}, t + 1);
+                }
+            } else {
+                for (int t = RAMP_STEPS; t < steps; t += 2) {
+                    step(std::false_type{}, std::false_type{}, t);
+                    step(std::false_type{}, std::false_type{}, t + 1);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -413,9 +496,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                     const int ss = (jj - 1) / strip_cols, cc = (jj - 1) % strip_cols, ll = cc / K, kk = cc % K;
                     const int hh = kk >> 4, nq = min(K - 16 * hh, 16);
                     sh = 2 * (nq - 1 - (kk & 15));
-                    eo = LAST_PACKED && hh == NH - 1 ? 0 : WAVE;
-                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * NW + 2 * hh) * WAVE + (lane & GMASK) + ll;
+                    eo = LAST_PACKED && hh == NH - 1 ? 0 : 1;
+                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * WAVE + (lane & GMASK) + ll) * NW + 2 * hh;
                 };
+                constexpr int BQ = SW_L >= 32 ? 1 : 32 / SW_L;  // cells a lane fetches per round trip of the walk
                 int p1 = best.p1, p2 = best.p2;
                 if (segment_length > 0 && p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
                     cig.push(make_element(ST_CLIP, (uint32_t)segment_length));
@@ -424,13 +508,29 @@ void phmm_sw_align_kernel(const SwParams p) {
                 int state = ST_MATCH;
                 constexpr int HB = TR ? 1 : 0, VB = TR ? 0 : 1;  // the sweep's gap is shifted in first, the lanes' second
                 for (;;) {
-                    // lane l looks at cell (p1 - l, p2 - l); `run` = diagonal steps from (p1, p2) before anything else
+                    // lane l looks at the cells (p1 - d, p2 - d), d = l, l + SW_L, ... (BQ of them, 32 cells per group and round trip:
+                    // every fetch is a dependent read from HBM and the run of diagonal steps is usually the whole read);
+                    // `run` = diagonal steps from (p1, p2) before anything else
                     int sh, eo;
-                    const bool inside = p1 - l >= 1 && p2 - l >= 1;
-                    const uint32_t *w = cell_words(inside ? p1 - l : 1, inside ? p2 - l : 1, sh, eo);
-                    const uint32_t tag = inside ? (w[0] >> (30 - sh)) & 3u : 3u;
-                    const uint64_t others = ~(__ballot(tag == TAG_DIAG) >> (lane & GMASK)) & LMASK;  // lanes that do not see a diagonal step
-                    const int run = others ? __ffsll((long long)others) - 1 : SW_L;                 // 0 ... SW_L
+                    uint32_t tags[BQ];
+#pragma unroll
+                    for (int q = 0; q < BQ; ++q) {
+                        const int d = l + q * SW_L;
+                        const bool inside = p1 - d >= 1 && p2 - d >= 1;
+                        const uint32_t *w = cell_words(inside ? p1 - d : 1, inside ? p2 - d : 1, sh, eo);
+                        const uint32_t word = w[0];
+                        tags[q] = inside ? (word >> (30 - sh)) & 3u : 3u;
+                    }
+                    int run = BQ * SW_L;
+                    uint32_t tag = 3u;  // of the cell the run stops at (fetched by lane run % SW_L as its cell run / SW_L)
+#pragma unroll
+                    for (int q = BQ - 1; q >= 0; --q) {
+                        const uint64_t others = ~(__ballot(tags[q] == TAG_DIAG) >> (lane & GMASK)) & LMASK;  // lanes that do not see a diagonal step
+                        if (others) {
+                            run = q * SW_L + __ffsll((long long)others) - 1;
+                            tag = tags[q];
+                        }
+                    }
                     if (run > 0) {  // `run` times the reference's loop body with btrack == 0 (:372-417)
                         if (state != ST_MATCH) {
                             if (segment_length > 0) cig.push(make_element(state, (uint32_t)segment_length));
@@ -441,14 +541,14 @@ void phmm_sw_align_kernel(const SwParams p) {
                         p1 -= run;
                         p2 -= run;
                         if (p1 <= 0 || p2 <= 0) break;
-                        if (run == SW_L) continue;
+                        if (run == BQ * SW_L) continue;
                     }
                     // a gap ends at (p1, p2).  The reference's btrack entry (:257-266) is +k (k rows up) or -k (k columns
                     // left), k = the length the best gap ending here has: 1 where it opens, else one more than at the
                     // previous cell of the column / row
-                    const int src = (lane & GMASK) | run;  // the lane that fetched this cell
+                    const int src = (lane & GMASK) | (run & (SW_L - 1));  // the lane that fetched this cell
                     const uint32_t gtag = (uint32_t)__shfl((int)tag, src, WAVE);
-                    w = cell_words(p1, p2, sh, eo);
+                    const uint32_t *w = cell_words(p1, p2, sh, eo);
                     uint32_t e = w[eo];
                     int32_t k = 1;
                     if (gtag == TAG_RIGHT) {
@@ -526,27 +626,32 @@ const int kSwK64T[] = {2, 3, 4, 5, 6, 8};
 const int kNumSwK64T = sizeof(kSwK64T) / sizeof(int);
 
 // blocks (of one wave) of this instance a CU holds at once, by registers and LDS
-int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, bool wide) {
-    if (wide) {
-        auto kern = phmm_sw_align_kernel<16, 16, false, true>;
-        if (lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return 0;
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;
-        return nb;
+template <typename Kern>
+static int blocks_per_cu_of(Kern kern, size_t lds_bytes) {
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return 0;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;
+    return nb;
+}
+template <typename Kern>
+static hipError_t launch_of(Kern kern, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
     }
-#define PHMM_CASE_T(LL, KK, TT)                                                                                    \
-    if (L == LL && K == KK && transposed == TT) {                                                                  \
-        auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \
-        if (lds_bytes > 64 * 1024 &&                                                                               \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds_bytes) != hipSuccess)                                                     \
-            return 0;                                                                                              \
-        int nb = 0;                                                                                                \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, lds_bytes) != hipSuccess) nb = 0;        \
-        return nb;                                                                                                 \
-    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+// the special instances (sw_variant): one geometry each -- 16 lanes x 16 columns wide, 16 x 32 with rows in device memory
+int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int variant) {
+    if (variant == SW_WIDE) return blocks_per_cu_of(phmm_sw_align_kernel<16, 16, false, true, false>, lds_bytes);
+    if (variant == SW_EXT) return blocks_per_cu_of(phmm_sw_align_kernel<16, 32, false, false, true>, lds_bytes);
+    if (variant == (SW_WIDE | SW_EXT)) return blocks_per_cu_of(phmm_sw_align_kernel<16, 16, false, true, true>, lds_bytes);
+#define PHMM_CASE_T(LL, KK, TT) \
+    if (L == LL && K == KK && transposed == TT) return blocks_per_cu_of(phmm_sw_align_kernel<LL, KK, TT>, lds_bytes);
 #define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
 #define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)
@@ -557,29 +662,17 @@ int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, bool wide)
     return 0;
 }
 
-hipError_t launch_sw(int L, int K, bool transposed, bool wide, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_sw(int L, int K, bool transposed, int variant, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
     if (p.n_alignments <= p.a_begin) return hipSuccess;
-    if (wide) {  // one instance: 16 lanes x 16 columns (any lengths through strips)
-        if (L != 16 || K != 16 || transposed) return hipErrorInvalidValue;
-        auto kern = phmm_sw_align_kernel<16, 16, false, true>;
-        if (lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);
-        return hipGetLastError();
+    if (variant != SW_PLAIN) {
+        if (L != 16 || K != ((variant & SW_WIDE) ? 16 : 32) || transposed || ((variant & SW_EXT) != 0) != (p.ext != nullptr)) return hipErrorInvalidValue;
+        if (variant == SW_WIDE) return launch_of(phmm_sw_align_kernel<16, 16, false, true, false>, p, n_blocks, lds_bytes, stream);
+        if (variant == SW_EXT) return launch_of(phmm_sw_align_kernel<16, 32, false, false, true>, p, n_blocks, lds_bytes, stream);
+        return launch_of(phmm_sw_align_kernel<16, 16, false, true, true>, p, n_blocks, lds_bytes, stream);
     }
-#define PHMM_CASE_T(LL, KK, TT)                                                                                    \
-    if (L == LL && K == KK && transposed == TT) {                                                                  \
-        auto kern = phmm_sw_align_kernel<LL, KK, TT>;                                                                  \
-        if (lds_bytes > 64 * 1024) {                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
-            if (e != hipSuccess) return e;                                                                         \
-        }                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(WAVE), lds_bytes, stream, p);                                \
-        return hipGetLastError();                                                                                  \
-    }
+    if (p.ext) return hipErrorInvalidValue;
+#define PHMM_CASE_T(LL, KK, TT) \
+    if (L == LL && K == KK && transposed == TT) return launch_of(phmm_sw_align_kernel<LL, KK, TT>, p, n_blocks, lds_bytes, stream);
 #define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
 #define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)

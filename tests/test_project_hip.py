@@ -1,4 +1,4 @@
-"""phmm_project_to_reference on the MI355X: the read -> haplotype alignment projected onto the reference, read
+"""phmm_project_to_reference on the MI355X (NOTEBOOK.md §15): the read -> haplotype alignment projected onto the reference, read
 by read EQUAL (status, position, CIGAR) to oracle/cigar_oracle.c, which the reference's own test data pin
 (tests/test_cigar_oracle.py); and the reference's create_read_aligned_to_ref cases through the device directly."""
 import numpy as np

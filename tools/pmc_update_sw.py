@@ -1,4 +1,4 @@
-"""Developer tool: fold the PMC passes of `tools/sw_bench.py` (tools/run/g9.sh) into profiles/pmc_traffic.json as the
+"""Developer tool: fold the PMC passes of `tools/sw_bench.py` (tools/run/profiles.sh) into profiles/pmc_traffic.json as the
 entry bench.py's smith_waterman row reads (workload "smith_waterman", keyed by the alignments of the call and the hash of
 the kernel sources, like the PairHMM entries of tools/pmc_update.py).  Counters are summed over the kernels of one call
 (a large call is several pieces).    usage: python tools/pmc_update_sw.py gpurun_out/<tag> profiles/<name>"""
@@ -23,7 +23,7 @@ entry = {
     "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
     "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "wait_inst_any": c.get("SQ_WAIT_INST_ANY"),
     "wave_cycles": c.get("SQ_WAVE_CYCLES"), "waves": c.get("SQ_WAVES"),
-    "kernel_ms_bench": info["kernel_ms"], "cells_per_launch": info["cells"], "algorithmic_bytes_per_launch": info["backtrack_bytes"],
+    "kernel_ms_bench": info["kernel_ms"], "cells_per_launch": info["cells"], "backtrack_flag_bytes_per_launch": info["backtrack_bytes"],
     "clock_mhz": info["clock_mhz"], "source": os.path.basename(name) + "_summary.txt",
     "note": "one `launch` = one phmm_sw_align call (its pieces summed); rocprofv3 --pmc passes of tools/sw_bench.py; "
             "reads = 2 x FETCH_SIZE, writes = WRITE_SIZE as for the PairHMM entries",

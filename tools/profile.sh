@@ -12,9 +12,9 @@ mkdir -p $OUT
 BA="--steps 20 --warmup 5 --main-only $*"
 python bench.py $BA > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
-# the kernel trace collects the TIMED launches only (bench.py brackets them with roctxProfilerResume / Pause when PHMM_ROCTX=1):
-# the summary's average duration is the steady state the bench line reports, no warm-up dispatch in it
-PHMM_ROCTX=1 rocprofv3 --kernel-trace --stats --selected-regions -d $OUT/trace -o trace -- python bench.py $BA > $OUT/trace.log 2>&1
+# (tools/rocpd_summary.py reports the mean over the TIMED launches -- the last `steps` of every kernel -- beside the mean over
+# all dispatches: the steady state the bench line reports, no warm-up dispatch in it)
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py $BA > $OUT/trace.log 2>&1
 # (the counter passes keep every dispatch: instruction and byte counts do not depend on clocks or warm caches)
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)

@@ -12,6 +12,22 @@ if tr:
     lines.append("%-64s %8s %16s %14s %8s" % ("name", "calls", "total_ns", "avg_ns", "pct"))
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         lines.append("%-64s %8d %16.0f %14.0f %8.3f" % (r[0][:64], r[1], r[2] * 1e3, r[3] * 1e3, r[4]))
+    # steady state: the TIMED launches of bench.py are the LAST `steps` dispatches of every kernel of a launch (the warm-up
+    # launches come first), so their mean is the figure the bench line reports -- no warm-up dispatch in it
+    bj0 = os.path.join(src, "bench.json")
+    steps = json.loads(open(bj0).read().strip().splitlines()[-1]).get("steps") if os.path.exists(bj0) else None
+    if steps:
+        lines.append("")
+        lines.append("== steady state: mean over the last %d launches' dispatches of each kernel (the timed loop; warm-up excluded) ==" % steps)
+        lines.append("%-64s %8s %14s %14s %14s" % ("name", "calls", "avg_ns_all", "avg_ns_timed", "per_launch"))
+        names = [r[0] for r in c.execute("select name from top_kernels where name like '%phmm%'")]
+        for n in names:
+            d = [r[0] for r in c.execute("select duration from kernels where name = ? order by start", (n,))]
+            # a launch may dispatch a kernel several times (K ranges, rescue): dispatches per launch = total / (steps + warm-up)
+            total_launches = steps + json.loads(open(bj0).read().strip().splitlines()[-1]).get("warmup", 0)
+            per = max(1, len(d) // max(1, total_launches))
+            timed = d[-steps * per:]
+            lines.append("%-64s %8d %14.0f %14.0f %14d" % (n[:64], len(d), sum(d) / len(d), sum(timed) / len(timed), per))
     lines.append("")
     lines.append("== per-dispatch (first 12) ==")
     for r in c.execute("select name, duration, grid_x, grid_y, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels where name like '%phmm%' limit 12"):

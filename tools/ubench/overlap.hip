@@ -1,4 +1,4 @@
-// Micro-benchmark: does a host->device copy on one stream overlap a kernel on another?  (Behind DESIGN.md's statement
+// Micro-benchmark: does a host->device copy on one stream overlap a kernel on another?  (Behind NOTEBOOK.md's statement
 // on the pipelined host path.)  build: hipcc --offload-arch=gfx950 -O2 -o overlap overlap.hip
 #include <hip/hip_runtime.h>
 
