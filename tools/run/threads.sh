@@ -22,7 +22,11 @@ for pc in 2 4 8 16 64 256; do TB_MODE=fused TB_THREADS=1,4 tools/threads_bench 0
 echo "## kernels of one region call (rocprofv3 --kernel-trace --stats, one caller thread)"
 rm -rf gpurun_out/tb1; mkdir -p gpurun_out/tb1
 TB_MODE=fused TB_THREADS=1 rocprofv3 --kernel-trace --stats -d gpurun_out/tb1 -o tb1 --output-format csv -- tools/threads_bench 0.4 2>&1 | grep threads:
-column -s, -t gpurun_out/tb1/tb1_kernel_stats.csv 2>/dev/null | cut -c1-150 | head -12
+python3 - <<'PY'
+import csv, glob
+for r in list(csv.reader(open(glob.glob("gpurun_out/tb1/**/*kernel_stats.csv", recursive=True)[0])))[:12]:
+    print("%-72s %s" % (r[0][:72], "  ".join("%12s" % x[:12] for x in r[1:6])))
+PY
 rm -rf gpurun_out/tb1
 } > $O 2>&1
 tail -5 $O
