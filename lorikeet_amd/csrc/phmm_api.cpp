@@ -701,7 +701,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             const uint32_t gs = (uint32_t)(WAVE / c.L) / (uint32_t)c.streams;
             uint64_t items = 0;
             for (uint32_t g : c.regions)
-                items += (uint64_t)((shape[g].nh + gs - 1) / gs) * ((shape[g].nr + reg_run[g] - 1) / reg_run[g]);
+                items += (uint64_t)((shape[g].nh + gs - 1) / gs + 3) * ((shape[g].nr + reg_run[g] - 1) / reg_run[g]);  // (+ 3: a remainder in items of its own, below)
             class_meta += align_up(items * sizeof(ChainItem), 256);
         }
         if (!c.L) class_meta += align_up((c.pair_first.size() + 1) * 8, 256);
@@ -806,9 +806,26 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 // the haplotype groups of one run next to each other: they sweep the same read bytes, and items that are
                 // launched together find them in L2 (config 3, 10 000 regions: HBM traffic 2.7 x the algorithmic bytes
                 // with the groups a whole pass apart)
+                // A haplotype count that leaves the last wave of a one-stream class partly empty (5 haplotypes: 4 + 1) gives
+                // the remainder to items of its own with 2 or 4 streams of reads, which fill the wave's slots with the same
+                // haplotypes again (chain_streams): 5 haplotypes 0.63 -> 0.96 of the slots busy, 9: 0.75 -> 0.98.
+                uint32_t nq_main = nq, rest = 0, rest_streams = 1;
+                if (c.streams == 1 && c.L == 16 && !(h->flags & PHMM_FLAG_F32_FIRST) && sw.force_streams == 0 && shape[g].nh > 4 && shape[g].nh % 4 != 0) {
+                    rest = shape[g].nh % 4;
+                    rest_streams = (uint32_t)chain_streams(rest, nullptr);
+                    if (rest_streams > 1) nq_main = shape[g].nh / 4;
+                    else rest = 0;
+                }
                 for (uint32_t r = r0; r < r1; r += run)
-                    for (uint32_t q = 0; q < nq; ++q)
+                    for (uint32_t q = 0; q < nq_main; ++q)
                         c.chain_items.push_back(ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)c.streams, r, std::min(r1, r + run)});
+                if (rest) {
+                    const uint32_t gs2 = 4 / rest_streams, q0 = nq_main * 4 / gs2, nq2 = (rest + gs2 - 1) / gs2;
+                    const uint32_t run2 = std::min<uint32_t>(CHAIN_MAX_READS, run * rest_streams);
+                    for (uint32_t r = r0; r < r1; r += run2)
+                        for (uint32_t q = 0; q < nq2; ++q)
+                            c.chain_items.push_back(ChainItem{g, (uint16_t)(q0 + q), (uint8_t)c.K, (uint8_t)rest_streams, r, std::min(r1, r + run2)});
+                }
             }
             // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
             // be filled by the short ones (stable, so equal-length batches keep their order)
