@@ -50,3 +50,16 @@ def test_config5_all_256_stress_regions(hip_engine):
     b = synthetic.config5()
     assert b.n_regions == 256 and b.cells() == 256 * 512 * 150 * 64 * 400    # 5.03e11, SURVEY 8(d)
     _check_full_set(hip_engine, b, [0, 255])
+
+
+def test_ragged_mix_all_1536_regions(hip_engine):
+    """The bench's long-tailed mix (3 ... 5 000 reads, 1 ... 128 haplotypes of 60 ... 500 bases, reads of 30 ... 250 mixed
+    inside a region, 'N' runs): every one of its 1.57 M pairs, through every kernel class the planner picks for it -- per-read
+    kernels, the chained kernels of all four K ranges at 16 and 32 lanes per pair, multi-stream items for haplotype
+    remainders -- and the scalar oracle on the smallest, the largest and a few regions in between."""
+    b = synthetic.ragged()
+    assert b.n_regions == 1536
+    cells = np.diff(b.region_read_off.astype(np.int64)) * np.diff(b.region_hap_off.astype(np.int64))
+    order = np.argsort(cells)
+    sample = [int(order[0]), int(order[len(order) // 4]), int(order[len(order) // 2]), int(order[-40]), int(order[-1])]
+    _check_full_set(hip_engine, b, sample)
