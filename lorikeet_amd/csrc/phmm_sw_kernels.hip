@@ -85,6 +85,11 @@ __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a b
     return a.order < b.order;
 }
 
+// a backtrack flag word, read where the stores of this wave went (L2)
+__device__ __forceinline__ uint32_t flag_load(const uint32_t *at) {
+    return __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // NW dwords of backtrack flags, one streaming store (global_store_dword / x2 / x3 / x4; four-byte alignment is all they need)
 template <int NW, typename V>
 __device__ __forceinline__ void store_flags(uint32_t *at, const V &v) {
@@ -469,7 +474,11 @@ void phmm_sw_align_kernel(const SwParams p) {
             }
         }
         if (dp && best.order > 0) segment_length = m - best.p2;  // a bottom-row cell: the end of the alternate overhangs (:327)
-        __threadfence();  // every lane's backtrack entries are visible to the lane that walks them
+        // Every lane's backtrack entries have to be visible to the lanes that walk them: the wave's own stores are complete
+        // (acknowledged by L2) once its vector-memory counter is zero, and the walk reads them with device-scope loads (L2, not
+        // this CU's L1, which may still hold the slab's lines of the previous round).  (A device-scope fence here -- write back
+        // and invalidate -- cost 5 % of the kernel.)
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
 
         // ---- calculate_cigar (:332-443): the sixteen lanes of the alignment walk together ------------------------------
         // Every backtrack step is a dependent read from HBM; sixteen cells down the diagonal are fetched at once, one
@@ -518,7 +527,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                         const int d = l + q * SW_L;
                         const bool inside = p1 - d >= 1 && p2 - d >= 1;
                         const uint32_t *w = cell_words(inside ? p1 - d : 1, inside ? p2 - d : 1, sh, eo);
-                        const uint32_t word = w[0];
+                        const uint32_t word = flag_load(w);
                         tags[q] = inside ? (word >> (30 - sh)) & 3u : 3u;
                     }
                     int run = BQ * SW_L;
@@ -549,20 +558,20 @@ void phmm_sw_align_kernel(const SwParams p) {
                     const int src = (lane & GMASK) | (run & (SW_L - 1));  // the lane that fetched this cell
                     const uint32_t gtag = (uint32_t)__shfl((int)tag, src, WAVE);
                     const uint32_t *w = cell_words(p1, p2, sh, eo);
-                    uint32_t e = w[eo];
+                    uint32_t e = flag_load(w + eo);
                     int32_t k = 1;
                     if (gtag == TAG_RIGHT) {
                         for (int j2 = p2; !((e >> (sh + HB)) & 1u) && j2 > 1;) {
                             ++k;
                             --j2;
-                            e = cell_words(p1, j2, sh, eo)[eo];
+                            e = flag_load(cell_words(p1, j2, sh, eo) + eo);
                         }
                         p2 -= k;
                     } else {
                         for (int i2 = p1; !((e >> (sh + VB)) & 1u) && i2 > 1;) {
                             ++k;
                             --i2;
-                            e = cell_words(i2, p2, sh, eo)[eo];
+                            e = flag_load(cell_words(i2, p2, sh, eo) + eo);
                         }
                         p1 -= k;
                     }
