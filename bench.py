@@ -617,6 +617,15 @@ def main():
         dt = (time.perf_counter() - t) / 3
         kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernels of the last call
         flag_bytes = eng.stat("sw_backtrack_bytes")
+        # the same call as ONE piece (no staging overlapped with the kernels: slower end to end, but the kernels run back to back
+        # -- and in two passes where that pays: tags-only sweep, then the full instance over the alignments whose walk met a gap)
+        eng.set_switch("sw_chunks", 1)
+        one_s, one_again = 1e9, 0
+        for _ in range(3):
+            assert eng.lib.phmm_sw_align(*args) == 0
+            if eng.stat("sw_kernel_us") / 1e6 < one_s:
+                one_s, one_again = eng.stat("sw_kernel_us") / 1e6, eng.stat("sw_second_pass")
+        eng.set_switch("sw_chunks", 0)
         k = min(n, sample)
         L = oracle.lib()
         cores = usable_cores()
@@ -646,6 +655,9 @@ def main():
                 "kernel": {"ms": round(kern_s * 1e3, 3), "gcups_i32": round(cells / max(kern_s, 1e-9) / 1e9, 1),
                            "shader_clock_mhz": int(eng.stat("sw_clock_mhz")),
                            "note": "the phmm_sw_align_kernel<L,K> launches of the last call (HIP events in the library, phmm_get_stat)"},
+                "kernel_one_piece": {"ms": round(one_s * 1e3, 3), "gcups_i32": round(cells / max(one_s, 1e-9) / 1e9, 1),
+                                     "second_pass_alignments": int(one_again),
+                                     "note": "the same alignments as one piece (switch sw_chunks = 1): two passes where the handle expects few gaps"},
                 "cpu_oracle": {"gcups_i32": round(int(np.sum(rl[:k] * al[:k])) / tc / 1e9, 3), "alignments_per_s": round(k / tc, 1),
                                "cores": cores, "kind": "port",
                                "note": "oracle/sw_oracle.c (the reference's scalar arm), ctypes calls from a thread pool"}}, \

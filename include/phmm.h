@@ -489,7 +489,7 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
  * Developer switches and counters (tests, A/B measurements; never needed in production, NOTEBOOK.md §11).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
- * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy"; value -1 / 0 = back to the
+ * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy", "sw_lite", "submit_gather_us", "no_fork"; value -1 / 0 = back to the
  * planner's choice as documented there).  Not to be called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
  * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes" /

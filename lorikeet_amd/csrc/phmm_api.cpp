@@ -289,6 +289,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_SUBMIT_LANES", w.submit_lanes);
         env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
         env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
+        env("PHMM_SW_LITE", w.sw_lite);
         env("PHMM_SW_CHUNKS", w.sw_chunks);
         env("PHMM_SW_LANES", w.sw_lanes);
         env("PHMM_SW_TRANSPOSE", w.sw_transpose);
@@ -2076,6 +2077,10 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "trace") w.trace = value != 0;
     else if (n == "submit_gather_us") w.submit_gather_us = value > 0 ? value : 0;
     else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
+    else if (n == "sw_lite") {
+        w.sw_lite = value;
+        h->swork.lite_skip = 0;  // (what earlier calls have taught the handle starts over)
+    }
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
     else if (n == "sw_transpose") w.sw_transpose = value < 0 ? -1 : value > 0 ? 1 : 0;
     else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
@@ -2096,6 +2101,7 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "rescue_passes") own = h->stat_rescue_passes;
     else if (n == "sw_kernel_us") return h->swork.last_kernel_us;
     else if (n == "sw_backtrack_bytes") return h->swork.last_backtrack_bytes;
+    else if (n == "sw_second_pass") return h->swork.last_second_pass;
     else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);

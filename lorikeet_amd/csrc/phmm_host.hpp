@@ -38,6 +38,7 @@ struct Switches {
     int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int submit_gather_us = 40;  // PHMM_SUBMIT_GATHER_US: how long the leader of a flush lets submissions that are on their way arrive (0 = never)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
+    int sw_lite = -1;           // PHMM_SW_LITE: the tags-only first pass of the aligner -- -1 where it pays (adaptive), 0 never, 1 always
     int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
@@ -75,6 +76,8 @@ struct phmm_handle {
         size_t slab_bytes = 0;
         uint32_t *ws = nullptr;  // the projection's builders (phmm_realign_reads)
         size_t ws_bytes = 0;
+        int lite_skip = 0;             // calls that go straight to the full Smith-Waterman instance (the last two-pass call met too many gaps)
+        uint64_t last_second_pass = 0; // alignments of the last call that the full instance had to align again (phmm_get_stat "sw_second_pass")
         unsigned char *ext = nullptr;  // bottom rows / strip edges of alignments too long for LDS (SwGeometry::ext_stride)
         size_t ext_bytes = 0;
         static constexpr int kMaxChunks = 8;      // pieces of one call: piece c+1 is staged and copied while piece c computes

@@ -50,7 +50,7 @@ bool ok(phmm_handle *h, hipError_t e, const char *what) {
 // come back.  Every piece starts on a 256-byte boundary.
 struct Layout {
     size_t bases, q0, i0, d0, mapq, haps, refhap, pri, rstart, hco, hc, hs, oco, oc, outco, clip, status_in, in_end;
-    size_t q, i, d, g, thr, refidx, swc, nsw, swo;
+    size_t q, i, d, g, thr, refidx, swc, nsw, swo, todo;
     size_t res, keep, out, best, lk, conf, pst, pno, pos, pout, end;
     Layout() { memset(this, 0, sizeof *this); }
     Layout(size_t base, const RegionArgs &a, uint32_t sw_capacity) {
@@ -89,6 +89,7 @@ struct Layout {
         swc = take(4ull * nr * sw_capacity);
         nsw = take(4ull * nr);
         swo = take(4ull * nr);
+        todo = take(4ull * nr);  // the list the aligner's tags-only pass leaves to its second pass (SW_LITE)
         res = take(256);
         keep = take(nr);
         out = take(8ull * a.out_off[ng]);
@@ -439,7 +440,21 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         // (chunks of one call follow each other through the handle's one slab and workspace)
         if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
-        good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
+        // (reads against their haplotypes: the tags-only sweep first, the full instance over the alignments that met a gap;
+        // the counter is a word of the status block that is staged as zeros with the inputs)
+        const bool lite = G.variant == SW_PLAIN && h->sw.sw_lite != 0 &&
+                          (sp.strategy == PHMM_SW_SOFTCLIP || sp.strategy == PHMM_SW_IGNORE);
+        if (lite) {
+            SwParams s1 = sp, s2 = sp;
+            s1.todo_out = (uint32_t *)(A.dev + L.todo);
+            s1.todo_out_count = (uint32_t *)(A.dev + L.status_in) + 32;
+            s2.todo = s1.todo_out;
+            s2.todo_count = s1.todo_out_count;
+            good = good && ok(h, launch_sw(G.L, G.K, G.transposed, SW_LITE, s1, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel (tags)") &&
+                   ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, s2, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
+        } else {
+            good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
+        }
     } else if (good && nr) {  // nothing was aligned: the kernels behind the aligner still find defined alignments
         good = ok(h, hipMemsetAsync(A.dev + L.nsw, 0, 4ull * nr, S), "memset") && ok(h, hipMemsetAsync(A.dev + L.swo, 0, 4ull * nr, S), "memset");
     }

@@ -389,7 +389,16 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const int L = G.L, K = G.K;
     const bool transposed = G.transposed;
     const size_t strip_cols = (size_t)L * K, lds_ref = G.lds_ref, lds_alt = G.lds_alt, lds_group = G.lds_group, gpb = G.gpb, lds = G.lds,
-                 flag_words = G.flag_words, slab_stride = G.slab_stride, max_workers = G.max_workers;
+                 flag_words = G.flag_words, slab_stride = G.slab_stride;
+    // Two passes (SW_LITE) where gaps are the exception: reads against haplotypes (SoftClip / Ignore), in calls of one piece.
+    // A call that found a gap in more than three alignments of ten makes the next fifteen calls of this handle go straight to
+    // the full instance.
+    bool lite = G.variant == SW_PLAIN && h->sw.sw_lite != 0 && (J.strategy == PHMM_SW_SOFTCLIP || J.strategy == PHMM_SW_IGNORE);
+    if (lite && h->sw.sw_lite < 0 && h->swork.lite_skip > 0) {
+        h->swork.lite_skip -= 1;
+        lite = false;
+    }
+    const size_t max_workers = G.max_workers;
     // pieces: the bases of piece c+1 are staged and copied while piece c computes (the kernels follow each other on
     // one stream and share the slabs).  A piece is a whole number of rounds of the persistent blocks, so that only
     // the last piece of a call ends on a partly filled round.
@@ -430,6 +439,10 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     // one piece: everything in order on one stream, one copy each way, one wait (a region per call is the reference's pattern)
     const bool one_piece = n_chunks == 1;
+    // (A call in pieces is bound by its copies, not by its kernels, and every piece's second pass costs a whole sweep's
+    // latency however few alignments it holds -- 131 072 reads: 4.3 ms either way: only calls of one piece take two passes
+    // unless the switch asks for them.)
+    if (h->sw.sw_lite < 0 && !one_piece) lite = false;
     hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
     if (W.slab_bytes < slab_bytes) {
         (void)hipStreamSynchronize(S);
@@ -458,7 +471,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                  o_cg = o_of + up256(4ull * n_alignments), o_pfl = o_cg + up256(4ull * n_cig);
     const size_t o_pst = o_pfl + (PJ ? 256 : 0), o_pno = o_pst + (PJ ? up256(4ull * n_alignments) : 0),
                  o_ppos = o_pno + (PJ ? up256(4ull * n_alignments) : 0), o_pout = o_ppos + (PJ ? up256(8ull * n_alignments) : 0),
-                 o_extra = o_pout + (PJ ? up256(4ull * pj_out) : 0), total = o_extra + (J.view ? up256(J.view->extra_bytes) : 0);
+                 o_extra = o_pout + (PJ ? up256(4ull * pj_out) : 0), o_todo = o_extra + (J.view ? up256(J.view->extra_bytes) : 0),
+                 total = o_todo + up256(4ull * n_alignments);  // (the list of the tags-only pass: device memory only)
     if (!grow_staging(h, total)) return PHMM_ERR_HIP;
     // A small call in one piece (a region per call, the reference's pattern): the kernels store the results -- and the
     // status block -- straight into the pinned mirror, so that nothing is copied back (each copy costs the call some
@@ -637,7 +651,18 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         p.n_alignments = a1;
         const size_t workers = std::min<size_t>(max_workers, ((size_t)(a1 - a0) + gpb - 1) / gpb);
         (void)hipEventRecord(W.ev_k0[c], S);
-        good = ok(h, launch_sw(L, K, transposed, G.variant, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        if (lite) {  // tags only, then the full instance over what met a gap (the counters are zeroed with the head of the input)
+            SwParams p1 = p, p2 = p;
+            p1.todo_out = (uint32_t *)(W.dev + o_todo) + a0;
+            p1.todo_out_count = (uint32_t *)(W.dev + 192) + c;
+            p2.todo = p1.todo_out;
+            p2.todo_count = p1.todo_out_count;
+            p2.feedback = zero_copy ? (uint32_t *)(W.host_dev + o_st + 192) + c : nullptr;  // (otherwise the counters come back with the status block)
+            good = ok(h, launch_sw(L, K, transposed, SW_LITE, p1, (uint32_t)workers, lds, S), "phmm_sw_align_kernel (tags)") &&
+                   ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        } else {
+            good = ok(h, launch_sw(L, K, transposed, G.variant, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+        }
         if (good && PJ) {  // ... and the piece's alignments projected onto the reference, where they lie
             pp.r_begin = a0;
             pp.n_reads = a1;
@@ -652,8 +677,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (ri == SW_NO_REFERENCE) continue;
         const uint64_t rows = J.best ? max_ref : ref_off[ri + 1] - ref_off[ri];  // (the device chooses the haplotype: an upper bound)
         const uint64_t cols = alt_off[a + 1] - alt_off[a];
-        W.last_backtrack_bytes += transposed ? (cols + L - 1ull) * L * flag_words * 4ull
-                                             : (uint64_t)((cols + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * flag_words * 4ull;
+        const uint64_t words = lite ? (uint64_t)sw_tag_words(K) : flag_words;  // (what the second pass adds for the alignments with gaps is not counted)
+        W.last_backtrack_bytes += transposed ? (cols + L - 1ull) * L * words * 4ull
+                                             : (uint64_t)((cols + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * words * 4ull;
     }
     // Results come back piece by piece, on a stream of their own: a piece's D2H is issued once the host has seen
     // its kernel finish (a copy that waits in the queue for a kernel holds back the H2D copies behind it, NOTEBOOK.md
@@ -735,6 +761,14 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     for (int c = 0; c < n_chunks; ++c) {
         float ms = 0.f;
         if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
+    }
+    if (lite) {
+        uint64_t again = 0;
+        for (int c = 0; c < n_chunks; ++c) again += ((const uint32_t *)(W.host + o_st + 192))[c];
+        W.last_second_pass = again;
+        if (again * 10 > (uint64_t)n_alignments * 3) W.lite_skip = 15;
+    } else {
+        W.last_second_pass = 0;
     }
     const uint32_t *st = (const uint32_t *)(W.host + o_st + 64);  // [0], [1] conditions; [2], [3]: shader clocks / 100 MHz ticks of the last kernel's block 0
     W.last_clock_mhz = st[3] ? (uint64_t)((double)st[2] * 100.0 / (double)st[3]) : 0;

@@ -14,6 +14,7 @@ constexpr int SW_STATUS_CAPACITY = 1;  // some CIGAR did not fit its slot (n_cig
 // Flag dwords a lane stores per step for its K cells (four bits each): a pair -- candidate tags, gap-open bits -- per 16
 // cells, and for a remainder of at most 8 cells ONE dword with the tags in its top and the gap bits in its bottom half.
 constexpr int sw_flag_words(int K) { return 2 * (K / 16) + (K % 16 == 0 ? 0 : K % 16 <= 8 ? 1 : 2); }
+constexpr int sw_tag_words(int K) { return (K + 15) / 16; }  // the tags-only sweep (SW_LITE): two bits per cell
 
 struct SwParams {
     uint32_t a_begin, n_alignments;        // this launch aligns [a_begin, n_alignments)
@@ -35,12 +36,18 @@ struct SwParams {
     uint32_t lds_ref_bytes, lds_alt_bytes; // LDS reserved for the two sequences (multiples of 16)
     uint32_t lds_group_bytes;              // LDS of one alignment
     uint32_t groups_per_block;             // alignments a block works on side by side: 64 / L, or 1 for very long sequences
+    // two passes (SW_LITE): the tags-only launch lists the alignments whose walk met a gap (todo_out, *todo_out_count: device
+    // memory, the counter zeroed beforehand); the full launch behind it aligns todo[0 .. *todo_count) instead of a range
+    uint32_t *todo_out, *todo_out_count;
+    const uint32_t *todo, *todo_count;
+    uint32_t *feedback;                    // or null: where the full launch leaves *todo_count for the host (pinned memory)
     unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of
     size_t ext_stride;                     // block b live at ext + b * ext_stride (device memory), LDS holds the two sequences only
 };
 // L lanes per alignment (8 / 16 / 32 / 64), K columns per lane (one of kSwK<L>), 64 / L alignments per block
 // `wide`: the instance for weights beyond the x4 range (scores as they are, the reference's comparisons and clamp): L = K = 16
-enum : int { SW_PLAIN = 0, SW_WIDE = 1, SW_EXT = 2 };  // kernel variants (bit mask): un-scaled scores with the reference's clamp; rows in device memory
+enum : int { SW_PLAIN = 0, SW_WIDE = 1, SW_EXT = 2, SW_LITE = 4 };  // kernel variants: un-scaled scores with the reference's clamp; rows in device
+                                                                    // memory (the two combine); the tags-only sweep of an ordinary instance
 hipError_t launch_sw(int L, int K, bool transposed, int variant, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
 int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int variant);  // what a CU holds at once (registers, LDS); 0 on failure
 extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[], kSwK64T[];  // (T: rows per lane of the sweep along the alternate)

@@ -125,9 +125,14 @@ __device__ __forceinline__ void store_flags(uint32_t *at, const V &v) {
 // memory, one slice per block, LDS holds the two sequences only.  An instance of its own (16 lanes x 32 columns, and the
 // wide one): loads from device memory inside the sweep make the compiler wait for ALL outstanding memory operations of a
 // step -- the flag stores included -- which cost the ordinary instances 5-8 % while the two shared one body.
-template <int SW_L, int K, bool TR = false, bool WIDE = false, bool EXT = false>
+// LITE: the sweep leaves only the two-bit candidate tag per cell -- 11 instructions per cell instead of 16, half the flag
+// volume.  That is all the walk needs as long as it meets no gap (the usual read against its haplotype): an alignment whose
+// walk does meet one is put on a list and aligned again by the full instance, launched behind this one over that list
+// (SwParams::todo), so results never depend on which of the two ran.
+template <int SW_L, int K, bool TR = false, bool WIDE = false, bool EXT = false, bool LITE = false>
 __global__ __launch_bounds__(WAVE) PHMM_SW_OCCUPANCY(K)
 void phmm_sw_align_kernel(const SwParams p) {
+    static_assert(!LITE || (!WIDE && !EXT), "the tags-only sweep exists for the ordinary instances");
     // TR: the sweep runs along the ALTERNATE sequence and the lanes share out the reference's rows (K rows per lane) --
     // the same cells in another order.  For a small call of reads against longer haplotypes that is fewer steps of more
     // cells each (150 x 300 on 64 lanes: 210 steps of five cells instead of 350 of three), and a step's fixed cost is
@@ -148,9 +153,9 @@ void phmm_sw_align_kernel(const SwParams p) {
     int32_t *e_bgh = e_sw + (p.max_ref + 1);
     // backtrack flags of this block, [strip][step][dword][lane]
     constexpr int NH = (K + 15) / 16;  // flag accumulator pairs per lane: candidate tags, gap-open bits of 16 cells each
-    constexpr int NW = sw_flag_words(K);  // dwords stored per lane and step
+    constexpr int NW = LITE ? sw_tag_words(K) : sw_flag_words(K);  // dwords stored per lane and step
     constexpr int REM = K % 16;
-    constexpr bool LAST_PACKED = REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
+    constexpr bool LAST_PACKED = !LITE && REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
     uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
     // scores times four; the low two bits name the candidate
     constexpr int32_t SC = WIDE ? 1 : 4, TG = WIDE ? 0 : 1;  // scale of the scores; whether their low two bits carry the candidate
@@ -166,9 +171,13 @@ void phmm_sw_align_kernel(const SwParams p) {
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
     const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
-    for (uint32_t base = p.a_begin + blockIdx.x * gpb; base < p.n_alignments; base += gridDim.x * gpb) {
-        const uint32_t a = base + (uint32_t)g;
-        bool valid = (uint32_t)g < gpb && a < p.n_alignments;
+    // the alignments of this launch: [a_begin, n_alignments), or the list an earlier tags-only launch left (todo)
+    const uint32_t n_items = p.todo ? *p.todo_count : p.n_alignments;
+    if (p.todo && p.feedback && blockIdx.x == 0 && lane == 0) *p.feedback = n_items;  // (the host looks at it between calls)
+    for (uint32_t base = (p.todo ? 0u : p.a_begin) + blockIdx.x * gpb; base < n_items; base += gridDim.x * gpb) {
+        const uint32_t item = base + (uint32_t)g;
+        bool valid = (uint32_t)g < gpb && item < n_items;
+        const uint32_t a = !valid ? 0u : p.todo ? p.todo[item] : item;
         uint32_t ro = 0, ao = 0;
         int n = 0, m = 0;
         if (valid) {
@@ -319,11 +328,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                         const int32_t pv = up[k] + x_open_s;                                       // :207-218
                         const int32_t next_diag = k + 1 < K ? up[k] + score(k + 1) : 0;           // (before up[k] becomes this row's value)
                         const int32_t ev = bgv[k] + x_extend;
-                        acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(ev - pv), 31);  // 1: pv > ev, the gap opens here
+                        if constexpr (!LITE) acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(ev - pv), 31);  // 1: pv > ev, the gap opens here
                         bgv[k] = max(pv, ev);
                         const int32_t ph = left + x_open_l;                                        // :229-240 (tag: right)
                         const int32_t eh = h_bg + x_extend;
-                        acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(eh - ph), 31);
+                        if constexpr (!LITE) acc_e[k / 16] = __builtin_amdgcn_alignbit(acc_e[k / 16], (uint32_t)(eh - ph), 31);
                         h_bg = max(ph, eh);
                         // priority: diagonal, then right (horizontal), then down (:250-266) -- the tags break the ties
                         if constexpr (!WIDE) {
@@ -349,7 +358,9 @@ void phmm_sw_align_kernel(const SwParams p) {
                     flag_vec fv;
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh) {
-                        if (LAST_PACKED && hh == NH - 1) {
+                        if constexpr (LITE) {
+                            fv[hh] = acc_c[hh];  // (a last word of fewer than 16 cells has them in its top bits)
+                        } else if (LAST_PACKED && hh == NH - 1) {
                             constexpr uint32_t LO = REM >= 16 ? ~0u : (1u << (2 * (REM & 15))) - 1u;
                             fv[2 * hh] = (acc_c[hh] & ~(~0u >> (2 * (REM & 15)))) | (acc_e[hh] & LO);
                         } else {
@@ -488,6 +499,7 @@ void phmm_sw_align_kernel(const SwParams p) {
             CigarOut cig{p.cigar + (p.cigar_off ? p.cigar_off[a] : (uint64_t)a * p.cigar_slot),
                          p.cigar_off ? p.cigar_off[a + 1] - p.cigar_off[a] : (uint64_t)p.cigar_slot, l == 0};
             int32_t alignment_offset = 0;
+            bool again = false;  // (tags-only sweep) the walk met a gap
             if (n == 0 || m == 0) {  // the reference asserts (:65-68, :132-134); the host refuses such input beforehand
                 if (l == 0) p.status[SW_STATUS_EMPTY] = 1u;
             } else if (found >= 0) {
@@ -506,7 +518,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                     const int hh = kk >> 4, nq = min(K - 16 * hh, 16);
                     sh = 2 * (nq - 1 - (kk & 15));
                     eo = LAST_PACKED && hh == NH - 1 ? 0 : 1;
-                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * WAVE + (lane & GMASK) + ll) * NW + 2 * hh;
+                    return slab + (size_t)ss * strip_stride + ((size_t)(i - 1 + ll) * WAVE + (lane & GMASK) + ll) * NW + (LITE ? hh : 2 * hh);
                 };
                 constexpr int BQ = SW_L >= 32 ? 1 : 32 / SW_L;  // cells a lane fetches per round trip of the walk
                 int p1 = best.p1, p2 = best.p2;
@@ -552,6 +564,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                         if (p1 <= 0 || p2 <= 0) break;
                         if (run == BQ * SW_L) continue;
                     }
+                    if constexpr (LITE) {  // a gap: its length is not in the tags -- the full instance aligns this one again
+                        again = true;
+                        break;
+                    }
                     // a gap ends at (p1, p2).  The reference's btrack entry (:257-266) is +k (k rows up) or -k (k columns
                     // left), k = the length the best gap ending here has: 1 where it opens, else one more than at the
                     // previous cell of the column / row
@@ -585,7 +601,8 @@ void phmm_sw_align_kernel(const SwParams p) {
                     }
                     if (p1 <= 0 || p2 <= 0) break;
                 }
-                if (p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
+                if (again) {
+                } else if (p.strategy == PHMM_SW_STRATEGY_SOFTCLIP) {
                     cig.push(make_element(state, (uint32_t)segment_length));
                     if (p2 > 0) cig.push(make_element(ST_CLIP, (uint32_t)p2));
                     alignment_offset = p1;
@@ -601,7 +618,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                     alignment_offset = 0;
                 }
             }
-            if (l == 0) {
+            if (l == 0 && again) {
+                p.todo_out[atomicAdd(p.todo_out_count, 1u)] = a;
+                p.n_cigar[a] = 0;
+                p.alignment_offset[a] = 0;
+            } else if (l == 0) {
                 cig.finish();
                 p.n_cigar[a] = cig.n;
                 p.alignment_offset[a] = alignment_offset;
@@ -659,8 +680,10 @@ int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int varian
     if (variant == SW_WIDE) return blocks_per_cu_of(phmm_sw_align_kernel<16, 16, false, true, false>, lds_bytes);
     if (variant == SW_EXT) return blocks_per_cu_of(phmm_sw_align_kernel<16, 32, false, false, true>, lds_bytes);
     if (variant == (SW_WIDE | SW_EXT)) return blocks_per_cu_of(phmm_sw_align_kernel<16, 16, false, true, true>, lds_bytes);
-#define PHMM_CASE_T(LL, KK, TT) \
-    if (L == LL && K == KK && transposed == TT) return blocks_per_cu_of(phmm_sw_align_kernel<LL, KK, TT>, lds_bytes);
+#define PHMM_CASE_T(LL, KK, TT)                                                                                              \
+    if (L == LL && K == KK && transposed == TT)                                                                              \
+        return variant == SW_LITE ? blocks_per_cu_of(phmm_sw_align_kernel<LL, KK, TT, false, false, true>, lds_bytes)       \
+                                  : blocks_per_cu_of(phmm_sw_align_kernel<LL, KK, TT>, lds_bytes);
 #define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
 #define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)
@@ -672,16 +695,19 @@ int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int varian
 }
 
 hipError_t launch_sw(int L, int K, bool transposed, int variant, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {
-    if (p.n_alignments <= p.a_begin) return hipSuccess;
-    if (variant != SW_PLAIN) {
+    if (!p.todo && p.n_alignments <= p.a_begin) return hipSuccess;
+    if (variant == SW_LITE && (!p.todo_out || !p.todo_out_count || p.todo)) return hipErrorInvalidValue;
+    if (variant != SW_PLAIN && variant != SW_LITE) {
         if (L != 16 || K != ((variant & SW_WIDE) ? 16 : 32) || transposed || ((variant & SW_EXT) != 0) != (p.ext != nullptr)) return hipErrorInvalidValue;
         if (variant == SW_WIDE) return launch_of(phmm_sw_align_kernel<16, 16, false, true, false>, p, n_blocks, lds_bytes, stream);
         if (variant == SW_EXT) return launch_of(phmm_sw_align_kernel<16, 32, false, false, true>, p, n_blocks, lds_bytes, stream);
         return launch_of(phmm_sw_align_kernel<16, 16, false, true, true>, p, n_blocks, lds_bytes, stream);
     }
     if (p.ext) return hipErrorInvalidValue;
-#define PHMM_CASE_T(LL, KK, TT) \
-    if (L == LL && K == KK && transposed == TT) return launch_of(phmm_sw_align_kernel<LL, KK, TT>, p, n_blocks, lds_bytes, stream);
+#define PHMM_CASE_T(LL, KK, TT)                                                                                                  \
+    if (L == LL && K == KK && transposed == TT)                                                                                  \
+        return variant == SW_LITE ? launch_of(phmm_sw_align_kernel<LL, KK, TT, false, false, true>, p, n_blocks, lds_bytes, stream) \
+                                  : launch_of(phmm_sw_align_kernel<LL, KK, TT>, p, n_blocks, lds_bytes, stream);
 #define PHMM_CASE(LL, KK) PHMM_CASE_T(LL, KK, false)
 #define PHMM_CASE_TR(LL, KK) PHMM_CASE_T(LL, KK, true)
     PHMM_SW_LIST(PHMM_CASE)

@@ -286,3 +286,62 @@ def test_only_sequences_that_are_aligned_must_be_non_empty(hip_engine):
         assert got[k].alignment_offset == off and np.array_equal(got[k].elements, cig)
     with pytest.raises(AssertionError, match="non-empty"):
         al.align_indexed(refs, alts, [0, -1, 1, 2], NEW_SW_PARAMETERS, "SoftClip")   # the empty reference IS used
+
+
+def test_tags_only_first_pass_gives_the_same_alignments(hip_engine, aligner):
+    """SoftClip / Ignore calls sweep with the two-bit candidate tags only and send the alignments whose walk meets a gap
+    through the full instance again (switch `sw_lite`: 1 always, 0 never, -1 where it has been paying): the same CIGARs and
+    offsets either way -- reads without indels, reads with many, unrelated sequences, every lanes-per-alignment value, pieces
+    -- and the counter says how many went round again."""
+    rng = np.random.default_rng(17)
+    alpha = b"ACGT"
+    pairs = []
+    for k in range(240):
+        ref = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(30, 420))))
+        s = int(rng.integers(0, len(ref) // 2))
+        if k % 4 == 0:      # a clean read (mismatches only): no gap on its path
+            alt = _mutate(rng, ref[s:s + 150], 0.0, 0.02)
+        elif k % 4 == 1:    # 3-6 % indels
+            alt = _mutate(rng, ref[s:s + 150], float(rng.uniform(0.03, 0.06)), 0.01)
+        elif k % 4 == 2:    # overhanging
+            alt = b"TTGCA" + _mutate(rng, ref[s:s + 90], 0.01, 0.01) + b"GGGTT"
+        else:               # unrelated
+            alt = bytes(alpha[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 200))))
+        pairs.append((ref, alt))
+    try:
+        for strategy in ("SoftClip", "Ignore"):
+            for params in (STANDARD_NGS, Parameters(1, -1, -1, -1)):
+                hip_engine.set_switch("sw_lite", 0)
+                want = aligner.align_batch(pairs, params, strategy)
+                assert hip_engine.stat("sw_second_pass") == 0
+                for g, (r, a) in zip(want, pairs):
+                    _same(g, r, a, params, strategy)
+                hip_engine.set_switch("sw_lite", 1)
+                for lanes in (0, 8, 16, 32, 64):
+                    hip_engine.set_switch("sw_lanes", lanes)
+                    for chunks in (0, 3):
+                        hip_engine.set_switch("sw_chunks", chunks)
+                        got = aligner.align_batch(pairs, params, strategy)
+                        again = hip_engine.stat("sw_second_pass")
+                        assert 40 <= again < len(pairs), again      # the indel reads at least, the clean ones never
+                        for g, b in zip(got, want):
+                            assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements), (strategy, lanes, chunks)
+        # the default: two passes until a call meets gaps in more than three alignments of ten, then fifteen calls without
+        hip_engine.set_switch("sw_lite", -1)
+        hip_engine.set_switch("sw_lanes", 0)
+        hip_engine.set_switch("sw_chunks", 0)
+        gappy = [p for k, p in enumerate(pairs) if k % 4 == 1]
+        first = aligner.align_batch(gappy, STANDARD_NGS, "SoftClip")
+        assert hip_engine.stat("sw_second_pass") > len(gappy) * 0.3
+        second = aligner.align_batch(gappy, STANDARD_NGS, "SoftClip")
+        assert hip_engine.stat("sw_second_pass") == 0               # straight to the full instance
+        for g, b in zip(first, second):
+            assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements)
+        # InDel strategies never take the first pass
+        hip_engine.set_switch("sw_lite", 1)
+        aligner.align_batch(pairs[:20], NEW_SW_PARAMETERS, "InDel")
+        assert hip_engine.stat("sw_second_pass") == 0
+    finally:
+        hip_engine.set_switch("sw_lite", -1)
+        hip_engine.set_switch("sw_chunks", 0)
+        hip_engine.set_switch("sw_lanes", 0)
