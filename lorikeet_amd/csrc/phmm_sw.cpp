@@ -502,6 +502,17 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             W.ws_bytes = ws_bytes;
         }
     }
+    constexpr uint32_t kShortList = 1024;
+    phmm_host::SwGeometry GS;
+    bool have_short = false;
+    if (lite && L < 64 && n_alignments > 4 * kShortList) {  // (see the launches below)
+        const std::string keep_err = h->err;
+        const int keep_code = h->err_code;
+        have_short = phmm_host::sw_plan(h, who, kShortList, max_ref, max_alt, params, &GS) == PHMM_OK && GS.variant == SW_PLAIN && GS.L == 64 &&
+                     GS.slab_stride * 4 <= W.slab_bytes;
+        h->err = keep_err;
+        h->err_code = keep_code;
+    }
     for (int c = 0; c < n_chunks; ++c)  // (each event under its own check: a failure half way must not leave the piece with null events for good)
         if ((!W.ev_in[c] && !ok(h, hipEventCreateWithFlags(&W.ev_in[c], hipEventDisableTiming), "hipEventCreate")) ||
             (!W.ev_out[c] && !ok(h, hipEventCreateWithFlags(&W.ev_out[c], hipEventDisableTiming), "hipEventCreate")) ||
@@ -658,8 +669,25 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             p2.todo = p1.todo_out;
             p2.todo_count = p1.todo_out_count;
             p2.feedback = zero_copy ? (uint32_t *)(W.host_dev + o_st + 192) + c : nullptr;  // (otherwise the counters come back with the status block)
-            good = ok(h, launch_sw(L, K, transposed, SW_LITE, p1, (uint32_t)workers, lds, S), "phmm_sw_align_kernel (tags)") &&
-                   ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
+            good = ok(h, launch_sw(L, K, transposed, SW_LITE, p1, (uint32_t)workers, lds, S), "phmm_sw_align_kernel (tags)");
+            // The second pass of a large batch normally holds a handful of alignments, and in the batch's own geometry (eight to a
+            // wave) even one costs a whole sweep (0.23 ms behind 2.8 ms): a list of up to 1 024 goes to the instance a small call
+            // would get (one alignment per wave along the alternate, ~60 us), a longer one to the batch's; both launches look at
+            // the counter and one of them returns at once.
+            if (good && have_short) {
+                SwParams ps = p2;
+                ps.lds_ref_bytes = (uint32_t)GS.lds_ref;
+                ps.lds_alt_bytes = (uint32_t)GS.lds_alt;
+                ps.lds_group_bytes = (uint32_t)GS.lds_group;
+                ps.groups_per_block = (uint32_t)GS.gpb;
+                ps.slab_stride = GS.slab_stride;
+                ps.todo_max = kShortList;
+                p2.todo_min = kShortList + 1;
+                const size_t fit = W.slab_bytes / (GS.slab_stride * 4);
+                good = ok(h, launch_sw(GS.L, GS.K, GS.transposed, GS.variant, ps, (uint32_t)std::min<size_t>({(size_t)kShortList, fit, GS.max_workers}), GS.lds, S),
+                          "phmm_sw_align_kernel (short list)");
+            }
+            good = good && ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
         } else {
             good = ok(h, launch_sw(L, K, transposed, G.variant, p, (uint32_t)workers, lds, S), "phmm_sw_align_kernel");
         }

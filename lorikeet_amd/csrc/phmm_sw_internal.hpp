@@ -41,6 +41,8 @@ struct SwParams {
     uint32_t *todo_out, *todo_out_count;
     const uint32_t *todo, *todo_count;
     uint32_t *feedback;                    // or null: where the full launch leaves *todo_count for the host (pinned memory)
+    uint32_t todo_min, todo_max;           // a launch over the list runs only if todo_min <= *todo_count <= todo_max (0 = no upper bound):
+                                           // a short list goes to the instance with one alignment per wave, a long one to the batch's own
     unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of
     size_t ext_stride;                     // block b live at ext + b * ext_stride (device memory), LDS holds the two sequences only
 };

@@ -173,6 +173,7 @@ void phmm_sw_align_kernel(const SwParams p) {
     const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
     // the alignments of this launch: [a_begin, n_alignments), or the list an earlier tags-only launch left (todo)
     const uint32_t n_items = p.todo ? *p.todo_count : p.n_alignments;
+    if (p.todo && (n_items < p.todo_min || (p.todo_max && n_items > p.todo_max))) return;  // (the other geometry's launch takes this list)
     if (p.todo && p.feedback && blockIdx.x == 0 && lane == 0) *p.feedback = n_items;  // (the host looks at it between calls)
     for (uint32_t base = (p.todo ? 0u : p.a_begin) + blockIdx.x * gpb; base < n_items; base += gridDim.x * gpb) {
         const uint32_t item = base + (uint32_t)g;

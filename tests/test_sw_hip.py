@@ -326,11 +326,25 @@ def test_tags_only_first_pass_gives_the_same_alignments(hip_engine, aligner):
                         assert 40 <= again < len(pairs), again      # the indel reads at least, the clean ones never
                         for g, b in zip(got, want):
                             assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements), (strategy, lanes, chunks)
+        # a large batch: the second pass of a short list (<= 1 024 alignments) runs in the small-call geometry, a longer
+        # one in the batch's own -- 4 800 alignments with 60 and with 2 400 gapped ones
+        clean = [p for k, p in enumerate(pairs) if k % 4 == 0 and len(p[1]) <= 150]
+        gappy = [p for k, p in enumerate(pairs) if k % 4 == 1]
+        for big in (clean * 79 + gappy, (clean[:40] + gappy[:40]) * 60):
+            big = big[:4800]
+            hip_engine.set_switch("sw_lite", 0)
+            want = aligner.align_batch(big, STANDARD_NGS, "SoftClip")
+            hip_engine.set_switch("sw_lite", 1)
+            for chunks in (1, 0):
+                hip_engine.set_switch("sw_chunks", chunks)
+                got = aligner.align_batch(big, STANDARD_NGS, "SoftClip")
+                assert hip_engine.stat("sw_second_pass") >= 40
+                for g, b in zip(got, want):
+                    assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements), chunks
         # the default: two passes until a call meets gaps in more than three alignments of ten, then fifteen calls without
         hip_engine.set_switch("sw_lite", -1)
         hip_engine.set_switch("sw_lanes", 0)
         hip_engine.set_switch("sw_chunks", 0)
-        gappy = [p for k, p in enumerate(pairs) if k % 4 == 1]
         first = aligner.align_batch(gappy, STANDARD_NGS, "SoftClip")
         assert hip_engine.stat("sw_second_pass") > len(gappy) * 0.3
         second = aligner.align_batch(gappy, STANDARD_NGS, "SoftClip")
