@@ -112,6 +112,7 @@ struct PendingRegion {
                                                      // (phmm_region_submit), payload and results are theirs
     Layout L;
     bool d2h_pending = false, zero_copy = false;
+    bool lite = false;            // the aligner ran in two passes: the results' header holds how many alignments went round again
     uint32_t sw_capacity = 0;
     PendingRegion() = default;
 };
@@ -405,6 +406,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pj.workspace = W.ws;
         pj.capacity = pj_capacity;
     }
+    bool used_lite = false;
     if (good && align) {
         SwParams sp{};
         sp.a_begin = 0;
@@ -442,14 +444,20 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
         // (reads against their haplotypes: the tags-only sweep first, the full instance over the alignments that met a gap;
         // the counter is a word of the status block that is staged as zeros with the inputs)
-        const bool lite = G.variant == SW_PLAIN && h->sw.sw_lite != 0 &&
-                          (sp.strategy == PHMM_SW_SOFTCLIP || sp.strategy == PHMM_SW_IGNORE);
+        // (a call that met gaps in more than three alignments of ten sends the handle's next fifteen straight to the full instance)
+        bool lite = G.variant == SW_PLAIN && h->sw.sw_lite != 0 && (sp.strategy == PHMM_SW_SOFTCLIP || sp.strategy == PHMM_SW_IGNORE);
+        if (lite && h->sw.sw_lite < 0 && W.lite_skip > 0) {
+            W.lite_skip -= 1;
+            lite = false;
+        }
+        used_lite = lite;
         if (lite) {
             SwParams s1 = sp, s2 = sp;
             s1.todo_out = (uint32_t *)(A.dev + L.todo);
             s1.todo_out_count = (uint32_t *)(A.dev + L.status_in) + 32;
             s2.todo = s1.todo_out;
             s2.todo_count = s1.todo_out_count;
+            s2.feedback = (uint32_t *)(res_base + L.res + 192);
             good = good && ok(h, launch_sw(G.L, G.K, G.transposed, SW_LITE, s1, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel (tags)") &&
                    ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, s2, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
         } else {
@@ -483,6 +491,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     pending->d2h_pending = !eager && !mirror;
     pending->zero_copy = mirror != nullptr;
     pending->sw_capacity = sw_capacity;
+    pending->lite = used_lite;
     return PHMM_OK;
 }
 
@@ -512,6 +521,13 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
         return done(PHMM_ERR_HIP);
     const char *hs = A.host;
     const uint32_t *sw_st = (const uint32_t *)(hs + L.res + 64);
+    if (p->lite) {
+        const uint64_t again = *(const uint32_t *)(hs + L.res + 192);
+        h->swork.last_second_pass = again;
+        if (again * 10 > (uint64_t)nr * 3) h->swork.lite_skip = 15;
+    } else {
+        h->swork.last_second_pass = 0;
+    }
     if (nr && sw_st[SW_STATUS_CAPACITY]) {
         std::vector<uint32_t> n_sw(nr);
         if (!ok(h, hipMemcpy(n_sw.data(), A.dev + L.nsw, 4ull * nr, hipMemcpyDeviceToHost), "D2H sw")) return done(PHMM_ERR_HIP);

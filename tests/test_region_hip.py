@@ -284,3 +284,34 @@ def test_argument_errors(hip_engine):
     got = region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, capacity=1)
     want = region.region_compute(hip_engine, _cfg(), b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
     _same(got, want.likelihoods, want.keep, want.best, want.reads)
+
+
+def test_two_pass_alignment_is_invisible_in_the_results(hip_engine):
+    """The aligner of the region call sweeps with candidate tags only and sends the reads whose walk meets a gap through the
+    full instance (switch `sw_lite`): the same results with it forced, forbidden and left to the handle, which stops taking
+    the first pass for fifteen calls once a call has met gaps in more than three reads of ten."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(11, n_regions=6)
+    mapq = _noisy_quals(b, 11)
+    cfg = _cfg()
+    pri = _priorities(b, hap_cigars, ref_hap)
+    call = lambda: region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri)  # noqa: E731
+    try:
+        hip_engine.set_switch("sw_lite", 0)
+        want = call()
+        assert hip_engine.stat("sw_second_pass") == 0
+        hip_engine.set_switch("sw_lite", 1)
+        got = call()
+        again = hip_engine.stat("sw_second_pass")
+        assert 0 < again <= b.n_reads
+        hip_engine.set_switch("sw_lite", -1)
+        auto1 = call()
+        auto2 = call()
+        if again * 10 > b.n_reads * 3:
+            assert hip_engine.stat("sw_second_pass") == 0      # the second call went straight to the full instance
+        for g in (got, auto1, auto2):
+            assert np.array_equal(g.likelihoods, want.likelihoods) and np.array_equal(g.keep, want.keep)
+            assert np.array_equal(g.best.allele_index, want.best.allele_index)
+            assert np.array_equal(g.reads.status, want.reads.status) and np.array_equal(g.reads.new_pos, want.reads.new_pos)
+            assert all(np.array_equal(x, y) for x, y in zip(g.reads.cigars, want.reads.cigars))
+    finally:
+        hip_engine.set_switch("sw_lite", -1)
