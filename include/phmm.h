@@ -494,7 +494,8 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
  * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes" /
  * "sw_clock_mhz" (device time of the last phmm_sw_align's kernels by HIP events, the backtrack bytes they stored, the shader
- * clock one of their blocks saw); unknown names give 0.
+ * clock one of their blocks saw), "sw_second_pass" (alignments of the last aligner call whose walk met a gap behind the
+ * tags-only sweep and which the full instance aligned again; 0 when the call took one pass); unknown names give 0.
  */
 int phmm_set_switch(phmm_handle *h, const char *name, int value);
 uint64_t phmm_get_stat(phmm_handle *h, const char *name);

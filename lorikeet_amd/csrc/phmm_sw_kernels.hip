@@ -20,14 +20,18 @@
 // three candidates won (2 bits) and, for each direction, whether its best gap OPENS at this cell (1 = the `prev_gap >
 // best_gap` branch).  The gap length is recovered while backtracking -- k(i,j) = 1 if the gap opens at (i,j), else
 // 1 + k of the previous cell of that column / row -- so the kernel keeps no gap sizes at all, and the matrix in HBM is
-// 2 dwords per lane and step (4 when K > 16) laid out [strip][step][dword][lane]: every store of a wave covers 256
-// contiguous bytes.
+// 2 dwords per lane and step (3 - 4 when K > 16) laid out [strip][step][lane][dword]: one vector store per lane and step,
+// a wave's store covers 64 x NW x 4 contiguous bytes.  (The stores cost nothing: tools/ubench/store_cost.hip.)
 // Scores are carried times four, the low two bits naming the candidate (diagonal 2 > right 1 > down 0): one v_max3
 // both picks the value and resolves ties in the reference's priority order (:250-266), and v_alignbit shifts the two
 // bits into the lane's flag word.  (The host side bounds the parameters so that nothing overflows and the reference's
-// MATRIX_MIN_CUTOFF clamp, :31, can never be active.)
-// Backtracking: the sixteen lanes of an alignment fetch sixteen cells down the diagonal at once and take the run of
-// diagonal steps among them in one go (every step is a dependent read from HBM otherwise); lane 0 writes the CIGAR.
+// MATRIX_MIN_CUTOFF clamp, :31, can never be active; beyond that bound the WIDE instance carries scores as they are.)
+// Backtracking: the lanes of an alignment fetch 32 cells down the diagonal per round trip (device-scope loads: the flags
+// are in L2 / HBM, every fetch is a dependent read) and take the run of diagonal steps among them in one go; lane 0
+// writes the CIGAR.
+// Instances: <lanes per alignment, columns per lane>, TR (sweep along the alternate: small calls), WIDE (un-scaled scores with
+// the reference's clamp), EXT (rows in device memory: sequences beyond LDS), LITE (candidate tags only: the first of two
+// passes where gaps are rare) -- see the template below.
 #include <type_traits>
 #include "phmm_sw_internal.hpp"
 
