@@ -616,6 +616,14 @@ def main():
             assert eng.lib.phmm_sw_align(*args) == 0
         dt = (time.perf_counter() - t) / 3
         kern_s = eng.stat("sw_kernel_us") / 1e6            # HIP events around the kernels of the last call
+        second_default = eng.stat("sw_second_pass")        # alignments the full instance aligned again behind the tags-only sweep
+        eng.set_switch("sw_lite", 0)                       # ... and the full instance alone (one pass)
+        assert eng.lib.phmm_sw_align(*args) == 0
+        t = time.perf_counter()
+        assert eng.lib.phmm_sw_align(*args) == 0
+        dt_full, full_s = time.perf_counter() - t, eng.stat("sw_kernel_us") / 1e6
+        eng.set_switch("sw_lite", -1)
+        assert eng.lib.phmm_sw_align(*args) == 0           # (the flag volume below is the default path's)
         flag_bytes = eng.stat("sw_backtrack_bytes")
         # the same call as ONE piece (no staging overlapped with the kernels: slower end to end, but the kernels run back to back
         # -- and in two passes where that pays: tags-only sweep, then the full instance over the alignments whose walk met a gap)
@@ -654,7 +662,12 @@ def main():
                 "equal_to_oracle_on_sample": same, "sample": int(k),
                 "kernel": {"ms": round(kern_s * 1e3, 3), "gcups_i32": round(cells / max(kern_s, 1e-9) / 1e9, 1),
                            "shader_clock_mhz": int(eng.stat("sw_clock_mhz")),
-                           "note": "the phmm_sw_align_kernel<L,K> launches of the last call (HIP events in the library, phmm_get_stat)"},
+                           "second_pass_alignments": int(second_default),
+                           "note": "the phmm_sw_align_kernel<L,K> launches of the last call (HIP events in the library, phmm_get_stat): "
+                                   "a tags-only sweep, then the full instance over the alignments whose walk met a gap, where the "
+                                   "handle expects few gaps; one pass otherwise"},
+                "full_instance_only": {"ms_per_call": round(dt_full * 1e3, 3), "kernel_ms": round(full_s * 1e3, 3),
+                                       "kernel_gcups_i32": round(cells / max(full_s, 1e-9) / 1e9, 1), "note": "switch sw_lite = 0"},
                 "kernel_one_piece": {"ms": round(one_s * 1e3, 3), "gcups_i32": round(cells / max(one_s, 1e-9) / 1e9, 1),
                                      "second_pass_alignments": int(one_again),
                                      "note": "the same alignments as one piece (switch sw_chunks = 1): two passes where the handle expects few gaps"},

@@ -371,6 +371,7 @@ void phmm_destroy(phmm_handle *h) {
         for (hipEvent_t e : {h->swork.ev_in[c], h->swork.ev_out[c], h->swork.ev_k0[c], h->swork.ev_k1[c]})
             if (e) (void)hipEventDestroy(e);
     if (h->swork.region_sw_done) (void)hipEventDestroy(h->swork.region_sw_done);
+    if (h->swork.ev_second) (void)hipEventDestroy(h->swork.ev_second);
     for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
         if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);

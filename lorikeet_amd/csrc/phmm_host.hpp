@@ -76,6 +76,7 @@ struct phmm_handle {
         size_t slab_bytes = 0;
         uint32_t *ws = nullptr;  // the projection's builders (phmm_realign_reads)
         size_t ws_bytes = 0;
+        hipEvent_t ev_second = nullptr;  // the one second pass of a call in pieces is done
         int lite_skip = 0;             // calls that go straight to the full Smith-Waterman instance (the last two-pass call met too many gaps)
         uint64_t last_second_pass = 0; // alignments of the last call that the full instance had to align again (phmm_get_stat "sw_second_pass")
         unsigned char *ext = nullptr;  // bottom rows / strip edges of alignments too long for LDS (SwGeometry::ext_stride)

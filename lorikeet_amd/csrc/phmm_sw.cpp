@@ -355,6 +355,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     if (!n_refs) return fail(h, who + ": no reference sequences");
     uint32_t max_ref = 0, max_alt = 0;
+    uint64_t max_slot = 0;  // the largest CIGAR slot of the call
     // The reference asserts / panics on empty input (smith_waterman_aligner.rs:65-68, :132-134) -- for the sequences it
     // actually aligns: a reference no alignment names, or the read of a skipped alignment, may be empty.  Where the device
     // chooses the reference (the best allele) the kernel raises the condition for the alignments it meets (SW_STATUS_EMPTY).
@@ -372,6 +373,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (!skipped && !J.best && (alt_off[a + 1] == alt_off[a] || (J.ref_index && ref_off[J.ref_index[a] + 1] == ref_off[J.ref_index[a]])))
             return fail(h, who + empty_msg);
         max_alt = std::max(max_alt, alt_off[a + 1] - alt_off[a]);
+        max_slot = std::max<uint64_t>(max_slot, cigar_off[a + 1] - cigar_off[a]);
     }
     if (!max_alt) max_alt = 1;  // (only skipped alignments: nothing will be swept)
     const size_t rb = ref_off[n_refs], ab = alt_off[n_alignments];
@@ -442,7 +444,11 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     // (A call in pieces is bound by its copies, not by its kernels, and every piece's second pass costs a whole sweep's
     // latency however few alignments it holds -- 131 072 reads: 4.3 ms either way: only calls of one piece take two passes
     // unless the switch asks for them.)
-    if (h->sw.sw_lite < 0 && !one_piece) lite = false;
+    if (h->sw.sw_lite < 0 && !one_piece && on_device) lite = false;
+    // A call in pieces whose results go to the caller takes ONE second pass behind its last piece: every piece's results are
+    // fetched as soon as its first pass is done, and the few alignments the second pass redoes come back gathered (below).
+    constexpr uint32_t kPatchMax = 4096;
+    const bool deferred = lite && !one_piece && !on_device && max_slot <= 4096;
     hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
     if (W.slab_bytes < slab_bytes) {
         (void)hipStreamSynchronize(S);
@@ -472,7 +478,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const size_t o_pst = o_pfl + (PJ ? 256 : 0), o_pno = o_pst + (PJ ? up256(4ull * n_alignments) : 0),
                  o_ppos = o_pno + (PJ ? up256(4ull * n_alignments) : 0), o_pout = o_ppos + (PJ ? up256(8ull * n_alignments) : 0),
                  o_extra = o_pout + (PJ ? up256(4ull * pj_out) : 0), o_todo = o_extra + (J.view ? up256(J.view->extra_bytes) : 0),
-                 total = o_todo + up256(4ull * n_alignments);  // (the list of the tags-only pass: device memory only)
+                 o_patch = o_todo + up256(4ull * n_alignments),  // (the list of the tags-only pass: device memory only)
+                 patch_bytes = 4ull * kPatchMax * (3 + max_slot), total = o_patch + (deferred ? up256(patch_bytes) : 0);
     if (!grow_staging(h, total)) return PHMM_ERR_HIP;
     // A small call in one piece (a region per call, the reference's pattern): the kernels store the results -- and the
     // status block -- straight into the pinned mirror, so that nothing is copied back (each copy costs the call some
@@ -664,12 +671,16 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         (void)hipEventRecord(W.ev_k0[c], S);
         if (lite) {  // tags only, then the full instance over what met a gap (the counters are zeroed with the head of the input)
             SwParams p1 = p, p2 = p;
-            p1.todo_out = (uint32_t *)(W.dev + o_todo) + a0;
-            p1.todo_out_count = (uint32_t *)(W.dev + 192) + c;
+            p1.todo_out = (uint32_t *)(W.dev + o_todo) + (deferred ? 0 : a0);
+            p1.todo_out_count = (uint32_t *)(W.dev + 192) + (deferred ? 0 : c);
             p2.todo = p1.todo_out;
             p2.todo_count = p1.todo_out_count;
             p2.feedback = zero_copy ? (uint32_t *)(W.host_dev + o_st + 192) + c : nullptr;  // (otherwise the counters come back with the status block)
             good = ok(h, launch_sw(L, K, transposed, SW_LITE, p1, (uint32_t)workers, lds, S), "phmm_sw_align_kernel (tags)");
+            if (deferred) {  // (the second pass follows the last piece)
+                (void)hipEventRecord(W.ev_k1[c], S);
+                continue;
+            }
             // The second pass of a large batch normally holds a handful of alignments, and in the batch's own geometry (eight to a
             // wave) even one costs a whole sweep (0.23 ms behind 2.8 ms): a list of up to 1 024 goes to the instance a small call
             // would get (one alignment per wave along the alternate, ~60 us), a longer one to the batch's; both launches look at
@@ -697,6 +708,32 @@ int sw_run(phmm_handle *h, const SwJob &J) {
             good = ok(h, launch_project(pp, S), "phmm_project_kernel");
         }
         (void)hipEventRecord(W.ev_k1[c], S);
+    }
+    if (deferred && good) {
+        if (!W.ev_second && !ok(h, hipEventCreate(&W.ev_second), "hipEventCreate")) return PHMM_ERR_HIP;
+        SwParams p2 = p;
+        p2.a_begin = 0;
+        p2.n_alignments = n_alignments;
+        p2.todo = (const uint32_t *)(W.dev + o_todo);
+        p2.todo_count = (const uint32_t *)(W.dev + 192);
+        if (have_short) {
+            SwParams ps = p2;
+            ps.lds_ref_bytes = (uint32_t)GS.lds_ref;
+            ps.lds_alt_bytes = (uint32_t)GS.lds_alt;
+            ps.lds_group_bytes = (uint32_t)GS.lds_group;
+            ps.groups_per_block = (uint32_t)GS.gpb;
+            ps.slab_stride = GS.slab_stride;
+            ps.todo_max = kShortList;
+            p2.todo_min = kShortList + 1;
+            const size_t fit = W.slab_bytes / (GS.slab_stride * 4);
+            good = ok(h, launch_sw(GS.L, GS.K, GS.transposed, GS.variant, ps, (uint32_t)std::min<size_t>({(size_t)kShortList, fit, GS.max_workers}), GS.lds, S),
+                      "phmm_sw_align_kernel (short list)");
+        }
+        const size_t all_workers = std::min<size_t>({max_workers, ((size_t)n_alignments + gpb - 1) / gpb, W.slab_bytes / (slab_stride * 4)});
+        good = good && ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)all_workers, lds, S), "phmm_sw_align_kernel") &&
+               ok(h, launch_sw_gather(p2.todo, p2.todo_count, p.n_cigar, p.alignment_offset, p.cigar, p.cigar_off, (uint32_t)max_slot, kPatchMax,
+                                      (uint32_t *)(W.dev + o_patch), S), "phmm_sw_gather_kernel") &&
+               ok(h, hipEventRecord(W.ev_second, S), "hipEventRecord");
     }
     // (while the device works) what the kernels store per alignment: (rows + L - 1) steps x L lanes x flag words per strip
     W.last_backtrack_bytes = 0;
@@ -766,6 +803,9 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (good && prev >= 0) good = unpack(prev);
         prev = c;
     }
+    if (deferred && good)  // the status block and the gathered alignments are final once the second pass is through
+        good = ok(h, hipEventSynchronize(W.ev_second), "sync(sw second pass)") &&
+               ok(h, hipMemcpyAsync(W.host + o_patch, W.dev + o_patch, patch_bytes, hipMemcpyDeviceToHost, S_out), "D2H sw");
     good = good && (zero_copy || ok(h, hipMemcpyAsync(W.host + o_st, W.dev, 256, hipMemcpyDeviceToHost, S_out), "D2H sw"));
     if (one_piece) {
         good = good && ok(h, hipStreamSynchronize(S_out), "sync(sw)");
@@ -780,6 +820,24 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         (void)hipStreamSynchronize(S_out);
         return PHMM_ERR_HIP;
     }
+    if (deferred) {  // what the second pass redid, over what the pieces brought
+        const uint32_t again = *(const uint32_t *)(W.host + o_st + 192);
+        if (again <= kPatchMax) {
+            const uint32_t *e = (const uint32_t *)(W.host + o_patch);
+            for (uint32_t t = 0; t < again; ++t, e += 3 + max_slot) {
+                const uint32_t a = e[0];
+                J.n_cigar[a] = e[1];
+                J.alignment_offset[a] = (int32_t)e[2];
+                const uint64_t slot = cigar_off[a + 1] - cigar_off[a];
+                if (slot) memcpy(J.cigar + cigar_off[a], e + 3, 4ull * std::min<uint64_t>(slot, e[1]));
+            }
+        } else {  // (a call full of gaps: everything once more; the handle then stops taking the first pass)
+            if (!ok(h, hipMemcpy(W.host + o_nc, W.dev + o_nc, o_pfl - o_nc, hipMemcpyDeviceToHost), "D2H sw")) return PHMM_ERR_HIP;
+            memcpy(J.n_cigar, W.host + o_nc, 4ull * n_alignments);
+            memcpy(J.alignment_offset, W.host + o_of, 4ull * n_alignments);
+            if (n_cig) memcpy(J.cigar, W.host + o_cg, 4ull * n_cig);
+        }
+    }
     if (J.best) {
         memcpy(J.best->best_allele, W.host + BL.best, 4ull * J.best->n_reads);
         memcpy(J.best->likelihood, W.host + BL.olk, 8ull * J.best->n_reads);
@@ -790,9 +848,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         float ms = 0.f;
         if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
     }
+    if (deferred) {  // ... and the second pass behind the last piece
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, W.ev_k1[last_piece], W.ev_second) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
+    }
     if (lite) {
         uint64_t again = 0;
-        for (int c = 0; c < n_chunks; ++c) again += ((const uint32_t *)(W.host + o_st + 192))[c];
+        for (int c = 0; c < (deferred ? 1 : n_chunks); ++c) again += ((const uint32_t *)(W.host + o_st + 192))[c];
         W.last_second_pass = again;
         if (again * 10 > (uint64_t)n_alignments * 3) W.lite_skip = 15;
     } else {

@@ -51,6 +51,8 @@ struct SwParams {
 enum : int { SW_PLAIN = 0, SW_WIDE = 1, SW_EXT = 2, SW_LITE = 4 };  // kernel variants: un-scaled scores with the reference's clamp; rows in device
                                                                     // memory (the two combine); the tags-only sweep of an ordinary instance
 hipError_t launch_sw(int L, int K, bool transposed, int variant, const SwParams &p, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_sw_gather(const uint32_t *todo, const uint32_t *todo_count, const uint32_t *n_cigar, const int32_t *alignment_offset,
+                            const uint32_t *cigar, const uint64_t *cigar_off, uint32_t cap, uint32_t max_entries, uint32_t *out, hipStream_t stream);
 int sw_blocks_per_cu(int L, int K, size_t lds_bytes, bool transposed, int variant);  // what a CU holds at once (registers, LDS); 0 on failure
 extern const int kSwK16[], kSwK8[], kSwK32[], kSwK64[], kSwK64T[];  // (T: rows per lane of the sweep along the alternate)
 extern const int kNumSwK16, kNumSwK8, kNumSwK32, kNumSwK64, kNumSwK64T;

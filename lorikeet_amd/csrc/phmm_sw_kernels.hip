@@ -32,6 +32,7 @@
 // Instances: <lanes per alignment, columns per lane>, TR (sweep along the alternate: small calls), WIDE (un-scaled scores with
 // the reference's clamp), EXT (rows in device memory: sequences beyond LDS), LITE (candidate tags only: the first of two
 // passes where gaps are rare) -- see the template below.
+#include <algorithm>
 #include <type_traits>
 #include "phmm_sw_internal.hpp"
 
@@ -640,6 +641,33 @@ void phmm_sw_align_kernel(const SwParams p) {
         p.status[2] = (uint32_t)(clock64() - clk0);        // shader clocks
         p.status[3] = (uint32_t)(wall_clock64() - wall0);  // 100 MHz ticks
     }
+}
+
+// The alignments a second pass has redone, gathered for the host: entry t = { alignment, n_cigar, offset, slot[cap] } for the
+// first `max_entries` of the list (a call in pieces fetches every piece's results as soon as its first pass is done; what the
+// one second pass at the end of the call changes comes back this way, in one small copy).
+__global__ __launch_bounds__(WAVE) void phmm_sw_gather_kernel(const uint32_t *todo, const uint32_t *todo_count, const uint32_t *n_cigar,
+                                                             const int32_t *alignment_offset, const uint32_t *cigar, const uint64_t *cigar_off,
+                                                             uint32_t cap, uint32_t max_entries, uint32_t *out) {
+    const uint32_t n = min(*todo_count, max_entries);
+    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+        const uint32_t a = todo[t];
+        uint32_t *e = out + (size_t)t * (3 + cap);
+        if (threadIdx.x == 0) {
+            e[0] = a;
+            e[1] = n_cigar[a];
+            e[2] = (uint32_t)alignment_offset[a];
+        }
+        const uint64_t c0 = cigar_off[a], slot = cigar_off[a + 1] - c0;
+        for (uint32_t i = threadIdx.x; i < cap; i += WAVE) e[3 + i] = i < slot ? cigar[c0 + i] : 0u;
+    }
+}
+
+hipError_t launch_sw_gather(const uint32_t *todo, const uint32_t *todo_count, const uint32_t *n_cigar, const int32_t *alignment_offset,
+                            const uint32_t *cigar, const uint64_t *cigar_off, uint32_t cap, uint32_t max_entries, uint32_t *out, hipStream_t stream) {
+    hipLaunchKernelGGL(phmm_sw_gather_kernel, dim3(std::min<uint32_t>(max_entries, 1024)), dim3(WAVE), 0, stream, todo, todo_count, n_cigar, alignment_offset,
+                       cigar, cigar_off, cap, max_entries, out);
+    return hipGetLastError();
 }
 
 // instantiated <lanes per alignment, columns per lane>; the host side picks the pair (phmm_sw.cpp)

@@ -341,6 +341,18 @@ def test_tags_only_first_pass_gives_the_same_alignments(hip_engine, aligner):
                 assert hip_engine.stat("sw_second_pass") >= 40
                 for g, b in zip(got, want):
                     assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements), chunks
+        # a call in pieces takes one second pass behind its last piece and patches the results; more than 4 096 alignments
+        # to redo are fetched wholesale instead
+        many = (gappy * 101)[:6000]
+        hip_engine.set_switch("sw_lite", 0)
+        hip_engine.set_switch("sw_chunks", 3)
+        want = aligner.align_batch(many, STANDARD_NGS, "SoftClip")
+        hip_engine.set_switch("sw_lite", 1)
+        got = aligner.align_batch(many, STANDARD_NGS, "SoftClip")
+        assert hip_engine.stat("sw_second_pass") > 4096
+        for g, b in zip(got, want):
+            assert g.alignment_offset == b.alignment_offset and np.array_equal(g.elements, b.elements)
+        hip_engine.set_switch("sw_chunks", 0)
         # the default: two passes until a call meets gaps in more than three alignments of ten, then fifteen calls without
         hip_engine.set_switch("sw_lite", -1)
         hip_engine.set_switch("sw_lanes", 0)
