@@ -712,7 +712,8 @@ def main():
                               "achieved": round(cells / max(kern_s, 1e-9) / 1e9, 1), "peak": SW_CELL_CEILING_GCUPS,
                               "unit": "GCUPS-i32", "frac": round(cells / max(kern_s, 1e-9) / 1e9 / SW_CELL_CEILING_GCUPS, 4),
                               "lane_ops_per_s": round(pe["valu_insts_per_launch"] * 64 / max(kern_s, 1e-9) / 1e12, 2),
-                              "note": "peak = what the 16-instruction cell body alone sustains on the whole chip at four waves per "
+                              "note": "(the default path sweeps with candidate tags only, 11 instructions per cell, and sends walks that met "
+                                      "a gap through the full 16-instruction instance) peak = what the 16-instruction cell body alone sustains on the whole chip at four waves per "
                                       "SIMD (tools/ubench/sw_cell.hip, profiles/r02_ubench_sw_cell.txt: 61 clocks per wave-level "
                                       "cell at 2.4 GHz; nine of the instructions issue every 2.55 clocks, seven every 4.3-4.8: "
                                       "profiles/r02_ubench_rates.txt); valu_insts_per_cell = SQ_INSTS_VALU of the call "
