@@ -441,14 +441,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     }
     // one piece: everything in order on one stream, one copy each way, one wait (a region per call is the reference's pattern)
     const bool one_piece = n_chunks == 1;
-    // (A call in pieces is bound by its copies, not by its kernels, and every piece's second pass costs a whole sweep's
-    // latency however few alignments it holds -- 131 072 reads: 4.3 ms either way: only calls of one piece take two passes
-    // unless the switch asks for them.)
-    if (h->sw.sw_lite < 0 && !one_piece && on_device) lite = false;
+    // (A second pass per piece costs a whole sweep's latency each, however few alignments it holds: a call in pieces takes two
+    // passes on its own accord only where one second pass can serve all pieces -- below.)
+    if (h->sw.sw_lite < 0 && !one_piece && (on_device || max_slot > 64)) lite = false;
     // A call in pieces whose results go to the caller takes ONE second pass behind its last piece: every piece's results are
     // fetched as soon as its first pass is done, and the few alignments the second pass redoes come back gathered (below).
     constexpr uint32_t kPatchMax = 4096;
-    const bool deferred = lite && !one_piece && !on_device && max_slot <= 4096;
+    const bool deferred = lite && !one_piece && !on_device && max_slot <= 64;  // (the gathered entries are as wide as the widest slot)
     hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
     if (W.slab_bytes < slab_bytes) {
         (void)hipStreamSynchronize(S);
