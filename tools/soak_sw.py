@@ -14,7 +14,8 @@ from oracle import oracle  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
-al = SmithWatermanAligner(HipPairHMMEngine(0))
+eng = HipPairHMMEngine(0)
+al = SmithWatermanAligner(eng)
 alpha = b"ACGT"
 
 
@@ -43,6 +44,7 @@ def mutate(seq):
 t_end = time.time() + budget
 n_batches = n_pairs = n_cells = 0
 kinds = {}
+modes = {}
 while time.time() < t_end:
     kind = str(rng.choice(["reads", "reads", "haps", "tiny", "unrelated", "long", "lowcomplexity"]))
     pairs = []
@@ -68,6 +70,11 @@ while time.time() < t_end:
     prm = [Parameters(3, -1, -4, -3), Parameters(25, -50, -110, -6), Parameters(200, -150, -260, -11), Parameters(10, -15, -30, -5),
            Parameters(int(rng.integers(1, 30)), -int(rng.integers(1, 30)), -(ext + int(rng.integers(0, 40))), -ext)][int(rng.integers(0, 5))]
     strategy = str(rng.choice(["SoftClip", "InDel", "LeadingInDel", "Ignore"]))
+    # how the call is cut and whether it takes the tags-only first pass: the planner's choice, or forced either way
+    lite, chunks = int(rng.choice([-1, -1, 0, 1, 1])), int(rng.choice([0, 0, 1, 2, 3]))
+    eng.set_switch("sw_lite", lite)
+    eng.set_switch("sw_chunks", chunks)
+    modes[(lite, chunks)] = modes.get((lite, chunks), 0) + 1
     got = al.align_batch(pairs, prm, strategy, capacity=int(rng.choice([4, 24, 200])))
     p4 = [prm.match_value, prm.mismatch_penalty, prm.gap_open_penalty, prm.gap_extend_penalty]
     for g, (ref, alt) in zip(got, pairs):
@@ -77,4 +84,5 @@ while time.time() < t_end:
     n_batches += 1
     n_pairs += len(pairs)
     kinds[kind] = kinds.get(kind, 0) + 1
-print("sw soak ok: %d batches, %d alignments, %.3g cells, every CIGAR and offset equal to the oracle; kinds %s" % (n_batches, n_pairs, n_cells, kinds))
+print("sw soak ok: %d batches, %d alignments, %.3g cells, every CIGAR and offset equal to the oracle; kinds %s; "
+      "(sw_lite, sw_chunks) switches drawn per batch: %d combinations" % (n_batches, n_pairs, n_cells, kinds, len(modes)))
