@@ -443,11 +443,14 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     const bool one_piece = n_chunks == 1;
     // (A second pass per piece costs a whole sweep's latency each, however few alignments it holds: a call in pieces takes two
     // passes on its own accord only where one second pass can serve all pieces -- below.)
-    if (h->sw.sw_lite < 0 && !one_piece && (on_device || max_slot > 64)) lite = false;
+    if (h->sw.sw_lite < 0 && !one_piece && (PJ ? false : on_device || max_slot > 64)) lite = false;
     // A call in pieces whose results go to the caller takes ONE second pass behind its last piece: every piece's results are
     // fetched as soon as its first pass is done, and the few alignments the second pass redoes come back gathered (below).
     constexpr uint32_t kPatchMax = 4096;
     const bool deferred = lite && !one_piece && !on_device && max_slot <= 64;  // (the gathered entries are as wide as the widest slot)
+    // ... and a call in pieces whose alignments are projected where they lie (phmm_realign_reads) runs its second pass and then
+    // the projection of every piece behind the last first pass: nothing of a piece is final before, its results follow then.
+    const bool deferred_project = lite && !one_piece && PJ != nullptr;
     hipStream_t S = h->streams[0], S_in = one_piece ? S : h->streams[1];
     if (W.slab_bytes < slab_bytes) {
         (void)hipStreamSynchronize(S);
@@ -670,13 +673,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         (void)hipEventRecord(W.ev_k0[c], S);
         if (lite) {  // tags only, then the full instance over what met a gap (the counters are zeroed with the head of the input)
             SwParams p1 = p, p2 = p;
-            p1.todo_out = (uint32_t *)(W.dev + o_todo) + (deferred ? 0 : a0);
-            p1.todo_out_count = (uint32_t *)(W.dev + 192) + (deferred ? 0 : c);
+            p1.todo_out = (uint32_t *)(W.dev + o_todo) + (deferred || deferred_project ? 0 : a0);
+            p1.todo_out_count = (uint32_t *)(W.dev + 192) + (deferred || deferred_project ? 0 : c);
             p2.todo = p1.todo_out;
             p2.todo_count = p1.todo_out_count;
             p2.feedback = zero_copy ? (uint32_t *)(W.host_dev + o_st + 192) + c : nullptr;  // (otherwise the counters come back with the status block)
             good = ok(h, launch_sw(L, K, transposed, SW_LITE, p1, (uint32_t)workers, lds, S), "phmm_sw_align_kernel (tags)");
-            if (deferred) {  // (the second pass follows the last piece)
+            if (deferred || deferred_project) {  // (the second pass follows the last piece)
                 (void)hipEventRecord(W.ev_k1[c], S);
                 continue;
             }
@@ -708,7 +711,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         }
         (void)hipEventRecord(W.ev_k1[c], S);
     }
-    if (deferred && good) {
+    if ((deferred || deferred_project) && good) {
         if (!W.ev_second && !ok(h, hipEventCreate(&W.ev_second), "hipEventCreate")) return PHMM_ERR_HIP;
         SwParams p2 = p;
         p2.a_begin = 0;
@@ -729,10 +732,17 @@ int sw_run(phmm_handle *h, const SwJob &J) {
                       "phmm_sw_align_kernel (short list)");
         }
         const size_t all_workers = std::min<size_t>({max_workers, ((size_t)n_alignments + gpb - 1) / gpb, W.slab_bytes / (slab_stride * 4)});
-        good = good && ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)all_workers, lds, S), "phmm_sw_align_kernel") &&
-               ok(h, launch_sw_gather(p2.todo, p2.todo_count, p.n_cigar, p.alignment_offset, p.cigar, p.cigar_off, (uint32_t)max_slot, kPatchMax,
-                                      (uint32_t *)(W.dev + o_patch), S), "phmm_sw_gather_kernel") &&
-               ok(h, hipEventRecord(W.ev_second, S), "hipEventRecord");
+        good = good && ok(h, launch_sw(L, K, transposed, G.variant, p2, (uint32_t)all_workers, lds, S), "phmm_sw_align_kernel");
+        if (deferred)
+            good = good && ok(h, launch_sw_gather(p2.todo, p2.todo_count, p.n_cigar, p.alignment_offset, p.cigar, p.cigar_off, (uint32_t)max_slot,
+                                                  kPatchMax, (uint32_t *)(W.dev + o_patch), S), "phmm_sw_gather_kernel");
+        for (int c = 0; c < n_chunks && good && deferred_project; ++c) {  // (piece by piece: the workspace is a piece's)
+            if (cut[c + 1] == cut[c]) continue;
+            pp.r_begin = cut[c];
+            pp.n_reads = cut[c + 1];
+            good = ok(h, launch_project(pp, S), "phmm_project_kernel");
+        }
+        good = good && ok(h, hipEventRecord(W.ev_second, S), "hipEventRecord");
     }
     // (while the device works) what the kernels store per alignment: (rows + L - 1) steps x L lanes x flag words per strip
     W.last_backtrack_bytes = 0;
@@ -775,7 +785,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         const uint32_t a0 = cut[c], a1 = cut[c + 1];
         if (a1 == a0) continue;
         const uint64_t g0 = cigar_off[a0], g1 = cigar_off[a1];
-        good = one_piece || ok(h, hipEventSynchronize(W.ev_k1[c]), "sync(sw kernel)");
+        good = one_piece || ok(h, hipEventSynchronize(deferred_project ? W.ev_second : W.ev_k1[c]), "sync(sw kernel)");
         if (zero_copy) {
             // nothing to fetch
         } else if (one_piece) {  // the piece is the call: its results are one contiguous block of the staging buffer
@@ -847,13 +857,13 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         float ms = 0.f;
         if (cut[c + 1] > cut[c] && hipEventElapsedTime(&ms, W.ev_k0[c], W.ev_k1[c]) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
     }
-    if (deferred) {  // ... and the second pass behind the last piece
+    if (deferred || deferred_project) {  // ... and the second pass behind the last piece
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, W.ev_k1[last_piece], W.ev_second) == hipSuccess) W.last_kernel_us += (uint64_t)(ms * 1e3f);
     }
     if (lite) {
         uint64_t again = 0;
-        for (int c = 0; c < (deferred ? 1 : n_chunks); ++c) again += ((const uint32_t *)(W.host + o_st + 192))[c];
+        for (int c = 0; c < (deferred || deferred_project ? 1 : n_chunks); ++c) again += ((const uint32_t *)(W.host + o_st + 192))[c];
         W.last_second_pass = again;
         if (again * 10 > (uint64_t)n_alignments * 3) W.lite_skip = 15;
     } else {
