@@ -293,6 +293,8 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
         env("PHMM_SW_CHUNKS", w.sw_chunks);
         env("PHMM_SW_LANES", w.sw_lanes);
         env("PHMM_SW_TRANSPOSE", w.sw_transpose);
+        env("PHMM_REGION_SW_ALL", w.region_sw_all);
+        env("PHMM_REGION_PRIO", w.region_prio);
         w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
         w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
         w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
@@ -372,6 +374,9 @@ void phmm_destroy(phmm_handle *h) {
             if (e) (void)hipEventDestroy(e);
     if (h->swork.region_sw_done) (void)hipEventDestroy(h->swork.region_sw_done);
     if (h->swork.ev_second) (void)hipEventDestroy(h->swork.ev_second);
+    if (h->swork.ev_all) (void)hipEventDestroy(h->swork.ev_all);
+    if (h->swork.all_stream) (void)hipStreamDestroy(h->swork.all_stream);
+    if (h->swork.pair_main) (void)hipStreamDestroy(h->swork.pair_main);
     for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
         if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -1199,6 +1204,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.n_items = (uint32_t)c.reads.size();
         p.lds_rows = c.lds_rows;
         p.cnd_select = c.cnd_select;
+        p.high_priority = (h->sw.region_prio & 2) ? 1u : 0u;
         if (!p.n_items) continue;
         hipError_t e;
         if (c.chain && !c.f32_first) continue;  // done with its group above
@@ -1234,7 +1240,7 @@ int phmm_batch_status(phmm_batch *b) {
     uint32_t st = 0;
     HIP_TRY(h, hipMemcpy(&st, b->d_status, 4, hipMemcpyDeviceToHost), PHMM_ERR_HIP);
     if (st) HIP_TRY(h, hipMemset(b->d_status, 0, 4), PHMM_ERR_HIP);
-    if (st & STATUS_POSITIVE) {
+    if (status_positive(st, b->rescue_scratch != nullptr && !h->sw.no_rescue)) {  // (the exact pass rode behind every launch: its verdict)
         h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
         return PHMM_ERR_POSITIVE_RESULT;
     }
@@ -1969,7 +1975,7 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
             for (const auto &e : b->out_extents)
                 if (e.second) memcpy(p->out + e.first, v + e.first, e.second * 8);
         }
-        if (*(const uint32_t *)hs & STATUS_POSITIVE) {
+        if (status_positive(*(const uint32_t *)hs, b->rescue_scratch != nullptr && !h->sw.no_rescue)) {
             h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
             st = PHMM_ERR_POSITIVE_RESULT;
         }
@@ -2085,6 +2091,8 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
     else if (n == "sw_transpose") w.sw_transpose = value < 0 ? -1 : value > 0 ? 1 : 0;
     else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
+    else if (n == "region_sw_all") w.region_sw_all = value < 0 ? -1 : value;
+    else if (n == "region_prio") w.region_prio = value > 0 ? value : 0;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";
@@ -2104,6 +2112,7 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "sw_backtrack_bytes") return h->swork.last_backtrack_bytes;
     else if (n == "sw_second_pass") return h->swork.last_second_pass;
     else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
+    else if (n == "region_sw_all") own = h->swork.region_sw_all_calls;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }

@@ -30,6 +30,8 @@ struct ProjectParams {
     const int32_t *best_allele;        // [n_reads]
     const uint64_t *sw_cigar_off;      // [n_reads + 1], or null: read r owns the slot [r * sw_cigar_slot, (r + 1) * sw_cigar_slot)
     uint32_t sw_cigar_slot;
+    uint32_t sw_pair_stride;           // > 0: the aligner ran every read against every haplotype of its region (SwParams::pair_stride):
+                                       // read r's alignment is slot r * sw_pair_stride + best allele (sw_cigar_off must be null)
     const uint32_t *read_clip;         // [2 * n_reads] or null: (leading, trailing) soft-clipped bases inside read_bases that were not aligned
     const uint32_t *ref_index;         // [n_reads] or null: SW_NO_REFERENCE = the read was not aligned (it stays as it is)
     const uint32_t *sw_cigar, *n_sw_cigar;
@@ -44,6 +46,8 @@ struct ProjectParams {
     uint32_t capacity;
 };
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
+// phmm_post_best_reads and phmm_project_kernel of the same reads as one launch (phmm_pick_reads)
+hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream);
 // `bytes` (rounded up to 16; both buffers are 256-aligned and padded) from pinned host memory, by its device address, to `dev`
 hipError_t launch_stage_in(const void *host_as_device, void *dev, size_t bytes, hipStream_t stream);
 

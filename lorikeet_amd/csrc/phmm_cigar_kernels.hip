@@ -14,6 +14,7 @@
 // right-to-left list of left_align_indels); apply_cigar_to_cigar advances by runs instead of single bases -- the
 // builder merges what the reference adds base by base, so the result is the same.
 #include "phmm_cigar_internal.hpp"
+#include "phmm_post_device.hpp"
 
 namespace phmm {
 
@@ -250,16 +251,11 @@ __device__ int left_align(Builder &T, uint32_t *t_storage, uint32_t capacity, ui
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p) {
-    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n_reads) return;
+// read r (one lane): `ws` = its four builders of p.capacity elements each
+__device__ __forceinline__ void project_read(const ProjectParams &p, const uint32_t r, uint32_t *ws) {
     int status = CIGAR_UNCHANGED;
     int64_t new_pos = 0;
     uint32_t n_out = 0;
-    // (a small launch keeps the lanes' builders in LDS: every builder operation is a dependent memory access, and a
-    // region per call has too few reads to hide HBM latency behind other lanes)
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
-    uint32_t *ws = p.workspace ? p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity;
     Builder A, B, T;
     uint32_t *rtl = ws + 3 * (size_t)p.capacity;
 
@@ -274,7 +270,10 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
     // (phmm_region_compute keeps the best alleles in the caller's pinned memory and the reads' reference index on the device)
     const int32_t best = p.best_allele ? p.best_allele[r]
                          : p.ref_index[r] == SW_NO_REFERENCE ? -1 : (int32_t)(p.ref_index[r] - p.region_hap_off[g]);
-    const int32_t sw_offset = p.sw_offset[r];
+    // where the aligner left this read's alignment: its own slot, or (every read against every haplotype, SwParams::pair_stride)
+    // the slot of the read's best haplotype
+    const uint64_t sw_at = p.sw_pair_stride ? (uint64_t)r * p.sw_pair_stride + (uint32_t)(best < 0 ? 0 : best) : (uint64_t)r;
+    const int32_t sw_offset = p.sw_offset[sw_at];
     const int32_t ref_in_region = p.region_ref_hap[g];
     uint32_t *out = p.out_cigar + p.out_cigar_off[r];
     const uint64_t out_cap = p.out_cigar_off[r + 1] - p.out_cigar_off[r];
@@ -305,8 +304,8 @@ __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p)
         // :65-72 the alignment's cigar through a builder
         A.init(ws, p.capacity, true);
         {
-            const uint32_t *sw = p.sw_cigar + (p.sw_cigar_off ? p.sw_cigar_off[r] : (uint64_t)r * p.sw_cigar_slot);
-            for (uint32_t i = 0; i < p.n_sw_cigar[r]; ++i)
+            const uint32_t *sw = p.sw_cigar + (p.sw_cigar_off ? p.sw_cigar_off[r] : sw_at * p.sw_cigar_slot);
+            for (uint32_t i = 0; i < p.n_sw_cigar[sw_at]; ++i)
                 if (A.add(sw[i]) != CIGAR_OK) break;
             CHECK(A.error);
             CHECK(A.make());
@@ -411,6 +410,35 @@ done:
     if (status == CIGAR_OK && n_out > out_cap) *p.flags = 1u;
 }
 
+__global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p) {
+    const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    // (a small launch keeps the lanes' builders in LDS: every builder operation is a dependent memory access, and a
+    // region per call has too few reads to hide HBM latency behind other lanes)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
+    project_read(p, r, p.workspace ? p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
+}
+
+// Post-step, best allele and projection of a read in ONE launch (phmm_region_compute, small calls whose alignments were made
+// for every haplotype beside the PairHMM kernels): lane r normalises its row of likelihoods, decides keep[r], finds the best
+// allele and projects the alignment the aligner left in THAT haplotype's slot -- phmm_post_best_reads and
+// phmm_project_kernel, statement for statement, without the launch in between.
+__global__ __launch_bounds__(64) void phmm_pick_reads(const PostBestParams pb, const ProjectParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    const uint32_t g = pb.post.read_region[r];
+    const uint32_t nh = pb.post.region_hap_off[g + 1] - pb.post.region_hap_off[g];
+    if (nh <= 16) {
+        post_best_in_registers<16>(pb, r, g, nh);
+    } else {
+        const uint8_t keep = post_read(pb.post, r, true);
+        if (pb.keep_final) pb.keep_final[r] = keep;
+        best_allele_of(pb.best, r, g, keep != 0, !(pb.skip_single_allele && nh == 1));
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
+    project_read(p, r, p.workspace ? p.workspace + (size_t)r * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
+}
+
 // CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) behind the Smith-Waterman alignment of the padded
 // sequences: the two shortcuts (:365-385), is_s_w_failure (:469-487), the padding trimmed off (:421-428), the trailing
 // deletion put back for the left-alignment (:430-435), left_align_indels (:437-442), and the leading / trailing deletions
@@ -501,6 +529,21 @@ hipError_t launch_project(const ProjectParams &p, hipStream_t stream) {
         return hipGetLastError();
     }
     hipLaunchKernelGGL(phmm_project_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// (p.r_begin == 0: the launch covers the reads of the post-step)
+hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream) {
+    if (!p.n_reads) return hipSuccess;
+    if (p.r_begin != 0 || pb.post.n_reads != p.n_reads) return hipErrorInvalidValue;
+    const size_t lds_per_lane = 4ull * p.capacity * 4;
+    if (p.n_reads <= 4096 && 32 * lds_per_lane <= 64 * 1024) {
+        ProjectParams q = p;
+        q.workspace = nullptr;
+        hipLaunchKernelGGL(phmm_pick_reads, dim3((p.n_reads + 31) / 32), dim3(32), 32 * lds_per_lane, stream, pb, q);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(phmm_pick_reads, dim3((p.n_reads + 63) / 64), dim3(64), 0, stream, pb, p);
     return hipGetLastError();
 }
 

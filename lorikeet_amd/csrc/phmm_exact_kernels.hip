@@ -121,12 +121,15 @@ __global__ __launch_bounds__(64) void phmm_rescue(const RescueParams rp) {
         const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
         double *row = p.out + p.out_off[reg] + (uint64_t)((uint32_t)r - p.region_read_off[reg]) * (uint64_t)Nh;
         for (int a = 0; a < Nh; ++a) {
-            if (row[a] >= kRescueBelow) continue;  // false for NaN too
+            if (row[a] >= kRescueBelow) {  // false for NaN too
+                if (row[a] > 0.0) atomicOr(p.status, STATUS_POSITIVE_FINAL);
+                continue;
+            }
             const uint32_t ho = p.hap_off[h0 + a];
             const int H = (int)(p.hap_off[h0 + a + 1] - ho);
             const double v = exact_pair(p, ro, R, ho, H, rw);
             row[a] = v;
-            if (!(v <= 0.0)) atomicOr(p.status, STATUS_POSITIVE);
+            if (!(v <= 0.0)) atomicOr(p.status, STATUS_POSITIVE | STATUS_POSITIVE_FINAL);
         }
     }
 }

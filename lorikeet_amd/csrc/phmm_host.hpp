@@ -44,6 +44,9 @@ struct Switches {
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
     int sw_transpose = -1;      // PHMM_SW_TRANSPOSE: 0 = small calls never sweep along the alternate sequence, 1 = whenever possible, -1 = by cost
     int sw_no_zero_copy = 0;    // PHMM_SW_NO_ZERO_COPY: small one-piece calls fetch their results by copies like large ones (A/B only)
+    int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
+    int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
+                                // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
@@ -85,6 +88,10 @@ struct phmm_handle {
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
         uint64_t last_kernel_us = 0, last_backtrack_bytes = 0, last_clock_mhz = 0;
+        hipStream_t all_stream = nullptr;     // phmm_region_compute, small calls: the aligner over every (read, haplotype) pair runs
+        hipEvent_t ev_all = nullptr;          // here, beside the PairHMM kernels; recorded behind it
+        hipStream_t pair_main = nullptr;      // ... and the other kernels of such a call here (hardware queues of their own, phmm_region.cpp)
+        uint64_t region_sw_all_calls = 0;     // how many calls went that way (phmm_get_stat "region_sw_all")
         hipEvent_t region_sw_done = nullptr;  // phmm_region_compute in chunks: the slab and the workspace are one per handle, so
         bool region_sw_pending = false;       // a chunk's alignment kernels wait for those of the chunk before it
         std::unordered_map<uint64_t, int> blocks_per_cu;  // by (lanes, columns, LDS bytes): asked of the runtime once
@@ -94,6 +101,7 @@ struct phmm_handle {
     struct Combiner *comb = nullptr;  // phmm_submit / phmm_wait state, created by the first phmm_submit
     uint32_t gpu_sharers = 1;         // flows computing at the same time (phmm_wait, combined flushes): the planner stops
                                       // trading lanes for waves once the batch fills its share of the chip
+    uint32_t busy_lanes = 1;          // a lane of a shared handle: lanes computing right now, this one included (phmm_wait)
     bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
     std::once_flag comb_once;
 };

@@ -36,6 +36,7 @@ struct ForwardParams {
     double initial_condition_log10;  // log10(2^1020), host libm
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
     const uint8_t *redo;             // not null: only reads with redo[r] != 0 are computed (f64 pass of the f32-first mode)
+    uint32_t high_priority;          // 1: the per-read kernel's waves raise their issue priority (s_setprio; A/B switch region_prio)
     uint32_t cnd_select;             // 1: v_cndmask prior select (launches with < 2 waves per SIMD, K <= PHMM_CND_MAX_K)
     uint32_t *status;                // device status word (STATUS_POSITIVE | STATUS_RESCUE)
 };
@@ -43,6 +44,12 @@ struct ForwardParams {
 // Status word bits the forward kernels raise.
 constexpr uint32_t STATUS_POSITIVE = 1u;  // some log10 likelihood came out > 0 (or NaN): pair_hmm.rs:478-481 asserts
 constexpr uint32_t STATUS_RESCUE = 2u;    // some result lies below kRescueBelow: phmm_rescue recomputes those pairs
+constexpr uint32_t STATUS_POSITIVE_FINAL = 4u;  // raised by phmm_rescue where a value is > 0 (or NaN) AFTER its pass: once that pass
+                                                // has run (STATUS_RESCUE), this bit is the verdict and STATUS_POSITIVE -- which a fast
+                                                // kernel may have raised for a pair the pass then replaced -- is not
+__host__ __device__ inline bool status_positive(uint32_t bits, bool rescue_rides_inline) {
+    return rescue_rides_inline && (bits & STATUS_RESCUE) ? (bits & STATUS_POSITIVE_FINAL) != 0 : (bits & STATUS_POSITIVE) != 0;
+}
 // Below this log10 likelihood the scaled row sum of the reference (2^1020 / H scale, pair_hmm.rs:515-529,598-614) gets
 // close to the denormal range, where every rounding counts: the fast kernels (folded row constants, FMA contraction,
 // the chained kernel's common 2^1010 start) are no longer within 1e-9 of the reference there, and they reach -inf at a

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
     const int grp = lane / L, l = lane % L;
     const uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= p.n_items) return;  // wave-uniform
+    if (p.high_priority) __builtin_amdgcn_s_setprio(3);
     const uint32_t r = p.class_reads ? p.class_reads[item] : item;
     if (p.redo && p.redo[r] == 0) return;  // f32-first mode: this launch only redoes the flagged reads (wave-uniform)
     const uint32_t reg = p.read_region[r];

@@ -10,8 +10,10 @@
 // alignments stay in device memory from one kernel to the next.  Host side only: validation, staging, launch geometry,
 // the chunk pipeline of large calls, status.  No CPU path.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -53,8 +55,10 @@ struct Layout {
     size_t q, i, d, g, thr, refidx, swc, nsw, swo, todo;
     size_t res, keep, out, best, lk, conf, pst, pno, pos, pout, end;
     Layout() { memset(this, 0, sizeof *this); }
-    Layout(size_t base, const RegionArgs &a, uint32_t sw_capacity) {
+    // pair_stride > 0: the aligner's slots are one per (read, haplotype of its region), pair_stride of them per read
+    Layout(size_t base, const RegionArgs &a, uint32_t sw_capacity, uint32_t pair_stride) {
         const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
+        const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;
         const size_t rb = a.read_off[nr], hb = a.hap_off[nh];
         size_t used = base;
         auto take = [&](size_t bytes) {
@@ -86,9 +90,9 @@ struct Layout {
         g = take(rb);
         thr = take(8ull * nr);
         refidx = take(4ull * nr);
-        swc = take(4ull * nr * sw_capacity);
-        nsw = take(4ull * nr);
-        swo = take(4ull * nr);
+        swc = take(4ull * n_sw * sw_capacity);
+        nsw = take(4ull * n_sw);
+        swo = take(4ull * n_sw);
         todo = take(4ull * nr);  // the list the aligner's tags-only pass leaves to its second pass (SW_LITE)
         res = take(256);
         keep = take(nr);
@@ -107,6 +111,7 @@ struct Layout {
 struct PendingRegion {
     phmm_batch *b = nullptr;
     int slot = 0;
+    hipStream_t stream = nullptr; // the stream the batch was enqueued on
     RegionArgs a;                 // the (chunk's) arguments: where the results go
     const std::vector<RegionArgs> *parts = nullptr;  // non-null: `a` holds the combined offset arrays of several submissions
                                                      // (phmm_region_submit), payload and results are theirs
@@ -114,7 +119,16 @@ struct PendingRegion {
     bool d2h_pending = false, zero_copy = false;
     bool lite = false;            // the aligner ran in two passes: the results' header holds how many alignments went round again
     uint32_t sw_capacity = 0;
+    bool inline_rescue = false;   // the exact pass below -600 rode behind the forward kernels
+    uint32_t pair_stride = 0;     // > 0: the aligner took every read against every haplotype of its region, beside the PairHMM kernels
     PendingRegion() = default;
+};
+
+std::atomic<int> g_region_calls[16];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
+struct InFlight {
+    std::atomic<int> &n;
+    explicit InFlight(int device) : n(g_region_calls[device & 15]) { n.fetch_add(1, std::memory_order_relaxed); }
+    ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
 };
 
 constexpr uint32_t kFirstSwCapacity = 24;  // CIGAR elements reserved per read -> haplotype alignment (grown and redone when one needs more)
@@ -190,20 +204,37 @@ bool ensure_sw_buffers(phmm_handle *h, size_t slab_bytes, size_t ws_bytes) {
 
 // Stage one batch of regions in the current slot's arena and enqueue everything on its stream.  No sync.
 int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<RegionArgs> *parts, uint32_t sw_capacity, bool chained,
-                   PendingRegion *pending) {
+                   bool may_align_all, PendingRegion *pending) {
     const std::string who = "phmm_region_compute";
     const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
-    const Layout sizing(0, a, sw_capacity);
+    // A small call leaves most of the chip idle and is a chain of dependent kernels, the aligner the longest of them -- and
+    // the aligner needs nothing the PairHMM kernels make except WHICH haplotype a read is aligned to.  So it aligns every
+    // read against every haplotype of its region on a stream of its own, beside pre-step and PairHMM, and the kernel behind
+    // both takes the best allele's slot: the same alignments as the chain's, Nh times the aligner's work on SIMDs that had
+    // none, one kernel less on the critical path (haplotype_caller_engine.rs:1311-1357 is the sequence this replaces).
+    uint32_t pair_stride = 0;
+    if (may_align_all && !chained && nr && nh && h->sw.region_sw_all != 0) {
+        uint32_t max_nh = 0;
+        for (uint32_t g = 0; g < ng; ++g) max_nh = std::max(max_nh, a.region_hap_off[g + 1] - a.region_hap_off[g]);
+        // (by itself only while this is the one region call in flight in the process: with several callers the chip is not idle,
+        // and Nh times the aligner's work comes out of the other calls' time -- 4 threads: 21 k regions/s the plain way, 14 k this way)
+        const bool alone = h->busy_lanes <= 1 && g_region_calls[h->device & 15].load(std::memory_order_relaxed) <= 1;
+        const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all : alone ? 2048u : 0u;
+        if (max_nh >= 2 && (uint64_t)nr * max_nh <= limit) pair_stride = max_nh;
+    }
+    const Layout sizing(0, a, sw_capacity, pair_stride);
     phmm_batch *b = batch_create_in_arena(h, ng, a.region_read_off, a.region_hap_off, a.read_off, a.hap_off, a.out_off, sizing.end + 512);
     if (!b) return h->err_code ? h->err_code : PHMM_ERR_INVALID_ARG;
     const BatchView V = batch_view(b);
     Arena &A = h->A();
-    hipStream_t S = h->S();
-    const Layout L(A.used, a, sw_capacity);
+    hipStream_t S = h->S();  // (a call that aligns every pair moves to a stream of its own, below)
+    Layout L(A.used, a, sw_capacity, pair_stride);
     int st = PHMM_OK;
+    bool inline_rescue = false;
     auto bail = [&](int code) {
         std::string keep_err = h->err;
         (void)hipStreamSynchronize(S);
+        if (h->swork.all_stream) (void)hipStreamSynchronize(h->swork.all_stream);
         phmm_batch_destroy(b);
         h->err = keep_err;
         return h->err_code = code;
@@ -248,6 +279,17 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     put(L.outco, a.out_cigar_off, 8ull * (nr + 1));
     memset(A.host + L.status_in, 0, 256);
     h->stat_staged_bytes += (2 + (a.ins_q ? 1 : 0) + (a.del_q ? 1 : 0)) * V.read_bytes + V.hap_bytes;
+    // A small one-shot call (a region per call, the reference's pattern) does without the copy engine: a kernel fetches
+    // the inputs from the pinned mirror, and the kernels store what the caller gets back straight into it.
+    const size_t res_bytes = L.end - L.res;
+    char *mirror = nullptr;
+    if (eager_d2h(h) && V.tight_out && nr && L.in_end <= stage_in_bytes() && res_bytes <= zero_copy_out_bytes()) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, A.host, 0) == hipSuccess && dp) mirror = (char *)dp;
+    }
+    char *const res_base = mirror ? mirror : A.dev;  // what only the caller reads
+    if (!mirror) pair_stride = 0;  // (the aligner beside the other kernels reads its sequences from the mirror: small calls only)
+    const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;  // alignments the aligner makes
     // ---- shapes ----------------------------------------------------------------------------------------------------------
     uint32_t max_r = 0, max_hap_cigar = 0;
     for (uint32_t r = 0; r < nr; ++r) max_r = std::max(max_r, a.read_off[r + 1] - a.read_off[r]);
@@ -259,19 +301,40 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     if (align) {
         st = sw_plan(h, who, nr, V.max_h, std::max<uint32_t>(max_r, 1), &a.rcfg.sw_parameters, &G);
         if (st != PHMM_OK) return bail(st);
-        workers = std::min<size_t>(G.max_workers, ((size_t)nr + G.gpb - 1) / G.gpb);
+        if (G.ext_stride) pair_stride = 0;  // (refused below)
+        workers = std::min<size_t>(G.max_workers, ((pair_stride ? n_sw : (size_t)nr) + G.gpb - 1) / G.gpb);
         pj_capacity = 4 * (sw_capacity + max_hap_cigar + 2) + 8;  // the lanes' builders: see phmm_cigar.cpp
         if (!ensure_sw_buffers(h, workers * G.slab_stride * 4, (size_t)nr * 4ull * pj_capacity * 4ull)) return bail(PHMM_ERR_HIP);
+    } else {
+        pair_stride = 0;
     }
-    // A small one-shot call (a region per call, the reference's pattern) does without the copy engine: a kernel fetches
-    // the inputs from the pinned mirror, and the kernels store what the caller gets back straight into it.
-    const size_t res_bytes = L.end - L.res;
-    char *mirror = nullptr;
-    if (eager_d2h(h) && V.tight_out && nr && L.in_end <= stage_in_bytes() && res_bytes <= zero_copy_out_bytes()) {
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, A.host, 0) == hipSuccess && dp) mirror = (char *)dp;
+    phmm_handle::SwWork &W = h->swork;
+    if (pair_stride) {
+        if (!W.all_stream) {
+            // Two streams with hardware queues of their own, created one behind the other: the call's kernels run on the first,
+            // the all-pairs aligner on the second.  What was measured (rocprofv3 queue ids, 128 x 8 reads x haplotypes per call):
+            // the slot stream and an ordinary second stream may share one of the runtime's four queues (one kernel after the
+            // other: 166 us per call); two queues whose ids are equal modulo four -- one pipe of the command processor --
+            // stretch the pre-step from 20 to 57 us (160 us per call); a stream of another PRIORITY delivers its event ~55 us
+            // late (190 us); queues with consecutive ids: 120 us.  A stream with a CU mask always gets a new queue, and the
+            // mask names every CU.
+            static std::mutex creation;
+            std::lock_guard<std::mutex> lk(creation);
+            uint32_t mask[32];
+            for (uint32_t &m : mask) m = 0xffffffffu;
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+            const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
+            if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(&W.pair_main, words, mask) != hipSuccess) W.pair_main = nullptr;
+            if (hipExtStreamCreateWithCUMask(&W.all_stream, words, mask) != hipSuccess) {
+                W.all_stream = nullptr;
+                if (!ok(h, hipStreamCreateWithFlags(&W.all_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(PHMM_ERR_HIP);
+            }
+        }
+        if (W.pair_main) S = W.pair_main;
+        if (!W.ev_all && !ok(h, hipEventCreateWithFlags(&W.ev_all, hipEventDisableTiming), "hipEventCreate")) return bail(PHMM_ERR_HIP);
     }
-    char *const res_base = mirror ? mirror : A.dev;  // what only the caller reads
     bool good;
     if (mirror) {  // (the inputs are fetched by blocks of the pre-step's launch, below)
         memset(A.host + L.res, 0, 256);
@@ -281,6 +344,52 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         batch_set_status(b, (uint32_t *)(A.dev + L.res));
         good = ok(h, hipMemcpyAsync(A.dev, A.host, L.in_end, hipMemcpyHostToDevice, S), "H2D batch") &&
                ok(h, hipMemsetAsync(A.dev + L.res, 0, 256, S), "memset status");
+    }
+    // ---- the aligner, every read against every haplotype of its region: beside everything below, straight from the mirror ------
+    auto sw_params = [&](const char *in_base) {
+        SwParams sp{};
+        sp.a_begin = 0;
+        sp.n_alignments = (uint32_t)n_sw;
+        sp.ref_off = (const uint32_t *)(in_base + ((const char *)V.d_hap_off - A.dev));
+        sp.alt_off = (const uint32_t *)(in_base + ((const char *)V.d_read_off - A.dev));
+        sp.ref_index = (const uint32_t *)(A.dev + L.refidx);
+        sp.ref_bases = (const uint8_t *)(in_base + L.haps);
+        sp.alt_bases = (const uint8_t *)(in_base + L.bases);
+        sp.w_match = a.rcfg.sw_parameters.match_value;
+        sp.w_mismatch = a.rcfg.sw_parameters.mismatch_penalty;
+        sp.w_open = a.rcfg.sw_parameters.gap_open_penalty;
+        sp.w_extend = a.rcfg.sw_parameters.gap_extend_penalty;
+        sp.strategy = a.rcfg.overhang_strategy;
+        sp.cigar_off = nullptr;
+        sp.cigar_slot = sw_capacity;
+        sp.alt_clip = a.read_soft_clip ? (const uint32_t *)(in_base + L.clip) : nullptr;
+        sp.cigar = (uint32_t *)(A.dev + L.swc);
+        sp.n_cigar = (uint32_t *)(A.dev + L.nsw);
+        sp.alignment_offset = (int32_t *)(A.dev + L.swo);
+        sp.slab = W.slab;
+        sp.slab_stride = G.slab_stride;
+        sp.status = (uint32_t *)(res_base + L.res + 64);
+        sp.max_ref = V.max_h;
+        sp.max_alt = std::max<uint32_t>(max_r, 1);
+        sp.lds_ref_bytes = (uint32_t)G.lds_ref;
+        sp.lds_alt_bytes = (uint32_t)G.lds_alt;
+        sp.lds_group_bytes = (uint32_t)G.lds_group;
+        sp.groups_per_block = (uint32_t)G.gpb;
+        return sp;
+    };
+    // (enqueued FIRST: started 10 us ahead of the pre-step it runs 80 us beside pre-step + PairHMM's 20 + 64 -- the waves of the
+    // two kernels share the SIMDs' issue slots, alone they take 57 and 15 + 40; started together with the PairHMM kernel it
+    // takes 94 and that one 85.  Raising either kernel's wave priority (switch region_prio) only moves the time to the other.)
+    if (good && pair_stride) {
+        SwParams sp = sw_params(mirror);
+        sp.ref_index = nullptr;
+        sp.pair_stride = pair_stride;
+        sp.high_priority = (h->sw.region_prio & 1) ? 1u : 0u;
+        sp.read_region = (const uint32_t *)(mirror + ((const char *)V.d_read_region - A.dev));
+        sp.region_hap_off = (const uint32_t *)(mirror + ((const char *)V.d_region_hap_off - A.dev));
+        good = ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, W.all_stream), "phmm_sw_align_kernel (all pairs)") &&
+               ok(h, hipEventRecord(W.ev_all, W.all_stream), "hipEventRecord");
+        if (good) W.region_sw_all_calls += 1;
     }
     // ---- pre-step ----------------------------------------------------------------------------------------------------------
     if (good && nr) {
@@ -326,15 +435,16 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     if (good && nr) {
         const bool can_underflow = a.cfg.constant_gcp == 0 || 53.0 + (double)max_r * a.cfg.constant_gcp / 10.0 >= 590.0;
         if (can_underflow) good = batch_set_inline_rescue(h, b);
+        inline_rescue = can_underflow && !h->sw.no_rescue;
         if (!good) return bail(PHMM_ERR_HIP);
         good = phmm_batch_bind_device(b, (const uint8_t *)(A.dev + L.bases), (const uint8_t *)(A.dev + L.q), (const uint8_t *)(A.dev + L.i),
                                       (const uint8_t *)(A.dev + L.d), (const uint8_t *)(A.dev + L.g), (const uint8_t *)(A.dev + L.haps),
                                       (double *)(A.dev + L.out)) == PHMM_OK &&
-               phmm_batch_launch(b, nullptr) == PHMM_OK;
+               phmm_batch_launch(b, S) == PHMM_OK;
     }
     // ---- post-step + best alleles: one kernel, the matrix stays where the forward kernels wrote it ---------------------------
+    PostBestParams pb{};
     if (good && nr) {
-        PostBestParams pb{};
         PostParams &po = pb.post;
         po.n_reads = nr;
         po.read_region = V.d_read_region;
@@ -367,10 +477,9 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         bp.ref_index = (uint32_t *)(A.dev + L.refidx);
         pb.skip_single_allele = (a.rcfg.flags & PHMM_REGION_SKIP_SINGLE_ALLELE) ? 1u : 0u;
         pb.keep_final = mirror ? (uint8_t *)(mirror + L.keep) : nullptr;
-        good = ok(h, launch_post_best(pb, S), "phmm_post_best_reads");
+        if (!pair_stride) good = ok(h, launch_post_best(pb, S), "phmm_post_best_reads");  // (else: part of phmm_pick_reads, below)
     }
     // ---- alignments to the best haplotypes and their projection onto the reference -----------------------------------------
-    phmm_handle::SwWork &W = h->swork;
     ProjectParams pj{};
     if (nr) {
         pj.r_begin = 0;
@@ -391,6 +500,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pj.ref_index = (const uint32_t *)(A.dev + L.refidx);
         pj.sw_cigar_off = nullptr;
         pj.sw_cigar_slot = sw_capacity;
+        pj.sw_pair_stride = pair_stride;
         pj.sw_cigar = (const uint32_t *)(A.dev + L.swc);
         pj.n_sw_cigar = (const uint32_t *)(A.dev + L.nsw);
         pj.sw_offset = (const int32_t *)(A.dev + L.swo);
@@ -407,39 +517,14 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pj.capacity = pj_capacity;
     }
     bool used_lite = false;
-    if (good && align) {
-        SwParams sp{};
-        sp.a_begin = 0;
-        sp.n_alignments = nr;
-        sp.ref_off = V.d_hap_off;
-        sp.alt_off = V.d_read_off;
-        sp.ref_index = (const uint32_t *)(A.dev + L.refidx);
-        sp.ref_bases = (const uint8_t *)(A.dev + L.haps);
-        sp.alt_bases = (const uint8_t *)(A.dev + L.bases);
-        sp.w_match = a.rcfg.sw_parameters.match_value;
-        sp.w_mismatch = a.rcfg.sw_parameters.mismatch_penalty;
-        sp.w_open = a.rcfg.sw_parameters.gap_open_penalty;
-        sp.w_extend = a.rcfg.sw_parameters.gap_extend_penalty;
-        sp.strategy = a.rcfg.overhang_strategy;
-        sp.cigar_off = nullptr;
-        sp.cigar_slot = sw_capacity;
-        sp.alt_clip = a.read_soft_clip ? (const uint32_t *)(A.dev + L.clip) : nullptr;
-        sp.cigar = (uint32_t *)(A.dev + L.swc);
-        sp.n_cigar = (uint32_t *)(A.dev + L.nsw);
-        sp.alignment_offset = (int32_t *)(A.dev + L.swo);
-        sp.slab = W.slab;
-        sp.slab_stride = G.slab_stride;
-        sp.status = (uint32_t *)(res_base + L.res + 64);
-        sp.max_ref = V.max_h;
-        sp.max_alt = std::max<uint32_t>(max_r, 1);
-        sp.lds_ref_bytes = (uint32_t)G.lds_ref;
-        sp.lds_alt_bytes = (uint32_t)G.lds_alt;
-        sp.lds_group_bytes = (uint32_t)G.lds_group;
-        sp.groups_per_block = (uint32_t)G.gpb;
-        if (G.ext_stride) {  // (reads and haplotypes never get there; the aligner's own entry points handle such lengths)
-            h->err = who + ": sequences too long for the per-region pipeline (about 8 000 bases each)";
-            return bail(PHMM_ERR_INVALID_ARG);
-        }
+    if (good && align && G.ext_stride) {  // (reads and haplotypes never get there; the aligner's own entry points handle such lengths)
+        h->err = who + ": sequences too long for the per-region pipeline (about 8 000 bases each)";
+        return bail(PHMM_ERR_INVALID_ARG);
+    }
+    if (good && pair_stride) {  // the alignments were made beside all this: wait for them, then post-step + best allele + projection
+        good = ok(h, hipStreamWaitEvent(S, W.ev_all, 0), "hipStreamWaitEvent") && ok(h, launch_pick(pb, pj, S), "phmm_pick_reads");
+    } else if (good && align) {
+        SwParams sp = sw_params(A.dev);
         // (chunks of one call follow each other through the handle's one slab and workspace)
         if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
         // (reads against their haplotypes: the tags-only sweep first, the full instance over the alignments that met a gap;
@@ -464,9 +549,11 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
             good = good && ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, S), "phmm_sw_align_kernel");
         }
     } else if (good && nr) {  // nothing was aligned: the kernels behind the aligner still find defined alignments
-        good = ok(h, hipMemsetAsync(A.dev + L.nsw, 0, 4ull * nr, S), "memset") && ok(h, hipMemsetAsync(A.dev + L.swo, 0, 4ull * nr, S), "memset");
+        // (the projection below works in the handle's one workspace like every chunk's: behind the chunk before it)
+        if (chained && W.region_sw_pending) good = ok(h, hipStreamWaitEvent(S, W.region_sw_done, 0), "hipStreamWaitEvent");
+        good = good && ok(h, hipMemsetAsync(A.dev + L.nsw, 0, 4ull * nr, S), "memset") && ok(h, hipMemsetAsync(A.dev + L.swo, 0, 4ull * nr, S), "memset");
     }
-    if (good && nr) {
+    if (good && nr && !pair_stride) {
         if (!align && !ensure_sw_buffers(h, 0, (size_t)nr * 4ull * (4 * (sw_capacity + max_hap_cigar + 2) + 8) * 4ull)) return bail(PHMM_ERR_HIP);
         if (!align) {
             pj.workspace = W.ws;
@@ -485,12 +572,15 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     if (!good) return bail(h->err_code ? h->err_code : PHMM_ERR_HIP);
     pending->b = b;
     pending->slot = h->slot;
+    pending->stream = S;
     pending->a = a;
     pending->parts = parts;
     pending->L = L;
     pending->d2h_pending = !eager && !mirror;
     pending->zero_copy = mirror != nullptr;
     pending->sw_capacity = sw_capacity;
+    pending->pair_stride = pair_stride;
+    pending->inline_rescue = inline_rescue;
     pending->lite = used_lite;
     return PHMM_OK;
 }
@@ -504,7 +594,7 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
     const RegionArgs &a = p->a;
     const Layout &L = p->L;
     const Arena &A = h->arenas[p->slot];
-    hipStream_t S = h->streams[p->slot];
+    hipStream_t S = p->stream ? p->stream : h->streams[p->slot];
     const uint32_t ng = a.n_regions, nr = a.region_read_off[ng];
     int st = PHMM_OK;
     auto done = [&](int code) {
@@ -528,9 +618,9 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
     } else {
         h->swork.last_second_pass = 0;
     }
-    if (nr && sw_st[SW_STATUS_CAPACITY]) {
-        std::vector<uint32_t> n_sw(nr);
-        if (!ok(h, hipMemcpy(n_sw.data(), A.dev + L.nsw, 4ull * nr, hipMemcpyDeviceToHost), "D2H sw")) return done(PHMM_ERR_HIP);
+    if (nr && sw_st[SW_STATUS_CAPACITY]) {  // (with every pair aligned: whichever pair's; the call goes round again the plain way)
+        std::vector<uint32_t> n_sw(p->pair_stride ? (size_t)nr * p->pair_stride : nr);
+        if (!ok(h, hipMemcpy(n_sw.data(), A.dev + L.nsw, 4ull * n_sw.size(), hipMemcpyDeviceToHost), "D2H sw")) return done(PHMM_ERR_HIP);
         if (sw_needed) *sw_needed = *std::max_element(n_sw.begin(), n_sw.end());
         h->err = "phmm_region_compute: a read -> haplotype CIGAR needs more elements than the library reserved";
         return done(PHMM_ERR_CIGAR_CAPACITY);
@@ -568,7 +658,8 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
             g0 += q.n_regions;
         }
     }
-    if (*(const uint32_t *)(hs + L.res) & STATUS_POSITIVE) {
+    // (with the exact pass in-stream its verdict counts: a fast kernel may have raised the bit for a pair the pass replaced)
+    if (status_positive(*(const uint32_t *)(hs + L.res), p->inline_rescue)) {
         h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
         st = PHMM_ERR_POSITIVE_RESULT;
     } else if (nr && sw_st[SW_STATUS_EMPTY]) {  // the reference asserts (smith_waterman_aligner.rs:65-68, :132-134)
@@ -583,9 +674,10 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
 
 // one batch, start to end, on the current slot; grows the alignments' slots once if one of them needs it
 int region_one_shot(phmm_handle *h, const RegionArgs &a, const std::vector<RegionArgs> *parts, uint32_t *sw_capacity) {
+    const InFlight in_flight(h->device);
     for (int attempt = 0;; ++attempt) {
         PendingRegion p;
-        int st = region_enqueue(h, a, parts, *sw_capacity, false, &p);
+        int st = region_enqueue(h, a, parts, *sw_capacity, false, attempt == 0, &p);
         uint32_t needed = 0;
         if (st == PHMM_OK) st = region_finish(h, &p, &needed);
         if (st == PHMM_ERR_CIGAR_CAPACITY && needed > *sw_capacity && attempt == 0) {
@@ -737,7 +829,7 @@ int region_compute(phmm_handle *h, const RegionArgs &a) {
         if (st != PHMM_OK) break;
         h->slot = slot;
         slots[slot].args.build(a, c);
-        st = region_enqueue(h, slots[slot].args.a, nullptr, sw_capacity, true, &slots[slot].pend);
+        st = region_enqueue(h, slots[slot].args.a, nullptr, sw_capacity, true, false, &slots[slot].pend);
         ++n_chunks;
     }
     for (int i = 0; i < kSlots; ++i) {  // drain in submission order

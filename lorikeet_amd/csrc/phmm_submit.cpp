@@ -542,6 +542,7 @@ int phmm_wait(phmm_handle *h, uint64_t ticket) {
             uint32_t busy = 0;
             for (int l = 0; l < c->n_lanes; ++l) busy += c->lane_busy[l] ? 1u : 0u;
             c->lane[lane]->gpu_sharers = subs.size() >= 2 ? busy : 1u;
+            c->lane[lane]->busy_lanes = busy;
         }
         c->n_flushes += 1;
         c->n_parts += subs.size();

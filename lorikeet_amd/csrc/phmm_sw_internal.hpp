@@ -43,6 +43,13 @@ struct SwParams {
     uint32_t *feedback;                    // or null: where the full launch leaves *todo_count for the host (pinned memory)
     uint32_t todo_min, todo_max;           // a launch over the list runs only if todo_min <= *todo_count <= todo_max (0 = no upper bound):
                                            // a short list goes to the instance with one alignment per wave, a long one to the batch's own
+    // every read against every haplotype of its region (phmm_region_compute, small calls: the aligner runs beside the
+    // PairHMM kernels and the best allele picks its slot afterwards): pair_stride > 0 = slots per read (>= the largest
+    // haplotype count of a region); alignment a is read a / pair_stride against haplotype a % pair_stride of that read's
+    // region (no such haplotype: an empty CIGAR); ref_index is not looked at
+    uint32_t pair_stride;
+    uint32_t high_priority;                // 1: the waves raise their issue priority (s_setprio) over other kernels' waves on their SIMDs
+    const uint32_t *read_region, *region_hap_off;
     unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of
     size_t ext_stride;                     // block b live at ext + b * ext_stride (device memory), LDS holds the two sequences only
 };

@@ -103,9 +103,14 @@ __device__ __forceinline__ void store_flags(uint32_t *at, const V &v) {
         asm volatile("global_store_dword %0, %1, off nt" ::"v"(at), "v"(one) : "memory");
     }
     else if constexpr (NW == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
-    else if constexpr (NW == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+    // (a store of more than 64 bits needs two wait states before a VALU instruction may overwrite its data registers on
+    // gfx940+, and the compiler's hazard recogniser does not look into inline assembly: the s_nop keeps that distance)
+    else if constexpr (NW == 3) asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(at), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(at), "v"(v) : "memory");
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the flag stores ('nt' modifier, hazard distance) and the raw s_waitcnt immediate of the walk are written for gfx942 / gfx950"
+#endif
 
 #ifndef PHMM_SW_K4
 #define PHMM_SW_K4 19
@@ -175,6 +180,7 @@ void phmm_sw_align_kernel(const SwParams p) {
     const size_t strip_stride = (size_t)(p.max_ref + SW_L) * NW * WAVE;  // flag dwords of one strip
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
+    if (p.high_priority) __builtin_amdgcn_s_setprio(3);
     const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
     // the alignments of this launch: [a_begin, n_alignments), or the list an earlier tags-only launch left (todo)
     const uint32_t n_items = p.todo ? *p.todo_count : p.n_alignments;
@@ -184,10 +190,17 @@ void phmm_sw_align_kernel(const SwParams p) {
         const uint32_t item = base + (uint32_t)g;
         bool valid = (uint32_t)g < gpb && item < n_items;
         const uint32_t a = !valid ? 0u : p.todo ? p.todo[item] : item;
-        uint32_t ro = 0, ao = 0;
+        uint32_t ro = 0, ao = 0, aa = a;  // aa: the alternate sequence of alignment a
         int n = 0, m = 0;
         if (valid) {
-            const uint32_t ri = p.ref_index ? p.ref_index[a] : a;  // reads name their haplotype; pairs come one to one
+            uint32_t ri;
+            if (p.pair_stride) {  // every read against EVERY haplotype of its region: alignment a = (read a / stride, haplotype a % stride)
+                aa = a / p.pair_stride;
+                const uint32_t j = a - aa * p.pair_stride, reg = p.read_region[aa], h0 = p.region_hap_off[reg];
+                ri = j < p.region_hap_off[reg + 1] - h0 ? h0 + j : SW_NO_REFERENCE;
+            } else {
+                ri = p.ref_index ? p.ref_index[a] : a;  // reads name their haplotype; pairs come one to one
+            }
             if (ri == SW_NO_REFERENCE) {  // nothing to align (evidence removed / no allele): an empty CIGAR
                 if (l == 0) {
                     p.n_cigar[a] = 0;
@@ -196,11 +209,11 @@ void phmm_sw_align_kernel(const SwParams p) {
                 valid = false;
             } else {
                 ro = p.ref_off[ri];
-                ao = p.alt_off[a];
+                ao = p.alt_off[aa];
                 n = (int)(p.ref_off[ri + 1] - ro);
-                m = (int)(p.alt_off[a + 1] - ao);
+                m = (int)(p.alt_off[aa + 1] - ao);
                 if (p.alt_clip) {  // the read minus its soft clips (alignment_utils.rs:47-50)
-                    const uint32_t cl = p.alt_clip[2 * a], cr = p.alt_clip[2 * a + 1];
+                    const uint32_t cl = p.alt_clip[2 * aa], cr = p.alt_clip[2 * aa + 1];
                     ao += cl;
                     m -= (int)(cl + cr);
                 }

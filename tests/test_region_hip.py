@@ -296,6 +296,7 @@ def test_two_pass_alignment_is_invisible_in_the_results(hip_engine):
     pri = _priorities(b, hap_cigars, ref_hap)
     call = lambda: region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri)  # noqa: E731
     try:
+        hip_engine.set_switch("region_sw_all", 0)  # (the chain: a call that aligns every pair beside the PairHMM takes the full instance)
         hip_engine.set_switch("sw_lite", 0)
         want = call()
         assert hip_engine.stat("sw_second_pass") == 0
@@ -315,3 +316,66 @@ def test_two_pass_alignment_is_invisible_in_the_results(hip_engine):
             assert all(np.array_equal(x, y) for x, y in zip(g.reads.cigars, want.reads.cigars))
     finally:
         hip_engine.set_switch("sw_lite", -1)
+        hip_engine.set_switch("region_sw_all", -1)
+
+
+def _equal_calls(g, want):
+    assert np.array_equal(g.likelihoods, want.likelihoods) and np.array_equal(g.keep, want.keep)
+    assert np.array_equal(g.best.allele_index, want.best.allele_index)
+    assert np.array_equal(g.best.likelihood, want.best.likelihood) and np.array_equal(g.best.confidence, want.best.confidence, equal_nan=True)
+    assert np.array_equal(g.reads.status, want.reads.status) and np.array_equal(g.reads.new_pos, want.reads.new_pos)
+    assert all(np.array_equal(x, y) for x, y in zip(g.reads.cigars, want.reads.cigars))
+
+
+@pytest.mark.parametrize("seed,low,n_regions,pcr,symmetric", [(71, False, 1, 3, True), (72, True, 3, 0, False), (73, False, 6, 2, True), (74, True, 1, 1, False)])
+def test_aligning_every_pair_beside_the_pairhmm_is_invisible_in_the_results(hip_engine, seed, low, n_regions, pcr, symmetric):
+    """A small call aligns every read against EVERY haplotype of its region on a stream of its own while pre-step and PairHMM
+    run, and one kernel behind both normalises, finds the best allele and projects the alignment in that allele's slot
+    (switch `region_sw_all`: pairs up to which a call goes that way, 0 = never).  Field by field the chain's results."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(seed, n_regions=n_regions, low_complexity=low)
+    mapq = _noisy_quals(b, seed)
+    cfg = _cfg(pcr=pcr, symmetric=symmetric)
+    pri = _priorities(b, hap_cigars, ref_hap)
+    call = lambda **kw: region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri, **kw)  # noqa: E731
+    try:
+        hip_engine.set_switch("region_sw_all", 0)
+        n0 = hip_engine.stat("region_sw_all")
+        want = call()
+        assert hip_engine.stat("region_sw_all") == n0
+        hip_engine.set_switch("region_sw_all", 1 << 20)
+        got = call()
+        assert hip_engine.stat("region_sw_all") == n0 + 1
+        _equal_calls(got, want)
+        skip = region.realign_config(skip_single_allele=True)
+        _equal_calls(call(rcfg=skip), (hip_engine.set_switch("region_sw_all", 0), call(rcfg=skip))[1])
+    finally:
+        hip_engine.set_switch("region_sw_all", -1)
+    assert (want.reads.status == 0).sum() >= 1
+
+
+def test_every_pair_alignments_that_outgrow_the_slots_send_the_call_round_the_plain_way(hip_engine):
+    """With every pair aligned, ANY pair may need more than the 24 elements reserved -- here the read against the haplotype
+    that is not its best: the call is made again, the chain's way, with slots of the size needed."""
+    rng = np.random.default_rng(9)
+    hap = bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    other = bytearray(hap)
+    for k in range(20, 680, 44):  # fifteen 3-base deletions relative to `hap`
+        del other[k - 3 * (k // 44):k - 3 * (k // 44) + 3]
+    read = bytes(hap[5:650])
+    reads = [Read(read, np.full(len(read), 30, np.uint8), np.full(len(read), 45, np.uint8), np.full(len(read), 45, np.uint8), np.full(len(read), 10, np.uint8))]
+    b = RegionBatch.from_regions([(reads, [hap, bytes(other)])])
+    extras = ([oracle.parse_cigar("700M"), oracle.parse_cigar("%dM" % len(other))], [0, 0], [0], [5000], [oracle.parse_cigar("%dM" % len(read))])
+    cfg = _cfg(pcr=0)
+    try:
+        hip_engine.set_switch("region_sw_all", 0)
+        want = region.region_compute(hip_engine, cfg, b, np.array([60], np.uint8), *extras)
+        hip_engine.set_switch("region_sw_all", 1 << 20)
+        n0 = hip_engine.stat("region_sw_all")
+        got = region.region_compute(hip_engine, cfg, b, np.array([60], np.uint8), *extras)
+        assert hip_engine.stat("region_sw_all") == n0 + 1
+    finally:
+        hip_engine.set_switch("region_sw_all", -1)
+    _equal_calls(got, want)
+    assert want.best.allele_index[0] == 0 and want.reads.status[0] == 0
+    cig, _ = oracle.sw_align(bytes(other), read, [10, -15, -30, -5], "SoftClip")
+    assert len(cig) > 24  # (the pair that does not fit)
