@@ -11,8 +11,34 @@
 //! shared between threads.  Workers are spread over the visible devices round-robin.
 use std::cell::RefCell;
 use std::ffi::CStr;
+use std::sync::atomic::{AtomicU32, Ordering};
 
 use crate::pair_hmm::hip_ffi::*;
+
+/// Flags every engine of this process is created with (`phmm_create`, include/phmm.h).
+static ENGINE_FLAGS: AtomicU32 = AtomicU32::new(0);
+
+/// `--pairhmm-backend hip-f32`: engines compute in f32 first (state scaled by 2^120) and redo in f64 what underflows --
+/// the arithmetic of the reference's production arm (gkl's AVX kernel, called at src/pair_hmm/pair_hmm.rs:348-366), within
+/// 1e-5 of the scalar arm like that one, and 1.5x the f64 rate.  `--pairhmm-backend hip` is f64 throughout (the scalar
+/// arm's arithmetic).  Takes effect for engines created afterwards: `AVXMode::select` calls it before any region is computed.
+pub fn set_f32_first(on: bool) {
+    if on {
+        ENGINE_FLAGS.fetch_or(PHMM_FLAG_F32_FIRST as u32, Ordering::Relaxed);
+    } else {
+        ENGINE_FLAGS.fetch_and(!(PHMM_FLAG_F32_FIRST as u32), Ordering::Relaxed);
+    }
+}
+
+/// ... or LORIKEET_HIP_F32_FIRST=1 in the environment (read when an engine is created), for runs that cannot change the
+/// command line.
+fn engine_flags() -> std::os::raw::c_uint {
+    let mut flags = ENGINE_FLAGS.load(Ordering::Relaxed);
+    if std::env::var("LORIKEET_HIP_F32_FIRST").map(|v| !v.is_empty() && v != "0").unwrap_or(false) {
+        flags |= PHMM_FLAG_F32_FIRST as u32;
+    }
+    flags as std::os::raw::c_uint
+}
 
 struct Engine(*mut phmm_handle);
 
@@ -41,7 +67,7 @@ fn with_engine<R>(f: impl FnOnce(*mut phmm_handle) -> R) -> R {
         if slot.is_none() {
             let n = device_count().max(1);
             let device = (rayon::current_thread_index().unwrap_or(0) as i32) % n;
-            let h = unsafe { phmm_create(device, 0) };
+            let h = unsafe { phmm_create(device, engine_flags()) };
             if h.is_null() {
                 panic!("HIP PairHMM: {}", last_error(std::ptr::null_mut()));
             }
@@ -473,7 +499,7 @@ lazy_static! {
         Shared(
             (0..n)
                 .map(|device| {
-                    let h = unsafe { phmm_create(device, 0) };
+                    let h = unsafe { phmm_create(device, engine_flags()) };
                     if h.is_null() {
                         panic!("HIP PairHMM: {}", last_error(std::ptr::null_mut()));
                     }

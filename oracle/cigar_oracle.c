@@ -221,6 +221,16 @@ static int consolidated_padded_cigar(const elem_t *cigar, size_t n, uint32_t pad
     return st;
 }
 
+/* ... as the reference's test calls it (tests/haplotype_unit_tests.rs:96-146; tests/golden/consolidate_cigar_cases.json) */
+ORACLE_API int oracle_consolidated_padded_cigar(const uint32_t *cigar, uint32_t n, uint32_t pad, uint32_t *out, uint32_t cap, uint32_t *n_out) {
+    builder_t *b = (builder_t *)malloc(sizeof *b);
+    if (!b) return CIG_ERR_PANIC;
+    int st = consolidated_padded_cigar(cigar, n, pad, b);
+    if (st == CIG_OK) st = copy_out(b, out, cap, n_out);
+    free(b);
+    return st;
+}
+
 /* ---- alignment_utils.rs -------------------------------------------------------------------------------------------- */
 /* :283-311 */
 static int read_start_on_reference_haplotype(const elem_t *cigar, size_t n, uint32_t read_start_on_haplotype, uint32_t *out) {

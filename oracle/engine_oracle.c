@@ -87,6 +87,20 @@ static size_t find_number_of_repetitions(const uint8_t *repeat_unit, size_t unit
     return find_number_of_repetitions_main(repeat_unit, 0, unit_len, test_string, 0, test_len, leading_repeats);
 }
 
+/* the two functions above as the reference's tests call them (tests/variant_context_utils_unit_tests.rs:23-294), so that the
+ * restatement is pinned by those assertions (tests/golden/repetition_cases.json) and not only through their caller below */
+ORACLE_API size_t oracle_find_number_of_repetitions(const uint8_t *repeat_unit, size_t unit_len, const uint8_t *test_string,
+                                                    size_t test_len, int leading_repeats) {
+    return find_number_of_repetitions(repeat_unit, unit_len, test_string, test_len, leading_repeats);
+}
+ORACLE_API size_t oracle_find_number_of_repetitions_main(const uint8_t *repeat_unit_full, size_t offset_in_repeat_unit_full,
+                                                         size_t repeat_unit_length, const uint8_t *test_string_full,
+                                                         size_t offset_in_test_string_full, size_t test_string_length,
+                                                         int leading_repeats) {
+    return find_number_of_repetitions_main(repeat_unit_full, offset_in_repeat_unit_full, repeat_unit_length, test_string_full,
+                                           offset_in_test_string_full, test_string_length, leading_repeats);
+}
+
 /* engine.rs:528-611  find_tandem_repeat_units -> repeat length (the unit itself is not used by the caller) */
 ORACLE_API size_t oracle_find_tandem_repeat_length(const uint8_t *read_bases, size_t n, size_t offset) {
     size_t max_bw = 0;

@@ -65,6 +65,10 @@ def _load(path):
     lib.oracle_pcr_error_model_cache.argtypes = [C.c_int, _u8p]
     lib.oracle_find_tandem_repeat_length.restype = C.c_size_t
     lib.oracle_find_tandem_repeat_length.argtypes = [_u8p, C.c_size_t, C.c_size_t]
+    lib.oracle_find_number_of_repetitions.restype = C.c_size_t
+    lib.oracle_find_number_of_repetitions.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int]
+    lib.oracle_find_number_of_repetitions_main.restype = C.c_size_t
+    lib.oracle_find_number_of_repetitions_main.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, C.c_int]
     lib.oracle_modify_read_qualities.restype = None
     lib.oracle_modify_read_qualities.argtypes = [C.c_int, _u8p, C.c_size_t, C.c_uint8, _u8p, _u8p, _u8p, C.c_uint8, C.c_int]
     lib.oracle_read_disqualification_threshold.restype = C.c_double
@@ -80,6 +84,8 @@ def _load(path):
     _i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     lib.oracle_cigar_builder.restype = C.c_int
     lib.oracle_cigar_builder.argtypes = [_u32p, C.c_uint32, C.c_int, C.c_int, _u32p, C.c_uint32, _u32p, _u32p, _u32p]
+    lib.oracle_consolidated_padded_cigar.restype = C.c_int
+    lib.oracle_consolidated_padded_cigar.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _u32p]
     lib.oracle_read_start_on_reference_haplotype.restype = C.c_int
     lib.oracle_read_start_on_reference_haplotype.argtypes = [_u32p, C.c_uint32, C.c_uint32, _u32p]
     lib.oracle_trim_cigar.restype = C.c_int
@@ -232,6 +238,20 @@ def pcr_error_model_cache(model):
     return c
 
 
+def find_number_of_repetitions(repeat_unit, test_string, leading_repeats):
+    """VariantContextUtils::find_number_of_repetitions (variant_context_utils.rs:240-257)."""
+    (u, up), (t, tp) = _u8(repeat_unit), _u8(test_string)
+    return int(lib().oracle_find_number_of_repetitions(up, len(u), tp, len(t), int(leading_repeats)))
+
+
+def find_number_of_repetitions_main(repeat_unit_full, offset_in_repeat_unit_full, repeat_unit_length, test_string_full,
+                                    offset_in_test_string_full, test_string_length, leading_repeats):
+    """VariantContextUtils::find_number_of_repetitions_main (variant_context_utils.rs:276-335)."""
+    (u, up), (t, tp) = _u8(repeat_unit_full), _u8(test_string_full)
+    return int(lib().oracle_find_number_of_repetitions_main(up, offset_in_repeat_unit_full, repeat_unit_length, tp,
+                                                            offset_in_test_string_full, test_string_length, int(leading_repeats)))
+
+
 def modify_read_qualities(model, bases, mapq, quals, ins, dele, base_quality_score_threshold,
                           disable_cap_read_qualities_to_mapq=False):
     """Returns modified copies (quals, ins, dele) -- engine.rs:352-388."""
@@ -347,6 +367,16 @@ def cigar_builder(elements, remove_deletions_at_ends=True, allow_empty=False):
     if st:
         raise CigarError(st)
     return cigar_to_string(out[:n.value]), lead.value, trail.value
+
+
+def consolidated_padded_cigar(cigar, pad_size):
+    """Haplotype::get_consolidated_padded_cigar (haplotype.rs:248-256) -> cigar string."""
+    c = _elems(cigar)
+    out, n = np.zeros(len(c) + 4, np.uint32), C.c_uint32()
+    st = lib().oracle_consolidated_padded_cigar(_pu32(c), len(c), int(pad_size), _pu32(out), len(out), C.byref(n))
+    if st:
+        raise CigarError(st)
+    return cigar_to_string(out[:n.value])
 
 
 def read_start_on_reference_haplotype(cigar, read_start_on_haplotype):

@@ -270,3 +270,19 @@ def test_the_patch_binds_every_call_site_of_the_path():
     for i, l in enumerate(added[:-1]):
         if l.strip() == '#[cfg(feature = "hip")]':
             assert not added[i + 1].strip().startswith("if "), added[i + 1]
+
+
+def test_the_f32_first_engine_is_reachable_from_the_command_line():
+    """the reference's production arm (gkl, pair_hmm.rs:348-366) is f32-first; `--pairhmm-backend hip-f32` (or
+    LORIKEET_HIP_F32_FIRST=1) creates every engine with PHMM_FLAG_F32_FIRST, `--pairhmm-backend hip` stays f64."""
+    patch = open(PATCH).read()
+    backend = open(os.path.join(ROOT, "integration", "hip_backend.rs")).read()
+    header = open(os.path.join(ROOT, "include", "phmm.h")).read()
+    flag = int(re.search(r"#define PHMM_FLAG_F32_FIRST (\d+)u", header).group(1))
+    assert re.search(r"pub const PHMM_FLAG_F32_FIRST: c_uint = %d;" % flag, open(FFI).read())
+    # no engine is created with a literal flag word any more: both creation sites ask engine_flags()
+    assert backend.count("phmm_create(device, engine_flags())") == 2 and "phmm_create(device, 0)" not in backend
+    assert "pub fn set_f32_first(on: bool)" in backend and 'std::env::var("LORIKEET_HIP_F32_FIRST")' in backend
+    assert patch.count('.value_parser(["auto", "avx", "hip", "hip-f32", "scalar"])') == 3
+    assert 'Some("hip-f32") => Self::hip_or_panic(true)' in patch and 'Some("hip") => Self::hip_or_panic(false)' in patch
+    assert "crate::pair_hmm::hip_backend::set_f32_first(f32_first);" in patch
