@@ -49,6 +49,9 @@ VALU_F64_PEAK_TFLOPS = 78.6  # vector FP64 peak (256 CU * 2.4 GHz * 128 flop/clk
 VALU_F32_PEAK_TFLOPS = 157.3
 NUM_SIMD = 1024              # 256 CUs x 4
 VALU_ISSUE_PEAK = 0.6        # G wave64 VALU instructions / s / SIMD at 2.4 GHz, one per 4 clk
+VALU_ISSUE_PEAK_32 = 1.2     # ... for 32-bit VALU instructions: one per 2 clk (the hardware rate; what the aligner is priced against)
+SW_MIX_ISSUE_CEILING = 0.70  # ... what the aligner's own 16-instruction cell can reach: nine of its instructions issue every 2.55 clk,
+                             # seven (max3, alignbit, compares) every 4.3-4.8 (profiles/r02_ubench_rates.txt) -> 3.4 clk on average
 VALU_ISSUE_UBENCH = 0.595    # what the f64 kernel's own cell body sustains alone (tools/ubench/issue.hip, 2 waves/SIMD)
 FLOP_PER_CELL = 12           # M 4 mul + 2 add, I 2+1, D 2+1
 PAYLOAD = ("read_bases", "base_q", "ins_q", "del_q", "gcp", "hap_bases")
@@ -394,6 +397,103 @@ def strong_row(D, eng, stream, name, steps, sample):
     return row
 
 
+def write_full_record(line):
+    """Everything the run measured, with its explanatory notes, as a file (stdout carries the compact line below)."""
+    out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.environ.get("TMPDIR", "/tmp")
+    path = os.path.join(out_dir, "bench_full.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        return None
+
+
+def compact_line(line, full_path):
+    """The bench line the driver records: the contract's fields, `roofline`, `cpu_baseline`, and ONE numbers-only object
+    `rows` for every other measurement of the run -- under 4 KB, so that the stored tail of stdout holds all of it.  What each
+    number is, how it was measured and what it is priced against: profiles/BENCH_NOTES.md (field by field)."""
+    def g(d, *path, nd=None):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return round(d, nd) if nd is not None and isinstance(d, float) else d
+
+    def pick(d, **fields):  # {short name: path or key}; rows that failed keep their error text
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": str(d["error"])[:80]}
+        return {k: g(d, *(v if isinstance(v, tuple) else (v,))) for k, v in fields.items()}
+
+    c = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "devices_aliased", "dtype", "data")}
+    cfg = line["config"]
+    prc = cfg.get("per_rank_cells") or []
+    c["config"] = {"workload": cfg["workload"].split(":")[0] if line["scaling"] == "strong" else cfg["workload"].split(" (")[0],
+                   "regions_per_gpu": cfg["regions_per_gpu"], "cells_per_gpu_per_step": cfg["cells_per_gpu_per_step"], "seed": cfg["seed"],
+                   "per_rank_cells": prc if len(prc) <= 8 else None,
+                   "imbalance": round(max(prc) * len(prc) / max(sum(prc), 1), 4) if prc else None, "sharding": "regions; no collective"}
+    c["regions_per_s"] = line["regions_per_s"]
+    c["roofline"] = pick(line["roofline"], bound="bound", achieved="achieved", peak="peak", unit="unit", frac="frac", traffic="traffic",
+                         l2_hit_rate="l2_hit_rate", kernel="kernel", kernel_ms="kernel_ms",
+                         algorithmic_bytes_per_launch="algorithmic_bytes_per_launch", src_hash="src_hash")
+    c["valu_f64"] = pick(line["valu_f64"], achieved="achieved", peak="peak", unit="unit", frac="frac")
+    c["valu_issue"] = pick(line["valu_issue"], achieved="achieved", peak="peak", frac="frac", valu_per_cell="valu_per_cell")
+    for k in ("cpu_baseline", "cpu_baseline_simd"):
+        if line.get(k):
+            c[k] = pick(line[k], value="value", unit="unit", cores="cores", kind="kind", sample="sample")
+            if isinstance(c[k].get("sample"), str):
+                c[k]["sample"] = c[k]["sample"].split(";")[0][:90]  # (what was timed; the rest is in the full record)
+    strong = lambda r: pick(r, gcups="gcups", ms="ms_per_step", regions_per_s="regions_per_s", valu_f64_frac=("valu_f64", "frac"),  # noqa: E731
+                            imbalance="imbalance", f32_first_gcups=("f32_first", "gcups"), max_abs_diff=("oracle_sample", "max_abs_diff"))
+    hc = line.get("host_calls") or {}
+    rps = lambda k: g(hc, k, "regions_per_s")  # noqa: E731
+    sw = line.get("smith_waterman")
+    rl = line.get("realign_to_best")
+    rows = {
+        "config3_10k": strong(line.get("config3_10k")), "config5_256": strong(line.get("config5_256")),
+        "ragged": pick(line.get("ragged"), gcups="gcups", ms="ms_per_step", regions_per_s="regions_per_s", launches="launches_per_step",
+                       host_gcups=("host_buffers_incl_pcie", "gcups"), host_ms=("host_buffers_incl_pcie", "ms_per_call"),
+                       valu_f64_frac=("valu_f64", "frac"), max_abs_diff=("oracle_sample", "max_abs_diff")),
+        "f32_first": pick(line.get("f32_first"), gcups="value", ms="ms_per_step", valu_f32_frac=("valu_f32", "frac"),
+                          issue_frac=("valu_issue", "frac"), valu_per_cell=("valu_issue", "valu_per_cell"), max_abs_diff="max_abs_diff_vs_f64"),
+        "single_region_us": g(line, "single_region", "us_per_region"),
+        "engine_call": pick(line.get("engine_call"), gcups_incl_pcie="gcups_incl_pcie", ms="ms_per_call", regions="regions"),
+        # regions/s through host buffers, one region per call unless the name says otherwise (tools/threads_bench)
+        "host_calls": None if not hc else ({"error": str(hc["error"])[:80]} if "error" in hc else {
+            "pairhmm_8t_own": rps("one_region_per_call_8_threads_own_handles"), "pairhmm_32t_shared": rps("one_region_per_call_32_threads_shared_handle_submit_wait"),
+            "region_1t": rps("region_call_one_region_per_call_1_thread"), "region_1t_us": g(hc, "region_call_one_region_per_call_1_thread", "us_per_call"),
+            "region_8t_own": rps("region_call_one_region_per_call_8_threads_own_handles"),
+            "region_8t_shared": rps("region_call_one_region_per_call_8_threads_shared_handle"),
+            "region_32t_shared": rps("region_call_one_region_per_call_32_threads_shared_handle"),
+            "region_4t_x8": rps("region_call_eight_regions_per_call_4_threads_own_handles"), "region_1t_x64": rps("region_call_64_regions_per_call_1_thread"),
+            "small_1t": rps("region_call_small_30x3_1_thread"), "small_1t_us": g(hc, "region_call_small_30x3_1_thread", "us_per_call"),
+            "small_8t_shared": rps("region_call_small_30x3_8_threads_shared_handle"), "small_32t_shared": rps("region_call_small_30x3_32_threads_shared_handle"),
+            "ragged_1t": rps("region_call_ragged_1_thread"), "ragged_8t_shared": rps("region_call_ragged_8_threads_shared_handle"),
+            "ragged_32t_shared": rps("region_call_ragged_32_threads_shared_handle"),
+            "two_calls_1t": rps("likelihoods_then_realignment_one_region_per_call_1_thread")}),
+        "smith_waterman": pick(sw, gcups_i32="gcups_i32", ms="ms_per_call", kernel_gcups_i32=("kernel", "gcups_i32"), kernel_ms=("kernel", "ms"),
+                               one_piece_gcups_i32=("kernel_one_piece", "gcups_i32"), full_instance_gcups_i32=("full_instance_only", "kernel_gcups_i32"),
+                               issue=("valu_issue", "achieved"), issue_peak=("valu_issue", "peak"), issue_frac=("valu_issue", "frac"),
+                               mix_ceiling=("valu_issue", "mix_ceiling"), frac_of_mix_ceiling=("valu_issue", "frac_of_mix_ceiling"),
+                               valu_per_cell=("valu_issue", "valu_per_cell"), algorithmic_bytes=("roofline", "algorithmic_bytes_per_launch"),
+                               traffic=("roofline", "traffic"), flag_bytes=("roofline", "backtrack_flag_bytes_per_launch"),
+                               equal_to_oracle="equal_to_oracle_on_sample", cpu_gcups_i32=("cpu_oracle", "gcups_i32"),
+                               indel_reads_gcups_i32=("indel_rich", "reads_150_with_2_to_5_percent_indels", "gcups_i32"),
+                               indel_haps_gcups_i32=("indel_rich", "haplotype_to_reference_400x400", "gcups_i32")),
+        "realign": pick(rl, ms="ms_per_call", reads_per_s="reads_per_s", project_ms=("project_to_reference", "ms_per_call"),
+                        one_call_ms=("realign_reads_one_call", "ms_per_call"), equal_to_oracle="equal_to_oracle_on_sample",
+                        project_equal_to_oracle=("project_to_reference", "equal_to_oracle_on_sample")),
+        "oracle_sample_max_abs_diff": g(line, "oracle_sample", "max_abs_diff"),
+    }
+    c["rows"] = {k: v for k, v in rows.items() if v is not None}
+    c["notes"] = "profiles/BENCH_NOTES.md"
+    c["full_record"] = full_path
+    return c
+
+
 def main():
     a = parse()
     D = Dist(a)
@@ -423,10 +523,9 @@ def main():
     elapsed, kern_ms = timed_launches(D, res, stream, a.steps, a.warmup, flush)
     cells_total = plan.cells * world  # identical shapes on every rank
     regions_total = regions * world
-    per_rank_cells = None
+    per_rank_cells = [int(c) for c in D.gather(plan.cells)]  # (every rank takes part)
     if strong:
         cells_total, regions_total = strong["cells"], strong["regions"]
-        per_rank_cells = [int(c) for c in D.gather(plan.cells)]
 
     def optional(fn):
         try:
@@ -539,12 +638,15 @@ def main():
         import subprocess
         exe = os.path.join(ROOT, "tools", "threads_bench")
 
-        def point(mode, threads, per_call):
+        def point(mode, threads, per_call, shape=("128", "8", "150", "300"), seconds="1.0"):
             env = dict(os.environ, TB_MODE=mode, TB_THREADS=str(threads))
-            r = subprocess.run([exe, "1.0", "128", "8", "150", "300", str(per_call)], env=env, capture_output=True,
-                               text=True, timeout=60)
-            m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS", r.stdout)
-            return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2))}
+            if shape == "ragged":
+                env["TB_SHAPE"] = "ragged"
+                shape = ("128", "8", "150", "300")
+            r = subprocess.run([exe, seconds, *shape, str(per_call)], env=env, capture_output=True, text=True, timeout=120)
+            m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS\s+([\d.]+) us per call", r.stdout)
+            return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2)), "us_per_call": float(m.group(3))}
+        small = ("30", "3", "150", "300")  # (what most real regions look like: a few dozen reads, two or three haplotypes)
         return {"note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
                 "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
                 "one_region_per_call_32_threads_shared_handle_submit_wait": point("shared", 32, 1),
@@ -562,7 +664,14 @@ def main():
                 "region_call_one_region_per_call_8_threads_shared_handle": point("gshared", 8, 1),
                 "region_call_one_region_per_call_32_threads_shared_handle": point("gshared", 32, 1),
                 "region_call_eight_regions_per_call_4_threads_own_handles": point("fused", 4, 8),
-                "region_call_64_regions_per_call_1_thread": point("fused", 1, 64)}
+                "region_call_64_regions_per_call_1_thread": point("fused", 1, 64),
+                # ... on the regions a real `lorikeet call` mostly issues: 30 reads x 3 haplotypes, and the ragged mix
+                "region_call_small_30x3_1_thread": point("fused", 1, 1, small, "0.6"),
+                "region_call_small_30x3_8_threads_shared_handle": point("gshared", 8, 1, small, "0.6"),
+                "region_call_small_30x3_32_threads_shared_handle": point("gshared", 32, 1, small, "0.6"),
+                "region_call_ragged_1_thread": point("fused", 1, 1, "ragged", "0.8"),
+                "region_call_ragged_8_threads_shared_handle": point("gshared", 8, 1, "ragged", "0.8"),
+                "region_call_ragged_32_threads_shared_handle": point("gshared", 32, 1, "ragged", "0.8")}
 
     def ragged():
         """Real regions span 3 x 2 ... 5 000 x 128: the planner on a long-tailed mix, resident and through host buffers."""
@@ -585,6 +694,8 @@ def main():
                "gcups": round(r.plan.cells * 5 / el / 1e9, 1), "regions_per_s": round(rb.n_regions * 5 / el, 1),
                "ms_per_step": round(el / 5 * 1e3, 4), "launches_per_step": r.plan.num_launches,
                "dominant_kernel": r.plan.dominant_kernel,
+               "valu_f64": {"achieved": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9, 3), "peak": VALU_F64_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9 / VALU_F64_PEAK_TFLOPS, 4)},
                "host_buffers_incl_pcie": {"ms_per_call": round(t_host * 1e3, 3), "gcups": round(rb.cells() / t_host / 1e9, 1),
                                           "regions_per_s": round(rb.n_regions / t_host, 1)},
                "oracle_sample": oracle_sample_diff(rb, got, 64, int(1.5e9))}
@@ -708,6 +819,11 @@ def main():
         # the cell is 16 instructions: 9 that issue every 2.55 clocks per wave64 (add, and, cndmask) and 7 that issue
         # every 4.3-4.8 (max, max3, alignbit, compare) -- tools/ubench/rates.hip; the cell body alone, no memory, no
         # branches, runs at 56-61 clocks per wave-level cell (tools/ubench/sw_cell.hip): that is `peak`
+        if pe:
+            rate = pe["valu_insts_per_launch"] / max(kern_s, 1e-9) / NUM_SIMD / 1e9
+            row["valu_issue"] = {"achieved": round(rate, 4), "peak": VALU_ISSUE_PEAK_32, "unit": "G wave64-instr/s per SIMD",
+                                 "frac": round(rate / VALU_ISSUE_PEAK_32, 4), "valu_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
+                                 "mix_ceiling": SW_MIX_ISSUE_CEILING, "frac_of_mix_ceiling": round(rate / SW_MIX_ISSUE_CEILING, 4)}
         row["valu_int32"] = ({"valu_insts_per_cell": round(pe["valu_insts_per_launch"] * 64 / cells, 2),
                               "achieved": round(cells / max(kern_s, 1e-9) / 1e9, 1), "peak": SW_CELL_CEILING_GCUPS,
                               "unit": "GCUPS-i32", "frac": round(cells / max(kern_s, 1e-9) / 1e9 / SW_CELL_CEILING_GCUPS, 4),
@@ -992,7 +1108,8 @@ def main():
             scalar, simd = cpu_baselines(batch)
             line["cpu_baseline"] = scalar
             line["cpu_baseline_simd"] = simd
-        print(json.dumps(line), flush=True)
+        full_path = write_full_record(line)
+        print(json.dumps(compact_line(line, full_path), separators=(",", ":")), flush=True)
     res.close()
     D.close()
 

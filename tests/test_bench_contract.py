@@ -42,3 +42,39 @@ def test_committed_pmc_entries_have_the_keys_bench_reads():
     for e in entries:
         for k in ("workload", "regions", "precision", "kernel_short", "src_hash", "hbm_bytes_per_launch", "valu_insts_per_launch"):
             assert k in e, (e.get("workload"), k)
+
+
+def test_the_compact_line_holds_the_contract_and_every_row_in_four_kilobytes():
+    """what the driver stores of stdout must carry config 3 / 5, ragged, f32-first, the single region and
+    the region-call rates -- numbers only, the prose lives in profiles/BENCH_NOTES.md.  Built here from a committed full
+    record (round 3's), with the rows that are new this round filled in."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_final_bench.json")))
+    point = {"regions_per_s": 12345, "gcups_incl_pcie": 1234.5, "us_per_call": 123.4}
+    for k in ("region_call_small_30x3_1_thread", "region_call_small_30x3_8_threads_shared_handle", "region_call_small_30x3_32_threads_shared_handle",
+              "region_call_ragged_1_thread", "region_call_ragged_8_threads_shared_handle", "region_call_ragged_32_threads_shared_handle"):
+        full["host_calls"][k] = dict(point)
+    full["smith_waterman"]["valu_issue"] = {"achieved": 0.4812, "peak": 1.2, "frac": 0.401, "valu_per_cell": 15.5, "mix_ceiling": 0.7,
+                                            "frac_of_mix_ceiling": 0.6874}
+    full["config"]["per_rank_cells"] = [47185920000] * 8
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and "workload" in line["config"]
+    assert line["config"]["imbalance"] == 1.0 and len(line["config"]["per_rank_cells"]) == 8
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    rows = line["rows"]
+    assert rows["config3_10k"]["gcups"] > 0 and rows["config5_256"]["gcups"] > 0 and rows["ragged"]["host_gcups"] > 0
+    assert rows["f32_first"]["gcups"] > 0 and rows["single_region_us"] > 0
+    hc = rows["host_calls"]
+    assert hc["region_1t"] > 0 and hc["region_8t_shared"] > 0 and hc["small_1t"] == 12345 and hc["ragged_32t_shared"] == 12345
+    assert rows["smith_waterman"]["issue_peak"] == 1.2 and rows["smith_waterman"]["mix_ceiling"] == 0.7
+    # numbers only: no string in `rows` but kernel-free booleans / error texts
+    def strings(x):
+        if isinstance(x, dict):
+            return [s for v in x.values() for s in strings(v)]
+        return [x] if isinstance(x, str) else []
+    assert strings(rows) == []
+    assert os.path.exists(os.path.join(ROOT, line["notes"]))

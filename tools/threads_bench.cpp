@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -44,17 +46,36 @@ static uint32_t rnd() {  // splitmix64
     return (uint32_t)((z ^ (z >> 31)) >> 16);
 }
 
-// `per_call` regions of the same shape, as one call's arrays
-static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_call) {
+static double rnd_normal() {  // Box-Muller
+    const double u = (rnd() + 1.0) / 4294967296.0, v = rnd() / 4294967296.0;  // u in (0, 1]
+    return std::sqrt(-2.0 * std::log(u)) * std::cos(6.283185307179586 * v);
+}
+
+// `per_call` regions of the same shape, as one call's arrays.  TB_SHAPE=ragged (nr_in == 0): every region draws its own shape
+// from the long-tailed mix of the bench's ragged workload (lorikeet_amd/synthetic.py: reads per region log-normal around 60,
+// haplotypes log-normal around 5, haplotype length 60 ... 500, read lengths 30 ... 250 mixed inside a region; the tail is
+// cut at 2 000 reads so that a thread's cycle of regions stays a few megabytes).
+static Region make_region(uint64_t seed, int nr_in, int nh_in, int R_in, int H_in, int per_call) {
     rng_state = seed;
     Region g;
+    const bool ragged = nr_in == 0;
+    int nr = nr_in, nh = nh_in, R = R_in, H = H_in;
+    std::vector<uint32_t> read_len;
     const char acgt[] = "ACGT";
     g.ho.push_back(0);
     g.ro.push_back(0);
     g.rro.push_back(0);
     g.rho.push_back(0);
     g.oo.push_back(0);
+  size_t n_reads = 0, n_haps = 0;
   for (int reg = 0; reg < per_call; ++reg) {
+    if (ragged) {
+        nr = (int)std::fmin(2000.0, std::fmax(3.0, std::exp(std::log(60.0) + 1.3 * rnd_normal())));
+        nh = (int)std::fmin(128.0, std::fmax(1.0, std::exp(std::log(5.0) + 0.9 * rnd_normal())));
+        H = 60 + (int)(rnd() % 441);
+    }
+    n_reads += (size_t)nr;
+    n_haps += (size_t)nh;
     std::vector<uint8_t> root(H);
     for (auto &b : root) b = acgt[rnd() & 3];
     const size_t hap0 = g.haps.size();
@@ -65,7 +86,11 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_c
         g.haps.insert(g.haps.end(), h.begin(), h.end());
         g.ho.push_back((uint32_t)g.haps.size());
     }
+    uint64_t sum_r = 0;
     for (int r = 0; r < nr; ++r) {
+        if (ragged) R = 30 + (int)(rnd() % (uint32_t)(std::min(250, H) - 30 + 1));
+        sum_r += (uint64_t)R;
+        read_len.push_back((uint32_t)R);
         const int a = rnd() % nh, s = rnd() % (H - R + 1);
         for (int i = 0; i < R; ++i) {
             uint8_t b = g.haps[hap0 + (size_t)a * H + s + i];
@@ -82,18 +107,17 @@ static Region make_region(uint64_t seed, int nr, int nh, int R, int H, int per_c
     g.rro.push_back(g.rro.back() + nr);
     g.rho.push_back(g.rho.back() + nh);
     g.oo.push_back(g.oo.back() + (uint64_t)nr * nh);
+    g.cells += sum_r * (uint64_t)nh * H;
+    for (int a = 0; a < nh; ++a) g.hc.push_back((uint32_t)H << 4);
   }
-    g.out.assign((size_t)nr * nh * per_call, 0.0);
-    g.cells = (uint64_t)nr * R * (uint64_t)nh * H * per_call;
-    const size_t n_reads = (size_t)nr * per_call, n_haps = (size_t)nh * per_call;
+    g.out.assign((size_t)g.oo.back(), 0.0);
     g.pri.assign(n_haps, 0);
     g.ref_hap.assign(per_call, 0);
     for (int reg = 0; reg < per_call; ++reg) g.rstart.push_back(1000ull * (reg + 1));
     for (size_t a = 0; a <= n_haps; ++a) g.hc_off.push_back((uint32_t)a);
-    g.hc.assign(n_haps, (uint32_t)H << 4);
     g.hs.assign(n_haps, 0);
     for (size_t r = 0; r <= n_reads; ++r) g.oc_off.push_back((uint32_t)r), g.out_cig_off.push_back(8ull * r);
-    g.oc.assign(n_reads, (uint32_t)R << 4);
+    for (size_t r = 0; r < n_reads; ++r) g.oc.push_back(read_len[r] << 4);
     g.cig.assign(8 * n_reads, 0);
     g.n_cig.assign(n_reads, 0);
     g.pos.assign(n_reads, 0);
@@ -161,12 +185,17 @@ int main(int argc, char **argv) {
     const double dur = argc > 1 ? atof(argv[1]) : 1.0;
     const int nr = argc > 5 ? atoi(argv[2]) : 128, nh = argc > 5 ? atoi(argv[3]) : 8, R = argc > 5 ? atoi(argv[4]) : 150,
               H = argc > 5 ? atoi(argv[5]) : 300, per_call = argc > 6 ? atoi(argv[6]) : 1;
+    const bool ragged = getenv("TB_SHAPE") && std::string(getenv("TB_SHAPE")) == "ragged";
+    const int cycle = ragged ? 32 : 4;  // regions a thread cycles through
     if (phmm_device_count() < 1) {
         fprintf(stderr, "no HIP device\n");
         return 2;
     }
-    printf("%d region(s) per call: %d reads x %d haplotypes, R=%d, H=%d (%.3g cells each), %.1f s per point\n", per_call, nr, nh,
-           R, H, (double)nr * R * nh * H, dur);
+    if (ragged)
+        printf("%d region(s) per call: the ragged mix (reads ~ logN(60), haplotypes ~ logN(5), H 60-500, R 30-250), %.1f s per point\n", per_call, dur);
+    else
+        printf("%d region(s) per call: %d reads x %d haplotypes, R=%d, H=%d (%.3g cells each), %.1f s per point\n", per_call, nr, nh,
+               R, H, (double)nr * R * nh * H, dur);
     std::vector<int> Ts = {1, 2, 4, 8, 16, 32, 64};
     if (const char *e = getenv("TB_THREADS")) {  // e.g. TB_THREADS=4,8,16
         Ts.clear();
@@ -191,8 +220,8 @@ int main(int argc, char **argv) {
             // every thread cycles through regions of its own (different data, same shape)
             std::vector<std::vector<Region>> regs(T);
             for (int t = 0; t < T; ++t)
-                for (int k = 0; k < 4; ++k) regs[t].push_back(make_region(1000 + 16 * t + k, nr, nh, R, H, per_call));
-            std::atomic<uint64_t> n_calls{0};
+                for (int k = 0; k < cycle; ++k) regs[t].push_back(make_region(1000 + 64 * t + k, ragged ? 0 : nr, nh, R, H, per_call));
+            std::atomic<uint64_t> n_calls{0}, n_cells{0};
             std::atomic<int> failed{0};
             std::atomic<bool> go{false}, stop{false};
             std::vector<std::thread> th;
@@ -200,18 +229,21 @@ int main(int argc, char **argv) {
                 th.emplace_back([&, t] {
                     phmm_handle *h = hs[!one_handle ? t : 0];
                     auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : mode == 3 ? call_realign : mode == 4 ? call_fused : call_fused_shared;
-                    for (int k = 0; k < 4; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
+                    for (int k = 0; k < cycle; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
                         if ((mode == 3 && call_own(h, regs[t][k])) || call(h, regs[t][k])) failed = 1;
                     while (!go.load()) std::this_thread::yield();
-                    uint64_t n = 0;
+                    uint64_t n = 0, cells = 0;
                     for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
-                        if (call(h, regs[t][k & 3])) {
+                        Region &g = regs[t][k % (size_t)cycle];
+                        if (call(h, g)) {
                             failed = 1;
                             break;
                         }
                         ++n;
+                        cells += g.cells;
                     }
                     n_calls += n;
+                    n_cells += cells;
                 });
             std::this_thread::sleep_for(std::chrono::milliseconds(200));
             uint64_t f0 = 0, s0 = 0, f1 = 0, s1 = 0;
@@ -229,7 +261,7 @@ int main(int argc, char **argv) {
             }
             const double rate = n_calls * per_call / dt;
             printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : mode == 3 ? "realign" : mode == 4 ? "fused" : "gshared", T,
-                   rate, rate * regs[0][0].cells / per_call / 1e9, dt * T / (double)n_calls * 1e6);
+                   rate, (double)n_cells / dt / 1e9, dt * T / (double)n_calls * 1e6);
             if (one_handle) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
             printf("\n");
             fflush(stdout);
