@@ -24,6 +24,7 @@
 #include <unordered_map>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -58,6 +59,9 @@ constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 // 4 MB chunks vs 45.5 ms with 512 KB chunks throughout.  (PHMM_CHUNK_KB, PHMM_FIRST_CHUNK_KB, PHMM_ONESHOT_KB: tuning.)
 static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
 static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
+static const size_t kMixedFirstChunkBytes = getenv("PHMM_MIXED_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_FIRST_CHUNK_KB")) << 10 : (4u << 20);
+static const size_t kMixedChunkBytes = getenv("PHMM_MIXED_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_CHUNK_KB")) << 10 : (32u << 20);
+static const bool kNoStageThreads = getenv("PHMM_NO_STAGE_THREADS") != nullptr;  // (A/B only) large chunks staged by the calling thread alone
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
 static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (256u << 10);
 static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
@@ -247,6 +251,35 @@ double shape_efficiency(int L, int K, uint32_t nh, uint32_t mean_r, uint32_t max
 
 }  // namespace
 
+// The one place the PHMM_* developer switches are read (phmm_set_switch changes them per handle afterwards): phmm_create,
+// and phmm_plan_describe for its host-only handle, so that a described plan is the plan an engine of this process makes.
+static void read_env_switches(Switches &w) {
+    auto env = [](const char *name, int &dst) {
+        if (const char *e = getenv(name)) dst = atoi(e);
+    };
+    env("PHMM_FORCE_L", w.force_L);
+    env("PHMM_FORCE_QUAD_SPLIT", w.force_split);
+    env("PHMM_FORCE_CHAIN", w.force_chain);
+    env("PHMM_FORCE_STREAMS", w.force_streams);
+    env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
+    env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
+    env("PHMM_SUBMIT_LANES", w.submit_lanes);
+    env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
+    env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
+    env("PHMM_SW_LITE", w.sw_lite);
+    env("PHMM_SW_CHUNKS", w.sw_chunks);
+    env("PHMM_SW_LANES", w.sw_lanes);
+    env("PHMM_SW_TRANSPOSE", w.sw_transpose);
+    env("PHMM_REGION_SW_ALL", w.region_sw_all);
+    env("PHMM_REGION_PRIO", w.region_prio);
+    w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
+    w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
+    w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
+    w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
+    w.no_fork = getenv("PHMM_NO_FORK") != nullptr;
+    w.trace = getenv("PHMM_TRACE") != nullptr;
+}
+
 extern "C" {
 
 int phmm_device_count(void) {
@@ -275,33 +308,7 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
     phmm_handle *h = new phmm_handle();
     h->device = device_id;
     h->flags = flags;
-    {   // the one place the PHMM_* developer switches are read (phmm_set_switch changes them per handle afterwards)
-        Switches &w = h->sw;
-        auto env = [](const char *name, int &dst) {
-            if (const char *e = getenv(name)) dst = atoi(e);
-        };
-        env("PHMM_FORCE_L", w.force_L);
-        env("PHMM_FORCE_QUAD_SPLIT", w.force_split);
-        env("PHMM_FORCE_CHAIN", w.force_chain);
-        env("PHMM_FORCE_STREAMS", w.force_streams);
-        env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
-        env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
-        env("PHMM_SUBMIT_LANES", w.submit_lanes);
-        env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
-        env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
-        env("PHMM_SW_LITE", w.sw_lite);
-        env("PHMM_SW_CHUNKS", w.sw_chunks);
-        env("PHMM_SW_LANES", w.sw_lanes);
-        env("PHMM_SW_TRANSPOSE", w.sw_transpose);
-        env("PHMM_REGION_SW_ALL", w.region_sw_all);
-        env("PHMM_REGION_PRIO", w.region_prio);
-        w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
-        w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
-        w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
-        w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
-        w.no_fork = getenv("PHMM_NO_FORK") != nullptr;
-        w.trace = getenv("PHMM_TRACE") != nullptr;
-    }
+    read_env_switches(h->sw);
     const auto &eps = table_eps();
     const auto &eps3 = table_eps_third();
     const auto &mm = table_match_to_match();
@@ -495,6 +502,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     b->home_stream = h->S();
 
     bool ok = true;
+    auto mark_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double marks[8] = {mark_now()};
+    int n_marks = 1;
+    auto mark = [&]() { if (n_marks < 8) marks[n_marks++] = mark_now(); };
 
     // ---- per-region shape, totals -----------------------------------------------------------
     struct RegionShape {
@@ -528,6 +539,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         shape[g] = s;
     }
 
+    mark();  // 1: shapes
     // ---- choose <L,K> per region ------------------------------------------------------------
     // Candidates L in {16,32,64}; K = ceil(max_h / L) rounded up to an instantiated value.
     // Pick the most efficient one, then trade lanes-per-pair for more waves while the batch is
@@ -635,6 +647,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         fprintf(stderr, "phmm plan: %u regions, min_L %d, units %llu, chain_reads %u, region0 <%d,%d> chainable %d\n", n_regions,
                 min_L, (unsigned long long)units, chain_reads, n_regions ? reg_L[0] : 0, n_regions ? reg_K[0] : 0,
                 n_regions ? (int)chainable(0) : 0);
+    mark();  // 2: <L,K> choice
     std::map<std::tuple<int, int, int>, ShapeClass> by_shape;  // (L, K, 0 = per-read kernel | streams of the chained kernel)
     for (uint32_t g = 0; g < n_regions; ++g) {
         if (reg_L[g] < 0) continue;
@@ -713,6 +726,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         }
         if (!c.L) class_meta += align_up((c.pair_first.size() + 1) * 8, 256);
     }
+    mark();  // 3: classes, run lengths
     // ---- device memory provider (after planning: the arena is sized from the plan) -----------------
     // arena mode: bump-allocate from the handle's arena, "uploads" go to the pinned mirror and travel in
     // one copy later; otherwise hipMalloc per piece and async copies on the handle's stream.
@@ -792,6 +806,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         }
     }
 
+    mark();  // 4: arena, metadata
     // ---- finalise classes -------------------------------------------------------------------
     uint64_t best_cells = 0;
     for (auto &kv : by_shape) {
@@ -834,11 +849,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                             c.chain_items.push_back(ChainItem{g, (uint16_t)(q0 + q), (uint8_t)c.K, (uint8_t)rest_streams, r, std::min(r1, r + run2)});
                 }
             }
-            // longest runs first: with mixed read lengths the runs differ in rows, and the last wave slots should
-            // be filled by the short ones (stable, so equal-length batches keep their order)
-            std::stable_sort(c.chain_items.begin(), c.chain_items.end(), [&](const ChainItem &x, const ChainItem &y) {
-                return read_off[x.read_end] - read_off[x.read_begin] > read_off[y.read_end] - read_off[y.read_begin];
-            });
+            // (the launch is ordered longest item first below, across all classes: one sort there instead of one per class and
+            // another over the whole -- the planner of a 186-region chunk of the ragged mix spent 1.3 of its 2.6 ms here)
             c.f32_first = (h->flags & PHMM_FLAG_F32_FIRST) && (c.L == 16 || c.L == 32);
             {   // the chained classes of one lanes-per-pair value (and one precision) share a launch
                 phmm_batch::ChainGroup *grp = nullptr;
@@ -921,6 +933,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     c.reads.size(), c.chain_items.size(), (double)c.cells, c.max_h);
         b->classes.push_back(std::move(c));
     }
+    mark();  // 5: work items per class
     for (auto &grp : b->chain_groups) {
         // longest item first across all classes of the launch: (rows of the run + its SUM / RESET rows) x the cost of a
         // step at the item's K (7 VALU per column + ~11 per step)
@@ -928,7 +941,29 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             return (uint64_t)(read_off[x.read_end] - read_off[x.read_begin] + 2 * (x.read_end - x.read_begin) + grp.L) *
                    (uint64_t)(7 * x.k + 11);
         };
-        std::stable_sort(grp.items.begin(), grp.items.end(), [&](const ChainItem &x, const ChainItem &y) { return cost(x) > cost(y); });
+        {   // (keys made once -- the comparator used to fetch four offsets per comparison -- and unique, so a plain sort keeps
+            // items of equal cost in the order they were made: the groups of a run stay next to each other)
+            const size_t n = grp.items.size();
+            std::vector<uint64_t> cst(n);
+            uint64_t top = 0;
+            for (size_t i = 0; i < n; ++i) top = std::max(top, cst[i] = cost(grp.items[i]));
+            std::vector<uint32_t> idx(n), tmp(n);
+            for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+            if (top < (1ull << 33)) {  // LSD radix sort, descending, 11 bits a pass (stable): tens of microseconds for 10^4 items
+                for (int shift = 0; (top >> shift) != 0; shift += 11) {
+                    uint32_t count[2049] = {0};
+                    for (size_t i = 0; i < n; ++i) count[2047 - ((cst[idx[i]] >> shift) & 2047) + 1] += 1;
+                    for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+                    for (size_t i = 0; i < n; ++i) tmp[count[2047 - ((cst[idx[i]] >> shift) & 2047)]++] = idx[i];
+                    idx.swap(tmp);
+                }
+            } else {
+                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cst[x] > cst[y]; });
+            }
+            std::vector<ChainItem> sorted(n);
+            for (size_t i = 0; i < n; ++i) sorted[i] = grp.items[idx[i]];
+            grp.items.swap(sorted);
+        }
         // XCD-aware placement.  The haplotype groups of one run (same region, same reads: equal cost, so the stable sort
         // left them next to each other) sweep the same read bytes.  Workgroups are dealt to the eight XCDs round robin,
         // each XCD with an L2 of its own, so neighbours in the launch never share one: take eight runs at a time and
@@ -1028,6 +1063,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         }
         break;
     }
+    mark();  // 6: sorting, placement, ranges
+    if (sw.trace)
+        fprintf(stderr, "  plan phases (us): shapes %.0f, <L,K> %.0f, classes %.0f, metadata %.0f, items %.0f, order %.0f\n", marks[1] - marks[0],
+                marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3], marks[5] - marks[4], marks[6] - marks[5]);
     for (auto &grp : b->chain_groups) {
         void *mirror;
         grp.d_items = (ChainItem *)dalloc(grp.items.size() * sizeof(ChainItem), &mirror);
@@ -1167,7 +1206,7 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // (not while the chunks of a pipelined host call are in flight: those already overlap each other on the slot streams,
     // and forks of several chunks would queue behind one another on the side streams -- 1 536 mixed regions through host
     // buffers: 25 ms without, 32 ms with)
-    const bool fork = n_groups >= 2 && !h->sw.no_fork && !h->defer_d2h;
+    const bool fork = n_groups >= 2 && !h->sw.no_fork && !h->defer_d2h;  // (round 4, three large chunks: forking them changes nothing either)
     if (fork) {
         for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
             if (!h->side_streams[i] && !hip_ok(h, hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking), "hipStreamCreate")) return PHMM_ERR_HIP;
@@ -1297,6 +1336,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         // payload into the arena mirror, then [status | out] last so that one copy each way suffices
         const uint8_t *src[6] = {read_bases, base_q, ins_q, del_q, gcp, hap_bases};
         const uint8_t *d[6];
+        size_t offs[6] = {0};
         for (int i = 0; i < 6; ++i) {
             const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
             const size_t off = align_up(A.used, 256);
@@ -1306,20 +1346,46 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
                 st = PHMM_ERR_HIP;
                 break;
             }
-            // everything rides in the single copy of the pinned mirror (the chunked path keeps every array of a
-            // chunk at or below kChunkBytes so that staging chunk i+1 overlaps the kernels of chunk i)
+            offs[i] = off;
+            h->stat_staged_bytes += bytes;
+            d[i] = (const uint8_t *)(A.dev + off);
+        }
+        // everything rides in the single copy of the pinned mirror (the chunked path keeps every array of a
+        // chunk at or below kChunkBytes so that staging chunk i+1 overlaps the kernels of chunk i)
+        auto stage_array = [&](int i) {
+            const size_t bytes = i < 5 ? b->read_bytes : b->hap_bytes;
             if (parts) {
-                size_t o = off;
+                size_t o = offs[i];
                 for (size_t s = 0; s < parts->src[i].size(); ++s) {
                     const size_t n = i < 5 ? parts->read_bytes[s] : parts->hap_bytes[s];
                     if (n) memcpy(A.host + o, parts->src[i][s], n);
                     o += n;
                 }
             } else if (bytes) {
-                memcpy(A.host + off, src[i], bytes);
+                memcpy(A.host + offs[i], src[i], bytes);
             }
-            h->stat_staged_bytes += bytes;
-            d[i] = (const uint8_t *)(A.dev + off);
+        };
+        if (st == PHMM_OK) {
+            // A chunk of a large call is five arrays of megabytes: the quality tracks go through helper threads while this one
+            // copies the bases and the haplotypes (1 536 mixed regions: 0.7-1.1 ms of staging per chunk on the calling thread,
+            // a quarter of the call).  Small calls stay on the calling thread -- a thread costs more than their copies.
+            if (b->read_bytes >= (1u << 20) && !kNoStageThreads) {
+                std::thread helpers[4];
+                int started = 0;
+                try {
+                    for (int i = 1; i <= 4; ++i) {
+                        helpers[started] = std::thread(stage_array, i);
+                        ++started;
+                    }
+                } catch (const std::system_error &) {  // no thread to be had: the rest on this one
+                }
+                stage_array(0);
+                stage_array(5);
+                for (int i = started + 1; i <= 4; ++i) stage_array(i);
+                for (int i = 0; i < started; ++i) helpers[i].join();
+            } else {
+                for (int i = 0; i < 6; ++i) stage_array(i);
+            }
         }
         const size_t in_bytes = align_up(A.used, 256);
         b->out_arena_off = in_bytes;
@@ -1399,8 +1465,12 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     // f64: 0.5 MB per array four times, then 1, 1, 2, 2, 4, 4 ... (mid-size batches want many small chunks, large ones
     // large launches).  f32-first handles: 1, 2, 4, 4 ... -- the f32 sweep only exists as the chained kernel, which needs
     // a few hundred regions per launch.
-    const uint32_t step = c.f32_first ? c.index + 1 : (c.index < 4 ? 0 : (c.index - 2) / 2);
-    const size_t limit = std::min(kChunkBytes, (c.f32_first ? (1u << 20) / 2 : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
+    // Mixed batches (round 4): 4 MB per array, then 8, 16, 32 ... -- every chunk of a long-tailed mix is a launch per range of K
+    // with a tail of its own, and since planning and staging take 0.85 instead of 2 ms per 4 MB the device no longer waits for
+    // the host: 1 536 mixed regions 24.0 ms in seven chunks of 4 MB, 20.4 in three of 4 / 8 / 16 (resident: 15.8).
+    const uint32_t step = c.f32_first ? c.index + 1 : c.mixed ? c.index : (c.index < 4 ? 0 : (c.index - 2) / 2);
+    const size_t max_bytes = c.mixed && !c.f32_first ? kMixedChunkBytes : kChunkBytes;
+    const size_t limit = std::min(max_bytes, (c.f32_first ? (1u << 20) / 2 : c.mixed ? kMixedFirstChunkBytes : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
     if (whole) {
         g1 = n_regions;
     } else if (!c.mixed) {
@@ -1416,7 +1486,7 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
         uint64_t u = units(g0);
         while (g1 < n_regions) {
             const size_t bytes = (size_t)read_off[region_read_off[g1 + 1]] - base_r;
-            if (bytes > kChunkBytes || (bytes > limit && u >= 8ull * 2 * kNumSimd * 4)) break;
+            if (bytes > max_bytes || (bytes > limit && u >= 8ull * 2 * kNumSimd * 4)) break;
             u += units(g1);
             ++g1;
         }
@@ -2126,11 +2196,14 @@ int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_r
         if (region_read_off && region_hap_off)
             for (uint32_t g = 0; g < n_regions; ++g)
                 oo[g + 1] = oo[g] + (uint64_t)(region_read_off[g + 1] - region_read_off[g]) * (region_hap_off[g + 1] - region_hap_off[g]);
-        phmm_handle h;  // host-only: carries the flags and the planner's switches, never a device
+        phmm_handle h;  // host-only: carries the flags and the planner's switches (this process's PHMM_* environment), never a device
+        read_env_switches(h.sw);
         h.flags = flags;
         h.gpu_sharers = concurrent_callers ? concurrent_callers : 1u;
-        phmm_batch *b = batch_create_impl(&h, n_regions, region_read_off, region_hap_off, read_off, hap_off, oo.data(), false, 0, true);
-        if (!b) return PHMM_ERR_INVALID_ARG;
+        // (a dry batch owns nothing on a device: plain delete, also when something below throws)
+        std::unique_ptr<phmm_batch> owner(batch_create_impl(&h, n_regions, region_read_off, region_hap_off, read_off, hap_off, oo.data(), false, 0, true));
+        phmm_batch *b = owner.get();
+        if (!b) return h.err_code == PHMM_ERR_NO_MEMORY ? PHMM_ERR_NO_MEMORY : PHMM_ERR_INVALID_ARG;
         info->cells = b->cells;
         info->n_launches = phmm_batch_num_launches(b);
         for (const auto &g : b->chain_groups) {
@@ -2143,10 +2216,11 @@ int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_r
         for (const auto &c : b->classes)
             if (c.chain) info->chain_cells += c.cells;
         snprintf(info->dominant_kernel, sizeof info->dominant_kernel, "%s", b->dominant.c_str());
-        delete b;
         return PHMM_OK;
-    } catch (...) {
+    } catch (const std::bad_alloc &) {
         return PHMM_ERR_NO_MEMORY;
+    } catch (...) {
+        return PHMM_ERR_INTERNAL;
     }
 }
 
