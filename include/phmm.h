@@ -471,6 +471,22 @@ int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm
                        const uint64_t *out_cigar_off, double *out, uint8_t *keep, int32_t *best_allele, double *likelihood,
                        double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status,
                        uint64_t *ticket);
+/* ... and over several engines, normally one per device, like phmm_compute_multi: whole regions in contiguous ranges
+ * balanced by cells (phmm_split_regions), every engine on a host thread of its own next to its GPU, each range staged
+ * straight from the caller's arrays, results where phmm_region_compute would put them; the arguments are checked once
+ * for the whole call; on failure the message is phmm_last_error(handles[0]).  (The reference reaches several devices
+ * through its rayon workers instead -- one shared handle per device, phmm_region_submit, integration/hip_backend.rs --
+ * which tools/threads_bench TB_DEVICES=n imitates; this entry point is for callers that hold many regions at once.) */
+int phmm_region_compute_multi(phmm_handle *const *handles, uint32_t n_handles, const phmm_engine_config *cfg,
+                              const phmm_realign_config *rcfg, uint32_t n_regions, const uint32_t *region_read_off,
+                              const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases,
+                              const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq,
+                              const uint32_t *read_soft_clip, const uint32_t *hap_off, const uint8_t *hap_bases,
+                              const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                              const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                              const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar,
+                              const uint64_t *out_cigar_off, double *out, uint8_t *keep, int32_t *best_allele, double *likelihood,
+                              double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status);
 
 /*
  * CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) for n (reference, haplotype) pairs: the haplotype's CIGAR

@@ -476,6 +476,44 @@ extern "C" {
         ticket: *mut u64,
     ) -> c_int;
 
+    pub fn phmm_region_compute_multi(
+        handles: *const *mut phmm_handle,
+        n_handles: u32,
+        cfg: *const phmm_engine_config,
+        rcfg: *const phmm_realign_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        read_soft_clip: *const u32,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        hap_priority: *const i32,
+        region_reference_start: *const u64,
+        hap_cigar_off: *const u32,
+        hap_cigar: *const u32,
+        hap_start_wrt_ref: *const u32,
+        orig_cigar_off: *const u32,
+        orig_cigar: *const u32,
+        out_cigar_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+        best_allele: *mut i32,
+        likelihood: *mut f64,
+        confidence: *mut f64,
+        out_cigar: *mut u32,
+        n_out_cigar: *mut u32,
+        new_pos: *mut i64,
+        status: *mut i32,
+    ) -> c_int;
+
     pub fn phmm_calculate_cigar(
         h: *mut phmm_handle,
         n: u32,

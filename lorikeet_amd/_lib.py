@@ -112,6 +112,7 @@ SYMBOLS = [
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), f64p, f64p]),
     ("phmm_region_compute", C.c_int, _REGION_ARGS),
     ("phmm_region_submit", C.c_int, _REGION_ARGS + [C.POINTER(C.c_uint64)]),
+    ("phmm_region_compute_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_uint32] + _REGION_ARGS[1:]),
     ("phmm_calculate_cigar", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p, C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),

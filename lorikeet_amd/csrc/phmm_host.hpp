@@ -227,6 +227,15 @@ std::string region_validate(const RegionArgs &a);
 // the call itself on validated arguments (phmm_region.cpp); one thread per handle
 int region_compute(phmm_handle *h, const RegionArgs &a);
 int region_compute_parts(phmm_handle *h, const RegionArgs &combined, const std::vector<RegionArgs> &parts);
+int region_compute_range(phmm_handle *h, const RegionArgs &a, uint32_t g0, uint32_t g1);  // regions [g0, g1) of validated arguments
+RegionArgs region_pack_args(const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions, const uint32_t *region_read_off,
+                            const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                            const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq, const uint32_t *read_soft_clip, const uint32_t *hap_off,
+                            const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                            const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                            const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar, const uint64_t *out_cigar_off,
+                            double *out, uint8_t *keep, int32_t *best_allele, double *likelihood, double *confidence, uint32_t *out_cigar,
+                            uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status);
 
 // What every entry point checks before it touches the arrays; returns the message of the first violation or nullptr.
 const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,

@@ -228,4 +228,88 @@ int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t
     }
 }
 
+// The whole per-region path (phmm_region_compute) over several engines: contiguous cell-balanced ranges of regions, one
+// host thread per engine pinned next to its GPU, every range staged straight from the caller's arrays and its results
+// written where phmm_region_compute on one engine would write them.
+int phmm_region_compute_multi(phmm_handle *const *handles, uint32_t n_handles, const phmm_engine_config *cfg, const phmm_realign_config *rcfg,
+                              uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                              const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq,
+                              const uint32_t *read_soft_clip, const uint32_t *hap_off, const uint8_t *hap_bases, const int32_t *region_ref_hap,
+                              const uint64_t *out_off, const int32_t *hap_priority, const uint64_t *region_reference_start,
+                              const uint32_t *hap_cigar_off, const uint32_t *hap_cigar, const uint32_t *hap_start_wrt_ref,
+                              const uint32_t *orig_cigar_off, const uint32_t *orig_cigar, const uint64_t *out_cigar_off, double *out, uint8_t *keep,
+                              int32_t *best_allele, double *likelihood, double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar,
+                              int64_t *new_pos, int32_t *status) {
+    if (!handles || !n_handles || !handles[0] || !cfg || !rcfg) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h0 = handles[0];
+    for (uint32_t k = 0; k < n_handles; ++k)
+        if (!handles[k]) {
+            h0->err = "phmm_region_compute_multi: null handle";
+            return PHMM_ERR_INVALID_ARG;
+        }
+    clear_thread_error(h0);
+    try {
+        const RegionArgs a = region_pack_args(cfg, rcfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq,
+                                              read_soft_clip, hap_off, hap_bases, region_ref_hap, out_off, hap_priority, region_reference_start,
+                                              hap_cigar_off, hap_cigar, hap_start_wrt_ref, orig_cigar_off, orig_cigar, out_cigar_off, out, keep,
+                                              best_allele, likelihood, confidence, out_cigar, n_out_cigar, new_pos, status);
+        const std::string bad = region_validate(a);  // the whole call, before any engine indexes anything
+        if (!bad.empty()) {
+            h0->err = bad;
+            return h0->err_code = PHMM_ERR_INVALID_ARG;
+        }
+        if (n_handles == 1) {
+            h0->err_code = PHMM_OK;
+            return region_compute(h0, a);
+        }
+        std::vector<uint32_t> first(n_handles + 1);
+        split_contiguous(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_handles, first.data());
+        std::vector<int> st(n_handles, PHMM_OK);
+        std::vector<std::string> errs(n_handles);
+        std::vector<std::thread> workers;
+        workers.reserve(n_handles);
+        struct JoinAll {
+            std::vector<std::thread> &w;
+            ~JoinAll() {
+                for (auto &t : w)
+                    if (t.joinable()) t.join();
+            }
+        } join_all{workers};
+        for (uint32_t k = 0; k < n_handles; ++k) {
+            if (first[k] == first[k + 1]) continue;
+            workers.emplace_back([&, k] {
+                phmm_handle *h = handles[k];
+                try {
+                    pin_near_device(h->device);
+                    h->err_code = PHMM_OK;
+                    st[k] = region_compute_range(h, a, first[k], first[k + 1]);
+                    if (st[k] != PHMM_OK) errs[k] = h->err;
+                } catch (const std::bad_alloc &) {
+                    st[k] = PHMM_ERR_NO_MEMORY;
+                    errs[k] = "phmm_region_compute_multi: out of host memory";
+                } catch (const std::exception &e) {
+                    st[k] = PHMM_ERR_INTERNAL;
+                    errs[k] = std::string("phmm_region_compute_multi: ") + e.what();
+                }
+            });
+        }
+        for (auto &w : workers)
+            if (w.joinable()) w.join();
+        // the first failure in region order; a CIGAR slot that is too small on one engine does not hide a real failure on another
+        int worst = PHMM_OK;
+        for (uint32_t k = 0; k < n_handles; ++k)
+            if (st[k] != PHMM_OK && (worst == PHMM_OK || worst == PHMM_ERR_CIGAR_CAPACITY)) {
+                worst = st[k];
+                h0->err = errs[k];
+            }
+        return h0->err_code = worst;
+    } catch (const std::bad_alloc &) {
+        h0->err = "phmm_region_compute_multi: out of host memory";
+        return PHMM_ERR_NO_MEMORY;
+    } catch (const std::exception &e) {
+        h0->err = std::string("phmm_region_compute_multi: ") + e.what();
+        return PHMM_ERR_INTERNAL;
+    }
+}
+
 }  // extern "C"

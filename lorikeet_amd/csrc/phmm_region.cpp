@@ -845,6 +845,19 @@ int region_compute(phmm_handle *h, const RegionArgs &a) {
     return st;
 }
 
+// regions [g0, g1) of validated arguments on one handle (phmm_region_compute_multi: one range per engine): offsets rebased,
+// every pointer moved on, nothing gathered
+int region_compute_range(phmm_handle *h, const RegionArgs &a, uint32_t g0, uint32_t g1) {
+    if (g0 >= g1) return PHMM_OK;
+    if (g0 == 0 && g1 == a.n_regions) return region_compute(h, a);
+    ChunkView c;
+    c.g1 = g0;
+    (void)next_chunk(c, g1, a.region_read_off, a.region_hap_off, a.read_off, a.hap_off, a.out_off, true);
+    ChunkArgs part;
+    part.build(a, c);
+    return region_compute(h, part.a);
+}
+
 }  // namespace phmm_host
 
 namespace {
@@ -895,6 +908,21 @@ RegionArgs pack_args(const phmm_engine_config *cfg, const phmm_realign_config *r
 }
 
 }  // namespace
+
+namespace phmm_host {
+RegionArgs region_pack_args(const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions, const uint32_t *region_read_off,
+                            const uint32_t *region_hap_off, const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q,
+                            const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *mapq, const uint32_t *read_soft_clip, const uint32_t *hap_off,
+                            const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off, const int32_t *hap_priority,
+                            const uint64_t *region_reference_start, const uint32_t *hap_cigar_off, const uint32_t *hap_cigar,
+                            const uint32_t *hap_start_wrt_ref, const uint32_t *orig_cigar_off, const uint32_t *orig_cigar, const uint64_t *out_cigar_off,
+                            double *out, uint8_t *keep, int32_t *best_allele, double *likelihood, double *confidence, uint32_t *out_cigar,
+                            uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status) {
+    return pack_args(cfg, rcfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq, read_soft_clip, hap_off,
+                     hap_bases, region_ref_hap, out_off, hap_priority, region_reference_start, hap_cigar_off, hap_cigar, hap_start_wrt_ref,
+                     orig_cigar_off, orig_cigar, out_cigar_off, out, keep, best_allele, likelihood, confidence, out_cigar, n_out_cigar, new_pos, status);
+}
+}  // namespace phmm_host
 
 extern "C" int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg, const phmm_realign_config *rcfg, uint32_t n_regions,
                                    const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,

@@ -46,10 +46,11 @@ def realign_config(parameters=ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, overhan
 
 
 def region_compute(engine, cfg, batch, mapq, hap_cigars, hap_start_wrt_ref, region_ref_hap, region_reference_start, original_cigars,
-                   hap_priority=None, read_soft_clip=None, use_indel_quals=True, rcfg=None, capacity=16, shared=False):
+                   hap_priority=None, read_soft_clip=None, use_indel_quals=True, rcfg=None, capacity=16, shared=False, engines=None):
     """cfg: _lib.EngineConfig; batch: RegionBatch whose base_q / ins_q / del_q are the ORIGINAL qualities (as
     phmm_engine_compute takes them; use_indel_quals=False passes NULL = flat Q45).  shared=True goes through
-    phmm_region_submit / phmm_wait on a shared handle."""
+    phmm_region_submit / phmm_wait on a shared handle; engines=[...] spreads the call over several engines (one per
+    device: phmm_region_compute_multi), `engine` being the first of them."""
     n, nh = batch.n_reads, batch.n_haps
     assert len(hap_cigars) == nh and len(original_cigars) == n
     rcfg = rcfg if rcfg is not None else realign_config()
@@ -74,7 +75,10 @@ def region_compute(engine, cfg, batch, mapq, hap_cigars, hap_start_wrt_ref, regi
                 _p(pri, _i32p), _p(rs, _lib.u64p), _p(hc_off, _lib.u32p), _p(hc, _lib.u32p), _p(hs, _lib.u32p), _p(oc_off, _lib.u32p),
                 _p(oc, _lib.u32p), _p(out_off, _lib.u64p), _p(out, _lib.f64p), _p(keep, _lib.u8p), _p(best, _i32p), _p(lk, _lib.f64p),
                 _p(conf, _lib.f64p), _p(oc_out, _lib.u32p), _p(n_out, _lib.u32p), _p(pos, _i64p), _p(status, _i32p))
-        if shared:
+        if engines is not None:
+            hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+            code = engine.lib.phmm_region_compute_multi(hs, len(engines), *args[1:])
+        elif shared:
             ticket = C.c_uint64(0)
             code = engine.lib.phmm_region_submit(*args, C.byref(ticket))
             if code == _lib.PHMM_OK:

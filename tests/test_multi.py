@@ -41,8 +41,48 @@ def test_one_engine_per_device():
         assert all(x > 0 for x in staged) and sum(staged) == 5 * int(b.read_off[-1]) + int(b.hap_off[-1]), staged
         assert np.max(np.abs(got - engines[0].compute(b))) <= 1e-12      # every device computes what device 0 computes
         assert np.max(np.abs(got - engines[-1].compute(b))) <= 1e-12
+    # ... and the whole per-region path (phmm_region_compute_multi): every device's share equal to what device 0 makes of it
+    _region_call_over(engines, n_regions=4 * len(engines))
     for e in engines:
         e.close()
+
+
+def _region_call_over(engines, n_regions, seed=5):
+    """phmm_region_compute_multi over `engines` == phmm_region_compute on the first of them, field by field."""
+    from lorikeet_amd import region
+    from project_scenarios import scenario
+    from test_region_hip import _cfg, _equal_calls, _noisy_quals, _priorities
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = scenario(seed, n_regions=n_regions)
+    mapq = _noisy_quals(b, seed)
+    pri = _priorities(b, hap_cigars, ref_hap)
+    cfg = _cfg()
+    call = lambda **kw: region.region_compute(engines[0], cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars,  # noqa: E731
+                                              hap_priority=pri, **kw)
+    want = call()
+    got = call(engines=engines)
+    _equal_calls(got, want)
+    assert (want.reads.status == 0).sum() >= 1
+    return b
+
+
+def test_region_call_over_several_engines():
+    """the per-region call has its multi-engine entry point too.  (Engines on distinct devices where the
+    node has them; on a one-GPU box this exercises the splitting, the rebased ranges and the threads.)"""
+    engines = _engines(3)
+    b = _region_call_over(engines, n_regions=11)
+    _region_call_over(engines[:1], n_regions=3, seed=6)       # one engine: plain phmm_region_compute
+    _region_call_over(engines, n_regions=2, seed=7)           # fewer regions than engines
+    # argument errors are caught once, for the whole call
+    from lorikeet_amd import region
+    from project_scenarios import scenario
+    from test_region_hip import _cfg
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = scenario(8, n_regions=4)
+    with pytest.raises(PhmmError) as e:
+        region.region_compute(engines[0], _cfg(pcr=9), b, np.full(b.n_reads, 60, np.uint8), hap_cigars, hap_starts, ref_hap, ref_start,
+                              orig_cigars, engines=engines)
+    assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "PCR" in str(e.value)
+    for x in engines:
+        x.close()
 
 
 def test_several_engines_one_call():

@@ -9,7 +9,9 @@
 //                                     projection in ONE call -- the likelihoods never leave the device in between
 //   gshared  (TB_MODE=gshared only)   one shared handle; phmm_region_submit + phmm_wait (the fused call, batched across threads)
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
-// env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>
+// env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>,
+//      TB_SHAPE=ragged (every call a region of the long-tailed mix), TB_DEVICES=n (the binding's pattern on a multi-GPU node,
+//      integration/hip_backend.rs: thread t works on device t % n -- its own handle there, or that device's ONE shared handle)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -210,8 +212,9 @@ int main(int argc, char **argv) {
         const bool one_handle = mode == 1 || mode == 5;
         for (int T : Ts) {
             std::vector<phmm_handle *> hs;
-            for (int i = 0; i < (!one_handle ? T : 1); ++i) {
-                hs.push_back(phmm_create(0, getenv("TB_FLAGS") ? (unsigned)atoi(getenv("TB_FLAGS")) : 0u));
+            const int n_dev = std::max(1, std::min(getenv("TB_DEVICES") ? atoi(getenv("TB_DEVICES")) : 1, phmm_device_count()));
+            for (int i = 0; i < (!one_handle ? T : n_dev); ++i) {
+                hs.push_back(phmm_create(i % n_dev, getenv("TB_FLAGS") ? (unsigned)atoi(getenv("TB_FLAGS")) : 0u));
                 if (!hs.back()) {
                     fprintf(stderr, "phmm_create: %s\n", phmm_last_error(nullptr));
                     return 2;
@@ -227,7 +230,7 @@ int main(int argc, char **argv) {
             std::vector<std::thread> th;
             for (int t = 0; t < T; ++t)
                 th.emplace_back([&, t] {
-                    phmm_handle *h = hs[!one_handle ? t : 0];
+                    phmm_handle *h = hs[!one_handle ? t : t % n_dev];
                     auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : mode == 3 ? call_realign : mode == 4 ? call_fused : call_fused_shared;
                     for (int k = 0; k < cycle; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
                         if ((mode == 3 && call_own(h, regs[t][k])) || call(h, regs[t][k])) failed = 1;
@@ -247,14 +250,22 @@ int main(int argc, char **argv) {
                 });
             std::this_thread::sleep_for(std::chrono::milliseconds(200));
             uint64_t f0 = 0, s0 = 0, f1 = 0, s1 = 0;
-            if (one_handle) phmm_submit_stats(hs[0], &f0, &s0);
+            auto submit_stats = [&](uint64_t *f, uint64_t *n) {
+                for (auto *h : hs) {
+                    uint64_t a = 0, b = 0;
+                    phmm_submit_stats(h, &a, &b);
+                    *f += a;
+                    *n += b;
+                }
+            };
+            if (one_handle) submit_stats(&f0, &s0);
             const auto t0 = std::chrono::steady_clock::now();
             go = true;
             std::this_thread::sleep_for(std::chrono::duration<double>(dur));
             stop = true;
             for (auto &x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (one_handle) phmm_submit_stats(hs[0], &f1, &s1);
+            if (one_handle) submit_stats(&f1, &s1);
             if (failed) {
                 fprintf(stderr, "a call failed: %s\n", phmm_last_error(hs[0]));
                 return 1;
@@ -263,6 +274,7 @@ int main(int argc, char **argv) {
             printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : mode == 3 ? "realign" : mode == 4 ? "fused" : "gshared", T,
                    rate, (double)n_cells / dt / 1e9, dt * T / (double)n_calls * 1e6);
             if (one_handle) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
+            if (n_dev > 1) printf("   %d devices", n_dev);
             printf("\n");
             fflush(stdout);
             for (auto *h : hs) phmm_destroy(h);
