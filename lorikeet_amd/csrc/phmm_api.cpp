@@ -381,9 +381,11 @@ void phmm_destroy(phmm_handle *h) {
             if (e) (void)hipEventDestroy(e);
     if (h->swork.region_sw_done) (void)hipEventDestroy(h->swork.region_sw_done);
     if (h->swork.ev_second) (void)hipEventDestroy(h->swork.ev_second);
-    if (h->swork.ev_all) (void)hipEventDestroy(h->swork.ev_all);
-    if (h->swork.all_stream) (void)hipStreamDestroy(h->swork.all_stream);
-    if (h->swork.pair_main) (void)hipStreamDestroy(h->swork.pair_main);
+    if (h->swork.d_pair_done) (void)hipFree(h->swork.d_pair_done);
+    for (int i = 0; i < 2; ++i) {
+        if (h->swork.all_stream[i]) (void)hipStreamDestroy(h->swork.all_stream[i]);
+        if (h->swork.pair_main[i]) (void)hipStreamDestroy(h->swork.pair_main[i]);
+    }
     for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
         if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);

@@ -44,6 +44,10 @@ struct ProjectParams {
     uint32_t *flags;                   // bit 0: some cigar did not fit its slot
     uint32_t *workspace;               // [n_reads - r_begin][4][capacity]
     uint32_t capacity;
+    // phmm_pick_reads only: the aligner ran on another stream -- wait until *wait_counter has reached wait_target (its blocks
+    // count themselves in behind a release, SwParams::done_counter; compared modulo 2^32) instead of for an event
+    const uint32_t *wait_counter;
+    uint32_t wait_target;
 };
 hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
 // phmm_post_best_reads and phmm_project_kernel of the same reads as one launch (phmm_pick_reads)

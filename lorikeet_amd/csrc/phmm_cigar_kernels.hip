@@ -435,6 +435,11 @@ __global__ __launch_bounds__(64) void phmm_pick_reads(const PostBestParams pb, c
         if (pb.keep_final) pb.keep_final[r] = keep;
         best_allele_of(pb.best, r, g, keep != 0, !(pb.skip_single_allele && nh == 1));
     }
+    if (p.wait_counter) {  // the alignments come from a kernel on another stream: until every block of it has counted itself in
+        while ((int32_t)(__hip_atomic_load(p.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_target) < 0)
+            __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
     project_read(p, r, p.workspace ? p.workspace + (size_t)r * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
 }

@@ -88,9 +88,11 @@ struct phmm_handle {
         hipEvent_t ev_in[kMaxChunks] = {}, ev_out[kMaxChunks] = {}, ev_k0[kMaxChunks] = {}, ev_k1[kMaxChunks] = {};  // inputs landed; results landed; around each kernel
                                                    // (phmm_get_stat "sw_kernel_us" = the kernels' own time, summed)
         uint64_t last_kernel_us = 0, last_backtrack_bytes = 0, last_clock_mhz = 0;
-        hipStream_t all_stream = nullptr;     // phmm_region_compute, small calls: the aligner over every (read, haplotype) pair runs
-        hipEvent_t ev_all = nullptr;          // here, beside the PairHMM kernels; recorded behind it
-        hipStream_t pair_main = nullptr;      // ... and the other kernels of such a call here (hardware queues of their own, phmm_region.cpp)
+        hipStream_t all_stream[2] = {};       // phmm_region_compute, small calls: the aligner over every (read, haplotype) pair runs
+        uint32_t *d_pair_done = nullptr;      // here, beside the PairHMM kernels; its blocks count themselves in here when done, and
+        uint32_t pair_done_target = 0;        // phmm_pick_reads on the other stream waits for the count (never reset: compared modulo 2^32)
+        hipStream_t pair_main[2] = {};        // ... and the other kernels of such a call here (hardware queues of their own; [1]: the
+                                              // pair whose two streams own disjoint halves of the CUs, phmm_region.cpp)
         uint64_t region_sw_all_calls = 0;     // how many calls went that way (phmm_get_stat "region_sw_all")
         hipEvent_t region_sw_done = nullptr;  // phmm_region_compute in chunks: the slab and the workspace are one per handle, so
         bool region_sw_pending = false;       // a chunk's alignment kernels wait for those of the chunk before it

@@ -124,6 +124,8 @@ struct PendingRegion {
     PendingRegion() = default;
 };
 
+constexpr size_t kHalvesUpToPairs = 512;  // (read, haplotype) pairs up to which a call's two streams get half the CUs each
+const bool kNoCuHalves = getenv("PHMM_REGION_NO_CU_HALVES") != nullptr;  // (A/B)
 std::atomic<int> g_region_calls[16];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
 struct InFlight {
     std::atomic<int> &n;
@@ -234,7 +236,8 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     auto bail = [&](int code) {
         std::string keep_err = h->err;
         (void)hipStreamSynchronize(S);
-        if (h->swork.all_stream) (void)hipStreamSynchronize(h->swork.all_stream);
+        for (hipStream_t t : h->swork.all_stream)
+            if (t) (void)hipStreamSynchronize(t);
         phmm_batch_destroy(b);
         h->err = keep_err;
         return h->err_code = code;
@@ -309,31 +312,43 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pair_stride = 0;
     }
     phmm_handle::SwWork &W = h->swork;
+    hipStream_t T_all = nullptr;  // the all-pairs aligner's stream
     if (pair_stride) {
-        if (!W.all_stream) {
-            // Two streams with hardware queues of their own, created one behind the other: the call's kernels run on the first,
-            // the all-pairs aligner on the second.  What was measured (rocprofv3 queue ids, 128 x 8 reads x haplotypes per call):
-            // the slot stream and an ordinary second stream may share one of the runtime's four queues (one kernel after the
-            // other: 166 us per call); two queues whose ids are equal modulo four -- one pipe of the command processor --
-            // stretch the pre-step from 20 to 57 us (160 us per call); a stream of another PRIORITY delivers its event ~55 us
-            // late (190 us); queues with consecutive ids: 120 us.  A stream with a CU mask always gets a new queue, and the
-            // mask names every CU.
+        // Two streams with hardware queues of their own, created one behind the other: the call's kernels run on the first,
+        // the all-pairs aligner on the second.  What was measured (rocprofv3 queue ids, 128 x 8 reads x haplotypes per call):
+        // the slot stream and an ordinary second stream may share one of the runtime's four queues (one kernel after the
+        // other: 166 us per call); two queues whose ids are equal modulo four -- one pipe of the command processor --
+        // stretch the pre-step from 20 to 57 us (160 us per call); a stream of another PRIORITY delivers its event ~55 us
+        // late (190 us); queues with consecutive ids: 120 us.  A stream with a CU mask always gets a new queue.
+        // Two such pairs.  WHOLE: both masks name every CU -- a call whose kernels fill the chip anyway (128 x 8: a wave per
+        // SIMD each).  HALVES: the call's kernels on one half of the CUs, the aligner on the other -- a call of a few hundred
+        // pairs, whose waves the dispatcher would otherwise put on the SAME first CUs of every XCD although nine tenths of the
+        // chip are idle (30 x 3: PairHMM kernel 59 us beside the aligner on shared CUs, 37 on CUs of its own, as alone).
+        const int set = n_sw <= kHalvesUpToPairs && !kNoCuHalves ? 1 : 0;
+        if (!W.all_stream[set]) {
             static std::mutex creation;
             std::lock_guard<std::mutex> lk(creation);
-            uint32_t mask[32];
-            for (uint32_t &m : mask) m = 0xffffffffu;
+            uint32_t mask_a[32], mask_b[32];
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
             const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
-            if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
-            if (hipExtStreamCreateWithCUMask(&W.pair_main, words, mask) != hipSuccess) W.pair_main = nullptr;
-            if (hipExtStreamCreateWithCUMask(&W.all_stream, words, mask) != hipSuccess) {
-                W.all_stream = nullptr;
-                if (!ok(h, hipStreamCreateWithFlags(&W.all_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(PHMM_ERR_HIP);
+            for (uint32_t w = 0; w < 32; ++w) {
+                const uint32_t all = w + 1 < words || cus % 32 == 0 ? 0xffffffffu : (1u << (cus % 32)) - 1u;
+                mask_a[w] = set && w >= words / 2 && words >= 2 ? 0u : all;
+                mask_b[w] = set && w < words / 2 ? 0u : all;
+            }
+            if (hipExtStreamCreateWithCUMask(&W.pair_main[set], words, mask_a) != hipSuccess) W.pair_main[set] = nullptr;
+            if (hipExtStreamCreateWithCUMask(&W.all_stream[set], words, mask_b) != hipSuccess) {
+                W.all_stream[set] = nullptr;
+                if (!ok(h, hipStreamCreateWithFlags(&W.all_stream[set], hipStreamNonBlocking), "hipStreamCreate")) return bail(PHMM_ERR_HIP);
             }
         }
-        if (W.pair_main) S = W.pair_main;
-        if (!W.ev_all && !ok(h, hipEventCreateWithFlags(&W.ev_all, hipEventDisableTiming), "hipEventCreate")) return bail(PHMM_ERR_HIP);
+        if (W.pair_main[set]) S = W.pair_main[set];
+        T_all = W.all_stream[set];
+        if (!W.d_pair_done) {
+            if (!ok(h, hipMalloc((void **)&W.d_pair_done, 256), "hipMalloc") || !ok(h, hipMemset(W.d_pair_done, 0, 256), "hipMemset")) return bail(PHMM_ERR_HIP);
+            W.pair_done_target = 0;
+        }
     }
     bool good;
     if (mirror) {  // (the inputs are fetched by blocks of the pre-step's launch, below)
@@ -380,17 +395,25 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     // (enqueued FIRST: started 10 us ahead of the pre-step it runs 80 us beside pre-step + PairHMM's 20 + 64 -- the waves of the
     // two kernels share the SIMDs' issue slots, alone they take 57 and 15 + 40; started together with the PairHMM kernel it
     // takes 94 and that one 85.  Raising either kernel's wave priority (switch region_prio) only moves the time to the other.)
-    if (good && pair_stride) {
+    auto launch_all_pairs = [&]() {
         SwParams sp = sw_params(mirror);
         sp.ref_index = nullptr;
         sp.pair_stride = pair_stride;
         sp.high_priority = (h->sw.region_prio & 1) ? 1u : 0u;
         sp.read_region = (const uint32_t *)(mirror + ((const char *)V.d_read_region - A.dev));
         sp.region_hap_off = (const uint32_t *)(mirror + ((const char *)V.d_region_hap_off - A.dev));
-        good = ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, W.all_stream), "phmm_sw_align_kernel (all pairs)") &&
-               ok(h, hipEventRecord(W.ev_all, W.all_stream), "hipEventRecord");
-        if (good) W.region_sw_all_calls += 1;
-    }
+        // (no event between the streams: the aligner's blocks count themselves in, and the kernel that consumes the alignments
+        // -- enqueued right behind the PairHMM kernel -- waits for the count: an event that is still pending reaches the other
+        // queue ~12 us late, one that has fired still costs ~6 us of barrier packet)
+        sp.done_counter = W.d_pair_done;
+        good = ok(h, launch_sw(G.L, G.K, G.transposed, G.variant, sp, (uint32_t)workers, G.lds, T_all), "phmm_sw_align_kernel (all pairs)");
+        if (good) {
+            W.pair_done_target += (uint32_t)workers;  // (only what was launched is waited for)
+            W.region_sw_all_calls += 1;
+        }
+    };
+    const bool all_pairs_behind_prep = (h->sw.region_prio & 4) != 0;  // (A/B)
+    if (good && pair_stride && !all_pairs_behind_prep) launch_all_pairs();
     // ---- pre-step ----------------------------------------------------------------------------------------------------------
     if (good && nr) {
         PrepParams pp{};
@@ -427,6 +450,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         good = ok(h, launch_prep(pp, S), "phmm_prep_reads");
     }
+    if (good && pair_stride && all_pairs_behind_prep) launch_all_pairs();
     // ---- PairHMM ---------------------------------------------------------------------------------------------------------
     // The exact pass below -600 rides in-stream -- unless no pair of this batch can get there: every likelihood is at least
     // the path "first base matched anywhere, everything else inserted", 10^-(q/10)/3 x (1 - 10^-(gcp/10)) x 10^-(ins/10) x
@@ -521,8 +545,10 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         h->err = who + ": sequences too long for the per-region pipeline (about 8 000 bases each)";
         return bail(PHMM_ERR_INVALID_ARG);
     }
-    if (good && pair_stride) {  // the alignments were made beside all this: wait for them, then post-step + best allele + projection
-        good = ok(h, hipStreamWaitEvent(S, W.ev_all, 0), "hipStreamWaitEvent") && ok(h, launch_pick(pb, pj, S), "phmm_pick_reads");
+    if (good && pair_stride) {  // the alignments were made beside all this: post-step + best allele, wait for them, projection
+        pj.wait_counter = W.d_pair_done;
+        pj.wait_target = W.pair_done_target;
+        good = ok(h, launch_pick(pb, pj, S), "phmm_pick_reads");
     } else if (good && align) {
         SwParams sp = sw_params(A.dev);
         // (chunks of one call follow each other through the handle's one slab and workspace)
