@@ -207,6 +207,18 @@ int phmm_batch_status(phmm_batch *b);
 uint64_t phmm_batch_cells(const phmm_batch *b);           /* sum over regions of (sum R)*(sum H)      */
 uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b); /* sum 5R + sum H + 8*Nr*Nh    */
 uint32_t phmm_batch_num_launches(const phmm_batch *b);    /* kernel launches one phmm_batch_launch does */
+/*
+ * Shared haplotype prefixes -- what the reference's scalar arm gets from find_first_position_where_haplotypes_differ
+ * (pair_hmm.rs:452-464, 706-717): columns left of the first base where a haplotype differs from its region's first one
+ * hold the same numbers for every read.  phmm_batch_share_prefixes re-plans the regions of a batch of phmm_batch_create
+ * where that pays (16 lanes per pair, five haplotypes or more, no 'N'): the first haplotype's wave parks one column per
+ * group of sharers, the sharers' waves sweep their suffixes from there.  Results are bit-identical to the unshared plan.
+ * `hap_bases`: the haplotype bytes on the HOST under the batch's hap_off (a plan is made from offsets; this is the one
+ * step that looks at payload).  Call once, before phmm_batch_launch; no effect on PHMM_FLAG_F32_FIRST handles.
+ * phmm_batch_cells stays the metric's count (sum R x sum H); phmm_batch_executed_cells is what the kernels sweep.
+ */
+int phmm_batch_share_prefixes(phmm_batch *b, const uint8_t *hap_bases);
+uint64_t phmm_batch_executed_cells(const phmm_batch *b);
 /* Name of the kernel doing most cells of this batch as rocprofv3 reports it, e.g. "phmm_forward_chain_k<16,19>". */
 const char *phmm_batch_dominant_kernel(const phmm_batch *b);
 

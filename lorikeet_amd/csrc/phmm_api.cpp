@@ -151,6 +151,22 @@ struct phmm_batch {
     uint32_t rescue_blocks = 0;
     bool bound = false;
     std::string dominant;
+    // ---- shared haplotype prefixes (phmm_batch_share_prefixes; phmm_internal.hpp) ------------------------------------------
+    struct RegionPlan {  // what the planner decided for a region's chained class (persistent batches keep it for the sharing pass)
+        int8_t L = 0;
+        uint8_t K = 0, streams = 0;
+        uint32_t run = 0;  // reads per work item
+    };
+    std::vector<RegionPlan> rplan;
+    std::vector<uint32_t> h_rro, h_rho, h_ro, h_ho;  // host copies of the offset arrays (persistent batches)
+    struct Share {
+        std::vector<ChainItemX> park[kChainRanges], suffix[kChainRanges];
+        ChainItemX *d_park[kChainRanges] = {}, *d_suffix[kChainRanges] = {};
+        double *d_area = nullptr;      // the parking area
+        uint64_t rows = 0;             // its 16-byte rows
+        uint64_t skipped_cells = 0;    // cells of the metric's definition that are not executed
+        uint32_t regions = 0;
+    } share;
 };
 
 namespace {
@@ -713,6 +729,21 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     reg_run[g] = std::min<uint32_t>(CHAIN_MAX_READS, (uint32_t)r * (uint32_t)kv.second.streams);
                 }
     }
+    if (!use_arena && !dry) {  // (persistent batches: what phmm_batch_share_prefixes needs later)
+        b->rplan.assign(n_regions, phmm_batch::RegionPlan{});
+        for (const auto &kv : by_shape)
+            if (kv.second.chain)
+                for (uint32_t g : kv.second.regions) {
+                    b->rplan[g].L = (int8_t)kv.second.L;
+                    b->rplan[g].K = (uint8_t)kv.second.K;
+                    b->rplan[g].streams = (uint8_t)kv.second.streams;
+                    b->rplan[g].run = reg_run[g];
+                }
+        b->h_rro.assign(region_read_off, region_read_off + n_regions + 1);
+        b->h_rho.assign(region_hap_off, region_hap_off + n_regions + 1);
+        b->h_ro.assign(read_off, read_off + n_reads + 1);
+        b->h_ho.assign(hap_off, hap_off + n_haps + 1);
+    }
     // bytes of per-class work lists the plan will place in device memory
     size_t class_meta = 0;
     for (const auto &kv : by_shape) {
@@ -1090,6 +1121,158 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
     PHMM_GUARD_END(h, "phmm_batch_create", PHMM_FAIL_NULL)
 }
 
+// Shared haplotype prefixes (phmm_internal.hpp): regions of a persistent batch whose haplotypes share enough of their front with
+// the region's first haplotype are re-planned -- the trunk's wave parks a column, the sharers' waves sweep their suffixes only.
+// `hap_bases`: the haplotype bytes on the HOST, laid out by the batch's hap_off (the plan itself never sees payload).
+int phmm_batch_share_prefixes(phmm_batch *b, const uint8_t *hap_bases) {
+    if (!b) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h = b->h;
+    if (!hap_bases || b->rplan.empty() || b->arena) {
+        h->err = "phmm_batch_share_prefixes: a batch of phmm_batch_create and the haplotype bases on the host are required";
+        return h->err_code = PHMM_ERR_INVALID_ARG;
+    }
+    if (b->share.regions) return PHMM_OK;  // (done already)
+    PHMM_GUARD_BEGIN
+    if (h->flags & PHMM_FLAG_F32_FIRST) return PHMM_OK;  // (the f32 sweep has no such kernels)
+    DeviceGuard dg(h->device);
+    const uint32_t *rro = b->h_rro.data(), *rho = b->h_rho.data(), *ro = b->h_ro.data(), *ho = b->h_ho.data();
+    auto cost_of = [](int K) { return 7.0 * K + 11.0; };
+    std::vector<uint8_t> shared(b->n_regions, 0);
+    phmm_batch::Share &sh = b->share;
+    uint64_t rows_total = 0;
+    constexpr uint64_t kMaxParkBytes = 24ull << 30;
+    for (uint32_t g = 0; g < b->n_regions; ++g) {
+        const phmm_batch::RegionPlan &rp = b->rplan[g];
+        const uint32_t h0 = rho[g], nh = rho[g + 1] - h0, r0 = rro[g], r1 = rro[g + 1];
+        if (rp.L != 16 || rp.streams != 1 || !rp.run || nh < 5 || nh > 0xfffeu || r1 == r0) continue;
+        const int K = rp.K;
+        const uint8_t *root = hap_bases + ho[h0];
+        const uint32_t Hroot = ho[h0 + 1] - ho[h0];
+        bool has_n = false;
+        for (uint32_t i = ho[h0]; i < ho[h0 + nh] && !has_n; ++i) has_n = hap_bases[i] == 'N';
+        if (has_n) continue;  // (the wildcard path is the general sweep: whole pairs only)
+        // lanes of the trunk in front of a haplotype's first difference
+        std::vector<uint32_t> lanes(nh, 0), order;
+        for (uint32_t k = 1; k < nh; ++k) {
+            const uint8_t *y = hap_bases + ho[h0 + k];
+            const uint32_t Hk = ho[h0 + k + 1] - ho[h0 + k], n = std::min(Hroot, Hk);
+            uint32_t p = 0;
+            while (p < n && y[p] == root[p]) ++p;
+            lanes[k] = std::min<uint32_t>(std::min<uint32_t>(p / (uint32_t)K, (Hk - 1) / (uint32_t)K), 15u);
+            order.push_back(k);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return lanes[x] > lanes[y]; });
+        // the trunk's wave: the first haplotype and the three that share least; the others four to a wave, most sharing first
+        const uint32_t n_rest = nh - 1 - 3;
+        struct Group { uint32_t first, n, lanes; int K2; bool suffix; };
+        std::vector<Group> groups;
+        double cost_new = cost_of(K) + 6.0, cost_now = (double)((nh + 3) / 4) * cost_of(K);
+        bool any = false;
+        uint32_t mask = 0;
+        for (uint32_t i = 0; i < n_rest; i += 4) {
+            Group gr{i, std::min<uint32_t>(4, n_rest - i), 16, K, false};
+            uint32_t hmax = 0;
+            for (uint32_t j = 0; j < gr.n; ++j) {
+                gr.lanes = std::min(gr.lanes, lanes[order[i + j]]);
+                hmax = std::max(hmax, ho[h0 + order[i + j] + 1] - ho[h0 + order[i + j]]);
+            }
+            if (gr.lanes >= 1) {
+                const int k2 = std::max(2, round_up_k((int)((hmax - gr.lanes * (uint32_t)K + 15) / 16)));
+                if (k2 >= 2 && k2 <= chain_max_k() && cost_of(k2) + 6.0 < 0.97 * cost_of(K)) {
+                    gr.K2 = k2;
+                    gr.suffix = true;
+                    any = true;
+                    mask |= 1u << (gr.lanes - 1);
+                }
+            }
+            cost_new += gr.suffix ? cost_of(gr.K2) + 6.0 : cost_of(K);
+            groups.push_back(gr);
+        }
+        if (!any || cost_new > 0.95 * cost_now) continue;
+        // ---- the region's work items, run by run --------------------------------------------------------------------------
+        const uint32_t nb = (uint32_t)__builtin_popcount(mask);
+        bool fits = true;
+        std::vector<ChainItemX> park_items, suffix_items;
+        uint64_t skipped = 0;
+        for (uint32_t r = r0; r < r1 && fits; r += rp.run) {
+            const uint32_t re = std::min(r1, r + rp.run);
+            const uint64_t rows = (uint64_t)(ro[re] - ro[r]) + 2ull * (re - r);          // the stream: every read + SUM + RESET
+            const uint64_t T = (rows + 16) & ~1ull, park_rows = (T + 16 + 15) / 16 * 16;  // (the kernel's step count + the lanes' lead)
+            if (park_rows / 16 > 0xffffu || (rows_total + (uint64_t)nb * park_rows) * 16 > kMaxParkBytes ||
+                rows_total + (uint64_t)nb * park_rows > 0xffffffffull) {
+                fits = false;
+                break;
+            }
+            ChainItemX t{};
+            t.it = ChainItem{g, 0, (uint8_t)K, 1, r, re};
+            t.hap[0] = 0;
+            for (int j = 0; j < 3; ++j) t.hap[1 + j] = (uint16_t)order[n_rest + j];
+            t.park_row0 = (uint32_t)rows_total;
+            t.park_rows16 = (uint16_t)(park_rows / 16);
+            t.mask_or_col0 = (uint16_t)mask;
+            park_items.push_back(t);
+            for (const Group &gr : groups) {
+                ChainItemX x{};
+                x.it = ChainItem{g, 0, (uint8_t)gr.K2, 1, r, re};
+                for (uint32_t j = 0; j < 4; ++j) x.hap[j] = j < gr.n ? (uint16_t)order[gr.first + j] : (uint16_t)0xffffu;
+                x.park_rows16 = (uint16_t)(park_rows / 16);
+                if (gr.suffix) {
+                    const uint32_t bidx = (uint32_t)__builtin_popcount(mask & ((1u << (gr.lanes - 1)) - 1u));
+                    x.park_row0 = (uint32_t)(rows_total + (uint64_t)bidx * park_rows);
+                    x.mask_or_col0 = (uint16_t)(gr.lanes * (uint32_t)K);
+                    suffix_items.push_back(x);
+                    skipped += (uint64_t)(ro[re] - ro[r]) * gr.n * (uint64_t)(gr.lanes * (uint32_t)K);
+                } else {  // whole pairs under named haplotypes: the parking kernel with nothing to park
+                    x.mask_or_col0 = 0;
+                    park_items.push_back(x);
+                }
+            }
+            rows_total += (uint64_t)nb * park_rows;
+        }
+        if (!fits) break;  // (the parking area is full: the remaining regions stay as they are)
+        shared[g] = 1;
+        sh.regions += 1;
+        sh.skipped_cells += skipped;
+        for (const ChainItemX &x : park_items) sh.park[chain_range_of(x.it.k)].push_back(x);
+        for (const ChainItemX &x : suffix_items) sh.suffix[chain_range_of(x.it.k)].push_back(x);
+    }
+    if (!sh.regions) return PHMM_OK;
+    sh.rows = rows_total;
+    // ---- the re-planned regions leave the plain launches; longest item first in the new ones -------------------------------
+    for (auto &grp : b->chain_groups) {
+        if (grp.f32 || grp.L != 16) continue;
+        std::vector<ChainItem> kept;
+        kept.reserve(grp.items.size());
+        for (const ChainItem &it : grp.items)
+            if (!shared[it.region]) kept.push_back(it);
+        if (kept.size() == grp.items.size()) continue;
+        grp.items.swap(kept);
+        if (!grp.items.empty())
+            HIP_TRY(h, hipMemcpy(grp.d_items, grp.items.data(), grp.items.size() * sizeof(ChainItem), hipMemcpyHostToDevice), PHMM_ERR_HIP);
+    }
+    auto cost = [&](const ChainItemX &x) {
+        return (uint64_t)(ro[x.it.read_end] - ro[x.it.read_begin] + 2 * (x.it.read_end - x.it.read_begin) + 16) * (uint64_t)(7 * x.it.k + 11);
+    };
+    auto upload = [&](std::vector<ChainItemX> &v, ChainItemX **d) {
+        if (v.empty()) return true;
+        std::stable_sort(v.begin(), v.end(), [&](const ChainItemX &x, const ChainItemX &y) { return cost(x) > cost(y); });
+        if (!hip_ok(h, hipMalloc((void **)d, v.size() * sizeof(ChainItemX)), "hipMalloc(share items)")) return false;
+        b->mallocs.push_back(*d);
+        return hip_ok(h, hipMemcpy(*d, v.data(), v.size() * sizeof(ChainItemX), hipMemcpyHostToDevice), "H2D share items");
+    };
+    for (int r = 0; r < kChainRanges; ++r)
+        if (!upload(sh.park[r], &sh.d_park[r]) || !upload(sh.suffix[r], &sh.d_suffix[r])) return PHMM_ERR_HIP;
+    HIP_TRY(h, hipMalloc((void **)&sh.d_area, std::max<uint64_t>(rows_total, 1) * 16), PHMM_ERR_HIP);
+    b->mallocs.push_back(sh.d_area);
+    if (h->sw.trace)
+        fprintf(stderr, "phmm share: %u of %u regions re-planned, %.3f of the cells not executed, parking area %.1f MB\n", sh.regions, b->n_regions,
+                (double)sh.skipped_cells / (double)std::max<uint64_t>(b->cells, 1), (double)rows_total * 16 / 1e6);
+    return PHMM_OK;
+    PHMM_GUARD_END(h, "phmm_batch_share_prefixes", PHMM_FAIL_CODE)
+}
+
+uint64_t phmm_batch_executed_cells(const phmm_batch *b) { return b ? b->cells - b->share.skipped_cells : 0; }
+
 int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q, const uint8_t *d_ins_q,
                            const uint8_t *d_del_q, const uint8_t *d_gcp, const uint8_t *d_hap_bases, double *d_out) {
     if (!b) return PHMM_ERR_INVALID_ARG;
@@ -1204,7 +1387,20 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // The chained sweeps: one launch per lanes-per-pair value, precision and (mixed batches) range of K.  Several launches
     // run side by side: the first on the caller's stream, the others on the handle's side streams between a fork and a
     // join event -- each alone would leave the chip to its own tail before the next could start.
-    const size_t n_groups = b->chain_groups.size();
+    // shared haplotype prefixes: the trunks first (they park the columns the suffix launches below start from)
+    ChainShareParams shp{};
+    if (b->share.regions) {
+        shp.f = base_params(b);
+        shp.park = b->share.d_area;
+        for (int r = 0; r < kChainRanges; ++r) {
+            shp.items = b->share.d_park[r];
+            shp.n_items = (uint32_t)b->share.park[r].size();
+            if (shp.n_items && !hip_ok(h, launch_chain_share(CHAIN_PARK, r, shp, stream), "phmm_forward_chain_share (trunks)")) return PHMM_ERR_HIP;
+        }
+    }
+    int n_suffix = 0;
+    for (int r = 0; r < kChainRanges; ++r) n_suffix += b->share.suffix[r].empty() ? 0 : 1;
+    const size_t n_groups = b->chain_groups.size() + (size_t)n_suffix;
     // (not while the chunks of a pipelined host call are in flight: those already overlap each other on the slot streams,
     // and forks of several chunks would queue behind one another on the side streams -- 1 536 mixed regions through host
     // buffers: 25 ms without, 32 ms with)
@@ -1218,20 +1414,30 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         if (!hip_ok(h, hipEventRecord(h->ev_fork, stream), "hipEventRecord")) return PHMM_ERR_HIP;
     }
     bool side_used[phmm_handle::kSideStreams] = {};
-    for (size_t gi = 0; gi < n_groups; ++gi) {
+    for (size_t gi = 0, next_suffix = 0; gi < n_groups; ++gi) {
+        hipStream_t s_x = stream;
+        if (fork && gi > 0) {
+            const int si = (int)((gi - 1) % phmm_handle::kSideStreams);
+            s_x = h->side_streams[si];
+            if (!side_used[si] && !hip_ok(h, hipStreamWaitEvent(s_x, h->ev_fork, 0), "hipStreamWaitEvent")) return PHMM_ERR_HIP;
+            side_used[si] = true;
+        }
+        if (gi >= b->chain_groups.size()) {  // a suffix launch of the sharing plan
+            while (b->share.suffix[next_suffix].empty()) ++next_suffix;
+            shp.items = b->share.d_suffix[next_suffix];
+            shp.n_items = (uint32_t)b->share.suffix[next_suffix].size();
+            if (!hip_ok(h, launch_chain_share(CHAIN_SUFFIX, (int)next_suffix, shp, s_x), "phmm_forward_chain_share (suffixes)")) return PHMM_ERR_HIP;
+            ++next_suffix;
+            continue;
+        }
         auto &grp = b->chain_groups[gi];
+        if (grp.items.empty()) continue;
         ChainParams cp{};
         cp.f = base_params(b);
         cp.items = grp.d_items;
         cp.n_items = (uint32_t)grp.items.size();
         cp.redo = grp.f32 ? b->d_redo : nullptr;
-        hipStream_t s = stream;
-        if (fork && gi > 0) {
-            const int si = (int)((gi - 1) % phmm_handle::kSideStreams);
-            s = h->side_streams[si];
-            if (!side_used[si] && !hip_ok(h, hipStreamWaitEvent(s, h->ev_fork, 0), "hipStreamWaitEvent")) return PHMM_ERR_HIP;
-            side_used[si] = true;
-        }
+        hipStream_t s = s_x;
         const hipError_t e = grp.f32 ? launch_chain_f32(grp.L, grp.single_k, cp, s) : launch_chain(grp.L, grp.single_k, cp, s);
         if (!hip_ok(h, e, grp.f32 ? "phmm_forward_chain_f32" : "phmm_forward_chain")) return PHMM_ERR_HIP;
     }
@@ -2230,7 +2436,9 @@ uint64_t phmm_batch_cells(const phmm_batch *b) { return b ? b->cells : 0; }
 uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b) { return b ? b->alg_bytes : 0; }
 uint32_t phmm_batch_num_launches(const phmm_batch *b) {
     if (!b) return 0;
-    uint32_t n = (uint32_t)b->chain_groups.size();
+    uint32_t n = 0;
+    for (const auto &g : b->chain_groups) n += g.items.empty() ? 0u : 1u;
+    for (int r = 0; r < kChainRanges; ++r) n += (b->share.park[r].empty() ? 0u : 1u) + (b->share.suffix[r].empty() ? 0u : 1u);
     for (const auto &c : b->classes)
         if (!c.chain || c.f32_first) n += 1u;  // per-read classes, and the f64 redo behind an f32 sweep
     return n;

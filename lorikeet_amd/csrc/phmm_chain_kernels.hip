@@ -134,10 +134,16 @@ __device__ __forceinline__ void chain_fallback_streams(const ForwardParams &p, u
 }  // namespace
 
 // One work item = one wave: a run of reads of one region against one group of its haplotypes, K columns per lane.
-template <int CLT, int K>  // CLT == CL of this compilation unit (keeps the three units' kernel symbols apart)
-__device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainItem it, unsigned char *smem) {
+// MODE (phmm_internal.hpp, shared haplotype prefixes): CHAIN_PARK items store M~ / D' of the flagged lanes' last column for
+// every stream row (`x`: where), CHAIN_SUFFIX items start at haplotype column x.col0 and take their left neighbour from there.
+template <int CLT, int K, int MODE = CHAIN_PLAIN>  // CLT == CL of this compilation unit (keeps the three units' kernel symbols apart)
+__device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainItem it, unsigned char *smem, const ChainItemX *x = nullptr,
+                                           double *park = nullptr) {
     static_assert(CLT == CL, "one lanes-per-pair value per compilation unit");
-    const ForwardParams &p = cp.f;
+    static_assert(MODE == CHAIN_PLAIN || CL == 16, "prefix sharing: 16 lanes per pair");
+    const int col0 = MODE == CHAIN_SUFFIX ? (int)x->mask_or_col0 : 0;
+    const uint32_t park_rows = MODE == CHAIN_PLAIN ? 0u : 16u * x->park_rows16;
+    const uint32_t park_mask = MODE == CHAIN_PARK ? (uint32_t)x->mask_or_col0 : 0u;
     const int lane = threadIdx.x;
     const int grp = lane / CL, l = lane % CL;
     const bool group_head = (CL == 32) && (lane == 32);
@@ -149,7 +155,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     const int S = (CL == 16) ? (int)it.streams : 1;
     const int GS = (WAVE / CL) / S;             // haplotype slots per stream
     const int sid = grp / GS;                   // stream of this lane's group
-    const int a = (int)it.quad * GS + grp % GS;
+    const int a = MODE == CHAIN_PLAIN ? (int)it.quad * GS + grp % GS : (int)x->hap[grp & 3];  // (the sharing kernels name their haplotypes)
     const bool hv = a < Nh;
     const int n_sub = (n_chain + S - 1) / S;    // reads per stream (the last streams may get fewer, or none)
     const int TPS = (RING / 4) / S;             // rows produced per stream and tick == steps per tick (a quarter of the stream's ring)
@@ -173,7 +179,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     for (int w = 0; w < HapCols<K>::W; ++w) hc.y[w] = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int col = l * K + k;
+        const int col = col0 + l * K + k;
         uint32_t y = col < H ? (uint32_t)p.hap_bases[ho + col] : X_PAD;
         const bool is_n = (y == 'N');
         lane_n |= is_n;
@@ -187,6 +193,13 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     bool z = false;
     for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
+        if constexpr (MODE == CHAIN_SUFFIX) {
+            // (a suffix cannot be swept alone the general way: its pairs are left to the exact pass -- NaN asks for it)
+            for (uint32_t r = rb + (uint32_t)l; r < it.read_end && hv; r += CL)
+                p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = __longlong_as_double(0x7ff8000000000000ll);
+            if (lane == 0) atomicOr(p.status, STATUS_RESCUE);
+            return;
+        }
         if (S == 1)
             chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
         else if constexpr (CL == 16)
@@ -223,16 +236,20 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     // -- one tick = 64 steps later, when they have long arrived -- looks the (hot, L1/L2-resident) table values
     // up, builds the record and writes it to the ring.  Only the six bytes live in registers in between.
     uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
+    double pb_bM = 0.0, pb_bD = 0.0;  // CHAIN_SUFFIX: the parked column's M~, D' of the row in the making
+    int p_Q = 0;
     // producer side of this lane: row (lane % TPS) of stream (lane / TPS) of each tick.  Its position in that stream,
     // (p_lo = read of the stream, p_row = row of that read, counting SUM and RESET), moves on by TPS rows per tick.
     const bool producer = lane < S * TPS;       // RING / 4 lanes build a row per tick (all 64 with the 256-row ring)
     const int ps = producer ? lane / TPS : 0, pj = lane % TPS;
     const int pcb = ps * (n_sub + 1), pn = n_of(ps);
     int p_lo = 0, p_row = pj - LEAD - TPS;  // before the first advance(); rows < 0 are the neutral lead-in
+    p_Q = pj - TPS;                         // ring position of that row
     uint32_t p_ro = pn > 0 ? roff[pcb] : 0u;
     int p_R = pn > 0 ? (int)(roff[pcb + 1] - p_ro) : 0;
     auto advance = [&]() {
         p_row += TPS;
+        p_Q += TPS;
         while (p_lo < pn && p_row >= p_R + 2) {  // past SUM and RESET of the current read: on to the next one(s)
             p_row -= p_R + 2;
             ++p_lo;
@@ -246,6 +263,13 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
         advance();
         const int row = p_row, R = p_R;
         const uint32_t ro = p_ro;
+        if constexpr (MODE == CHAIN_SUFFIX) {
+            if (producer && p_lo < pn && row >= 0 && (uint32_t)p_Q < park_rows) {  // every row of the stream, SUM and RESET rows included
+                const double *at = park + 2 * ((size_t)x->park_row0 + (size_t)p_Q);
+                pb_bM = at[0];
+                pb_bD = at[1];
+            }
+        }
         if (producer && p_lo < pn && row >= 0 && row <= R) {
             pb_qp = row > 0 ? (uint32_t)p.base_q[ro + row - 1] : 0u;  // row == R: the SUM row needs pm(R)
             if (row < R) {
@@ -273,6 +297,10 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
                 n.mm = 0.0; n.bI = 0.0; n.gI = 0.0; n.dDp = 0.0; n.dd = 1.0; n.pm = 0.0; n.px = 0.0;
                 n.x = X_NONE; n.pad0 = 0;
                 n.pad1 = c_unit * (lo + 1 < pn ? 1.0 - p.eps[p.gcp[roff[pcb + lo + 1]]] : 1.0);
+            }
+            if constexpr (MODE == CHAIN_SUFFIX) {  // the left neighbour of the item's first lanes in this row (pm is not read by the sweep)
+                n.pm = pb_bM;
+                n.pad1 = pb_bD;
             }
         } else {
             n = neutral_row();
@@ -305,7 +333,7 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     double aM, aI, aD, bM = 0.0, bI = 0.0, bD = c0;
     // After the SUM row the last haplotype column c = H-1 holds I_S = M(R,c)+I(R,c), M_S = M(R,c-1)+I(R,c-1) and
     // D' = the sum over everything further left: the lane that owns it emits the result.
-    const int edge_lane = (H > 0 ? H - 1 : 0) / K, edge_k = (H > 0 ? H - 1 : 0) % K;
+    const int edge_lane = (H > col0 ? H - 1 - col0 : 0) / K, edge_k = (H > col0 ? H - 1 - col0 : 0) % K;
     const bool last_lane = (l == edge_lane);
     const uint32_t sum_code = last_lane ? X_PAD : 0xffffffffu;  // == c.x exactly when this lane has to emit
     const double log10_scale = log10(c_unit) + log10((double)H);  // result = log10(sum) - log10(2^1010 * H)
@@ -337,6 +365,15 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
     RowConst cA = lds_row(ring, my_ring + (q & NM)), cB;
     int q1 = q + 1;
     const int T = (S_max + CL - 1 + 1) & ~1;  // even number of steps; surplus steps run neutral rows
+    // CHAIN_PARK: this lane's column of the parking area, indexed by ring position (the lane is at q now, q + 1 next, ...);
+    // only the trunk -- slot 0 of the wave -- is parked
+    bool park_lane = false;
+    double2 *park_at = nullptr;
+    if constexpr (MODE == CHAIN_PARK) {
+        park_lane = grp == 0 && ((park_mask >> l) & 1u) != 0u && hv && (uint32_t)(q + T) <= park_rows;
+        const int b = __popc(park_mask & ((1u << l) - 1u));
+        park_at = reinterpret_cast<double2 *>(park) + ((size_t)x->park_row0 + (size_t)b * park_rows + (size_t)q);
+    }
     // Outer loop = one producer tick (TPS steps), inner loop = the sweep.  The producer's pending bytes are
     // defined before the inner loop and first used after it, so their loads have a tick to land.
     // The first tick is shortened by a per-block even phase (the ring only gets further ahead), so that the two
@@ -355,23 +392,81 @@ __device__ __forceinline__ void chain_body(const ChainParams &cp, const ChainIte
             uint32_t pair_at;
             asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_at) : "v"((uint32_t)(q1 & NM)), "s"((uint32_t)sizeof(RowConst)), "v"(my_rows));
             cB = lds_row_at(pair_at, 0);
-            aM = from_left<CL>(Mp[K - 1], group_head);
-            aI = from_left<CL>(Ip[K - 1], group_head);
+            if constexpr (MODE == CHAIN_SUFFIX) {  // the first lane's neighbour is the parked column: M~ and D' of this row from the
+                // record, I^ of this row from the row before (the operations the owner of that column performed: mul, then fma)
+                aI = from_left_inject(Ip[K - 1], fma(bM, cA.bI, bI * cA.gI), group_head);
+                aM = from_left_inject(Mp[K - 1], cA.pm, group_head);
+            } else {
+                aM = from_left<CL>(Mp[K - 1], group_head);
+                aI = from_left<CL>(Ip[K - 1], group_head);
+            }
             aD = from_left_inject(Dp[K - 1], cA.pad1, group_head);  // column 0 has D = 0; a RESET row injects the next read's D(0,0)
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, bM, bI, bD, aM, aD, cA, hc, 1.0);
+            if constexpr (MODE == CHAIN_PARK)
+                if (park_lane) park_at[0] = make_double2(Mp[K - 1], Dp[K - 1]);
             // a read's SUM row reaches its emitting lane once per read: a wave-uniform test per step, each on the row
             // that was just consumed (testing cB here as well would wait for its LDS load right after issuing it)
             if (__ballot(cA.x == sum_code) != 0ull) emit(cA);
             cA = lds_row_at(pair_at, 1);
-            bM = from_left<CL>(Mp[K - 1], group_head);
-            bI = from_left<CL>(Ip[K - 1], group_head);
+            if constexpr (MODE == CHAIN_SUFFIX) {
+                bI = from_left_inject(Ip[K - 1], fma(aM, cB.bI, aI * cB.gI), group_head);
+                bM = from_left_inject(Mp[K - 1], cB.pm, group_head);
+            } else {
+                bM = from_left<CL>(Mp[K - 1], group_head);
+                bI = from_left<CL>(Ip[K - 1], group_head);
+            }
             bD = from_left_inject(Dp[K - 1], cB.pad1, group_head);
             row_update<K, ROW_FAST_EXEC>(Mp, Ip, Dp, aM, aI, aD, bM, bD, cB, hc, 1.0);
+            if constexpr (MODE == CHAIN_PARK) {
+                if (park_lane) park_at[1] = make_double2(Mp[K - 1], Dp[K - 1]);
+                park_at += 2;
+            }
             if (__ballot(cB.x == sum_code) != 0ull) emit(cB);
             q1 += 2;
         }
     }
 }
+
+#ifdef PHMM_CHAIN_SHARE
+// ---- shared haplotype prefixes: the two item kinds as kernels of their own, one per range of K (this file compiled once
+// more with -DPHMM_CHAIN_SHARE -DPHMM_CHAIN_L=16; the plain kernels below stay exactly what they are) ---------------------
+#define PHMM_CHAIN_K_LIST_X(X) \
+    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
+    X(23) X(24) X(25)
+template <int CLT, int KLO, int KHI, int MODE>
+__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_share(const ChainShareParams sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ChainItemX *x = sp.items + blockIdx.x;
+    const ChainItem it = x->it;
+    switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
+#define PHMM_CASE(KK)                                                                                   \
+    case KK:                                                                                            \
+        if constexpr (KK >= KLO && KK <= KHI) chain_body<CLT, KK, MODE>(sp.f, it, smem, x, sp.park);    \
+        break;
+        PHMM_CHAIN_K_LIST_X(PHMM_CASE)
+#undef PHMM_CASE
+        default:
+            break;
+    }
+}
+
+hipError_t launch_chain_share(int mode, int range, const ChainShareParams &sp, hipStream_t stream) {
+    if (!sp.n_items) return hipSuccess;
+    const size_t lds = (size_t)RING_SLOTS * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
+#define PHMM_RANGE(R, LO, HI)                                                                                                    \
+    if (range == R && mode == CHAIN_PARK) {                                                                                      \
+        hipLaunchKernelGGL((phmm_forward_chain_share<CL, LO, HI, CHAIN_PARK>), dim3(sp.n_items), dim3(WAVE), lds, stream, sp);   \
+        return hipGetLastError();                                                                                                \
+    }                                                                                                                            \
+    if (range == R && mode == CHAIN_SUFFIX) {                                                                                    \
+        hipLaunchKernelGGL((phmm_forward_chain_share<CL, LO, HI, CHAIN_SUFFIX>), dim3(sp.n_items), dim3(WAVE), lds, stream, sp); \
+        return hipGetLastError();                                                                                                \
+    }
+    PHMM_CHAIN_RANGES(PHMM_RANGE)
+#undef PHMM_RANGE
+    return hipErrorInvalidValue;
+}
+#else  // PHMM_CHAIN_SHARE
 
 // ---- the kernel: every item carries its own K (and stream count), so ONE launch per lanes-per-pair value covers
 // every shape class of a batch.  A long-tailed mix of regions (3 x 2 ... 5 000 x 128, haplotypes of 60 ... 500 bases)
@@ -394,7 +489,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
     switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
 #define PHMM_CASE(KK)                                                  \
     case KK:                                                           \
-        if constexpr (KK >= KLO && KK <= KHI) chain_body<CLT, KK>(cp, it, smem); \
+        if constexpr (KK >= KLO && KK <= KHI) chain_body<CLT, KK>(cp.f, it, smem); \
         break;
         PHMM_CHAIN_K_LIST(PHMM_CASE)
 #undef PHMM_CASE
@@ -409,7 +504,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain(const ChainParams 
 template <int CLT, int K>
 __global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_k(const ChainParams cp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    chain_body<CLT, K>(cp, cp.items[blockIdx.x], smem);
+    chain_body<CLT, K>(cp.f, cp.items[blockIdx.x], smem);
 }
 
 #define PHMM_CHAIN_CAT2(a, b) a##b
@@ -447,5 +542,6 @@ hipError_t launch_chain(int L, int single_k, const ChainParams &cp, hipStream_t 
          : L == 64 ? launch_chain_L64(single_k, cp, stream) : hipErrorInvalidValue;
 }
 #endif
+#endif  // PHMM_CHAIN_SHARE
 
 }  // namespace phmm

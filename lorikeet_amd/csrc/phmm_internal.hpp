@@ -110,6 +110,35 @@ struct ChainParams {
     uint32_t n_items;
     uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
 };
+// ---- shared haplotype prefixes (phmm_batch_share_prefixes) -------------------------------------------------------------
+// Columns left of the first base where a haplotype differs from its region's first haplotype (the "trunk") hold the same
+// M / I / D for every read -- what the reference's scalar arm skips through find_first_position_where_haplotypes_differ
+// (pair_hmm.rs:452-464, 706-717).  Here: the trunk's item PARKS, for every stream row, M~ and D' of the last column of
+// the lanes in front of which a group of sharers starts (16 bytes per row; I^ follows from them); a sharers' item sweeps
+// the SUFFIX alone -- four haplotypes from the same lane boundary of the trunk on, re-blocked to K' = ceil(suffix / 16)
+// columns per lane -- and its first lanes take the parked column as their left neighbour.  Every cell is computed by the
+// same operations in the same order as in the full sweep, so results are bit-identical.  Items of both kinds name their
+// haplotypes (the planner sorts a region's haplotypes by how much they share); one stream of reads per item.
+enum : int { CHAIN_PLAIN = 0, CHAIN_PARK = 1, CHAIN_SUFFIX = 2 };
+struct ChainItemX {
+    ChainItem it;        // streams == 1; `quad` is not used
+    uint16_t hap[4];     // the haplotypes of the wave's four slots (index inside the region; 0xffff: none).  PARK: hap[0] is the trunk
+    uint32_t park_row0;  // PARK: first row of this item's block of the parking area (16-byte rows: boundary b and ring position Q at
+                         // park_row0 + b park_rows + Q); SUFFIX: the same with its boundary's b park_rows already added
+    uint16_t park_rows16;   // ring positions per boundary, in units of 16
+    uint16_t mask_or_col0;  // PARK: bit l = the last column of lane l of slot 0 is parked (boundary index = how many lower bits are
+                            // set); SUFFIX: first haplotype column of the item
+};
+static_assert(sizeof(ChainItemX) == 32, "work item record");
+struct ChainShareParams {
+    ForwardParams f;
+    const ChainItemX *items;
+    uint32_t n_items;
+    double *park;        // the parking area: (M~, D') per row
+};
+// one launch per kind (CHAIN_PARK | CHAIN_SUFFIX) and range of K (chain_range_of); L = 16
+hipError_t launch_chain_share(int mode, int range, const ChainShareParams &p, hipStream_t stream);
+
 // The K ranges a mixed launch is cut into: one kernel per range holds only that range's bodies (phmm_chain_kernels.hip).
 #define PHMM_CHAIN_RANGES(X) X(0, 2, 9) X(1, 10, 15) X(2, 16, 19) X(3, 20, 25)
 constexpr int kChainRanges = 4;

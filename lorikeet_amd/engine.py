@@ -60,9 +60,19 @@ class DevicePlan:
     def status(self):
         self.engine._check(self.engine.lib.phmm_batch_status(self._b))
 
+    def share_prefixes(self):
+        """phmm_batch_share_prefixes: re-plan the regions whose haplotypes share the front of their first one (bit-identical
+        results, fewer cells swept).  Before the first launch."""
+        self.engine._check(self.engine.lib.phmm_batch_share_prefixes(self._b, _p(self.batch.hap_bases, _lib.u8p)))
+        return self.executed_cells
+
     @property
     def cells(self):
         return int(self.engine.lib.phmm_batch_cells(self._b))
+
+    @property
+    def executed_cells(self):
+        return int(self.engine.lib.phmm_batch_executed_cells(self._b))
 
     @property
     def algorithmic_bytes(self):
