@@ -220,8 +220,11 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         for (uint32_t g = 0; g < ng; ++g) max_nh = std::max(max_nh, a.region_hap_off[g + 1] - a.region_hap_off[g]);
         // (by itself only while this is the one region call in flight in the process: with several callers the chip is not idle,
         // and Nh times the aligner's work comes out of the other calls' time -- 4 threads: 21 k regions/s the plain way, 14 k this way)
-        const bool alone = h->busy_lanes <= 1 && g_region_calls[h->device & 15].load(std::memory_order_relaxed) <= 1;
-        const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all : alone ? 2048u : 0u;
+        const int in_flight = std::max<int>((int)h->busy_lanes, g_region_calls[h->device & 15].load(std::memory_order_relaxed));
+        // (... two calls of a few hundred pairs each are still small against the chip: 30 x 3 regions from two threads 141 -> 100 us
+        // per call.  From four callers on every call's two queues of its own are more hardware queues than run at a time:
+        // 157 -> 218 us.)
+        const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all : in_flight <= 1 ? 2048u : in_flight == 2 ? 512u : 0u;
         if (max_nh >= 2 && (uint64_t)nr * max_nh <= limit) pair_stride = max_nh;
     }
     const Layout sizing(0, a, sw_capacity, pair_stride);
