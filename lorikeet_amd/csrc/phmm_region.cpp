@@ -125,7 +125,6 @@ struct PendingRegion {
 };
 
 constexpr size_t kHalvesUpToPairs = 512;  // (read, haplotype) pairs up to which a call's two streams get half the CUs each
-const bool kNoCuHalves = getenv("PHMM_REGION_NO_CU_HALVES") != nullptr;  // (A/B)
 std::atomic<int> g_region_calls[16];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
 struct InFlight {
     std::atomic<int> &n;
@@ -327,7 +326,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         // SIMD each).  HALVES: the call's kernels on one half of the CUs, the aligner on the other -- a call of a few hundred
         // pairs, whose waves the dispatcher would otherwise put on the SAME first CUs of every XCD although nine tenths of the
         // chip are idle (30 x 3: PairHMM kernel 59 us beside the aligner on shared CUs, 37 on CUs of its own, as alone).
-        const int set = n_sw <= kHalvesUpToPairs && !kNoCuHalves ? 1 : 0;
+        const int set = n_sw <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
         if (!W.all_stream[set]) {
             static std::mutex creation;
             std::lock_guard<std::mutex> lk(creation);
