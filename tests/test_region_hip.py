@@ -379,3 +379,39 @@ def test_every_pair_alignments_that_outgrow_the_slots_send_the_call_round_the_pl
     assert want.best.allele_index[0] == 0 and want.reads.status[0] == 0
     cig, _ = oracle.sw_align(bytes(other), read, [10, -15, -30, -5], "SoftClip")
     assert len(cig) > 24  # (the pair that does not fit)
+
+
+def test_two_callers_with_private_handles_align_every_pair_at_the_same_time(hip_engine):
+    """Two region calls in flight (the most for which a small call still takes the all-pairs way): each handle has queues and a
+    counter of its own, and both use the same halves of the CUs -- results equal to a lone caller's, call after call."""
+    jobs = []
+    for t in range(2):
+        for k in range(12):
+            b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(900 + 50 * t + k, n_regions=1 + (k % 2))
+            jobs.append((t, b, _noisy_quals(b, 7 * t + k), hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars))
+    cfg = _cfg(pcr=2)
+    hip_engine.set_switch("region_sw_all", 0)
+    try:
+        want = [region.region_compute(hip_engine, cfg, j[1], *j[2:]) for j in jobs]
+    finally:
+        hip_engine.set_switch("region_sw_all", -1)
+    engines = [HipPairHMMEngine(0), HipPairHMMEngine(0)]
+    got, errs = [None] * len(jobs), []
+
+    def worker(t):
+        try:
+            for i, j in enumerate(jobs):
+                if j[0] == t:
+                    for _ in range(6):  # (the same call again and again: the streams and the counter keep their state)
+                        got[i] = region.region_compute(engines[t], cfg, j[1], *j[2:])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for g, w in zip(got, want):
+        _equal_calls(g, w)
+    assert sum(e.stat("region_sw_all") for e in engines) > len(jobs) // 2   # (most calls did go the all-pairs way)
+    for e in engines:
+        e.close()
