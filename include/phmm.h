@@ -297,6 +297,13 @@ int phmm_engine_submit(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n
                        const uint8_t *del_q, const uint8_t *mapq, const uint32_t *hap_off,
                        const uint8_t *hap_bases, const int32_t *region_ref_hap, const uint64_t *out_off,
                        double *out, uint8_t *keep, uint64_t *ticket);
+/* ... and over several engines, one per device, like phmm_compute_multi (contiguous cell-balanced ranges of regions, one
+ * pinned host thread per engine, nothing gathered); on failure the message is phmm_last_error(handles[0]). */
+int phmm_engine_compute_multi(phmm_handle *const *handles, uint32_t n_handles, const phmm_engine_config *cfg, uint32_t n_regions,
+                              const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                              const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                              const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases,
+                              const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep);
 
 /*
  * Smith-Waterman alignment: SmithWatermanAligner::align of the reference

@@ -270,6 +270,27 @@ extern "C" {
         ticket: *mut u64,
     ) -> c_int;
 
+    pub fn phmm_engine_compute_multi(
+        handles: *const *mut phmm_handle,
+        n_handles: u32,
+        cfg: *const phmm_engine_config,
+        n_regions: u32,
+        region_read_off: *const u32,
+        region_hap_off: *const u32,
+        read_off: *const u32,
+        read_bases: *const u8,
+        base_q: *const u8,
+        ins_q: *const u8,
+        del_q: *const u8,
+        mapq: *const u8,
+        hap_off: *const u32,
+        hap_bases: *const u8,
+        region_ref_hap: *const i32,
+        out_off: *const u64,
+        out: *mut f64,
+        keep: *mut u8,
+    ) -> c_int;
+
     pub fn phmm_sw_align(
         h: *mut phmm_handle,
         n_alignments: u32,

@@ -97,6 +97,8 @@ SYMBOLS = [
                                       u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_engine_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
                                      u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p, C.POINTER(C.c_uint64)]),
+    ("phmm_engine_compute_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p,
+                                            u32p, u8p, C.POINTER(C.c_int32), u64p, f64p, u8p]),
     ("phmm_sw_align", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p,
                                 C.POINTER(C.c_int32)]),
     ("phmm_sw_align_indexed", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, C.c_uint32, u32p, u32p, u8p, C.c_void_p, C.c_int, u64p,

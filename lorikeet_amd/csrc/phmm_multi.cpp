@@ -228,6 +228,90 @@ int phmm_compute_multi(phmm_handle *const *handles, uint32_t n_handles, uint32_t
     }
 }
 
+// The engine-level call (phmm_engine_compute) over several engines: contiguous cell-balanced ranges, every range's offsets
+// rebased and its pointers moved on, nothing gathered; the whole call is validated by the first range's engine entry point
+// range by range (phmm_engine_compute checks what it is given), the offsets once here.
+int phmm_engine_compute_multi(phmm_handle *const *handles, uint32_t n_handles, const phmm_engine_config *cfg, uint32_t n_regions,
+                              const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                              const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q,
+                              const uint8_t *mapq, const uint32_t *hap_off, const uint8_t *hap_bases, const int32_t *region_ref_hap,
+                              const uint64_t *out_off, double *out, uint8_t *keep) {
+    if (!handles || !n_handles || !handles[0] || !cfg) return PHMM_ERR_INVALID_ARG;
+    phmm_handle *h0 = handles[0];
+    for (uint32_t k = 0; k < n_handles; ++k)
+        if (!handles[k]) {
+            h0->err = "phmm_engine_compute_multi: null handle";
+            return PHMM_ERR_INVALID_ARG;
+        }
+    clear_thread_error(h0);
+    if (n_handles == 1)
+        return phmm_engine_compute(h0, cfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq, hap_off,
+                                   hap_bases, region_ref_hap, out_off, out, keep);
+    if (const char *bad = validate_offsets(n_regions, region_read_off, region_hap_off, read_off, hap_off, out_off, nullptr)) {
+        h0->err = bad;
+        return PHMM_ERR_INVALID_ARG;
+    }
+    const uint32_t n_reads = region_read_off[n_regions];
+    if (cfg->pcr_error_model > 3 || (read_off[n_reads] && (!read_bases || !base_q)) || (n_reads && (!mapq || !keep)) ||
+        (hap_off[region_hap_off[n_regions]] && !hap_bases) || (out_off[n_regions] && !out)) {
+        h0->err = cfg->pcr_error_model > 3 ? "phmm_engine_compute: Unknown PCR Error Model" : "phmm_engine_compute_multi: null pointer";
+        return PHMM_ERR_INVALID_ARG;
+    }
+    try {
+        std::vector<uint32_t> first(n_handles + 1);
+        split_contiguous(region_cells(n_regions, region_read_off, region_hap_off, read_off, hap_off), n_handles, first.data());
+        std::vector<int> st(n_handles, PHMM_OK);
+        std::vector<std::string> errs(n_handles);
+        std::vector<std::thread> workers;
+        workers.reserve(n_handles);
+        struct JoinAll {
+            std::vector<std::thread> &w;
+            ~JoinAll() {
+                for (auto &t : w)
+                    if (t.joinable()) t.join();
+            }
+        } join_all{workers};
+        for (uint32_t k = 0; k < n_handles; ++k) {
+            if (first[k] == first[k + 1]) continue;
+            workers.emplace_back([&, k] {
+                phmm_handle *h = handles[k];
+                try {
+                    pin_near_device(h->device);
+                    ChunkView c;
+                    c.g1 = first[k];
+                    (void)next_chunk(c, first[k + 1], region_read_off, region_hap_off, read_off, hap_off, out_off, true);
+                    const size_t bo = c.read_byte0, co = c.hap_byte0;
+                    st[k] = phmm_engine_compute(h, cfg, c.g1 - c.g0, c.rro.data(), c.rho.data(), c.ro.data(), read_bases + bo, base_q + bo,
+                                                ins_q ? ins_q + bo : nullptr, del_q ? del_q + bo : nullptr, mapq + c.r0, c.ho.data(),
+                                                hap_bases + co, region_ref_hap ? region_ref_hap + c.g0 : nullptr, c.oo.data(),
+                                                out + out_off[c.g0], keep + c.r0);
+                    if (st[k] != PHMM_OK) errs[k] = h->err;
+                } catch (const std::bad_alloc &) {
+                    st[k] = PHMM_ERR_NO_MEMORY;
+                    errs[k] = "phmm_engine_compute_multi: out of host memory";
+                } catch (const std::exception &e) {
+                    st[k] = PHMM_ERR_INTERNAL;
+                    errs[k] = std::string("phmm_engine_compute_multi: ") + e.what();
+                }
+            });
+        }
+        for (auto &w : workers)
+            if (w.joinable()) w.join();
+        for (uint32_t k = 0; k < n_handles; ++k)
+            if (st[k] != PHMM_OK) {
+                h0->err = errs[k];
+                return st[k];
+            }
+        return PHMM_OK;
+    } catch (const std::bad_alloc &) {
+        h0->err = "phmm_engine_compute_multi: out of host memory";
+        return PHMM_ERR_NO_MEMORY;
+    } catch (const std::exception &e) {
+        h0->err = std::string("phmm_engine_compute_multi: ") + e.what();
+        return PHMM_ERR_INTERNAL;
+    }
+}
+
 // The whole per-region path (phmm_region_compute) over several engines: contiguous cell-balanced ranges of regions, one
 // host thread per engine pinned next to its GPU, every range staged straight from the caller's arrays and its results
 // written where phmm_region_compute on one engine would write them.

@@ -42,6 +42,7 @@ def test_one_engine_per_device():
         assert np.max(np.abs(got - engines[0].compute(b))) <= 1e-12      # every device computes what device 0 computes
         assert np.max(np.abs(got - engines[-1].compute(b))) <= 1e-12
     # ... and the whole per-region path (phmm_region_compute_multi): every device's share equal to what device 0 makes of it
+    # (phmm_engine_compute_multi runs the same ranges through the engine-level call: test_engine_call_over_several_engines)
     _region_call_over(engines, n_regions=4 * len(engines))
     for e in engines:
         e.close()
@@ -83,6 +84,39 @@ def test_region_call_over_several_engines():
     assert e.value.code == _lib.PHMM_ERR_INVALID_ARG and "PCR" in str(e.value)
     for x in engines:
         x.close()
+
+
+def test_engine_call_over_several_engines():
+    """phmm_engine_compute_multi == phmm_engine_compute on one engine: normalised likelihoods and keep flags, with and without
+    the indel quality tracks, fewer regions than engines, errors once for the whole call."""
+    import ctypes as C
+    from test_region_hip import _cfg, _engine_compute, _noisy_quals
+    from project_scenarios import scenario
+    engines = _engines(3)
+    hs = (C.c_void_p * 3)(*[e._h for e in engines])
+    pp = lambda a, t: None if a is None else a.ctypes.data_as(t)  # noqa: E731
+    for n_regions, tags in ((13, True), (2, False)):
+        b, _, _, ref_hap, _, _ = scenario(40 + n_regions, n_regions=n_regions)
+        mapq = _noisy_quals(b, n_regions)
+        cfg = _cfg(pcr=3, dynamic=True)
+        if not tags:
+            b.ins_q = b.del_q = None
+        out, keep = np.full(b.n_out, np.nan), np.zeros(b.n_reads, np.uint8)
+        rr = np.ascontiguousarray(ref_hap, np.int32)
+        args = (C.byref(cfg), b.n_regions, pp(b.region_read_off, _lib.u32p), pp(b.region_hap_off, _lib.u32p), pp(b.read_off, _lib.u32p),
+                pp(b.read_bases, _lib.u8p), pp(b.base_q, _lib.u8p), pp(b.ins_q, _lib.u8p), pp(b.del_q, _lib.u8p), pp(mapq, _lib.u8p),
+                pp(b.hap_off, _lib.u32p), pp(b.hap_bases, _lib.u8p), pp(rr, C.POINTER(C.c_int32)), pp(b.out_off, _lib.u64p))
+        st = engines[0].lib.phmm_engine_compute_multi(hs, 3, *args, pp(out, _lib.f64p), pp(keep, _lib.u8p))
+        assert st == 0, engines[0].last_error()
+        want, wkeep = np.full(b.n_out, np.nan), np.zeros(b.n_reads, np.uint8)
+        st = engines[0].lib.phmm_engine_compute(engines[0]._h, *args, pp(want, _lib.f64p), pp(wkeep, _lib.u8p))
+        assert st == 0, engines[0].last_error()
+        assert np.max(np.abs(out - want)) <= 1e-12 and np.array_equal(keep, wkeep)
+    bad = _cfg(pcr=9)
+    st = engines[0].lib.phmm_engine_compute_multi(hs, 3, C.byref(bad), *args[1:], pp(out, _lib.f64p), pp(keep, _lib.u8p))
+    assert st == _lib.PHMM_ERR_INVALID_ARG and "PCR" in engines[0].last_error()
+    for e in engines:
+        e.close()
 
 
 def test_several_engines_one_call():
