@@ -401,6 +401,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         SwParams sp = sw_params(mirror);
         sp.ref_index = nullptr;
         sp.pair_stride = pair_stride;
+        sp.pair_single_nh = ng == 1 ? nh : 0u;
         sp.high_priority = (h->sw.region_prio & 1) ? 1u : 0u;
         sp.read_region = (const uint32_t *)(mirror + ((const char *)V.d_read_region - A.dev));
         sp.region_hap_off = (const uint32_t *)(mirror + ((const char *)V.d_region_hap_off - A.dev));

@@ -48,6 +48,7 @@ struct SwParams {
     // haplotype count of a region); alignment a is read a / pair_stride against haplotype a % pair_stride of that read's
     // region (no such haplotype: an empty CIGAR); ref_index is not looked at
     uint32_t pair_stride;
+    uint32_t pair_single_nh;               // > 0: the call is ONE region with this many haplotypes (read_region / region_hap_off are not read)
     uint32_t *done_counter;                // or null: every block adds one when it has stored its last result (behind a device-scope
                                            // release): the kernel that consumes the alignments waits for the count instead of for an event
     uint32_t high_priority;                // 1: the waves raise their issue priority (s_setprio) over other kernels' waves on their SIMDs

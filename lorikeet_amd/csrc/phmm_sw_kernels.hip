@@ -196,8 +196,13 @@ void phmm_sw_align_kernel(const SwParams p) {
             uint32_t ri;
             if (p.pair_stride) {  // every read against EVERY haplotype of its region: alignment a = (read a / stride, haplotype a % stride)
                 aa = a / p.pair_stride;
-                const uint32_t j = a - aa * p.pair_stride, reg = p.read_region[aa], h0 = p.region_hap_off[reg];
-                ri = j < p.region_hap_off[reg + 1] - h0 ? h0 + j : SW_NO_REFERENCE;
+                const uint32_t j = a - aa * p.pair_stride;
+                if (p.pair_single_nh) {  // one region: no look-ups (over PCIe each is a round trip of its own in front of the bases)
+                    ri = j < p.pair_single_nh ? j : SW_NO_REFERENCE;
+                } else {
+                    const uint32_t reg = p.read_region[aa], h0 = p.region_hap_off[reg];
+                    ri = j < p.region_hap_off[reg + 1] - h0 ? h0 + j : SW_NO_REFERENCE;
+                }
             } else {
                 ri = p.ref_index ? p.ref_index[a] : a;  // reads name their haplotype; pairs come one to one
             }
@@ -220,8 +225,12 @@ void phmm_sw_align_kernel(const SwParams p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int k = l; k < n; k += SW_L) s_ref[k] = p.ref_bases[ro + k];
-        for (int k = l; k < m; k += SW_L) s_alt[k] = p.alt_bases[ao + k];
+        // (one loop: the loads of both sequences are in flight together -- one round trip to memory instead of two)
+        for (int k = l, nm = max(n, m); k < nm; k += SW_L) {
+            const uint8_t rb = k < n ? p.ref_bases[ro + k] : (uint8_t)0, ab = k < m ? p.alt_bases[ao + k] : (uint8_t)0;
+            if (k < n) s_ref[k] = rb;
+            if (k < m) s_alt[k] = ab;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
