@@ -289,6 +289,7 @@ static void read_env_switches(Switches &w) {
     env("PHMM_REGION_SW_ALL", w.region_sw_all);
     env("PHMM_REGION_PRIO", w.region_prio);
     env("PHMM_REGION_CU_HALVES", w.region_cu_halves);
+    env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
     w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
     w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
     w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
@@ -2373,6 +2374,7 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "region_sw_all") w.region_sw_all = value < 0 ? -1 : value;
     else if (n == "region_prio") w.region_prio = value > 0 ? value : 0;
     else if (n == "region_cu_halves") w.region_cu_halves = value != 0;
+    else if (n == "region_flag_wait") w.region_flag_wait = value != 0;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";

@@ -48,10 +48,17 @@ struct ProjectParams {
     // count themselves in behind a release, SwParams::done_counter; compared modulo 2^32) instead of for an event
     const uint32_t *wait_counter;
     uint32_t wait_target;
+    // The call's LAST kernel, results straight into the pinned mirror: every block counts itself in behind a release
+    // (*finish_counter, device memory, never reset), and the one that brings the count to finish_target stores 1 into
+    // *finish_flag -- a word of the mirror the calling thread polls instead of waiting in hipStreamSynchronize (the runtime
+    // reports a finished kernel ~6 us after its last store: tools/ubench/sync_latency.hip).  finish_target is set by the launch.
+    uint32_t *finish_counter;
+    uint32_t finish_target;
+    uint32_t *finish_flag;
 };
-hipError_t launch_project(const ProjectParams &p, hipStream_t stream);
+hipError_t launch_project(const ProjectParams &p, hipStream_t stream, uint32_t *blocks = nullptr);
 // phmm_post_best_reads and phmm_project_kernel of the same reads as one launch (phmm_pick_reads)
-hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream);
+hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream, uint32_t *blocks = nullptr);
 // `bytes` (rounded up to 16; both buffers are 256-aligned and padded) from pinned host memory, by its device address, to `dev`
 hipError_t launch_stage_in(const void *host_as_device, void *dev, size_t bytes, hipStream_t stream);
 

@@ -410,22 +410,35 @@ done:
     if (status == CIGAR_OK && n_out > out_cap) *p.flags = 1u;
 }
 
+// The last kernel of a call tells the calling thread itself (ProjectParams::finish_flag): a block is one wave, its lanes'
+// stores are behind the release; the block that completes the count publishes them all (release at system scope) with the flag.
+__device__ __forceinline__ void count_block_in(const ProjectParams &p) {
+    if (!p.finish_counter) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(p.finish_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1u == p.finish_target) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(p.finish_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void phmm_project_kernel(const ProjectParams p) {
     const uint32_t r = p.r_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n_reads) return;
     // (a small launch keeps the lanes' builders in LDS: every builder operation is a dependent memory access, and a
     // region per call has too few reads to hide HBM latency behind other lanes)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
-    project_read(p, r, p.workspace ? p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
+    if (r < p.n_reads)
+        project_read(p, r, p.workspace ? p.workspace + (size_t)(r - p.r_begin) * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
+    count_block_in(p);
 }
 
 // Post-step, best allele and projection of a read in ONE launch (phmm_region_compute, small calls whose alignments were made
 // for every haplotype beside the PairHMM kernels): lane r normalises its row of likelihoods, decides keep[r], finds the best
 // allele and projects the alignment the aligner left in THAT haplotype's slot -- phmm_post_best_reads and
 // phmm_project_kernel, statement for statement, without the launch in between.
-__global__ __launch_bounds__(64) void phmm_pick_reads(const PostBestParams pb, const ProjectParams p) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n_reads) return;
+__device__ __forceinline__ void pick_read(const PostBestParams &pb, const ProjectParams &p, uint32_t r) {
     const uint32_t g = pb.post.read_region[r];
     const uint32_t nh = pb.post.region_hap_off[g + 1] - pb.post.region_hap_off[g];
     if (nh <= 16) {
@@ -442,6 +455,12 @@ __global__ __launch_bounds__(64) void phmm_pick_reads(const PostBestParams pb, c
     }
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];
     project_read(p, r, p.workspace ? p.workspace + (size_t)r * 4 * p.capacity : lds_ws + (size_t)threadIdx.x * 4 * p.capacity);
+}
+
+__global__ __launch_bounds__(64) void phmm_pick_reads(const PostBestParams pb, const ProjectParams p) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < p.n_reads) pick_read(pb, p, r);
+    count_block_in(p);
 }
 
 // CigarUtils::calculate_cigar (src/reads/cigar_utils.rs:358-457) behind the Smith-Waterman alignment of the padded
@@ -523,32 +542,35 @@ hipError_t launch_calculate_cigar(const CalcParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_project(const ProjectParams &p, hipStream_t stream) {
+// (*blocks: how many blocks count themselves in -- p.finish_target comes in as the count before this launch)
+hipError_t launch_project(const ProjectParams &p, hipStream_t stream, uint32_t *blocks) {
+    if (blocks) *blocks = 0;
     if (p.n_reads <= p.r_begin) return hipSuccess;
     const uint32_t n = p.n_reads - p.r_begin;
     const size_t lds_per_lane = 4ull * p.capacity * 4;
-    if (n <= 4096 && 32 * lds_per_lane <= 64 * 1024) {  // workspace in LDS, half a wave per block (no attribute needed up to 64 KB)
-        ProjectParams q = p;
-        q.workspace = nullptr;
-        hipLaunchKernelGGL(phmm_project_kernel, dim3((n + 31) / 32), dim3(32), 32 * lds_per_lane, stream, q);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(phmm_project_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+    ProjectParams q = p;
+    const bool in_lds = n <= 4096 && 32 * lds_per_lane <= 64 * 1024;  // workspace in LDS, half a wave per block (no attribute needed up to 64 KB)
+    const uint32_t per_block = in_lds ? 32 : 64, grid = (n + per_block - 1) / per_block;
+    if (in_lds) q.workspace = nullptr;
+    q.finish_target = p.finish_target + grid;
+    if (blocks) *blocks = grid;
+    hipLaunchKernelGGL(phmm_project_kernel, dim3(grid), dim3(per_block), in_lds ? 32 * lds_per_lane : 0, stream, q);
     return hipGetLastError();
 }
 
 // (p.r_begin == 0: the launch covers the reads of the post-step)
-hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream) {
+hipError_t launch_pick(const PostBestParams &pb, const ProjectParams &p, hipStream_t stream, uint32_t *blocks) {
+    if (blocks) *blocks = 0;
     if (!p.n_reads) return hipSuccess;
     if (p.r_begin != 0 || pb.post.n_reads != p.n_reads) return hipErrorInvalidValue;
     const size_t lds_per_lane = 4ull * p.capacity * 4;
-    if (p.n_reads <= 4096 && 32 * lds_per_lane <= 64 * 1024) {
-        ProjectParams q = p;
-        q.workspace = nullptr;
-        hipLaunchKernelGGL(phmm_pick_reads, dim3((p.n_reads + 31) / 32), dim3(32), 32 * lds_per_lane, stream, pb, q);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(phmm_pick_reads, dim3((p.n_reads + 63) / 64), dim3(64), 0, stream, pb, p);
+    ProjectParams q = p;
+    const bool in_lds = p.n_reads <= 4096 && 32 * lds_per_lane <= 64 * 1024;
+    const uint32_t per_block = in_lds ? 32 : 64, grid = (p.n_reads + per_block - 1) / per_block;
+    if (in_lds) q.workspace = nullptr;
+    q.finish_target = p.finish_target + grid;
+    if (blocks) *blocks = grid;
+    hipLaunchKernelGGL(phmm_pick_reads, dim3(grid), dim3(per_block), in_lds ? 32 * lds_per_lane : 0, stream, pb, q);
     return hipGetLastError();
 }
 

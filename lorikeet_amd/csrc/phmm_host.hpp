@@ -45,6 +45,8 @@ struct Switches {
     int sw_transpose = -1;      // PHMM_SW_TRANSPOSE: 0 = small calls never sweep along the alternate sequence, 1 = whenever possible, -1 = by cost
     int sw_no_zero_copy = 0;    // PHMM_SW_NO_ZERO_COPY: small one-piece calls fetch their results by copies like large ones (A/B only)
     int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
+    int region_flag_wait = 1;   // PHMM_REGION_FLAG_WAIT: 0 = a small region call's thread waits in hipStreamSynchronize instead of polling the
+                                // word its last kernel stores into the pinned mirror (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
@@ -92,6 +94,8 @@ struct phmm_handle {
         hipStream_t all_stream[2] = {};       // phmm_region_compute, small calls: the aligner over every (read, haplotype) pair runs
         uint32_t *d_pair_done = nullptr;      // here, beside the PairHMM kernels; its blocks count themselves in here when done, and
         uint32_t pair_done_target = 0;        // phmm_pick_reads on the other stream waits for the count (never reset: compared modulo 2^32)
+        uint32_t finish_count = 0;            // blocks of last kernels that have counted / will count themselves in at d_pair_done[16]
+                                              // (ProjectParams::finish_counter)
         hipStream_t pair_main[2] = {};        // ... and the other kernels of such a call here (hardware queues of their own; [1]: the
                                               // pair whose two streams own disjoint halves of the CUs, phmm_region.cpp)
         uint64_t region_sw_all_calls = 0;     // how many calls went that way (phmm_get_stat "region_sw_all")

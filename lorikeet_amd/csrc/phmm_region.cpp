@@ -11,6 +11,7 @@
 // the chunk pipeline of large calls, status.  No CPU path.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -121,6 +122,7 @@ struct PendingRegion {
     uint32_t sw_capacity = 0;
     bool inline_rescue = false;   // the exact pass below -600 rode behind the forward kernels
     uint32_t pair_stride = 0;     // > 0: the aligner took every read against every haplotype of its region, beside the PairHMM kernels
+    const uint32_t *finish_flag = nullptr;  // a word of the pinned mirror the call's last kernel sets when every block of it is through
     PendingRegion() = default;
 };
 
@@ -347,10 +349,13 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         if (W.pair_main[set]) S = W.pair_main[set];
         T_all = W.all_stream[set];
-        if (!W.d_pair_done) {
-            if (!ok(h, hipMalloc((void **)&W.d_pair_done, 256), "hipMalloc") || !ok(h, hipMemset(W.d_pair_done, 0, 256), "hipMemset")) return bail(PHMM_ERR_HIP);
-            W.pair_done_target = 0;
-        }
+    }
+    // (the last kernel of a small call reports to the calling thread through the mirror: region_finish)
+    const bool flag_wait = mirror && !chained && nr && h->sw.region_flag_wait;
+    if ((pair_stride || flag_wait) && !W.d_pair_done) {
+        if (!ok(h, hipMalloc((void **)&W.d_pair_done, 256), "hipMalloc") || !ok(h, hipMemset(W.d_pair_done, 0, 256), "hipMemset")) return bail(PHMM_ERR_HIP);
+        W.pair_done_target = 0;
+        W.finish_count = 0;
     }
     bool good;
     if (mirror) {  // (the inputs are fetched by blocks of the pre-step's launch, below)
@@ -542,6 +547,11 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pj.flags = (uint32_t *)(res_base + L.res + 128);
         pj.workspace = W.ws;
         pj.capacity = pj_capacity;
+        if (flag_wait) {
+            pj.finish_counter = W.d_pair_done + 16;
+            pj.finish_target = W.finish_count;  // (the launch adds its blocks)
+            pj.finish_flag = (uint32_t *)(mirror + L.res + 224);
+        }
     }
     bool used_lite = false;
     if (good && align && G.ext_stride) {  // (reads and haplotypes never get there; the aligner's own entry points handle such lengths)
@@ -551,7 +561,9 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     if (good && pair_stride) {  // the alignments were made beside all this: post-step + best allele, wait for them, projection
         pj.wait_counter = W.d_pair_done;
         pj.wait_target = W.pair_done_target;
-        good = ok(h, launch_pick(pb, pj, S), "phmm_pick_reads");
+        uint32_t blocks = 0;
+        good = ok(h, launch_pick(pb, pj, S, &blocks), "phmm_pick_reads");
+        W.finish_count += pj.finish_counter ? blocks : 0u;
     } else if (good && align) {
         SwParams sp = sw_params(A.dev);
         // (chunks of one call follow each other through the handle's one slab and workspace)
@@ -588,7 +600,9 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
             pj.workspace = W.ws;
             pj.capacity = 4 * (sw_capacity + max_hap_cigar + 2) + 8;
         }
-        good = ok(h, launch_project(pj, S), "phmm_project_kernel");
+        uint32_t blocks = 0;
+        good = ok(h, launch_project(pj, S, &blocks), "phmm_project_kernel");
+        W.finish_count += pj.finish_counter ? blocks : 0u;
         if (good && chained) {
             if (!W.region_sw_done) good = ok(h, hipEventCreateWithFlags(&W.region_sw_done, hipEventDisableTiming), "hipEventCreate");
             good = good && ok(h, hipEventRecord(W.region_sw_done, S), "hipEventRecord");
@@ -609,6 +623,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     pending->zero_copy = mirror != nullptr;
     pending->sw_capacity = sw_capacity;
     pending->pair_stride = pair_stride;
+    pending->finish_flag = flag_wait ? (const uint32_t *)(A.host + L.res + 224) : nullptr;
     pending->inline_rescue = inline_rescue;
     pending->lite = used_lite;
     return PHMM_OK;
@@ -634,7 +649,20 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
         if (code != PHMM_OK) h->err_code = code;
         return code;
     };
-    if (!ok(h, hipStreamSynchronize(S), "sync") ||
+    // A small call's last kernel has told this thread itself, through the mirror, when its last block was through: the runtime
+    // reports the same ~6 us later (tools/ubench/sync_latency.hip).  The stream is left as it is -- in order, and the next
+    // call's kernels queue up behind a kernel that has nothing left to do.  (No word within 2 ms: the ordinary wait, which
+    // also surfaces a fault.)
+    bool told = false;
+    if (p->finish_flag) {
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (uint32_t spins = 0; !told; ++spins) {
+            told = __atomic_load_n(p->finish_flag, __ATOMIC_ACQUIRE) != 0;
+            if (!told && (spins & 255u) == 255u && std::chrono::steady_clock::now() >= give_up) break;
+            if (!told) __builtin_ia32_pause();
+        }
+    }
+    if ((!told && !ok(h, hipStreamSynchronize(S), "sync")) ||
         (p->d2h_pending && (!ok(h, hipMemcpyAsync(A.host + L.res, A.dev + L.res, L.end - L.res, hipMemcpyDeviceToHost, S), "D2H results") ||
                             !ok(h, hipStreamSynchronize(S), "sync(D2H)"))))
         return done(PHMM_ERR_HIP);
