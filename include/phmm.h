@@ -524,7 +524,7 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
  * Developer switches and counters (tests, A/B measurements; never needed in production, NOTEBOOK.md §11).
  * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
  * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
- * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy", "sw_lite", "submit_gather_us", "no_fork", "region_sw_all" (pairs up to which a small phmm_region_compute call aligns every read against every haplotype beside the PairHMM kernels: -1 by load, 0 never), "region_prio", "region_cu_halves"; value -1 / 0 = back to the
+ * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy", "sw_lite", "submit_gather_us", "no_fork", "region_sw_all" (pairs up to which a small phmm_region_compute call aligns every read against every haplotype beside the PairHMM kernels: -1 by load, 0 never), "region_prio", "region_cu_halves", "region_flag_wait" (0: a small region call waits in hipStreamSynchronize instead of polling the word its last kernel stores into the pinned mirror); value -1 / 0 = back to the
  * planner's choice as documented there).  Not to be called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
  * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes" /

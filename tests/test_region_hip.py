@@ -415,3 +415,26 @@ def test_two_callers_with_private_handles_align_every_pair_at_the_same_time(hip_
     assert sum(e.stat("region_sw_all") for e in engines) > len(jobs) // 2   # (most calls did go the all-pairs way)
     for e in engines:
         e.close()
+
+
+def test_the_last_kernels_word_in_the_mirror_replaces_the_runtimes_wait(hip_engine):
+    """A small call's thread polls a word its last kernel stores into the pinned mirror (switch `region_flag_wait`; the blocks
+    of that kernel count themselves in, the last one publishes) instead of sitting in hipStreamSynchronize.  Both ways of
+    waiting, the chain and the all-pairs call, many calls in a row on one handle (the counter is never reset): equal results."""
+    cfg = _cfg(pcr=1)
+    jobs = []
+    for k in range(10):
+        b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(1200 + k, n_regions=1 + (k % 3))
+        jobs.append((b, _noisy_quals(b, k), hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars))
+    try:
+        hip_engine.set_switch("region_flag_wait", 0)
+        want = [region.region_compute(hip_engine, cfg, *j) for j in jobs]
+        hip_engine.set_switch("region_flag_wait", 1)
+        for all_pairs in (0, 1 << 20):
+            hip_engine.set_switch("region_sw_all", all_pairs)
+            for _ in range(3):
+                for j, w in zip(jobs, want):
+                    _equal_calls(region.region_compute(hip_engine, cfg, *j), w)
+    finally:
+        hip_engine.set_switch("region_sw_all", -1)
+        hip_engine.set_switch("region_flag_wait", -1)
