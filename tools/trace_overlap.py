@@ -7,6 +7,7 @@ Prints the time-weighted distribution of the number of kernels in flight, the bu
 queue, and the same for the copies.  (The per-region pipeline of tools/threads_bench: are concurrent callers' kernels
 overlapping on the device, or queueing behind each other?)"""
 import csv
+import os
 import sys
 from collections import Counter, defaultdict
 
@@ -37,6 +38,10 @@ def concurrency(iv):
 
 def main():
     iv = load(sys.argv[1])
+    tail = float(os.environ.get("TRACE_TAIL", "1"))  # e.g. 0.4: only the last 40 % of the run (warm-up and set-up excluded)
+    if tail < 1:
+        t0, t1 = min(s for s, _, _, _ in iv), max(e for _, e, _, _ in iv)
+        iv = [x for x in iv if x[0] >= t1 - tail * (t1 - t0)]
     hist, total = concurrency(iv)
     print("%d dispatches over %.1f ms" % (len(iv), total / 1e6))
     print("kernels in flight (share of the time): " + ", ".join("%d: %.1f %%" % (k, 100 * v) for k, v in hist.items()))
