@@ -643,9 +643,15 @@ def main():
             if shape == "ragged":
                 env["TB_SHAPE"] = "ragged"
                 shape = ("128", "8", "150", "300")
-            r = subprocess.run([exe, seconds, *shape, str(per_call)], env=env, capture_output=True, text=True, timeout=120)
-            m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS\s+([\d.]+) us per call", r.stdout)
-            return {"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2)), "us_per_call": float(m.group(3))}
+            # (many threads on one handle: who leads which flush is the scheduler's business, a point moves by +-10 % from run
+            # to run -- the median of three shorter runs is quoted)
+            runs = []
+            for _ in range(3 if threads >= 8 else 1):
+                secs = "%.2f" % (float(seconds) * (0.6 if threads >= 8 else 1.0))
+                r = subprocess.run([exe, secs, *shape, str(per_call)], env=env, capture_output=True, text=True, timeout=120)
+                m = re.search(r"threads:\s+(\d+) regions/s\s+([\d.]+) GCUPS\s+([\d.]+) us per call", r.stdout)
+                runs.append({"regions_per_s": int(m.group(1)), "gcups_incl_pcie": float(m.group(2)), "us_per_call": float(m.group(3))})
+            return sorted(runs, key=lambda x: x["regions_per_s"])[len(runs) // 2]
         small = ("30", "3", "150", "300")  # (what most real regions look like: a few dozen reads, two or three haplotypes)
         return {"note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
                 "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
