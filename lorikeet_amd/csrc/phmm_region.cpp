@@ -563,7 +563,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         pj.wait_target = W.pair_done_target;
         uint32_t blocks = 0;
         good = ok(h, launch_pick(pb, pj, S, &blocks), "phmm_pick_reads");
-        W.finish_count += pj.finish_counter ? blocks : 0u;
+        if (good && pj.finish_counter) W.finish_count += blocks;  // (only blocks that were launched count themselves in)
     } else if (good && align) {
         SwParams sp = sw_params(A.dev);
         // (chunks of one call follow each other through the handle's one slab and workspace)
@@ -602,7 +602,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         uint32_t blocks = 0;
         good = ok(h, launch_project(pj, S, &blocks), "phmm_project_kernel");
-        W.finish_count += pj.finish_counter ? blocks : 0u;
+        if (good && pj.finish_counter) W.finish_count += blocks;  // (only blocks that were launched count themselves in)
         if (good && chained) {
             if (!W.region_sw_done) good = ok(h, hipEventCreateWithFlags(&W.region_sw_done, hipEventDisableTiming), "hipEventCreate");
             good = good && ok(h, hipEventRecord(W.region_sw_done, S), "hipEventRecord");
