@@ -438,3 +438,45 @@ def test_the_last_kernels_word_in_the_mirror_replaces_the_runtimes_wait(hip_engi
     finally:
         hip_engine.set_switch("region_sw_all", -1)
         hip_engine.set_switch("region_flag_wait", -1)
+
+
+def test_degenerate_regions_take_every_way_of_the_call(hip_engine):
+    """Reads without haplotypes (no best allele, status 1), haplotypes without reads, one read against one haplotype, and a
+    batch mixing them: the default call, the chain with the runtime's wait, and the all-pairs call with the mirror's word give
+    the same fields."""
+    rng = np.random.default_rng(3)
+    hap = bytes(rng.choice(list(b"ACGT"), 200).astype(np.uint8))
+    other = bytearray(hap)
+    other[100] = ord("A") if hap[100] != ord("A") else ord("C")
+    other = bytes(other)
+
+    def rd(s, e):
+        b = hap[s:e]
+        return Read(b, np.full(len(b), 30, np.uint8), np.full(len(b), 45, np.uint8), np.full(len(b), 45, np.uint8), np.full(len(b), 10, np.uint8))
+    whole, cig = oracle.parse_cigar("200M"), lambda n: oracle.parse_cigar("%dM" % n)  # noqa: E731
+    cases = {
+        "reads, no haplotypes": ([([rd(10, 110)], [])], [], [], [-1], [1000], [cig(100)]),
+        "haplotypes, no reads": ([([], [hap, other])], [whole] * 2, [0, 0], [0], [1000], []),
+        "one read, one haplotype": ([([rd(10, 110)], [hap])], [whole], [0], [0], [1000], [cig(100)]),
+        "mixed": ([([rd(10, 110), rd(50, 180)], [hap, other]), ([], [hap]), ([rd(0, 60)], [other, hap])], [whole] * 5, [0] * 5, [0, 0, 1],
+                  [1000, 2000, 3000], [cig(100), cig(130), cig(60)]),
+    }
+    cfg = _cfg(pcr=1)
+    try:
+        for name, (regs, hc, hs, ref_hap, ref_start, oc) in cases.items():
+            b = RegionBatch.from_regions(regs)
+            mapq = np.full(b.n_reads, 60, np.uint8)
+            got = []
+            for sw_all, flag in ((-1, 1), (0, 0), (1 << 20, 1)):
+                hip_engine.set_switch("region_sw_all", sw_all)
+                hip_engine.set_switch("region_flag_wait", flag)
+                got.append(region.region_compute(hip_engine, cfg, b, mapq, hc, hs, ref_hap, ref_start, oc))
+            for g in got[1:]:
+                _equal_calls(g, got[0])
+            if name == "reads, no haplotypes":
+                assert got[0].best.allele_index.tolist() == [-1] and got[0].reads.status.tolist() == [1]
+            if name == "mixed":
+                assert got[0].reads.status.tolist() == [0, 0, 0] and [len(c) for c in got[0].reads.cigars] == [1, 1, 1]
+    finally:
+        hip_engine.set_switch("region_sw_all", -1)
+        hip_engine.set_switch("region_flag_wait", -1)
