@@ -463,8 +463,10 @@ def compact_line(line, full_path):
         "engine_call": pick(line.get("engine_call"), gcups_incl_pcie="gcups_incl_pcie", ms="ms_per_call", regions="regions"),
         # regions/s through host buffers, one region per call unless the name says otherwise (tools/threads_bench)
         "host_calls": None if not hc else ({"error": str(hc["error"])[:80]} if "error" in hc else {
+            "pairhmm_4t_own": rps("one_region_per_call_4_threads_own_handles"),
             "pairhmm_8t_own": rps("one_region_per_call_8_threads_own_handles"), "pairhmm_32t_shared": rps("one_region_per_call_32_threads_shared_handle_submit_wait"),
             "region_1t": rps("region_call_one_region_per_call_1_thread"), "region_1t_us": g(hc, "region_call_one_region_per_call_1_thread", "us_per_call"),
+            "region_4t_own": rps("region_call_one_region_per_call_4_threads_own_handles"),
             "region_8t_own": rps("region_call_one_region_per_call_8_threads_own_handles"),
             "region_8t_shared": rps("region_call_one_region_per_call_8_threads_shared_handle"),
             "region_32t_shared": rps("region_call_one_region_per_call_32_threads_shared_handle"),
@@ -654,6 +656,7 @@ def main():
             return sorted(runs, key=lambda x: x["regions_per_s"])[len(runs) // 2]
         small = ("30", "3", "150", "300")  # (what most real regions look like: a few dozen reads, two or three haplotypes)
         return {"note": "config-2 regions through host buffers (PCIe, planning and staging included), C++ caller threads",
+                "one_region_per_call_4_threads_own_handles": point("own", 4, 1, seconds="0.6"),
                 "one_region_per_call_8_threads_own_handles": point("own", 8, 1),
                 "one_region_per_call_32_threads_shared_handle_submit_wait": point("shared", 32, 1),
                 "eight_regions_per_call_4_threads_own_handles": point("own", 4, 8),
@@ -666,6 +669,7 @@ def main():
                 # post-step, best alleles, Smith-Waterman, projection in one enqueue, the likelihood matrix never leaving
                 # the device (the engine-level pre- and post-step are work the two-call rows above do not do)
                 "region_call_one_region_per_call_1_thread": point("fused", 1, 1),
+                "region_call_one_region_per_call_4_threads_own_handles": point("fused", 4, 1, seconds="0.6"),
                 "region_call_one_region_per_call_8_threads_own_handles": point("fused", 8, 1),
                 "region_call_one_region_per_call_8_threads_shared_handle": point("gshared", 8, 1),
                 "region_call_one_region_per_call_32_threads_shared_handle": point("gshared", 32, 1),

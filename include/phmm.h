@@ -85,7 +85,9 @@ int phmm_device_count(void);
 
 /* Create an engine on HIP device `device_id`.  Builds the quality->probability tables
  * (quality_utils.rs:82-104, pair_hmm_model.rs:47-78) once and keeps them resident in HBM;
- * owns a stream, pinned staging and device arenas that grow on demand.
+ * owns a stream, pinned staging and device arenas that grow on demand.  While at most four engines are alive on a device,
+ * each runs its one-enqueue calls on a hardware queue of its own (callers with an engine each then run side by side whatever
+ * the runtime does with ordinary streams); env PHMM_REGION_OWN_QUEUE=0 at creation turns that off.
  * Replaces PairHMM::initialize's per-region table/matrix construction (pair_hmm.rs:63-165).
  * Returns NULL on failure (phmm_last_error(NULL) has the message). */
 phmm_handle *phmm_create(int device_id, unsigned flags);

@@ -290,6 +290,7 @@ static void read_env_switches(Switches &w) {
     env("PHMM_REGION_PRIO", w.region_prio);
     env("PHMM_REGION_CU_HALVES", w.region_cu_halves);
     env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
+    env("PHMM_REGION_OWN_QUEUE", w.region_own_queue);
     w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
     w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
     w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
@@ -326,13 +327,18 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
     phmm_handle *h = new phmm_handle();
     h->device = device_id;
     h->flags = flags;
+    phmm_host::handle_born(h);
     read_env_switches(h->sw);
     const auto &eps = table_eps();
     const auto &eps3 = table_eps_third();
     const auto &mm = table_match_to_match();
     bool ok = true;
+    // (slot 0 -- the stream of every call that is one enqueue -- is a hardware queue of the handle's own where the device's pool
+    // has one left: phmm_region.cpp, queues_acquire)
     for (int i = 0; i < kSlots && ok; ++i)
         ok = hip_ok(nullptr, hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking), "hipStreamCreate");
+    h->stream0_ordinary = h->streams[0];
+    if (ok && h->sw.region_own_queue) (void)phmm_host::queues_acquire(h);  // (which of the two a call uses: latch_slot0)
     ok = ok &&
               hip_ok(nullptr, hipMalloc(&h->d_eps, 256 * sizeof(double)), "hipMalloc eps") &&
               hip_ok(nullptr, hipMalloc(&h->d_eps_mis, 256 * sizeof(double)), "hipMalloc eps_mis") &&
@@ -376,6 +382,9 @@ void phmm_destroy(phmm_handle *h) {
     if (!h) return;
     if (h->comb) phmm_host::combiner_destroy(h->comb);
     DeviceGuard dg(h->device);
+    h->streams[0] = h->stream0_ordinary;
+    phmm_host::queues_release(h);
+    phmm_host::handle_died(h);
     for (int i = 0; i < kSlots; ++i)
         if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
     if (h->d_eps) (void)hipFree(h->d_eps);
@@ -2043,6 +2052,7 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
                  const uint64_t *out_off, double *out) {
     if (!h) return PHMM_ERR_INVALID_ARG;
     PHMM_GUARD_BEGIN
+    phmm_host::latch_slot0(h);
     // the whole batch is checked before anything is indexed: the chunked path walks the caller's arrays
     h->err_code = PHMM_OK;
     if (tl_err_h == h) tl_err_h = nullptr;
@@ -2276,6 +2286,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
                         const int32_t *region_ref_hap, const uint64_t *out_off, double *out, uint8_t *keep) {
     if (!h || !cfg) return PHMM_ERR_INVALID_ARG;
     PHMM_GUARD_BEGIN
+    phmm_host::latch_slot0(h);
     h->err_code = PHMM_OK;
     if (tl_err_h == h) tl_err_h = nullptr;
     if (cfg->pcr_error_model > 3) {

@@ -50,6 +50,7 @@ extern "C" int phmm_project_to_reference(phmm_handle *h, uint32_t n_regions, con
                                          int64_t *new_pos, int32_t *status) {
     if (!h) return PHMM_ERR_INVALID_ARG;
     try {
+        phmm_host::latch_slot0(h);
         h->err_code = PHMM_OK;
         if (!n_regions) return PHMM_OK;
         if (!region_read_off || !region_hap_off || !region_ref_hap || !region_reference_start) return fail(h, "null array");

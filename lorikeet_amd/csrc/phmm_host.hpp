@@ -47,6 +47,7 @@ struct Switches {
     int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
     int region_flag_wait = 1;   // PHMM_REGION_FLAG_WAIT: 0 = a small region call's thread waits in hipStreamSynchronize instead of polling the
                                 // word its last kernel stores into the pinned mirror (A/B)
+    int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = the handle's slot-0 stream is an ordinary stream (read at phmm_create; A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
@@ -63,6 +64,7 @@ struct phmm_handle {
     int slot = 0;
     Arena &A() { return arenas[slot]; }
     hipStream_t S() { return streams[slot]; }
+    hipStream_t stream0_ordinary = nullptr;  // streams[0] is this or swork.pair_main[0] (latch_slot0)
     // the chained launches of one batch run side by side: the first on the caller's stream, the others here (phmm_batch_launch)
     static constexpr int kSideStreams = 3;
     hipStream_t side_streams[kSideStreams] = {};
@@ -98,6 +100,7 @@ struct phmm_handle {
                                               // (ProjectParams::finish_counter)
         hipStream_t pair_main[2] = {};        // ... and the other kernels of such a call here (hardware queues of their own; [1]: the
                                               // pair whose two streams own disjoint halves of the CUs, phmm_region.cpp)
+        int queue_index = -1;                 // >= 0: pair_main[0] / all_stream[0] are this handle's pair of the device's queue pool (queues_acquire)
         uint64_t region_sw_all_calls = 0;     // how many calls went that way (phmm_get_stat "region_sw_all")
         hipEvent_t region_sw_done = nullptr;  // phmm_region_compute in chunks: the slab and the workspace are one per handle, so
         bool region_sw_pending = false;       // a chunk's alignment kernels wait for those of the chunk before it
@@ -188,6 +191,15 @@ struct ChunkView {
 bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                 const uint32_t *read_off, const uint32_t *hap_off, const uint64_t *out_off, bool whole = false);
 size_t one_shot_bytes();     // per-array bytes up to which a host-buffer call goes in one shot
+// Hardware queues of a handle's own for its small region calls (phmm_region.cpp): swork.pair_main[0] / all_stream[0].
+bool queues_acquire(phmm_handle *h);
+void queues_release(phmm_handle *h);  // (phmm_destroy)
+void handle_born(phmm_handle *h);     // (phmm_create / phmm_destroy: handles alive on the device)
+void handle_died(phmm_handle *h);
+// At the top of a call: slot 0's stream is the handle's own queue while at most four handles live on the device (beyond that
+// the queues would share the command processor's four pipes pairwise, and the runtime's own multiplexing of ordinary streams
+// does better: 8 private handles, two calls per region 20.5 k regions/s against 17.5 k), else its ordinary stream.
+void latch_slot0(phmm_handle *h);
 size_t stage_in_bytes();     // inputs up to this size are fetched from the pinned mirror by a kernel
 size_t zero_copy_out_bytes();  // results up to this size are stored into the pinned mirror by the kernels
 

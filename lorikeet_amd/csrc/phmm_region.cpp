@@ -10,6 +10,7 @@
 // alignments stay in device memory from one kernel to the next.  Host side only: validation, staging, launch geometry,
 // the chunk pipeline of large calls, status.  No CPU path.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -205,6 +206,94 @@ bool ensure_sw_buffers(phmm_handle *h, size_t slab_bytes, size_t ws_bytes) {
     return true;
 }
 
+}  // namespace
+
+// ---- hardware queues of a handle's own --------------------------------------------------------------------------------------
+// The runtime maps ordinary streams onto four hardware queues by its own rule: four private handles' slot streams were seen
+// on THREE of them (rocprofv3 queue ids, `kernels in flight: 3: 76 %, 4: 0 %`), three handles' on two -- their chains of
+// dependent kernels then run one behind the other.  A stream created with a CU mask always gets a hardware queue of its own,
+// and queues whose ids are equal modulo four share a pipe of the command processor (NOTEBOOK 18.1).  So the device keeps a pool:
+// eight full-mask streams created back to back, [o0 o1 o2 o3 a0 a1 a2 a3]; the k-th handle to ask gets o(k mod 4) for its
+// calls' kernels and a((k + 2) mod 4) for the all-pairs aligner -- four handles' chains on four pipes, a handle's two queues
+// two pipes apart.  A handle takes its pair when it is created (phmm_create: o is its slot-0 stream, the stream of every call
+// that is one enqueue).  One region per call, chain: 3 threads 13.3 -> 17.4 k regions/s, 4 threads 17.7 -> 21.4 k.
+namespace {
+constexpr int kPooledHandles = 4;
+struct QueuePool {
+    std::mutex mu;
+    std::vector<std::array<hipStream_t, 8>> batches;
+    std::vector<int> free_index;
+    int next = 0;
+} g_queue_pool[16];
+}  // namespace
+
+namespace phmm_host {
+
+bool queues_acquire(phmm_handle *h) {
+    phmm_handle::SwWork &W = h->swork;
+    if (W.queue_index >= 0) return true;
+    if (W.queue_index == -2) return false;  // (refused before)
+    QueuePool &P = g_queue_pool[h->device & 15];
+    std::lock_guard<std::mutex> lk(P.mu);
+    int k;
+    if (!P.free_index.empty()) {
+        k = P.free_index.back();
+        P.free_index.pop_back();
+    } else {
+        k = P.next;
+        if (k >= kPooledHandles) {  // (further handles stay on ordinary streams: the runtime's four queues)
+            W.queue_index = -2;
+            return false;
+        }
+        if ((size_t)(k / 4) >= P.batches.size()) {
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+            const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
+            uint32_t mask[32];
+            for (uint32_t w = 0; w < 32; ++w) mask[w] = w + 1 < words || cus % 32 == 0 ? 0xffffffffu : (1u << (cus % 32)) - 1u;
+            std::array<hipStream_t, 8> b{};
+            for (hipStream_t &s : b)
+                if (hipExtStreamCreateWithCUMask(&s, words, mask) != hipSuccess) {
+                    for (hipStream_t t : b)
+                        if (t) (void)hipStreamDestroy(t);
+                    (void)hipGetLastError();
+                    W.queue_index = -2;
+                    return false;
+                }
+            P.batches.push_back(b);
+        }
+        P.next = k + 1;
+    }
+    W.queue_index = k;
+    W.pair_main[0] = P.batches[k / 4][k % 4];
+    W.all_stream[0] = P.batches[k / 4][4 + (k + 2) % 4];
+    return true;
+}
+
+void queues_release(phmm_handle *h) {
+    phmm_handle::SwWork &W = h->swork;
+    if (W.queue_index < 0) return;
+    (void)hipStreamSynchronize(W.pair_main[0]);
+    (void)hipStreamSynchronize(W.all_stream[0]);
+    QueuePool &P = g_queue_pool[h->device & 15];
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.free_index.push_back(W.queue_index);
+    W.queue_index = -1;
+    W.pair_main[0] = W.all_stream[0] = nullptr;  // (the streams stay with the pool)
+}
+
+std::atomic<int> g_live_handles[16];
+void handle_born(phmm_handle *h) { g_live_handles[h->device & 15].fetch_add(1, std::memory_order_relaxed); }
+void handle_died(phmm_handle *h) { g_live_handles[h->device & 15].fetch_sub(1, std::memory_order_relaxed); }
+void latch_slot0(phmm_handle *h) {
+    const bool own = h->swork.queue_index >= 0 && g_live_handles[h->device & 15].load(std::memory_order_relaxed) <= 4;
+    h->streams[0] = own ? h->swork.pair_main[0] : h->stream0_ordinary;
+}
+
+}  // namespace phmm_host
+
+namespace {
+
 // Stage one batch of regions in the current slot's arena and enqueue everything on its stream.  No sync.
 int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<RegionArgs> *parts, uint32_t sw_capacity, bool chained,
                    bool may_align_all, PendingRegion *pending) {
@@ -328,7 +417,9 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         // SIMD each).  HALVES: the call's kernels on one half of the CUs, the aligner on the other -- a call of a few hundred
         // pairs, whose waves the dispatcher would otherwise put on the SAME first CUs of every XCD although nine tenths of the
         // chip are idle (30 x 3: PairHMM kernel 59 us beside the aligner on shared CUs, 37 on CUs of its own, as alone).
-        const int set = n_sw <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
+        int set = n_sw <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
+        // (WHOLE is the handle's pair of the device's queue pool, above; without one: the halves, which suit any small call)
+        if (set == 0 && !queues_acquire(h)) set = 1;
         if (!W.all_stream[set]) {
             static std::mutex creation;
             std::lock_guard<std::mutex> lk(creation);
@@ -992,6 +1083,7 @@ extern "C" int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg
                                    double *confidence, uint32_t *out_cigar, uint32_t *n_out_cigar, int64_t *new_pos, int32_t *status) {
     if (!h || !cfg || !rcfg) return PHMM_ERR_INVALID_ARG;
     try {
+        phmm_host::latch_slot0(h);
         h->err_code = PHMM_OK;
         clear_thread_error(h);
         const RegionArgs a = pack_args(cfg, rcfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq,

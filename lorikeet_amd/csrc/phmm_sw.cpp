@@ -904,6 +904,7 @@ template <class F>
 int guarded(phmm_handle *h, const char *who, F &&body) {
     if (!h) return PHMM_ERR_INVALID_ARG;
     try {
+        phmm_host::latch_slot0(h);
         return body();
     } catch (const std::bad_alloc &) {
         h->err = std::string(who) + ": out of host memory";

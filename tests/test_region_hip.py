@@ -480,3 +480,30 @@ def test_degenerate_regions_take_every_way_of_the_call(hip_engine):
     finally:
         hip_engine.set_switch("region_sw_all", -1)
         hip_engine.set_switch("region_flag_wait", -1)
+
+
+def test_handles_come_and_go_with_their_hardware_queues(hip_engine):
+    """Up to four handles alive on a device run their one-enqueue calls on hardware queues of their own (the device's pool:
+    phmm_region.cpp), more than four go back to ordinary streams, and a destroyed handle's pair is handed to the next one:
+    the same results whichever stream a call ran on, handle after handle."""
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(1400, n_regions=2)
+    mapq = _noisy_quals(b, 5)
+    cfg = _cfg(pcr=2)
+    want = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+    want_lk = hip_engine.compute(b)
+    for round_ in range(3):
+        engines = [HipPairHMMEngine(0) for _ in range(2 + 3 * round_)]  # 3, 6, 9 handles alive with the fixture's
+        try:
+            for e in engines:
+                for _ in range(2):
+                    _equal_calls(region.region_compute(e, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars), want)
+                assert np.array_equal(e.compute(b), want_lk)
+        finally:
+            for e in engines:
+                e.close()
+    for _ in range(12):  # (the pool's indices go round)
+        e = HipPairHMMEngine(0)
+        try:
+            _equal_calls(region.region_compute(e, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars), want)
+        finally:
+            e.close()
