@@ -63,8 +63,8 @@ static const size_t kMixedFirstChunkBytes = getenv("PHMM_MIXED_FIRST_CHUNK_KB") 
 static const size_t kMixedChunkBytes = getenv("PHMM_MIXED_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_CHUNK_KB")) << 10 : (32u << 20);
 static const bool kNoStageThreads = getenv("PHMM_NO_STAGE_THREADS") != nullptr;  // (A/B only) large chunks staged by the calling thread alone
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
-static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (256u << 10);
-static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (64u << 10);
+static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (640u << 10);
+static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (160u << 10);
 static const int kForcedEagerD2H = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
 // (these six are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
 
@@ -1530,6 +1530,10 @@ namespace phmm_host {
 bool eager_d2h(const phmm_handle *h) {
     return kForcedEagerD2H >= 0 ? kForcedEagerD2H != 0 : !h->defer_d2h;
 }
+
+// The zero-copy path (inputs fetched from the pinned mirror by a kernel, results stored into it) has no copies to keep out of
+// each other's way: a combined flush may take it too.  (PHMM_EAGER_D2H=0 still forces the copy path, for the tests.)
+bool zero_copy_allowed(const phmm_handle *) { return kForcedEagerD2H >= 0 ? kForcedEagerD2H != 0 : true; }
 
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
 int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,

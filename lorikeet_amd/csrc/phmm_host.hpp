@@ -176,6 +176,7 @@ void batch_set_status(phmm_batch *b, uint32_t *d_status);                       
 bool batch_set_inline_rescue(phmm_handle *h, phmm_batch *b);                    // the exact pass rides behind the forward kernels (arena scratch)
 void batch_copy_out(const phmm_batch *b, const double *src, double *out);        // results -> caller, gaps of out_off untouched
 bool eager_d2h(const phmm_handle *h);
+bool zero_copy_allowed(const phmm_handle *h);  // the mirror path (no copies at all): also inside a combined flush
 
 // Regions [g0, g1) of a caller's batch with every offset array rebased to zero: what one pipelined chunk is made of.
 struct ChunkView {

@@ -381,7 +381,8 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     // the inputs from the pinned mirror, and the kernels store what the caller gets back straight into it.
     const size_t res_bytes = L.end - L.res;
     char *mirror = nullptr;
-    if (eager_d2h(h) && V.tight_out && nr && L.in_end <= stage_in_bytes() && res_bytes <= zero_copy_out_bytes()) {
+    // (also inside a combined flush of phmm_region_submit: this path has no copies to defer)
+    if (zero_copy_allowed(h) && V.tight_out && nr && L.in_end <= stage_in_bytes() && res_bytes <= zero_copy_out_bytes()) {
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, A.host, 0) == hipSuccess && dp) mirror = (char *)dp;
     }
