@@ -106,7 +106,7 @@ static void wake_queue_head(Combiner *c) {
 namespace phmm_host {
 
 void combiner_destroy(Combiner *c) {
-    if (c->trace && c->n_flushes)
+    if ((c->trace || getenv("PHMM_SUBMIT_STATS")) && c->n_flushes)  // (PHMM_SUBMIT_STATS: this line alone, for A/B runs)
         fprintf(stderr, "phmm_submit: %llu flushes carried %llu submissions, mean flush %.1f us\n",
                 (unsigned long long)c->n_flushes, (unsigned long long)c->n_parts, c->flush_us / c->n_flushes);
     for (int l = 0; l < Combiner::kMaxLanes; ++l)
