@@ -498,6 +498,12 @@ def compact_line(line, full_path):
 
 def main():
     a = parse()
+    # This process launches whole batches on streams of its own choosing; the host_calls rows are measured in child processes
+    # (tools/threads_bench).  Idle hardware queues of ANOTHER process are not free for those (a second process holding two
+    # engines with their queue pool: 115.7 -> 120.7 us per region call), so this one keeps none: its engines stay on ordinary
+    # streams, the children run with the library's defaults.
+    own_queue_given = "PHMM_REGION_OWN_QUEUE" in os.environ
+    os.environ.setdefault("PHMM_REGION_OWN_QUEUE", "0")
     D = Dist(a)
     torch, dev, rank, world = D.torch, D.dev, D.rank, D.world
     extras = not a.main_only
@@ -642,6 +648,8 @@ def main():
 
         def point(mode, threads, per_call, shape=("128", "8", "150", "300"), seconds="1.0"):
             env = dict(os.environ, TB_MODE=mode, TB_THREADS=str(threads))
+            if not own_queue_given:
+                env.pop("PHMM_REGION_OWN_QUEUE", None)
             if shape == "ragged":
                 env["TB_SHAPE"] = "ragged"
                 shape = ("128", "8", "150", "300")
