@@ -1626,7 +1626,8 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         double *d_out = (double *)(A.dev + in_bytes + 256);
         // A small one-shot call gets no D2H copy at all: its kernels store the few results straight into the pinned
         // mirror (8 bytes per pair over PCIe), and finish_compute applies the reference's `<= 0` check on the host.
-        zero_copy = eager_d2h(h) && b->tight_out && b->n_out * 8 <= kZeroCopyOutBytes && !parts;
+        // (a combined flush of phmm_submit too: nothing on this path is a copy that could get in another flush's way)
+        zero_copy = zero_copy_allowed(h) && b->tight_out && b->n_out * 8 <= kZeroCopyOutBytes;
         if (zero_copy) {
             void *dp = nullptr;
             if (hipHostGetDevicePointer(&dp, A.host + in_bytes + 256, 0) == hipSuccess && dp)
@@ -1668,7 +1669,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     pending->slot = h->slot;
     pending->out = out;
     pending->parts = parts;
-    pending->d2h_pending = !eager;
+    pending->d2h_pending = !eager && !zero_copy;
     pending->zero_copy = zero_copy;
     return PHMM_OK;
 }
@@ -2154,7 +2155,7 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         // phmm_compute: a kernel fetches the inputs from the pinned mirror, and the post-step stores keep flags and
         // normalised likelihoods -- and hands on the status word -- straight into it.
         char *mirror = nullptr;
-        if (eager_d2h(h) && b->tight_out && n_reads && in_bytes <= kStageInBytes && res_bytes <= kZeroCopyOutBytes) {
+        if (zero_copy_allowed(h) && b->tight_out && n_reads && in_bytes <= kStageInBytes && res_bytes <= kZeroCopyOutBytes) {
             void *dp = nullptr;
             if (hipHostGetDevicePointer(&dp, A.host, 0) == hipSuccess && dp) mirror = (char *)dp;
         }
