@@ -338,7 +338,6 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
     for (int i = 0; i < kSlots && ok; ++i)
         ok = hip_ok(nullptr, hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking), "hipStreamCreate");
     h->stream0_ordinary = h->streams[0];
-    if (ok && h->sw.region_own_queue) (void)phmm_host::queues_acquire(h);  // (which of the two a call uses: latch_slot0)
     ok = ok &&
               hip_ok(nullptr, hipMalloc(&h->d_eps, 256 * sizeof(double)), "hipMalloc eps") &&
               hip_ok(nullptr, hipMalloc(&h->d_eps_mis, 256 * sizeof(double)), "hipMalloc eps_mis") &&
@@ -409,6 +408,7 @@ void phmm_destroy(phmm_handle *h) {
     if (h->swork.region_sw_done) (void)hipEventDestroy(h->swork.region_sw_done);
     if (h->swork.ev_second) (void)hipEventDestroy(h->swork.ev_second);
     if (h->swork.d_pair_done) (void)hipFree(h->swork.d_pair_done);
+    phmm_host::halves_release(h);
     for (int i = 0; i < 2; ++i) {
         if (h->swork.all_stream[i]) (void)hipStreamDestroy(h->swork.all_stream[i]);
         if (h->swork.pair_main[i]) (void)hipStreamDestroy(h->swork.pair_main[i]);

@@ -47,7 +47,7 @@ struct Switches {
     int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
     int region_flag_wait = 1;   // PHMM_REGION_FLAG_WAIT: 0 = a small region call's thread waits in hipStreamSynchronize instead of polling the
                                 // word its last kernel stores into the pinned mirror (A/B)
-    int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = the handle's slot-0 stream is an ordinary stream (read at phmm_create; A/B)
+    int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
@@ -195,6 +195,8 @@ size_t one_shot_bytes();     // per-array bytes up to which a host-buffer call g
 // Hardware queues of a handle's own for its small region calls (phmm_region.cpp): swork.pair_main[0] / all_stream[0].
 bool queues_acquire(phmm_handle *h);
 void queues_release(phmm_handle *h);  // (phmm_destroy)
+bool halves_acquire(phmm_handle *h);  // swork.pair_main[1] / all_stream[1]
+void halves_release(phmm_handle *h);
 void handle_born(phmm_handle *h);     // (phmm_create / phmm_destroy: handles alive on the device)
 void handle_died(phmm_handle *h);
 // At the top of a call: slot 0's stream is the handle's own queue while at most four handles live on the device (beyond that

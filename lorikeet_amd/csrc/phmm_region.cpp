@@ -215,15 +215,17 @@ bool ensure_sw_buffers(phmm_handle *h, size_t slab_bytes, size_t ws_bytes) {
 // and queues whose ids are equal modulo four share a pipe of the command processor (NOTEBOOK 18.1).  So the device keeps a pool:
 // eight full-mask streams created back to back, [o0 o1 o2 o3 a0 a1 a2 a3]; the k-th handle to ask gets o(k mod 4) for its
 // calls' kernels and a((k + 2) mod 4) for the all-pairs aligner -- four handles' chains on four pipes, a handle's two queues
-// two pipes apart.  A handle takes its pair when it is created (phmm_create: o is its slot-0 stream, the stream of every call
-// that is one enqueue).  One region per call, chain: 3 threads 13.3 -> 17.4 k regions/s, 4 threads 17.7 -> 21.4 k.
+// two pipes apart.  A handle takes its pair at its first one-enqueue call (latch_slot0: o becomes its slot-0 stream).  One region per call, chain: 3 threads 13.3 -> 17.4 k regions/s, 4 threads 17.7 -> 21.4 k.
 namespace {
-constexpr int kPooledHandles = 4;
+constexpr int kHalvesPairs = 4;
+constexpr int kPooledHandles = 4;  // ONE batch: a second one (sixteen queues beside the runtime's four and the lanes' halves) is more than the
+                                   // command processor keeps mapped -- 30 x 3 regions from 8 threads on the shared handle 42 -> 19 k regions/s
 struct QueuePool {
     std::mutex mu;
     std::vector<std::array<hipStream_t, 8>> batches;
     std::vector<int> free_index;
     int next = 0;
+    int halves_pairs = 0;
 } g_queue_pool[16];
 }  // namespace
 
@@ -282,11 +284,50 @@ void queues_release(phmm_handle *h) {
     W.pair_main[0] = W.all_stream[0] = nullptr;  // (the streams stay with the pool)
 }
 
+// The HALVES pair of a handle (swork.pair_main[1] / all_stream[1]: the call's kernels on one half of the CUs, the all-pairs
+// aligner on the other), created back to back; at most four such pairs on a device (more mapped queues than the command
+// processor holds at a time cost every call dearly: see kPooledHandles).
+bool halves_acquire(phmm_handle *h) {
+    phmm_handle::SwWork &W = h->swork;
+    if (W.all_stream[1]) return true;
+    QueuePool &P = g_queue_pool[h->device & 15];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (P.halves_pairs >= kHalvesPairs) return false;
+    uint32_t mask_a[32], mask_b[32];
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
+    for (uint32_t w = 0; w < 32; ++w) {
+        const uint32_t all = w + 1 < words || cus % 32 == 0 ? 0xffffffffu : (1u << (cus % 32)) - 1u;
+        mask_a[w] = w >= words / 2 && words >= 2 ? 0u : all;
+        mask_b[w] = w < words / 2 ? 0u : all;
+    }
+    hipStream_t m = nullptr, t = nullptr;
+    if (hipExtStreamCreateWithCUMask(&m, words, mask_a) != hipSuccess || hipExtStreamCreateWithCUMask(&t, words, mask_b) != hipSuccess) {
+        if (m) (void)hipStreamDestroy(m);
+        (void)hipGetLastError();
+        return false;
+    }
+    W.pair_main[1] = m;
+    W.all_stream[1] = t;
+    P.halves_pairs += 1;
+    return true;
+}
+
+void halves_release(phmm_handle *h) {  // (phmm_destroy, before it destroys the two streams)
+    if (!h->swork.all_stream[1]) return;
+    QueuePool &P = g_queue_pool[h->device & 15];
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.halves_pairs -= 1;
+}
+
 std::atomic<int> g_live_handles[16];
 void handle_born(phmm_handle *h) { g_live_handles[h->device & 15].fetch_add(1, std::memory_order_relaxed); }
 void handle_died(phmm_handle *h) { g_live_handles[h->device & 15].fetch_sub(1, std::memory_order_relaxed); }
 void latch_slot0(phmm_handle *h) {
-    const bool own = h->swork.queue_index >= 0 && g_live_handles[h->device & 15].load(std::memory_order_relaxed) <= 4;
+    // (taken at the first call, not at phmm_create: a shared handle never makes one itself, its lanes do)
+    const bool few = g_live_handles[h->device & 15].load(std::memory_order_relaxed) <= 4;
+    const bool own = few && h->sw.region_own_queue && queues_acquire(h);
     h->streams[0] = own ? h->swork.pair_main[0] : h->stream0_ordinary;
 }
 
@@ -318,6 +359,12 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all
                                : in_flight <= 1 ? 2048u : in_flight == 2 ? 512u : in_flight == 3 ? 256u : 0u;
         if (max_nh >= 2 && (uint64_t)nr * max_nh <= limit) pair_stride = max_nh;
+    }
+    int pair_set = 0;  // 0 WHOLE: the handle's pair of the device's pool; 1 HALVES (see where the streams are used, below)
+    if (pair_stride) {
+        pair_set = (size_t)nr * pair_stride <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
+        if (pair_set == 0 && !queues_acquire(h)) pair_set = 1;  // (the halves suit any small call)
+        if (pair_set == 1 && !halves_acquire(h)) pair_stride = 0;  // (no queues to be had: the chain)
     }
     const Layout sizing(0, a, sw_capacity, pair_stride);
     phmm_batch *b = batch_create_in_arena(h, ng, a.region_read_off, a.region_hap_off, a.read_off, a.hap_off, a.out_off, sizing.end + 512);
@@ -420,27 +467,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         // SIMD each).  HALVES: the call's kernels on one half of the CUs, the aligner on the other -- a call of a few hundred
         // pairs, whose waves the dispatcher would otherwise put on the SAME first CUs of every XCD although nine tenths of the
         // chip are idle (30 x 3: PairHMM kernel 59 us beside the aligner on shared CUs, 37 on CUs of its own, as alone).
-        int set = n_sw <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
-        // (WHOLE is the handle's pair of the device's queue pool, above; without one: the halves, which suit any small call)
-        if (set == 0 && !queues_acquire(h)) set = 1;
-        if (!W.all_stream[set]) {
-            static std::mutex creation;
-            std::lock_guard<std::mutex> lk(creation);
-            uint32_t mask_a[32], mask_b[32];
-            int cus = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-            const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
-            for (uint32_t w = 0; w < 32; ++w) {
-                const uint32_t all = w + 1 < words || cus % 32 == 0 ? 0xffffffffu : (1u << (cus % 32)) - 1u;
-                mask_a[w] = set && w >= words / 2 && words >= 2 ? 0u : all;
-                mask_b[w] = set && w < words / 2 ? 0u : all;
-            }
-            if (hipExtStreamCreateWithCUMask(&W.pair_main[set], words, mask_a) != hipSuccess) W.pair_main[set] = nullptr;
-            if (hipExtStreamCreateWithCUMask(&W.all_stream[set], words, mask_b) != hipSuccess) {
-                W.all_stream[set] = nullptr;
-                if (!ok(h, hipStreamCreateWithFlags(&W.all_stream[set], hipStreamNonBlocking), "hipStreamCreate")) return bail(PHMM_ERR_HIP);
-            }
-        }
+        const int set = pair_set;  // (chosen -- and its queues made sure of -- where the call decided to align every pair)
         if (W.pair_main[set]) S = W.pair_main[set];
         T_all = W.all_stream[set];
     }
