@@ -301,11 +301,34 @@ __device__ __forceinline__ void project_read(const ProjectParams &p, const uint3
         const uint8_t *read = p.read_bases + p.read_off[r] + clip_l;  // the read minus its soft clips (:47-50)
         const uint32_t read_len = p.read_off[r + 1] - p.read_off[r] - clip_l - clip_r;
 
+        const uint32_t *sw = p.sw_cigar + (p.sw_cigar_off ? p.sw_cigar_off[r] : sw_at * p.sw_cigar_slot);
+        const uint32_t n_sw = p.n_sw_cigar[sw_at];
+        const uint32_t *hc = p.hap_cigar + p.hap_cigar_off[hp];
+        const uint32_t nhc = p.hap_cigar_off[hp + 1] - p.hap_cigar_off[hp];
+        uint64_t start_on_reference = 0;
+        uint32_t leading_removed = 0, trailing_removed = 0;
+        // The usual read: aligned to its haplotype without a gap or a clip (one M element over the whole read), the haplotype
+        // without a gap against the reference (one M element).  Every step below then returns what went in -- the padded cigar
+        // trimmed to the read is one M run, the two cigars applied to each other are M x read length, nothing to left-align --
+        // and the start on the reference is the haplotype's plus the alignment offset.  A lane of its own is ~1 500 dependent
+        // instructions and LDS operations for the general case (8 us of every region call's tail); this is a dozen.
+        bool plain = false;
+        if (n_sw == 1 && nhc == 1) {
+            const uint32_t e = sw[0], hce = hc[0];
+            plain = op_of(e) == OP_M && read_len > 0 && len_of(e) == read_len && op_of(hce) == OP_M && len_of(hce) > 0 &&
+                    (uint64_t)(uint32_t)sw_offset + read_len <= (uint64_t)len_of(hce) + 1000u;
+        }
+        if (plain) {
+            T.init(ws + 2 * (size_t)p.capacity, p.capacity, true);
+            if (p.capacity < 1) CHECK(CIGAR_ERR_WORKSPACE);
+            T.el[0] = elem(OP_M, read_len);
+            T.n = 1;
+            start_on_reference = p.region_reference_start[g] + p.hap_start_wrt_ref[hp] + (uint32_t)sw_offset;
+        } else {
         // :65-72 the alignment's cigar through a builder
         A.init(ws, p.capacity, true);
         {
-            const uint32_t *sw = p.sw_cigar + (p.sw_cigar_off ? p.sw_cigar_off[r] : sw_at * p.sw_cigar_slot);
-            for (uint32_t i = 0; i < p.n_sw_cigar[sw_at]; ++i)
+            for (uint32_t i = 0; i < n_sw; ++i)
                 if (A.add(sw[i]) != CIGAR_OK) break;
             CHECK(A.error);
             CHECK(A.make());
@@ -313,8 +336,6 @@ __device__ __forceinline__ void project_read(const ProjectParams &p, const uint3
         // :84-100 the haplotype's cigar, padded with 1000M, and the read's start on the reference
         B.init(ws + p.capacity, p.capacity, true);
         {
-            const uint32_t *hc = p.hap_cigar + p.hap_cigar_off[hp];
-            const uint32_t nhc = p.hap_cigar_off[hp + 1] - p.hap_cigar_off[hp];
             for (uint32_t i = 0; i < nhc; ++i)
                 if (B.add(hc[i]) != CIGAR_OK) break;
             CHECK(B.error);
@@ -336,7 +357,7 @@ __device__ __forceinline__ void project_read(const ProjectParams &p, const uint3
             }
             if (!reached) CHECK(CIGAR_ERR_PANIC);  // "Cigar doesn't reach the read start"
         }
-        const uint64_t start_on_reference = p.region_reference_start[g] + p.hap_start_wrt_ref[hp] + start_on_ref_hap;
+        start_on_reference = p.region_reference_start[g] + p.hap_start_wrt_ref[hp] + start_on_ref_hap;
 
         // :107-113 trim_cigar_by_bases(padded cigar, offset, its read length - 1): elements behind the read's end stay
         T.init(ws + 2 * (size_t)p.capacity, p.capacity, true);
@@ -376,9 +397,9 @@ __device__ __forceinline__ void project_read(const ProjectParams &p, const uint3
         }
 
         // :116-122 left_align_indels(B, reference haplotype, read, start on the reference haplotype) into T
-        uint32_t leading_removed = 0, trailing_removed = 0;
         CHECK(left_align(T, ws + 2 * (size_t)p.capacity, p.capacity, rtl, B.el, B.n, ref_seq, ref_seq_len, read, read_len, start_on_ref_hap,
                          &leading_removed, &trailing_removed));
+        }  // (the general case)
 
         // :126-130 left-alignment may have moved a deletion to the front of the read and dropped it
         new_pos = (int64_t)(start_on_reference + leading_removed);

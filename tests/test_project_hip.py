@@ -226,3 +226,32 @@ def test_a_region_without_haplotypes_leaves_its_reads_unchanged(hip_engine):
     fused = region.region_compute(hip_engine, cfg, b2, np.full(b2.n_reads, 60, np.uint8), hc, hs, rh, ref_start, orig_cigars)
     assert np.all(fused.best.allele_index[mid] == -1) and np.all(fused.reads.status[mid] == _lib.PHMM_PROJECT_UNCHANGED)
     assert np.any(fused.reads.status[:mid.start] == 0)
+
+
+def test_plain_reads_take_the_short_way_to_the_same_answer(hip_engine):
+    """A read aligned to its haplotype as one M element over its whole length, the haplotype one M element against the
+    reference: the device skips the builders (project_read, `plain`).  Haplotype CIGARs of one M element that is shorter than,
+    as long as and longer than the haplotype's bases (the reference pads with 1000M either way), every haplotype of the
+    region: status, position and CIGAR equal to the oracle's general procedure."""
+    rng = np.random.default_rng(5)
+    n_plain = 0
+    for trial, m_len in enumerate([1, 17, 150, None, 5000]):
+        b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(300 + trial, n_regions=2)
+        for a in range(b.n_haps):
+            hap_len = int(b.hap_off[a + 1] - b.hap_off[a])
+            hap_cigars[a] = oracle.parse_cigar("%dM" % (hap_len if m_len is None else m_len))
+        reg = np.repeat(np.arange(b.n_regions), np.diff(b.region_read_off.astype(np.int64)))
+        nh = np.diff(b.region_hap_off.astype(np.int64))
+        best = rng.integers(0, nh[reg]).astype(np.int32)
+        idx = b.region_hap_off[:-1].astype(np.int64)[reg] + best
+        haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(b.n_haps)]
+        reads = [b.read_bases[int(b.read_off[r]):int(b.read_off[r + 1])] for r in range(b.n_reads)]
+        aligned = SmithWatermanAligner(hip_engine).align_indexed(haps, reads, idx, ALIGNMENT_TO_BEST_HAPLOTYPE_SW_PARAMETERS, "SoftClip")
+        got = realign.project_to_reference(hip_engine, b, best, aligned, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+        for r in range(b.n_reads):
+            st, pos, cig = _oracle_read(b, r, reg[r], best[r], hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars)
+            assert got.status[r] == st, (trial, r, got.status[r], st)
+            if st == 0:
+                assert got.new_pos[r] == pos and oracle.cigar_to_string(got.cigars[r]) == cig, (trial, r, oracle.cigar_to_string(got.cigars[r]), cig)
+                n_plain += len(aligned[r].elements) == 1
+    assert n_plain > 20
