@@ -9,5 +9,6 @@ timeout $((S * 2 + 100)) python tools/soak_engine.py $S 72 2>&1 | tail -1
 timeout $((S * 2 + 100)) python tools/soak_sw.py $S 73 2>&1 | tail -1
 timeout $((S * 2 + 100)) python tools/soak_project.py $S 74 2>&1 | tail -1
 timeout $((S * 2 + 100)) python tools/soak_region.py $S 75 2>&1 | tail -1
+timeout $((S * 2 + 100)) python tools/soak_region_threads.py $S 4 76 2>&1 | tail -1
 } > gpurun_out/${R}_soak_parity.txt 2>&1
 cat gpurun_out/${R}_soak_parity.txt
