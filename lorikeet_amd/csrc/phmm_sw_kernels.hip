@@ -659,13 +659,16 @@ void phmm_sw_align_kernel(const SwParams p) {
         }
         __builtin_amdgcn_s_barrier();  // (one wave per block: a scheduling point between rounds)
     }
-    if (p.done_counter) {  // (one wave per block: its stores are behind the fence, then it is counted)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (before the block counts itself in: once the count is complete the caller may have its results and the status block's
+    // memory -- the pinned mirror, for a call that aligns every pair -- may hold the next call's inputs.  These two words,
+    // stored behind the count, landed in a later call's read bases once in a few hundred calls: tools/threads_bench TB_VERIFY)
     if (blockIdx.x == 0 && lane == 0) {
         p.status[2] = (uint32_t)(clock64() - clk0);        // shader clocks
         p.status[3] = (uint32_t)(wall_clock64() - wall0);  // 100 MHz ticks
+    }
+    if (p.done_counter) {  // (one wave per block: its stores are behind the fence, then it is counted)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include <cstring>
 #include "../include/phmm.h"
 
 struct Region {
@@ -113,7 +114,12 @@ static Region make_region(uint64_t seed, int nr_in, int nh_in, int R_in, int H_i
     for (int a = 0; a < nh; ++a) g.hc.push_back((uint32_t)H << 4);
   }
     g.out.assign((size_t)g.oo.back(), 0.0);
+    // (distinct priorities inside a region, the first haplotype -- the reference -- highest, as haplotype_alignment_tiebreaking
+    // gives them: alleles whose likelihoods tie to within the informative threshold are then chosen by priority, not by the
+    // last bits of an f64 sum -- which differ by lane geometry, i.e. by who else is in a combined flush)
     g.pri.assign(n_haps, 0);
+    for (size_t reg = 0; reg + 1 < g.rho.size(); ++reg)
+        for (uint32_t k = g.rho[reg]; k < g.rho[reg + 1]; ++k) g.pri[k] = (int32_t)(g.rho[reg + 1] - k);
     g.ref_hap.assign(per_call, 0);
     for (int reg = 0; reg < per_call; ++reg) g.rstart.push_back(1000ull * (reg + 1));
     for (size_t a = 0; a <= n_haps; ++a) g.hc_off.push_back((uint32_t)a);
@@ -206,6 +212,7 @@ int main(int argc, char **argv) {
             if (Ts.back() < 1) return 2;
         }
     }
+    const bool verify = getenv("TB_VERIFY") != nullptr;
     const char *only = getenv("TB_MODE");  // "own", "shared" or "pipeline": just that one (pipeline only when asked for)
     for (int mode = 0; mode < 6; ++mode) {
         if (only ? only[0] != "osprfg"[mode] : mode >= 2) continue;
@@ -234,11 +241,70 @@ int main(int argc, char **argv) {
                     auto call = mode == 0 ? call_own : mode == 1 ? call_shared : mode == 2 ? call_pipeline : mode == 3 ? call_realign : mode == 4 ? call_fused : call_fused_shared;
                     for (int k = 0; k < cycle; ++k)  // warm the arenas (and compute the likelihoods mode "realign" starts from)
                         if ((mode == 3 && call_own(h, regs[t][k])) || call(h, regs[t][k])) failed = 1;
+                    // TB_VERIFY=1: what the first pass gave is what every later call must give, bit for bit, whichever way the
+                    // library takes it under load (all-pairs call or chain, own queue or not, alone or in a combined flush)
+                    std::vector<Region> first;
+                    if (verify) first = regs[t];
+                    // (likelihoods within 1e-9: a combined flush may sweep a region with another lane geometry than a lone call,
+                    // which changes the order of the f64 sums by ~1e-13; everything discrete must be equal)
+                    auto same = [&](const Region &a, const Region &b) {
+                        auto close = [](const std::vector<double> &x, const std::vector<double> &y) {
+                            for (size_t i = 0; i < x.size(); ++i)
+                                if (!(x[i] == y[i] || std::fabs(x[i] - y[i]) <= 1e-9 || (std::isnan(x[i]) && std::isnan(y[i])))) return false;
+                            return true;
+                        };
+                        const char *what = nullptr;
+                        if (!close(a.out, b.out)) {
+                            what = "likelihoods";
+                            size_t n_bad = 0, first_bad = 0, last_bad = 0;
+                            for (size_t i = 0; i < a.out.size(); ++i)
+                                if (!(a.out[i] == b.out[i] || std::fabs(a.out[i] - b.out[i]) <= 1e-9)) {
+                                    if (!n_bad++) first_bad = i;
+                                    last_bad = i;
+                                }
+                            fprintf(stderr, "TB_VERIFY: %zu of %zu likelihoods differ, [%zu, %zu]: out[%zu] = %.17g, first pass %.17g (regions %zu, reads %u, haps %u); keep %s best %s pos %s status %s\n",
+                                    n_bad, a.out.size(), first_bad, last_bad, first_bad, a.out[first_bad], b.out[first_bad], a.rro.size() - 1, a.rro.back(), a.rho.back(),
+                                    a.keep == b.keep ? "=" : "DIFF", a.best == b.best ? "=" : "DIFF", a.pos == b.pos ? "=" : "DIFF", a.status == b.status ? "=" : "DIFF");
+                            for (size_t i = first_bad; i < std::min(first_bad + 8, a.out.size()); ++i) fprintf(stderr, "   out[%zu] %.6f / %.6f\n", i, a.out[i], b.out[i]);
+                        }
+                        else if (mode < 4) return true;
+                        else if (a.keep != b.keep) what = "keep";
+                        else if (a.best != b.best) {
+                            what = "best allele";
+                            for (size_t r = 0; r < a.best.size(); ++r)
+                                if (a.best[r] != b.best[r]) {
+                                    const size_t nh_r = a.out.size() / a.best.size();  // (uniform shapes)
+                                    fprintf(stderr, "TB_VERIFY: read %zu: best %d (first pass %d), lk %.17g / %.17g, conf %.17g / %.17g; row:", r, a.best[r], b.best[r], a.lk[r], b.lk[r], a.conf[r], b.conf[r]);
+                                    for (size_t k = 0; k < nh_r; ++k) fprintf(stderr, " %.17g", a.out[r * nh_r + k]);
+                                    fprintf(stderr, " | first pass:");
+                                    for (size_t k = 0; k < nh_r; ++k) fprintf(stderr, " %.17g", b.out[r * nh_r + k]);
+                                    fprintf(stderr, " | priorities:");
+                                    for (size_t k = 0; k < nh_r; ++k) fprintf(stderr, " %d", a.pri[k]);
+                                    fprintf(stderr, "\n");
+                                    break;
+                                }
+                        }
+                        else if (a.n_cig != b.n_cig) what = "cigar lengths";
+                        else if (a.pos != b.pos) what = "positions";
+                        else if (a.status != b.status) what = "status";
+                        else if (!close(a.lk, b.lk)) what = "best likelihood";
+                        else if (!close(a.conf, b.conf)) what = "confidence";
+                        else
+                            for (size_t r = 0; r < a.n_cig.size() && !what; ++r)
+                                if (memcmp(a.cig.data() + a.out_cig_off[r], b.cig.data() + b.out_cig_off[r], 4 * (size_t)a.n_cig[r])) what = "cigars";
+                        if (what) fprintf(stderr, "TB_VERIFY: %s differ\n", what);
+                        return what == nullptr;
+                    };
                     while (!go.load()) std::this_thread::yield();
                     uint64_t n = 0, cells = 0;
                     for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
                         Region &g = regs[t][k % (size_t)cycle];
                         if (call(h, g)) {
+                            failed = 1;
+                            break;
+                        }
+                        if (verify && !same(g, first[k % (size_t)cycle])) {
+                            fprintf(stderr, "TB_VERIFY: thread %d, call %zu: results differ from the first pass\n", t, k);
                             failed = 1;
                             break;
                         }
