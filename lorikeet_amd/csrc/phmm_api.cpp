@@ -291,7 +291,11 @@ static void read_env_switches(Switches &w) {
     env("PHMM_REGION_CU_HALVES", w.region_cu_halves);
     env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
     env("PHMM_REGION_OWN_QUEUE", w.region_own_queue);
+    env("PHMM_REGION_PICK_TIMEOUT_US", w.region_pick_timeout_us);
+    env("PHMM_REGION_DEBUG_PICK", w.region_debug_pick);
+    env("PHMM_MIRROR_CANARY", w.mirror_canary);
     w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
+    w.sw_clock = getenv("PHMM_SW_CLOCK") != nullptr;
     w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
     w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
     w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
@@ -316,7 +320,7 @@ const char *phmm_last_error(phmm_handle *h) {
 
 phmm_handle *phmm_create(int device_id, unsigned flags) {
     int n = phmm_device_count();
-    if (device_id < 0 || device_id >= n) {
+    if (device_id < 0 || device_id >= n || device_id >= kMaxDevices) {
         std::lock_guard<std::mutex> g(g_err_mu);
         g_create_err = "phmm_create: no HIP device with that id (this engine has no CPU fallback)";
         return nullptr;
@@ -795,6 +799,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             if (!ok) return nullptr;
             A.cap = cap;
         }
+        if (!canary_before_staging(h, A)) return nullptr;  // (PHMM_MIRROR_CANARY: a store landed in the last call's result block after it returned)
         A.used = 0;
         b->arena = &A;
     }
@@ -1145,6 +1150,9 @@ int phmm_batch_share_prefixes(phmm_batch *b, const uint8_t *hap_bases) {
     if (b->share.regions) return PHMM_OK;  // (done already)
     PHMM_GUARD_BEGIN
     if (h->flags & PHMM_FLAG_F32_FIRST) return PHMM_OK;  // (the f32 sweep has no such kernels)
+    // (suffix items leave NaN + STATUS_RESCUE for reads the scaled sweep cannot hold and rely on the exact pass behind them: with
+    // PHMM_NO_RESCUE that pass never runs and the NaNs would reach the caller under PHMM_OK -- such a handle keeps the plain plan)
+    if (h->sw.no_rescue) return PHMM_OK;
     DeviceGuard dg(h->device);
     const uint32_t *rro = b->h_rro.data(), *rho = b->h_rho.data(), *ro = b->h_ro.data(), *ho = b->h_ho.data();
     auto cost_of = [](int K) { return 7.0 * K + 11.0; };
@@ -1535,6 +1543,57 @@ bool eager_d2h(const phmm_handle *h) {
 // each other's way: a combined flush may take it too.  (PHMM_EAGER_D2H=0 still forces the copy path, for the tests.)
 bool zero_copy_allowed(const phmm_handle *) { return kForcedEagerD2H >= 0 ? kForcedEagerD2H != 0 : true; }
 
+// ---- PHMM_MIRROR_CANARY ------------------------------------------------------------------------------------------------
+// Small calls hand inputs and results over through the pinned mirror, and their kernels tell the calling thread themselves
+// when they are through (region_finish): nothing but the kernels' own ordering stands between a late store and the next
+// call's staged inputs.  Round 4 shipped such a store (two timing words of the aligner, NOTEBOOK 18.7) that only a C++
+// caller saw, as one read's likelihoods 20 decades low.  With the switch set every such store is a failed call:
+//   * when a zero-copy call returns, its result block in the mirror is filled with 0xA5 and must still be 0xA5 when the arena
+//     is staged again (a store that lands between two calls);
+//   * the inputs a zero-copy call staged are kept aside and compared with the mirror when the call ends (a store that lands
+//     in the NEXT call's inputs -- the device never writes there).
+static bool canary_fail(phmm_handle *h, const char *what, size_t at, unsigned got) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "PHMM_MIRROR_CANARY: %s: pinned mirror offset %zu holds 0x%02x", what, at, got);
+    fprintf(stderr, "%s\n", msg);
+    if (h->sw.mirror_canary >= 2) abort();
+    h->err = msg;
+    h->err_code = PHMM_ERR_INTERNAL;
+    return false;
+}
+bool canary_before_staging(phmm_handle *h, Arena &A) {
+    A.canary_inputs.clear();
+    if (!h->sw.mirror_canary || !A.canary_bytes || !A.host) return true;
+    const size_t off = A.canary_off, n = A.canary_bytes;
+    A.canary_bytes = 0;
+    if (off + n > A.cap) return true;  // (the arena was replaced by a larger one)
+    const unsigned char *q = (const unsigned char *)A.host + off;
+    for (size_t i = 0; i < n; ++i)
+        if (q[i] != 0xA5) return canary_fail(h, "a device store landed in a result block after its call had returned", off + i, q[i]);
+    return true;
+}
+void canary_staged(phmm_handle *h, Arena &A, size_t in_bytes) {
+    if (!h->sw.mirror_canary) return;
+    A.canary_inputs.assign((const unsigned char *)A.host, (const unsigned char *)A.host + in_bytes);
+}
+bool canary_after_call(phmm_handle *h, Arena &A, size_t res_off, size_t res_bytes) {
+    if (!h->sw.mirror_canary) return true;
+    bool good = true;
+    const size_t n = std::min(A.canary_inputs.size(), A.cap);
+    if (n && memcmp(A.host, A.canary_inputs.data(), n) != 0) {
+        size_t i = 0;
+        while (i < n && (unsigned char)A.host[i] == A.canary_inputs[i]) ++i;
+        good = canary_fail(h, "a device store landed in the staged inputs of a call", i, (unsigned char)A.host[i]);
+    }
+    A.canary_inputs.clear();
+    if (res_off + res_bytes <= A.cap) {
+        memset(A.host + res_off, 0xA5, res_bytes);
+        A.canary_off = res_off;
+        A.canary_bytes = res_bytes;
+    }
+    return good;
+}
+
 // Stage one batch in the current slot's arena and enqueue H2D, kernels and D2H on its stream.  No sync.
 int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
                     const uint32_t *read_off, const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q,
@@ -1639,6 +1698,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
         // dependency in front of the first launch; phmm_cigar_kernels.hip)
         void *host_dp = nullptr;
         if (zero_copy && in_bytes + 256 <= kStageInBytes && hipHostGetDevicePointer(&host_dp, A.host, 0) == hipSuccess && host_dp) {
+            canary_staged(h, A, in_bytes);
             if (!hip_ok(h, launch_stage_in(host_dp, A.dev, in_bytes + 256, h->S()), "phmm_stage_in_kernel")) st = PHMM_ERR_HIP;
         } else if (!hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes + 256, hipMemcpyHostToDevice, h->S()), "H2D batch")) {
             st = PHMM_ERR_HIP;
@@ -1669,6 +1729,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
     pending->slot = h->slot;
     pending->out = out;
     pending->parts = parts;
+    pending->stream = h->S();
     pending->d2h_pending = !eager && !zero_copy;
     pending->zero_copy = zero_copy;
     return PHMM_OK;
@@ -1750,7 +1811,7 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
     int st = PHMM_OK;
     phmm_batch *b = p->b;
     Arena &A = h->arenas[p->slot];
-    hipStream_t S = h->streams[p->slot];
+    hipStream_t S = p->stream ? p->stream : h->streams[p->slot];
     const size_t res_bytes = 256 + b->n_out * 8;
     auto fetch = [&]() {  // [status | out] -> pinned mirror
         return hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, res_bytes, hipMemcpyDeviceToHost, S),
@@ -1814,6 +1875,8 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
                 h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
                 st = PHMM_ERR_POSITIVE_RESULT;
             }
+            // (PHMM_MIRROR_CANARY: the results are with the caller -- nothing may store into this call's block from here on)
+            if (p->zero_copy && !canary_after_call(h, A, b->out_arena_off, res_bytes) && st == PHMM_OK) st = PHMM_ERR_INTERNAL;
         }
     }
     std::string keep = h->err;
@@ -2081,6 +2144,8 @@ namespace {
 struct PendingEngine {
     phmm_batch *b = nullptr;
     int slot = 0;
+    hipStream_t stream = nullptr;  // the stream the batch was enqueued on
+    bool zero_copy = false;        // the kernels stored the results into the pinned mirror
     double *out = nullptr;
     uint8_t *keep = nullptr;
     size_t res_off = 0, keep_bytes = 0, res_bytes = 0;
@@ -2162,6 +2227,7 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
         bool ok;
         if (mirror) {
             b->d_status = d_status_in;
+            canary_staged(h, A, in_bytes);
             ok = hip_ok(h, launch_stage_in(mirror, A.dev, in_bytes, h->S()), "phmm_stage_in_kernel");
         } else {
             ok = hip_ok(h, hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, h->S()), "H2D batch") &&
@@ -2233,6 +2299,8 @@ int engine_enqueue(phmm_handle *h, const phmm_engine_config *cfg, uint32_t n_reg
             pending->slot = h->slot;
             pending->out = out;
             pending->keep = keep;
+            pending->stream = h->S();
+            pending->zero_copy = mirror != nullptr;
             pending->res_off = res_off;
             pending->keep_bytes = keep_bytes;
             pending->n_reads = n_reads;
@@ -2252,8 +2320,8 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
     if (!p->b) return PHMM_OK;
     int st = PHMM_OK;
     phmm_batch *b = p->b;
-    const Arena &A = h->arenas[p->slot];
-    hipStream_t S = h->streams[p->slot];
+    Arena &A = h->arenas[p->slot];
+    hipStream_t S = p->stream ? p->stream : h->streams[p->slot];
     if (!hip_ok(h, hipStreamSynchronize(S), "sync") ||
         (p->d2h_pending &&
          (!hip_ok(h, hipMemcpyAsync(A.host + p->res_off, A.dev + p->res_off, p->res_bytes, hipMemcpyDeviceToHost, S),
@@ -2274,6 +2342,7 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
             h->err = "PairHmm Log Probability cannot be greater than 0.0";  // pair_hmm.rs:478-481
             st = PHMM_ERR_POSITIVE_RESULT;
         }
+        if (p->zero_copy && !canary_after_call(h, A, p->res_off, p->res_bytes) && st == PHMM_OK) st = PHMM_ERR_INTERNAL;
     }
     std::string keep_err = h->err;
     phmm_batch_destroy(b);
@@ -2387,10 +2456,14 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "sw_chunks") w.sw_chunks = value > 0 ? value : 0;
     else if (n == "sw_transpose") w.sw_transpose = value < 0 ? -1 : value > 0 ? 1 : 0;
     else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
+    else if (n == "sw_clock") w.sw_clock = value != 0;
     else if (n == "region_sw_all") w.region_sw_all = value < 0 ? -1 : value;
     else if (n == "region_prio") w.region_prio = value > 0 ? value : 0;
     else if (n == "region_cu_halves") w.region_cu_halves = value != 0;
     else if (n == "region_flag_wait") w.region_flag_wait = value != 0;
+    else if (n == "region_pick_timeout_us") w.region_pick_timeout_us = value > 0 ? value : 1;
+    else if (n == "region_debug_pick") w.region_debug_pick = value > 0 ? value : 0;
+    else if (n == "mirror_canary") w.mirror_canary = value > 0 ? value : 0;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";
@@ -2411,6 +2484,7 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "sw_second_pass") return h->swork.last_second_pass;
     else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
     else if (n == "region_sw_all") own = h->swork.region_sw_all_calls;
+    else if (n == "region_pick_timeouts") own = h->swork.region_pick_timeouts;
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }

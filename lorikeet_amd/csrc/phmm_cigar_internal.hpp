@@ -41,13 +41,14 @@ struct ProjectParams {
     uint32_t *out_cigar, *n_out_cigar;
     int64_t *new_pos;
     int32_t *status;
-    uint32_t *flags;                   // bit 0: some cigar did not fit its slot
+    uint32_t *flags;                   // [0] bit 0: some cigar did not fit its slot; [1] (phmm_pick_reads) != 0: the wait for the aligner ran out of time
     uint32_t *workspace;               // [n_reads - r_begin][4][capacity]
     uint32_t capacity;
     // phmm_pick_reads only: the aligner ran on another stream -- wait until *wait_counter has reached wait_target (its blocks
     // count themselves in behind a release, SwParams::done_counter; compared modulo 2^32) instead of for an event
     const uint32_t *wait_counter;
     uint32_t wait_target;
+    uint32_t wait_ticks;               // how long a lane waits at most, in ticks of the 100 MHz clock (wall_clock64); then flags[1] = 1
     // The call's LAST kernel, results straight into the pinned mirror: every block counts itself in behind a release
     // (*finish_counter, device memory, never reset), and the one that brings the count to finish_target stores 1 into
     // *finish_flag -- a word of the mirror the calling thread polls instead of waiting in hipStreamSynchronize (the runtime

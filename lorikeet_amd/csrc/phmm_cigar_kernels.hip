@@ -470,8 +470,27 @@ __device__ __forceinline__ void pick_read(const PostBestParams &pb, const Projec
         best_allele_of(pb.best, r, g, keep != 0, !(pb.skip_single_allele && nh == 1));
     }
     if (p.wait_counter) {  // the alignments come from a kernel on another stream: until every block of it has counted itself in
-        while ((int32_t)(__hip_atomic_load(p.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_target) < 0)
+        // The wait is BOUNDED (ProjectParams::wait_ticks of the 100 MHz clock): forward progress of that other kernel rests on
+        // the two streams owning different hardware queues, which is how this runtime maps CU-masked streams, not a contract.
+        // Out of time (the queues were multiplexed into one, the aligner faulted, its queue is not mapped): the lane raises
+        // flags[1], projects nothing and leaves -- the kernel always ends, the host synchronises both streams
+        // and runs the call again the chained way (region_one_shot).
+        const uint64_t t0 = wall_clock64();
+        bool in_time = true;
+        while ((int32_t)(__hip_atomic_load(p.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_target) < 0) {
+            if (wall_clock64() - t0 > (uint64_t)p.wait_ticks) {
+                in_time = false;
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
+        }
+        if (!in_time) {
+            p.flags[1] = 1u;  // (a word of its own, a plain store: the block may live in the caller's pinned memory)
+            p.status[r] = CIGAR_UNCHANGED;
+            p.new_pos[r] = 0;
+            p.n_out_cigar[r] = 0;
+            return;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_ws[];

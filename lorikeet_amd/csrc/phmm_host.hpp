@@ -20,6 +20,11 @@ struct Arena {
     size_t cap = 0, used = 0;
     double *rescue = nullptr;  // scratch of phmm_rescue for batches staged in this arena (grown on demand)
     size_t rescue_cap = 0;
+    // PHMM_MIRROR_CANARY (debug): the result block of the last zero-copy call staged here was poisoned when the call returned
+    // and must still be poison when the arena is staged again; and the inputs a zero-copy call staged must still be what was
+    // staged when the call ends -- a device store that lands in the pinned mirror after (or outside) its call fails loudly
+    size_t canary_off = 0, canary_bytes = 0;
+    std::vector<unsigned char> canary_inputs;
 };
 
 // Developer switches: read from the PHMM_* environment variables ONCE, in phmm_create, and
@@ -43,10 +48,17 @@ struct Switches {
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
     int sw_transpose = -1;      // PHMM_SW_TRANSPOSE: 0 = small calls never sweep along the alternate sequence, 1 = whenever possible, -1 = by cost
+    int sw_clock = 0;           // PHMM_SW_CLOCK: the aligner's block 0 reports the shader clock it ran at (phmm_get_stat "sw_clock_mhz"; also with PHMM_TRACE)
     int sw_no_zero_copy = 0;    // PHMM_SW_NO_ZERO_COPY: small one-piece calls fetch their results by copies like large ones (A/B only)
     int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
     int region_flag_wait = 1;   // PHMM_REGION_FLAG_WAIT: 0 = a small region call's thread waits in hipStreamSynchronize instead of polling the
                                 // word its last kernel stores into the pinned mirror (A/B)
+    int region_pick_timeout_us = 5000;  // PHMM_REGION_PICK_TIMEOUT_US: how long phmm_pick_reads waits for the all-pairs aligner on the other
+                                // stream before it gives up (the host then runs the call again the chained way)
+    int region_debug_pick = 0;  // PHMM_REGION_DEBUG_PICK (tests): 1 = the all-pairs aligner is enqueued BEHIND phmm_pick_reads on the call's own
+                                // stream (both on one hardware queue, in order: the wait can only run out of time); 2 = the all-pairs aligner
+                                // stores two words into the call's status block ~30 us AFTER it has counted itself in (round 4's bug, on purpose)
+    int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
@@ -54,6 +66,7 @@ struct Switches {
 };
 
 constexpr int kSlots = 3;  // pipeline depth of the chunked host path
+constexpr int kMaxDevices = 64;  // per-device tables of the process (queue pool, calls in flight); phmm_create refuses ids beyond
 
 
 struct phmm_handle {
@@ -102,6 +115,8 @@ struct phmm_handle {
                                               // pair whose two streams own disjoint halves of the CUs, phmm_region.cpp)
         int queue_index = -1;                 // >= 0: pair_main[0] / all_stream[0] are this handle's pair of the device's queue pool (queues_acquire)
         uint64_t region_sw_all_calls = 0;     // how many calls went that way (phmm_get_stat "region_sw_all")
+        uint64_t region_pick_timeouts = 0;    // ... and how many of them were run again as the chain because phmm_pick_reads' wait ran
+                                              // out of time (phmm_get_stat "region_pick_timeouts")
         hipEvent_t region_sw_done = nullptr;  // phmm_region_compute in chunks: the slab and the workspace are one per handle, so
         bool region_sw_pending = false;       // a chunk's alignment kernels wait for those of the chunk before it
         std::unordered_map<uint64_t, int> blocks_per_cu;  // by (lanes, columns, LDS bytes): asked of the runtime once
@@ -132,6 +147,7 @@ struct Parts {
 struct PendingCompute {
     phmm_batch *b = nullptr;
     int slot = 0;
+    hipStream_t stream = nullptr;  // the stream the batch was enqueued on (slot 0's may change between calls: latch_slot0)
     double *out = nullptr;
     const Parts *parts = nullptr;  // non-null: results go to parts->out[s] instead of `out`
     bool d2h_pending = false;      // the D2H copy of [status | out] is still to be issued (see eager_d2h)
@@ -203,6 +219,12 @@ void handle_died(phmm_handle *h);
 // the queues would share the command processor's four pipes pairwise, and the runtime's own multiplexing of ordinary streams
 // does better: 8 private handles, two calls per region 20.5 k regions/s against 17.5 k), else its ordinary stream.
 void latch_slot0(phmm_handle *h);
+// PHMM_MIRROR_CANARY (no-ops unless the switch is set).  before_staging: the poison of the arena's last zero-copy call is
+// intact (false: h->err / err_code are set).  staged: a zero-copy call has staged `in_bytes` of inputs -- keep a copy.
+// after_call: the inputs are still what was staged, then poison [res_off, res_off + res_bytes) (false as above).
+bool canary_before_staging(phmm_handle *h, Arena &A);
+void canary_staged(phmm_handle *h, Arena &A, size_t in_bytes);
+bool canary_after_call(phmm_handle *h, Arena &A, size_t res_off, size_t res_bytes);
 size_t stage_in_bytes();     // inputs up to this size are fetched from the pinned mirror by a kernel
 size_t zero_copy_out_bytes();  // results up to this size are stored into the pinned mirror by the kernels
 

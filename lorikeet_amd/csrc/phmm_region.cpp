@@ -124,17 +124,21 @@ struct PendingRegion {
     bool inline_rescue = false;   // the exact pass below -600 rode behind the forward kernels
     uint32_t pair_stride = 0;     // > 0: the aligner took every read against every haplotype of its region, beside the PairHMM kernels
     const uint32_t *finish_flag = nullptr;  // a word of the pinned mirror the call's last kernel sets when every block of it is through
+    hipStream_t all_stream = nullptr;       // pair_stride > 0: the stream the all-pairs aligner was enqueued on
     PendingRegion() = default;
 };
 
 constexpr size_t kHalvesUpToPairs = 512;  // (read, haplotype) pairs up to which a call's two streams get half the CUs each
-std::atomic<int> g_region_calls[16];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
+std::atomic<int> g_region_calls[kMaxDevices];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
 struct InFlight {
     std::atomic<int> &n;
-    explicit InFlight(int device) : n(g_region_calls[device & 15]) { n.fetch_add(1, std::memory_order_relaxed); }
+    explicit InFlight(int device) : n(g_region_calls[device % kMaxDevices]) { n.fetch_add(1, std::memory_order_relaxed); }
     ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
 };
 
+// region_finish -> region_one_shot: phmm_pick_reads gave up waiting for the all-pairs aligner (ProjectParams::wait_ticks); both
+// streams are idle again, nothing was handed over, the call goes round once more the chained way.  Never leaves this file.
+constexpr int kPickTimedOut = -1000;
 constexpr uint32_t kFirstSwCapacity = 24;  // CIGAR elements reserved per read -> haplotype alignment (grown and redone when one needs more)
 
 }  // namespace
@@ -226,7 +230,7 @@ struct QueuePool {
     std::vector<int> free_index;
     int next = 0;
     int halves_pairs = 0;
-} g_queue_pool[16];
+} g_queue_pool[kMaxDevices];
 }  // namespace
 
 namespace phmm_host {
@@ -235,7 +239,7 @@ bool queues_acquire(phmm_handle *h) {
     phmm_handle::SwWork &W = h->swork;
     if (W.queue_index >= 0) return true;
     if (W.queue_index == -2) return false;  // (refused before)
-    QueuePool &P = g_queue_pool[h->device & 15];
+    QueuePool &P = g_queue_pool[h->device % kMaxDevices];
     std::lock_guard<std::mutex> lk(P.mu);
     int k;
     if (!P.free_index.empty()) {
@@ -248,6 +252,7 @@ bool queues_acquire(phmm_handle *h) {
             return false;
         }
         if ((size_t)(k / 4) >= P.batches.size()) {
+            DevGuard on_device(h->device);  // (hipExtStreamCreateWithCUMask creates on the calling thread's current device)
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
             const uint32_t words = (uint32_t)std::min(32, std::max(1, (cus + 31) / 32));
@@ -277,7 +282,7 @@ void queues_release(phmm_handle *h) {
     if (W.queue_index < 0) return;
     (void)hipStreamSynchronize(W.pair_main[0]);
     (void)hipStreamSynchronize(W.all_stream[0]);
-    QueuePool &P = g_queue_pool[h->device & 15];
+    QueuePool &P = g_queue_pool[h->device % kMaxDevices];
     std::lock_guard<std::mutex> lk(P.mu);
     P.free_index.push_back(W.queue_index);
     W.queue_index = -1;
@@ -290,9 +295,10 @@ void queues_release(phmm_handle *h) {
 bool halves_acquire(phmm_handle *h) {
     phmm_handle::SwWork &W = h->swork;
     if (W.all_stream[1]) return true;
-    QueuePool &P = g_queue_pool[h->device & 15];
+    QueuePool &P = g_queue_pool[h->device % kMaxDevices];
     std::lock_guard<std::mutex> lk(P.mu);
     if (P.halves_pairs >= kHalvesPairs) return false;
+    DevGuard on_device(h->device);
     uint32_t mask_a[32], mask_b[32];
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -316,18 +322,29 @@ bool halves_acquire(phmm_handle *h) {
 
 void halves_release(phmm_handle *h) {  // (phmm_destroy, before it destroys the two streams)
     if (!h->swork.all_stream[1]) return;
-    QueuePool &P = g_queue_pool[h->device & 15];
+    QueuePool &P = g_queue_pool[h->device % kMaxDevices];
     std::lock_guard<std::mutex> lk(P.mu);
     P.halves_pairs -= 1;
 }
 
-std::atomic<int> g_live_handles[16];
-void handle_born(phmm_handle *h) { g_live_handles[h->device & 15].fetch_add(1, std::memory_order_relaxed); }
-void handle_died(phmm_handle *h) { g_live_handles[h->device & 15].fetch_sub(1, std::memory_order_relaxed); }
+std::atomic<int> g_live_handles[kMaxDevices];
+void handle_born(phmm_handle *h) { g_live_handles[h->device % kMaxDevices].fetch_add(1, std::memory_order_relaxed); }
+void handle_died(phmm_handle *h) { g_live_handles[h->device % kMaxDevices].fetch_sub(1, std::memory_order_relaxed); }
 void latch_slot0(phmm_handle *h) {
     // (taken at the first call, not at phmm_create: a shared handle never makes one itself, its lanes do)
-    const bool few = g_live_handles[h->device & 15].load(std::memory_order_relaxed) <= 4;
-    const bool own = few && h->sw.region_own_queue && queues_acquire(h);
+    const bool few = g_live_handles[h->device % kMaxDevices].load(std::memory_order_relaxed) <= 4;
+    bool own = false;
+    if (few && h->sw.region_own_queue) {
+        // (the entry points call this before their own device guard, and hipExtStreamCreateWithCUMask creates on the CALLING
+        // THREAD's current device: a worker thread of phmm_*_compute_multi, or a rayon thread of hip_backend.rs, is on device 0
+        // whatever the handle's -- the pool's streams must belong to the device they are filed under)
+        if (h->swork.queue_index == -1) {
+            DevGuard dg(h->device);
+            own = queues_acquire(h);
+        } else {
+            own = h->swork.queue_index >= 0;
+        }
+    }
     h->streams[0] = own ? h->swork.pair_main[0] : h->stream0_ordinary;
 }
 
@@ -351,7 +368,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         for (uint32_t g = 0; g < ng; ++g) max_nh = std::max(max_nh, a.region_hap_off[g + 1] - a.region_hap_off[g]);
         // (by itself only while this is the one region call in flight in the process: with several callers the chip is not idle,
         // and Nh times the aligner's work comes out of the other calls' time -- 4 threads: 21 k regions/s the plain way, 14 k this way)
-        const int in_flight = std::max<int>((int)h->busy_lanes, g_region_calls[h->device & 15].load(std::memory_order_relaxed));
+        const int in_flight = std::max<int>((int)h->busy_lanes, g_region_calls[h->device % kMaxDevices].load(std::memory_order_relaxed));
         // (... two calls of a few hundred pairs each are still small against the chip: 30 x 3 regions from two threads 141 -> 100 us
         // per call.  From four callers on every call's two queues of its own are more hardware queues than run at a time:
         // 157 -> 218 us.)
@@ -359,6 +376,16 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all
                                : in_flight <= 1 ? 2048u : in_flight == 2 ? 512u : in_flight == 3 ? 256u : 0u;
         if (max_nh >= 2 && (uint64_t)nr * max_nh <= limit) pair_stride = max_nh;
+        // (the aligner raises "empty sequence" for every pair it meets; the chain only meets a kept read against its best allele.
+        // With an empty haplotype or a read that is all soft clip in the batch the two ways could report differently for the
+        // same input -- a read the filter drops, a haplotype that is nobody's best: such a call goes the chain's way.)
+        for (uint32_t x = 0; x < nh && pair_stride; ++x)
+            if (a.hap_off[x + 1] == a.hap_off[x]) pair_stride = 0;
+        for (uint32_t r = 0; r < nr && pair_stride; ++r) {
+            const uint32_t len = a.read_off[r + 1] - a.read_off[r];
+            const uint32_t clipped = a.read_soft_clip ? a.read_soft_clip[2 * r] + a.read_soft_clip[2 * r + 1] : 0u;
+            if (clipped >= len) pair_stride = 0;
+        }
     }
     int pair_set = 0;  // 0 WHOLE: the handle's pair of the device's pool; 1 HALVES (see where the streams are used, below)
     if (pair_stride) {
@@ -480,6 +507,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     }
     bool good;
     if (mirror) {  // (the inputs are fetched by blocks of the pre-step's launch, below)
+        canary_staged(h, A, L.in_end);
         memset(A.host + L.res, 0, 256);
         batch_set_status(b, (uint32_t *)(A.dev + L.status_in));
         good = true;
@@ -529,6 +557,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         sp.pair_stride = pair_stride;
         sp.pair_single_nh = ng == 1 ? nh : 0u;
         sp.high_priority = (h->sw.region_prio & 1) ? 1u : 0u;
+        sp.report_clock = (h->sw.region_debug_pick & 2) ? 2u : 0u;  // (never the clock words here; 2 = the canary's negative control)
         sp.read_region = (const uint32_t *)(mirror + ((const char *)V.d_read_region - A.dev));
         sp.region_hap_off = (const uint32_t *)(mirror + ((const char *)V.d_region_hap_off - A.dev));
         // (no event between the streams: the aligner's blocks count themselves in, and the kernel that consumes the alignments
@@ -542,7 +571,10 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
     };
     const bool all_pairs_behind_prep = (h->sw.region_prio & 4) != 0;  // (A/B)
-    if (good && pair_stride && !all_pairs_behind_prep) launch_all_pairs();
+    // (tests: the aligner BEHIND phmm_pick_reads on the call's own stream -- in order on one queue the wait cannot be met)
+    const bool all_pairs_behind_pick = pair_stride && (h->sw.region_debug_pick & 1) != 0;
+    if (all_pairs_behind_pick) T_all = S;
+    if (good && pair_stride && !all_pairs_behind_prep && !all_pairs_behind_pick) launch_all_pairs();
     // ---- pre-step ----------------------------------------------------------------------------------------------------------
     if (good && nr) {
         PrepParams pp{};
@@ -579,7 +611,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         good = ok(h, launch_prep(pp, S), "phmm_prep_reads");
     }
-    if (good && pair_stride && all_pairs_behind_prep) launch_all_pairs();
+    if (good && pair_stride && all_pairs_behind_prep && !all_pairs_behind_pick) launch_all_pairs();
     // ---- PairHMM ---------------------------------------------------------------------------------------------------------
     // The exact pass below -600 rides in-stream -- unless no pair of this batch can get there: every likelihood is at least
     // the path "first base matched anywhere, everything else inserted", 10^-(q/10)/3 x (1 - 10^-(gcp/10)) x 10^-(ins/10) x
@@ -681,10 +713,12 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     }
     if (good && pair_stride) {  // the alignments were made beside all this: post-step + best allele, wait for them, projection
         pj.wait_counter = W.d_pair_done;
-        pj.wait_target = W.pair_done_target;
+        pj.wait_target = all_pairs_behind_pick ? W.pair_done_target + (uint32_t)workers : W.pair_done_target;
+        pj.wait_ticks = (uint32_t)std::min<uint64_t>(100ull * (uint64_t)std::max(1, h->sw.region_pick_timeout_us), 0xffffffffull);
         uint32_t blocks = 0;
         good = ok(h, launch_pick(pb, pj, S, &blocks), "phmm_pick_reads");
         if (good && pj.finish_counter) W.finish_count += blocks;  // (only blocks that were launched count themselves in)
+        if (good && all_pairs_behind_pick) launch_all_pairs();
     } else if (good && align) {
         SwParams sp = sw_params(A.dev);
         // (chunks of one call follow each other through the handle's one slab and workspace)
@@ -745,6 +779,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     pending->sw_capacity = sw_capacity;
     pending->pair_stride = pair_stride;
     pending->finish_flag = flag_wait ? (const uint32_t *)(A.host + L.res + 224) : nullptr;
+    pending->all_stream = pair_stride ? T_all : nullptr;
     pending->inline_rescue = inline_rescue;
     pending->lite = used_lite;
     return PHMM_OK;
@@ -767,7 +802,7 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
         phmm_batch_destroy(b);
         h->err = keep_err;
         p->b = nullptr;
-        if (code != PHMM_OK) h->err_code = code;
+        if (code != PHMM_OK && code != kPickTimedOut) h->err_code = code;
         return code;
     };
     // A small call's last kernel has told this thread itself, through the mirror, when its last block was through: the runtime
@@ -789,6 +824,15 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
         return done(PHMM_ERR_HIP);
     const char *hs = A.host;
     const uint32_t *sw_st = (const uint32_t *)(hs + L.res + 64);
+    if (p->pair_stride && ((const uint32_t *)(hs + L.res + 128))[1]) {
+        // phmm_pick_reads ran out of time waiting for the aligner on the other stream (the two were not running side by side: one
+        // hardware queue for both, an unmapped queue, a stalled device).  Let the aligner finish -- it writes into this call's
+        // arena -- and hand nothing over: region_one_shot runs the call again as the chain, which needs no second queue.
+        h->swork.region_pick_timeouts += 1;
+        const bool synced = ok(h, hipStreamSynchronize(S), "sync") && (!p->all_stream || ok(h, hipStreamSynchronize(p->all_stream), "sync(all pairs)"));
+        (void)canary_after_call(h, h->arenas[p->slot], L.res, L.end - L.res);
+        return done(synced ? kPickTimedOut : PHMM_ERR_HIP);
+    }
     if (p->lite) {
         const uint64_t again = *(const uint32_t *)(hs + L.res + 192);
         h->swork.last_second_pass = again;
@@ -847,20 +891,33 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
         h->err = "phmm_region_compute: a CIGAR needs more elements than its slot holds (n_out_cigar has the sizes)";
         st = PHMM_ERR_CIGAR_CAPACITY;
     }
+    // (PHMM_MIRROR_CANARY: the results are with the caller -- nothing may store into this call's block from here on)
+    if (p->zero_copy && !canary_after_call(h, h->arenas[p->slot], L.res, L.end - L.res) && st == PHMM_OK) st = PHMM_ERR_INTERNAL;
     return done(st);
 }
 
 // one batch, start to end, on the current slot; grows the alignments' slots once if one of them needs it
 int region_one_shot(phmm_handle *h, const RegionArgs &a, const std::vector<RegionArgs> *parts, uint32_t *sw_capacity) {
     const InFlight in_flight(h->device);
-    for (int attempt = 0;; ++attempt) {
+    bool may_align_all = true, grown = false;
+    for (;;) {
         PendingRegion p;
-        int st = region_enqueue(h, a, parts, *sw_capacity, false, attempt == 0, &p);
+        int st = region_enqueue(h, a, parts, *sw_capacity, false, may_align_all, &p);
         uint32_t needed = 0;
         if (st == PHMM_OK) st = region_finish(h, &p, &needed);
-        if (st == PHMM_ERR_CIGAR_CAPACITY && needed > *sw_capacity && attempt == 0) {
+        if (st == PHMM_ERR_CIGAR_CAPACITY && needed > *sw_capacity && !grown) {
             *sw_capacity = needed;
+            grown = true;
+            may_align_all = false;
             continue;
+        }
+        if (st == kPickTimedOut) {  // (only a call that aligned every pair comes back with this)
+            if (may_align_all) {
+                may_align_all = false;
+                continue;
+            }
+            h->err = "phmm_region_compute: internal error, the chained call waited for an all-pairs aligner";
+            return h->err_code = PHMM_ERR_INTERNAL;
         }
         return st;
     }

@@ -553,6 +553,7 @@ int sw_run(phmm_handle *h, const SwJob &J) {
     p.lds_alt_bytes = (uint32_t)lds_alt;
     p.lds_group_bytes = (uint32_t)lds_group;
     p.groups_per_block = (uint32_t)gpb;
+    p.report_clock = (h->sw.trace || h->sw.sw_clock) ? 1u : 0u;  // (measurement only: the status block is this call's own until it returns)
     p.ext = G.ext_stride ? W.ext : nullptr;
     p.ext_stride = G.ext_stride;
     // the offset arrays, the status word, the index and the best-allele inputs travel with the first piece -- and, when

@@ -51,6 +51,9 @@ struct SwParams {
     uint32_t pair_single_nh;               // > 0: the call is ONE region with this many haplotypes (read_region / region_hap_off are not read)
     uint32_t *done_counter;                // or null: every block adds one when it has stored its last result (behind a device-scope
                                            // release): the kernel that consumes the alignments waits for the count instead of for an event
+    uint32_t report_clock;                 // 1: block 0 stores shader clocks / 100 MHz ticks into status[2..3] (measurement: PHMM_TRACE or the
+                                           // switch "sw_clock"; phmm_sw.cpp only, whose status block is the call's own until it returns);
+                                           // 2 (tests, switch region_debug_pick bit 1): two words stored LATE, behind the count -- the canary's negative control
     uint32_t high_priority;                // 1: the waves raise their issue priority (s_setprio) over other kernels' waves on their SIMDs
     const uint32_t *read_region, *region_hap_off;
     unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of

@@ -181,7 +181,9 @@ void phmm_sw_align_kernel(const SwParams p) {
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
     if (p.high_priority) __builtin_amdgcn_s_setprio(3);
-    const long long clk0 = clock64(), wall0 = wall_clock64();  // block 0 reports the shader clock it ran at (phmm_get_stat)
+    // (block 0 reports the shader clock it ran at -- phmm_get_stat "sw_clock_mhz" -- only where the launch asks for it:
+    // SwParams::report_clock, measurement runs of the aligner's own entry points; never inside a region call)
+    const long long clk0 = p.report_clock ? clock64() : 0, wall0 = p.report_clock ? wall_clock64() : 0;
     // the alignments of this launch: [a_begin, n_alignments), or the list an earlier tags-only launch left (todo)
     const uint32_t n_items = p.todo ? *p.todo_count : p.n_alignments;
     if (p.todo && (n_items < p.todo_min || (p.todo_max && n_items > p.todo_max))) return;  // (the other geometry's launch takes this list)
@@ -661,14 +663,24 @@ void phmm_sw_align_kernel(const SwParams p) {
     }
     // (before the block counts itself in: once the count is complete the caller may have its results and the status block's
     // memory -- the pinned mirror, for a call that aligns every pair -- may hold the next call's inputs.  These two words,
-    // stored behind the count, landed in a later call's read bases once in a few hundred calls: tools/threads_bench TB_VERIFY)
-    if (blockIdx.x == 0 && lane == 0) {
+    // stored behind the count, landed in a later call's read bases once in a few hundred calls: tools/threads_bench TB_VERIFY.
+    // Since round 5 they are measurement only: no production launch stores them, and phmm_region.cpp never asks.)
+    if (p.report_clock == 1u && blockIdx.x == 0 && lane == 0) {
         p.status[2] = (uint32_t)(clock64() - clk0);        // shader clocks
         p.status[3] = (uint32_t)(wall_clock64() - wall0);  // 100 MHz ticks
     }
     if (p.done_counter) {  // (one wave per block: its stores are behind the fence, then it is counted)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (tests only, report_clock == 2: round 4's bug on purpose -- two words stored BEHIND the count, ~30 us late, i.e. when the
+    // caller may already have staged its next call where this call's status block was.  tests/test_mirror_canary.py shows
+    // that PHMM_MIRROR_CANARY turns such a store into a failed call.)
+    if (p.report_clock == 2u && blockIdx.x == 0 && lane == 0) {
+        const long long t_late = wall_clock64();
+        while (wall_clock64() - t_late < 3000) __builtin_amdgcn_s_sleep(16);
+        p.status[2] = 0xdeadbeefu;
+        p.status[3] = 0xdeadbeefu;
     }
 }
 

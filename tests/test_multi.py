@@ -48,6 +48,51 @@ def test_one_engine_per_device():
         e.close()
 
 
+def test_first_call_on_a_handle_of_another_device_than_the_threads_current_one():
+    """the entry points take the handle's own hardware queue (latch_slot0 -> queues_acquire) before their
+    device guard, and hipExtStreamCreateWithCUMask creates on the calling thread's CURRENT device.  A thread that sits on device 0
+    -- every fresh worker thread does -- making the FIRST call on a handle of device 1 must get queues of device 1: its
+    one-region calls (phmm_compute, phmm_region_compute, all-pairs and chain) equal device 0's."""
+    nd = _device_count()
+    if nd < 2:
+        pytest.skip("one HIP device visible")
+    import ctypes as C
+    import threading
+    from lorikeet_amd import region
+    from project_scenarios import scenario
+    from test_region_hip import _cfg, _equal_calls, _noisy_quals
+    hip = C.CDLL("libamdhip64.so")
+    b = synthetic.make_regions(1, 24, 4, 200, [60, 100], seed=77)
+    sc = scenario(78, n_regions=1)
+    mapq = _noisy_quals(sc[0], 78)
+    e0 = HipPairHMMEngine(0)
+    want_lk, want_region = e0.compute(b), region.region_compute(e0, _cfg(), sc[0], mapq, *sc[1:])
+    result = {}
+
+    def worker():  # a fresh thread: current device 0
+        assert hip.hipSetDevice(0) == 0
+        e1 = HipPairHMMEngine(1)
+        try:
+            result["lk"] = e1.compute(b)                    # the FIRST one-enqueue call latches the queue pair
+            for sw_all in (1 << 20, 0):
+                e1.set_switch("region_sw_all", sw_all)
+                result[sw_all] = region.region_compute(e1, _cfg(), sc[0], mapq, *sc[1:])
+            dev = C.c_int(-1)
+            hip.hipGetDevice(C.byref(dev))
+            result["device_after"] = dev.value
+        finally:
+            e1.close()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert np.array_equal(result["lk"], want_lk)
+    _equal_calls(result[1 << 20], want_region)
+    _equal_calls(result[0], want_region)
+    assert result["device_after"] == 0                      # the guards put the thread's device back
+    e0.close()
+
+
 def _region_call_over(engines, n_regions, seed=5):
     """phmm_region_compute_multi over `engines` == phmm_region_compute on the first of them, field by field."""
     from lorikeet_amd import region

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lorikeet_amd import HipPairHMMEngine, _lib, synthetic  # noqa: E402
 
 eng = HipPairHMMEngine(0)
+eng.set_switch("sw_clock", 1)
 i32p = C.POINTER(C.c_int32)
 pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
 SHAPES = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(1, 16, 2), (1, 128, 8), (1, 1024, 8), (8, 128, 8), (64, 128, 8)]

@@ -3,6 +3,7 @@
 # engine-level call, Smith-Waterman, the projection).  usage (on the GPU box): bash tools/run/soak.sh <round> [seconds each]
 R=${1:-r03}; S=${2:-150}
 cd "$(dirname "$0")/../.."
+export PHMM_MIRROR_CANARY=1   # a device store that lands in the pinned mirror outside its call fails that call (phmm_api.cpp)
 {
 timeout $((S * 2 + 100)) python tools/soak.py $S 71 2>&1 | tail -1
 timeout $((S * 2 + 100)) python tools/soak_engine.py $S 72 2>&1 | tail -1

@@ -4,7 +4,7 @@
 # usage (on the GPU box): bash tools/run/verify_threads.sh <round> [seconds per point]
 R=${1:-r04}; S=${2:-2}
 cd "$(dirname "$0")/../.."
-export TMPDIR=/tmp TB_VERIFY=1
+export TMPDIR=/tmp TB_VERIFY=1 PHMM_MIRROR_CANARY=1
 out=gpurun_out/${R}_verify_threads.txt
 mkdir -p gpurun_out
 echo "# tools/threads_bench TB_VERIFY=1, $S s per point: a line per point; 'TB_VERIFY' lines are failures" > $out

@@ -39,6 +39,7 @@ cig_off = np.arange(n + 1, dtype=np.uint64) * cap
 cigar, n_cig, off = np.zeros(n * cap, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
 prm = _lib.SwParameters(200, -150, -260, -11) if haps_mode else _lib.SwParameters(10, -15, -30, -5)
 eng = HipPairHMMEngine(0)
+eng.set_switch("sw_clock", 1)
 pp = lambda x, t: x.ctypes.data_as(t)  # noqa: E731
 args = (eng._h, n, pp(ref_off, _lib.u32p), pp(ref, _lib.u8p), pp(alt_off, _lib.u32p), pp(alt, _lib.u8p), C.byref(prm), strategy,
         pp(cig_off, _lib.u64p), pp(cigar, _lib.u32p), pp(n_cig, _lib.u32p), pp(off, C.POINTER(C.c_int32)))
