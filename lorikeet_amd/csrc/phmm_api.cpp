@@ -48,6 +48,11 @@ std::string g_create_err = "";
 // per calling thread; every other entry point resets the pair.
 thread_local std::string tl_err;
 thread_local const phmm_handle *tl_err_h = nullptr;
+thread_local bool tl_internal_create = false;  // phmm_create is making a lane / a backing handle (phmm_host::create_internal)
+// the caller's own handles alive per device, and the shared handles their small calls are routed through (phmm_host::route_shared)
+std::atomic<int> g_user_handles[kMaxDevices];
+std::mutex g_backing_mu;
+std::map<std::pair<int, unsigned>, phmm_handle *> g_backing;
 
 constexpr size_t kLdsBytesPerCU = 160 * 1024;
 constexpr size_t kLdsRowBytes = 72;  // sizeof(RowConst) in phmm_kernels.hip
@@ -294,6 +299,7 @@ static void read_env_switches(Switches &w) {
     env("PHMM_REGION_PICK_TIMEOUT_US", w.region_pick_timeout_us);
     env("PHMM_REGION_DEBUG_PICK", w.region_debug_pick);
     env("PHMM_MIRROR_CANARY", w.mirror_canary);
+    env("PHMM_ROUTE_SHARED", w.route_shared);
     w.sw_no_zero_copy = getenv("PHMM_SW_NO_ZERO_COPY") != nullptr;
     w.sw_clock = getenv("PHMM_SW_CLOCK") != nullptr;
     w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
@@ -331,6 +337,8 @@ phmm_handle *phmm_create(int device_id, unsigned flags) {
     phmm_handle *h = new phmm_handle();
     h->device = device_id;
     h->flags = flags;
+    h->internal = tl_internal_create;
+    if (!h->internal) g_user_handles[device_id].fetch_add(1, std::memory_order_relaxed);
     phmm_host::handle_born(h);
     read_env_switches(h->sw);
     const auto &eps = table_eps();
@@ -422,7 +430,23 @@ void phmm_destroy(phmm_handle *h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    const bool last_of_the_callers = !h->internal && g_user_handles[h->device].fetch_sub(1, std::memory_order_acq_rel) == 1;
+    const int device = h->device;
     delete h;
+    if (last_of_the_callers) {  // nobody is left to route: the device's backing handles go too
+        std::vector<phmm_handle *> gone;
+        {
+            std::lock_guard<std::mutex> lk(g_backing_mu);
+            for (auto it = g_backing.begin(); it != g_backing.end();)
+                if (it->first.first == device) {
+                    gone.push_back(it->second);
+                    it = g_backing.erase(it);
+                } else {
+                    ++it;
+                }
+        }
+        for (phmm_handle *b : gone) phmm_destroy(b);
+    }
 }
 
 size_t phmm_table_eps(const double **eps) {
@@ -451,6 +475,32 @@ void set_thread_error(const phmm_handle *h, const std::string &msg) {
 }
 void clear_thread_error(const phmm_handle *h) {
     if (tl_err_h == h) tl_err_h = nullptr;
+}
+
+phmm_handle *create_internal(int device, unsigned flags) {
+    struct Mark {
+        bool prev = tl_internal_create;
+        Mark() { tl_internal_create = true; }
+        ~Mark() { tl_internal_create = prev; }
+    } mark;
+    return phmm_create(device, flags);
+}
+
+phmm_handle *route_shared(phmm_handle *h) {
+    if (h->internal || h->sw_touched || h->comb || h->sw.route_shared == 0) return nullptr;
+    const int above = h->sw.route_shared < 0 ? 4 : h->sw.route_shared;
+    if (g_user_handles[h->device].load(std::memory_order_relaxed) <= above) return nullptr;
+    if (h->backing) return h->backing;  // (lives as long as one of the caller's handles does on the device: at least as long as h)
+    std::lock_guard<std::mutex> lk(g_backing_mu);
+    phmm_handle *&b = g_backing[{h->device, h->flags}];
+    if (!b) {
+        b = create_internal(h->device, h->flags);
+        if (!b) {
+            g_backing.erase({h->device, h->flags});
+            return nullptr;  // (no memory for another engine: the call stays where it is)
+        }
+    }
+    return h->backing = b;
 }
 
 const char *validate_offsets(uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off,
@@ -787,6 +837,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                             align_up(b->hap_bytes, 256) + 256 + align_up(b->n_out * 8, 256) + 4096 + extra_arena_bytes +
                             align_up((size_t)n_reads, 256) /* redo flags of the f32-first mode */;
         Arena &A = h->A();
+        if (!canary_before_staging(h, A)) return nullptr;  // (PHMM_MIRROR_CANARY: a store landed in the last call's result block after it returned)
         if (A.cap < need) {
             (void)hipStreamSynchronize(h->S());
             if (A.dev) (void)hipFree(A.dev);
@@ -799,7 +850,6 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             if (!ok) return nullptr;
             A.cap = cap;
         }
-        if (!canary_before_staging(h, A)) return nullptr;  // (PHMM_MIRROR_CANARY: a store landed in the last call's result block after it returned)
         A.used = 0;
         b->arena = &A;
     }
@@ -2134,6 +2184,19 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
         h->err = "phmm_compute: null pointer";
         return h->err_code = PHMM_ERR_INVALID_ARG;
     }
+    // (one of many private handles on the device: a one-shot call goes through the device's shared handle -- route_shared)
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes)
+        if (phmm_handle *via = route_shared(h)) {
+            uint64_t ticket = 0;
+            int st = phmm_submit(via, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp, hap_off, hap_bases,
+                                 out_off, out, &ticket);
+            if (st == PHMM_OK) st = phmm_wait(via, ticket);
+            if (st != PHMM_OK) {
+                h->err = phmm_last_error(via);
+                h->err_code = st;
+            }
+            return st;
+        }
     return compute_range(h, 0, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp,
                          hap_off, hap_bases, out_off, out);
     PHMM_GUARD_END(h, "phmm_compute", PHMM_FAIL_CODE)
@@ -2378,6 +2441,18 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
         h->err = "phmm_engine_compute: null pointer";
         return h->err_code = PHMM_ERR_INVALID_ARG;
     }
+    if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes)
+        if (phmm_handle *via = route_shared(h)) {  // (one of many private handles on the device: phmm_compute has the comment)
+            uint64_t ticket = 0;
+            int st = phmm_engine_submit(via, cfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq, hap_off,
+                                        hap_bases, region_ref_hap, out_off, out, keep, &ticket);
+            if (st == PHMM_OK) st = phmm_wait(via, ticket);
+            if (st != PHMM_OK) {
+                h->err = phmm_last_error(via);
+                h->err_code = st;
+            }
+            return st;
+        }
     DeviceGuard dg(h->device);
     // ---- small / medium batch: one shot ------------------------------------------------------------
     if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes || h->sw.no_pipeline) {
@@ -2464,11 +2539,13 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "region_pick_timeout_us") w.region_pick_timeout_us = value > 0 ? value : 1;
     else if (n == "region_debug_pick") w.region_debug_pick = value > 0 ? value : 0;
     else if (n == "mirror_canary") w.mirror_canary = value > 0 ? value : 0;
+    else if (n == "route_shared") w.route_shared = value;
     else if (n == "sw_lanes") w.sw_lanes = value == 8 || value == 16 || value == 32 || value == 64 ? value : 0;
     else {
         h->err = "phmm_set_switch: unknown switch";
         return PHMM_ERR_INVALID_ARG;
     }
+    h->sw_touched = true;  // (its calls stay on its own resources from now on: route_shared)
     if (h->comb) phmm_host::combiner_set_switches(h->comb, w);
     return PHMM_OK;
 }

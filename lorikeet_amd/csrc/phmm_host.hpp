@@ -57,7 +57,9 @@ struct Switches {
                                 // stream before it gives up (the host then runs the call again the chained way)
     int region_debug_pick = 0;  // PHMM_REGION_DEBUG_PICK (tests): 1 = the all-pairs aligner is enqueued BEHIND phmm_pick_reads on the call's own
                                 // stream (both on one hardware queue, in order: the wait can only run out of time); 2 = the all-pairs aligner
-                                // stores two words into the call's status block ~30 us AFTER it has counted itself in (round 4's bug, on purpose)
+                                // stores two words into the call's status block ~300 us AFTER it has counted itself in (round 4's bug, on purpose)
+    int route_shared = -1;      // PHMM_ROUTE_SHARED: while MORE than this many of the caller's handles are alive on a device, the one-shot calls of
+                                // private handles go through the device's shared combiner (its lanes) instead of their own streams -- -1 = 4, 0 = never
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
@@ -84,6 +86,9 @@ struct phmm_handle {
     hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
     int device = 0;
     unsigned flags = 0;
+    bool internal = false;     // a lane of a shared handle, or a device's backing handle (route_shared): not one of the caller's own
+    bool sw_touched = false;   // phmm_set_switch was called on this handle: its calls stay on its own resources (A/B runs, tests)
+    phmm_handle *backing = nullptr;  // the shared handle of (device, flags) this handle's small calls go through while many are alive
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr, *d_ratio_mis = nullptr, *d_inv_om = nullptr;
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model
     std::string err;
@@ -219,6 +224,14 @@ void handle_died(phmm_handle *h);
 // the queues would share the command processor's four pipes pairwise, and the runtime's own multiplexing of ordinary streams
 // does better: 8 private handles, two calls per region 20.5 k regions/s against 17.5 k), else its ordinary stream.
 void latch_slot0(phmm_handle *h);
+// Many private handles on one device (a handle per rayon worker, INTEGRATION.md section 4, at --threads 16 / 32): every caller
+// thread then sits in its own hipStreamSynchronize and every call is a lone latency-bound chain -- 32 private handles ran at
+// HALF the rate of 16 (threads_bench: own 32 threads 24 k regions/s against 47 k; fused 12.5 against 22 k).  Past four live
+// handles a private handle's one-shot call is therefore handed to the device's shared handle of the same flags (phmm_submit /
+// phmm_wait inside the library: concurrent callers merge into one flush, waiters sleep).  Returns that handle, or null: few
+// handles, a lane / backing handle itself, a handle whose switches were changed, or PHMM_ROUTE_SHARED=0.
+phmm_handle *route_shared(phmm_handle *h);
+phmm_handle *create_internal(int device, unsigned flags);  // phmm_create for lanes and backing handles (not counted as the caller's)
 // PHMM_MIRROR_CANARY (no-ops unless the switch is set).  before_staging: the poison of the arena's last zero-copy call is
 // intact (false: h->err / err_code are set).  staged: a zero-copy call has staged `in_bytes` of inputs -- keep a copy.
 // after_call: the inputs are still what was staged, then poison [res_off, res_off + res_bytes) (false as above).

@@ -1179,6 +1179,22 @@ extern "C" int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg
                                        best_allele, likelihood, confidence, out_cigar, n_out_cigar, new_pos, status);
         const std::string bad = region_validate(a);
         if (!bad.empty()) return fail(h, bad);
+        // (one of many private handles on the device: a one-shot call goes through the device's shared handle -- route_shared)
+        const uint32_t nr_all = region_read_off[n_regions];
+        if (nr_all && (n_regions < 8 || (size_t)read_off[nr_all] <= one_shot_bytes()))
+            if (phmm_handle *via = route_shared(h)) {
+                uint64_t ticket = 0;
+                int st = phmm_region_submit(via, cfg, rcfg, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, mapq,
+                                            read_soft_clip, hap_off, hap_bases, region_ref_hap, out_off, hap_priority, region_reference_start,
+                                            hap_cigar_off, hap_cigar, hap_start_wrt_ref, orig_cigar_off, orig_cigar, out_cigar_off, out, keep,
+                                            best_allele, likelihood, confidence, out_cigar, n_out_cigar, new_pos, status, &ticket);
+                if (st == PHMM_OK) st = phmm_wait(via, ticket);
+                if (st != PHMM_OK) {
+                    h->err = phmm_last_error(via);
+                    h->err_code = st;
+                }
+                return st;
+            }
         return region_compute(h, a);
     } catch (const std::bad_alloc &) {
         h->err = "phmm_region_compute: out of host memory";

@@ -322,7 +322,7 @@ int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
     std::lock_guard<std::mutex> lk(c->mu);
     for (int l = 0; l < c->n_lanes; ++l)
         if (!c->lane[l]) {  // first submission: the lanes are engines of their own on the same device
-            c->lane[l] = phmm_create(h->device, h->flags);
+            c->lane[l] = create_internal(h->device, h->flags);
             if (!c->lane[l]) return submit_fail(h, PHMM_ERR_HIP, phmm_last_error(nullptr));
             c->lane[l]->sw = h->sw;  // the lanes follow the shared handle's developer switches
         }

@@ -673,12 +673,13 @@ void phmm_sw_align_kernel(const SwParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // (tests only, report_clock == 2: round 4's bug on purpose -- two words stored BEHIND the count, ~30 us late, i.e. when the
+    // (tests only, report_clock == 2: round 4's bug on purpose -- two words stored BEHIND the count, ~300 us late, i.e. when the
     // caller may already have staged its next call where this call's status block was.  tests/test_mirror_canary.py shows
     // that PHMM_MIRROR_CANARY turns such a store into a failed call.)
-    if (p.report_clock == 2u && blockIdx.x == 0 && lane == 0) {
+    // (EVERY block: the one that completes the count is then ~300 us late for sure)
+    if (p.report_clock == 2u && lane == 0) {
         const long long t_late = wall_clock64();
-        while (wall_clock64() - t_late < 3000) __builtin_amdgcn_s_sleep(16);
+        while (wall_clock64() - t_late < 30000) __builtin_amdgcn_s_sleep(32);
         p.status[2] = 0xdeadbeefu;
         p.status[3] = 0xdeadbeefu;
     }

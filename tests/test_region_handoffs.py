@@ -6,7 +6,7 @@
   chain's results, and say so in `region_pick_timeouts`.
 * PHMM_MIRROR_CANARY (switch `mirror_canary`): a device store that lands in the pinned mirror after its call has returned,
   or in the staged inputs of a call, fails that call.  The negative control re-creates round 4's bug on purpose (switch
-  `region_debug_pick` = 2: the aligner stores two words ~30 us behind counting itself in) and must be caught; without the
+  `region_debug_pick` = 2: the aligner stores two words ~300 us behind counting itself in) and must be caught; without the
   bug thousands of calls of every entry point run clean under the canary.
 * tools/threads_bench TB_VERIFY=1 (C++ callers, no interpreter between the calls -- the harness that found that bug) over
   the matrix of tools/run/verify_threads.sh, as a collected test, canary on.
@@ -97,7 +97,7 @@ print("calls", 20 * len(jobs), "all-pairs", eng.stat("region_sw_all"), "timeouts
 
 
 def test_the_canary_catches_a_store_that_lands_after_its_call():
-    """Negative control: round 4's bug re-created on purpose (two words stored ~30 us behind the count).  Calls alternate between
+    """Negative control: round 4's bug re-created on purpose (two words stored ~300 us behind the count).  Calls alternate between
     a small and a larger region, so the late words of the small call land in the larger one's staged inputs, or in the
     small call's poisoned result block."""
     cfg = _cfg(pcr=3)

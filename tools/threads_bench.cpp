@@ -11,7 +11,8 @@
 // usage: threads_bench [seconds per point] [Nr Nh R H [regions per call]]      (default 1.0 s, 128 8 150 300 1 = config 2)
 // env: TB_THREADS=4,8,16 (thread counts), TB_MODE=own|shared (only that mode), TB_FLAGS=<phmm_create flags>,
 //      TB_SHAPE=ragged (every call a region of the long-tailed mix), TB_DEVICES=n (the binding's pattern on a multi-GPU node,
-//      integration/hip_backend.rs: thread t works on device t % n -- its own handle there, or that device's ONE shared handle)
+//      integration/hip_backend.rs: thread t works on device t % n -- its own handle there, or that device's ONE shared handle),
+//      TB_DEPTH=2 (shared / gshared: every thread keeps two tickets in flight -- submits region k+1 before it waits for region k)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -143,10 +144,13 @@ static int call_own(phmm_handle *h, Region &g) {
                         g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data());
 }
 
+static int submit_shared(phmm_handle *h, Region &g, uint64_t *t) {
+    return phmm_submit(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
+                       g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data(), t);
+}
 static int call_shared(phmm_handle *h, Region &g) {
     uint64_t t = 0;
-    int st = phmm_submit(h, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(), g.iq.data(), g.dq.data(),
-                         g.gcp.data(), g.ho.data(), g.haps.data(), g.oo.data(), g.out.data(), &t);
+    int st = submit_shared(h, g, &t);
     return st ? st : phmm_wait(h, t);
 }
 
@@ -179,13 +183,16 @@ static int call_fused(phmm_handle *h, Region &g) {
                                g.out.data(), g.keep.data(), g.best.data(), g.lk.data(), g.conf.data(), g.cig.data(), g.n_cig.data(), g.pos.data(),
                                g.status.data());
 }
+static int submit_fused_shared(phmm_handle *h, Region &g, uint64_t *t) {
+    return phmm_region_submit(h, &kCfg, &kRcfg, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(),
+                              g.iq.data(), g.dq.data(), g.mapq.data(), nullptr, g.ho.data(), g.haps.data(), g.ref_hap.data(), g.oo.data(),
+                              g.pri.data(), g.rstart.data(), g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(),
+                              g.out_cig_off.data(), g.out.data(), g.keep.data(), g.best.data(), g.lk.data(), g.conf.data(), g.cig.data(),
+                              g.n_cig.data(), g.pos.data(), g.status.data(), t);
+}
 static int call_fused_shared(phmm_handle *h, Region &g) {
     uint64_t t = 0;
-    int st = phmm_region_submit(h, &kCfg, &kRcfg, (uint32_t)g.rro.size() - 1, g.rro.data(), g.rho.data(), g.ro.data(), g.bases.data(), g.q.data(),
-                                g.iq.data(), g.dq.data(), g.mapq.data(), nullptr, g.ho.data(), g.haps.data(), g.ref_hap.data(), g.oo.data(),
-                                g.pri.data(), g.rstart.data(), g.hc_off.data(), g.hc.data(), g.hs.data(), g.oc_off.data(), g.oc.data(),
-                                g.out_cig_off.data(), g.out.data(), g.keep.data(), g.best.data(), g.lk.data(), g.conf.data(), g.cig.data(),
-                                g.n_cig.data(), g.pos.data(), g.status.data(), &t);
+    int st = submit_fused_shared(h, g, &t);
     return st ? st : phmm_wait(h, t);
 }
 
@@ -213,6 +220,7 @@ int main(int argc, char **argv) {
         }
     }
     const bool verify = getenv("TB_VERIFY") != nullptr;
+    const int depth = std::max(1, std::min(getenv("TB_DEPTH") ? atoi(getenv("TB_DEPTH")) : 1, 4));
     const char *only = getenv("TB_MODE");  // "own", "shared" or "pipeline": just that one (pipeline only when asked for)
     for (int mode = 0; mode < 6; ++mode) {
         if (only ? only[0] != "osprfg"[mode] : mode >= 2) continue;
@@ -297,6 +305,41 @@ int main(int argc, char **argv) {
                     };
                     while (!go.load()) std::this_thread::yield();
                     uint64_t n = 0, cells = 0;
+                    // TB_DEPTH=d (shared handles): a worker keeps d tickets in flight -- region k + d - 1 is submitted before region k
+                    // is waited for (what a caller with more work than cores does: twice the regions outstanding per thread)
+                    if (one_handle && depth > 1) {
+                        std::vector<uint64_t> tk((size_t)depth, 0);
+                        auto submit = [&](size_t k) {
+                            Region &g = regs[t][k % (size_t)cycle];
+                            return mode == 1 ? submit_shared(h, g, &tk[k % (size_t)depth]) : submit_fused_shared(h, g, &tk[k % (size_t)depth]);
+                        };
+                        size_t head = 0;  // next region to submit
+                        for (; head + 1 < (size_t)depth; ++head)
+                            if (submit(head)) failed = 1;
+                        for (size_t k = 0; !failed; ++k) {
+                            const bool more = !stop.load(std::memory_order_relaxed);
+                            if (more && submit(head++)) {
+                                failed = 1;
+                                break;
+                            }
+                            if (k >= head) break;  // (stopped and drained)
+                            Region &g = regs[t][k % (size_t)cycle];
+                            if (phmm_wait(h, tk[k % (size_t)depth])) {
+                                failed = 1;
+                                break;
+                            }
+                            if (verify && !same(g, first[k % (size_t)cycle])) {
+                                fprintf(stderr, "TB_VERIFY: thread %d, call %zu: results differ from the first pass\n", t, k);
+                                failed = 1;
+                                break;
+                            }
+                            ++n;
+                            cells += g.cells;
+                        }
+                        n_calls += n;
+                        n_cells += cells;
+                        return;
+                    }
                     for (size_t k = 0; !stop.load(std::memory_order_relaxed); ++k) {
                         Region &g = regs[t][k % (size_t)cycle];
                         if (call(h, g)) {
@@ -340,6 +383,7 @@ int main(int argc, char **argv) {
             printf("%-8s %2d threads: %8.0f regions/s  %7.1f GCUPS  %6.1f us per call per thread", mode == 0 ? "own" : mode == 1 ? "shared" : mode == 2 ? "pipeline" : mode == 3 ? "realign" : mode == 4 ? "fused" : "gshared", T,
                    rate, (double)n_cells / dt / 1e9, dt * T / (double)n_calls * 1e6);
             if (one_handle) printf("   %.2f regions per flush", f1 > f0 ? (double)(s1 - s0) / (double)(f1 - f0) : 0.0);
+            if (one_handle && depth > 1) printf("   %d tickets in flight per thread", depth);
             if (n_dev > 1) printf("   %d devices", n_dev);
             printf("\n");
             fflush(stdout);
