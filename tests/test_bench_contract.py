@@ -78,3 +78,30 @@ def test_the_compact_line_holds_the_contract_and_every_row_in_four_kilobytes():
         return [x] if isinstance(x, str) else []
     assert strings(rows) == []
     assert os.path.exists(os.path.join(ROOT, line["notes"]))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_the_n_gt_1_path_of_the_bench_runs_at_world_size_two_on_one_device():
+    """the driver's GPU box has one device, so the N > 1 code of bench.py (per-rank seeds, the gather of
+    per-rank cells, max-over-ranks timing, rank 0 alone printing) would otherwise never execute under GPUTEST.  Two ranks over
+    gloo share the device (`devices_aliased` says so): not a scaling measurement, the code path."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", TMPDIR="/tmp")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--regions", "256",
+           "--main-only"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["devices_aliased"] is True
+    prc = line["config"]["per_rank_cells"]
+    assert len(prc) == 2 and prc[0] == prc[1] == line["config"]["cells_per_gpu_per_step"]
+    # whole-job value: both ranks' cells over the slowest rank's time
+    assert abs(line["value"] - sum(prc) * 3 / (line["ms_per_step"] * 3e-3) / 1e9) <= 0.01 * line["value"]
+    assert line["roofline"]["bound"] == "valu_f64" and line["roofline"]["hbm"]["unit"] == "GB/s"
