@@ -144,8 +144,8 @@ def test_every_entry_point_is_clean_under_the_canary():
         eng.close()
 
 
-# (fused / gshared are the calls with device-side hand-offs between queues: 3 s per point; the others 1.5 s)
-MODES = [("own", 1.5), ("shared", 1.5), ("pipeline", 1.5), ("fused", 3.0), ("gshared", 3.0)]
+# (fused / gshared are the calls with device-side hand-offs between queues: 3 s per point; the others 1 s)
+MODES = [("own", 1.0), ("shared", 1.0), ("pipeline", 1.0), ("fused", 3.0), ("gshared", 3.0)]
 SHAPES = [("config2", ["128", "8", "150", "300", "1"]), ("small", ["30", "3", "150", "300", "1"]), ("ragged", None),
           ("four_per_call", ["128", "8", "150", "300", "4"])]
 
@@ -158,6 +158,7 @@ def test_cpp_callers_verify_every_call_against_its_first_pass(mode, seconds, sha
     assert os.path.exists(TB), "run __graft_entry__.build()"
     seconds = float(os.environ.get("PHMM_VERIFY_SECONDS", seconds))
     env = dict(os.environ, TB_VERIFY="1", TB_MODE=mode, TB_THREADS="1,2,3,4,8,16", PHMM_MIRROR_CANARY="1", TMPDIR="/tmp")
+    env.pop("PHMM_ROUTE_SHARED", None)      # the library's default: own / fused route through the shared lanes from five threads on
     if args is None:
         env["TB_SHAPE"] = "ragged"
     r = subprocess.run([TB, str(seconds)] + (args or []), capture_output=True, text=True, timeout=600, env=env)

@@ -232,7 +232,13 @@ def test_many_private_handles_are_served_by_the_devices_shared_lanes():
     lone = HipPairHMMEngine(0)
     work = _regions(10, 91)
     want = [lone.compute(b) for b, _ in work]
-    engines = [HipPairHMMEngine(0) for _ in range(12)]
+    import os
+    keep_env = os.environ.pop("PHMM_ROUTE_SHARED", None)     # (conftest.py switches the routing off for every other test's engines)
+    try:
+        engines = [HipPairHMMEngine(0) for _ in range(12)]   # the switch is read at phmm_create
+    finally:
+        if keep_env is not None:
+            os.environ["PHMM_ROUTE_SHARED"] = keep_env
     errors = []
 
     def worker(e):
@@ -281,8 +287,9 @@ def test_thirty_two_private_handles_are_not_slower_than_sixteen():
     from conftest import ROOT
     exe = os.path.join(ROOT, "tools", "threads_bench")
     for mode in ("own", "fused"):
-        r = subprocess.run([exe, "1.5"], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, TB_MODE=mode, TB_THREADS="16,32", TMPDIR="/tmp"))
+        env = dict(os.environ, TB_MODE=mode, TB_THREADS="16,32", TMPDIR="/tmp")
+        env.pop("PHMM_ROUTE_SHARED", None)                   # the library's default
+        r = subprocess.run([exe, "1.5"], capture_output=True, text=True, timeout=300, env=env)
         print(r.stdout, r.stderr[-1000:])
         assert r.returncode == 0, r.stdout + r.stderr
         rate = {int(t): float(v) for t, v in re.findall(r"(\d+) threads:\s+(\d+) regions/s", r.stdout)}
