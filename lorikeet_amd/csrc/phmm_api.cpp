@@ -65,7 +65,7 @@ constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
 static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
 static const size_t kMixedFirstChunkBytes = getenv("PHMM_MIXED_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_FIRST_CHUNK_KB")) << 10 : (4u << 20);
-static const size_t kMixedChunkBytes = getenv("PHMM_MIXED_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_CHUNK_KB")) << 10 : (32u << 20);
+static const size_t kMixedChunkBytes = getenv("PHMM_MIXED_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_CHUNK_KB")) << 10 : (8u << 20);
 static const bool kNoStageThreads = getenv("PHMM_NO_STAGE_THREADS") != nullptr;  // (A/B only) large chunks staged by the calling thread alone
 static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
 static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (640u << 10);
@@ -1803,7 +1803,11 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     // Mixed batches (round 4): 4 MB per array, then 8, 16, 32 ... -- every chunk of a long-tailed mix is a launch per range of K
     // with a tail of its own, and since planning and staging take 0.85 instead of 2 ms per 4 MB the device no longer waits for
     // the host: 1 536 mixed regions 24.0 ms in seven chunks of 4 MB, 20.4 in three of 4 / 8 / 16 (resident: 15.8).
-    const uint32_t step = c.f32_first ? c.index + 1 : c.mixed ? c.index : (c.index < 4 ? 0 : (c.index - 2) / 2);
+    // Round 5, the cap swept on one box (tools/hostpath_ragged_sweep.py, best of six calls, twice): 4 / 8 / 16: 18.75-18.85 ms;
+    // 4 / 8 / 8 / 7: 18.1-18.3; cap 6: 19.3-19.4; cap 12: 18.7-18.8; first chunk 3 / 6 MB: 18.5 / 20.1; a first chunk of 1 or 2 MB and
+    // 8 MB ones behind it (the device starts 0.5 ms earlier, one more set of launches): 18.1-18.3 -- so the cap is 8 MB.
+    static const bool mixed_flat = getenv("PHMM_MIXED_FLAT") != nullptr;  // (A/B: the first mixed chunk, then chunks of the cap at once)
+    const uint32_t step = c.f32_first ? c.index + 1 : c.mixed ? (mixed_flat && c.index ? 16u : c.index) : (c.index < 4 ? 0 : (c.index - 2) / 2);
     const size_t max_bytes = c.mixed && !c.f32_first ? kMixedChunkBytes : kChunkBytes;
     const size_t limit = std::min(max_bytes, (c.f32_first ? (1u << 20) / 2 : c.mixed ? kMixedFirstChunkBytes : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
     if (whole) {

@@ -752,7 +752,8 @@ int sw_run(phmm_handle *h, const SwJob &J) {
         if (ri == SW_NO_REFERENCE) continue;
         const uint64_t rows = J.best ? max_ref : ref_off[ri + 1] - ref_off[ri];  // (the device chooses the haplotype: an upper bound)
         const uint64_t cols = alt_off[a + 1] - alt_off[a];
-        const uint64_t words = lite ? (uint64_t)sw_tag_words(K) : flag_words;  // (what the second pass adds for the alignments with gaps is not counted)
+        const uint64_t words = lite ? 0ull : flag_words;  // (the tags-only sweep stores none since round 5; what the second pass adds for the
+                                                          // alignments with gaps is not counted)
         W.last_backtrack_bytes += transposed ? (cols + L - 1ull) * L * words * 4ull
                                              : (uint64_t)((cols + strip_cols - 1) / strip_cols) * (rows + L - 1ull) * L * words * 4ull;
     }

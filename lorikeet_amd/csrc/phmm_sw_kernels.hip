@@ -73,6 +73,15 @@ struct CigarOut {
 }  // namespace
 
 
+// f(integral_constant<0>), f(<4>), f(<8>) ... while below K
+template <int K, int K0 = 0, class F>
+__device__ __forceinline__ void static_for_chunks4(F &&f) {
+    if constexpr (K0 < K) {
+        f(std::integral_constant<int, K0>{});
+        static_for_chunks4<K, K0 + 4>(f);
+    }
+}
+
 template <int SW_L>
 __device__ __forceinline__ int32_t row_shr1(int32_t v) {  // lane l <- lane l-1 (first lane of a row of 16 / of the wave: 0)
     if constexpr (SW_L <= 16) return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
@@ -83,6 +92,7 @@ __device__ __forceinline__ int32_t row_shr1(int32_t v) {  // lane l <- lane l-1 
 // scores the smaller |p1 - p2|; among those the one met first (last column before bottom row, bottom row left to right).
 struct Start {
     int32_t score, dist, order, p1, p2;
+    uint32_t g = 0;  // (the tags-only sweep) the walk from this cell is one diagonal
 };
 __device__ __forceinline__ bool better(const Start &a, const Start &b) {  // a beats b
     if (a.score != b.score) return a.score > b.score;
@@ -135,10 +145,15 @@ __device__ __forceinline__ void store_flags(uint32_t *at, const V &v) {
 // memory, one slice per block, LDS holds the two sequences only.  An instance of its own (16 lanes x 32 columns, and the
 // wide one): loads from device memory inside the sweep make the compiler wait for ALL outstanding memory operations of a
 // step -- the flag stores included -- which cost the ordinary instances 5-8 % while the two shared one body.
-// LITE: the sweep leaves only the two-bit candidate tag per cell -- 11 instructions per cell instead of 16, half the flag
-// volume.  That is all the walk needs as long as it meets no gap (the usual read against its haplotype): an alignment whose
-// walk does meet one is put on a list and aligned again by the full instance, launched behind this one over that list
-// (SwParams::todo), so results never depend on which of the two ran.
+// LITE: the first of two passes where gaps are rare (the usual read against its haplotype) -- 11 instructions per cell instead
+// of 16 and, since round 5, NO backtrack flags at all.  A walk that meets no gap is the diagonal from its start cell to the
+// matrix's edge, and whether it meets one is a bit the sweep can carry: G(i, j) = [the diagonal candidate won at (i, j)] and
+// G(i-1, j-1), G = 1 on row 0 and column 0.  The lane keeps the G bits of its K columns in the same two-bits-per-cell layout the
+// tags are collected in (the tag's high bit IS "diagonal won"), so one step costs one shift-or and one AND per 16 columns plus
+// the hand-over of one bit to the next lane -- nothing per cell.  The start cell's G decides: 1 = the CIGAR is written from the
+// start cell alone (no flag was stored, none is read: 2.6 GB of flags per 131 072 reads and a dozen dependent round trips per
+// walk are gone); 0 = the alignment is put on a list and aligned again by the full instance, launched behind this one over that
+// list (SwParams::todo), so results never depend on which of the two ran.  One strip only (an alignment with more goes on the list).
 template <int SW_L, int K, bool TR = false, bool WIDE = false, bool EXT = false, bool LITE = false>
 __global__ __launch_bounds__(WAVE) PHMM_SW_OCCUPANCY(K)
 void phmm_sw_align_kernel(const SwParams p) {
@@ -166,6 +181,8 @@ void phmm_sw_align_kernel(const SwParams p) {
     constexpr int NW = LITE ? sw_tag_words(K) : sw_flag_words(K);  // dwords stored per lane and step
     constexpr int REM = K % 16;
     constexpr bool LAST_PACKED = !LITE && REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
+    // (LITE) a tag word holds its cells top-aligned: column q of a word of nq cells has its tag's high bit at 33 - 2 (nq - q)
+    constexpr int NQ0 = K < 16 ? K : 16, G_IN0 = 33 - 2 * NQ0;   // ... so the first column of the lane sits at G_IN0
     uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
     // scores times four; the low two bits name the candidate
     constexpr int32_t SC = WIDE ? 1 : 4, TG = WIDE ? 0 : 1;  // scale of the scores; whether their low two bits carry the candidate
@@ -289,6 +306,9 @@ void phmm_sw_align_kernel(const SwParams p) {
         // reaches it)
         const int lm = ((nl - 1) % strip_cols) / K, km = (nl - 1) % K, sm = (nl - 1) / strip_cols;
         int32_t lc_score = INT32_MIN, lc_row = 0;
+        uint32_t lc_g = 0u;  // (LITE) G of that cell
+        // (LITE) where the G bit of the lane's cell in the last column (row: TR) sits: word km / 16, bit 33 - 2 (nq - km % 16)
+        const int g_word = km >> 4, g_shift = 33 - 2 * (min(K - 16 * g_word, 16) - (km & 15));
         for (int s = 0; s < n_strips; ++s) {
             const bool strip_on = dp && s < my_strips;
             const int j0 = s * strip_cols + l * K;  // columns j0+1 .. j0+K
@@ -312,6 +332,13 @@ void phmm_sw_align_kernel(const SwParams p) {
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
             uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
+            // LITE: "the walk from this cell is one diagonal", a bit per column in the position of its tag's high bit (odd bit
+            // positions; every shift below is even, so the even positions -- the tags' low bits, garbage here -- never mix in)
+            uint32_t gw[NH];
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) gw[hh] = ~0u;   // row 0
+            uint32_t g_diag = 1u << G_IN0;               // G(i-1, j0): the diagonal of the lane's first column (row 0 / column 0: 1)
+            uint32_t o_g = 0u;                           // G of the lane's last column, handed to the right neighbour like o_sw
             uint32_t *bt = slab + (size_t)s * strip_stride + (size_t)lane * NW;
             // (the reference base of the NEXT step is fetched from LDS a step ahead: its latency hides behind the cells)
             int32_t a_next = (int32_t)seq_s[max(-l, 0)];
@@ -331,10 +358,22 @@ void phmm_sw_align_kernel(const SwParams p) {
                 kmask[k] = k == km ? ~0u : 0u;
                 asm volatile("" : "+v"(kmask[k]));       // (vector registers: as conditions they would be 2 K scalar registers, spilled)
             }
+            auto g_of = [&](int k) -> uint32_t {         // (LITE) G of the lane's column k, this row
+                const int hh = k >> 4, nq = min(K - 16 * hh, 16);
+                return (gw[hh] >> (33 - 2 * (nq - (k & 15)))) & 1u;
+            };
+            auto g_last = [&]() -> uint32_t {            // ... of its cell in the last column (a run-time position)
+                uint32_t w = gw[0];
+#pragma unroll
+                for (int hh = 1; hh < NH; ++hh) w = g_word == hh ? gw[hh] : w;
+                return (w >> g_shift) & 1u;
+            };
             auto step = [&](auto ramp_c, auto lean_c, const int t) {
                 constexpr bool RAMP = decltype(ramp_c)::value, LEAN = decltype(lean_c)::value;
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
+                uint32_t g_in = 0u;
+                if constexpr (LITE) g_in = (uint32_t)row_shr1<SW_L>((int32_t)o_g) | (l == 0 ? 1u << G_IN0 : 0u);  // (column 0: 1)
                 const bool live = strip_on && i >= 1 && i <= ns;
                 const bool active = RAMP ? live : true;
                 const int32_t a_base = a_next;
@@ -383,14 +422,31 @@ void phmm_sw_align_kernel(const SwParams p) {
                     // one store per lane and step: the lane's NW dwords lie next to each other ([strip][step][lane][dword]), a
                     // wave's store covers NW x 256 contiguous bytes.  (Three dword stores per step, 256 bytes apart, cost the
                     // kernel a fifth of its time: a vector-memory instruction holds up its wave's issue for ~100 clocks.)
+                    if constexpr (LITE) {
+                        // G(i, k) = [tag(i, k) is DIAG] & G(i-1, k-1): the words move up one cell (two bits), the diagonal of the
+                        // first column comes in at the bottom, a word's top cell goes on to the next word.  (A word of fewer than 16
+                        // cells keeps older steps' tags below them: masked off before the shift.)
+                        uint32_t carry = g_diag;
+#pragma unroll
+                        for (int hh = 0; hh < NH; ++hh) {
+                            const int nq = K - 16 * hh < 16 ? K - 16 * hh : 16;
+                            const uint32_t valid = nq == 16 ? ~0u : ~0u << (32 - 2 * nq);
+                            const uint32_t old = gw[hh] & valid;
+                            gw[hh] = ((old << 2) | carry) & acc_c[hh];
+                            if (hh + 1 < NH) {
+                                const int nq_next = K - 16 * (hh + 1) < 16 ? K - 16 * (hh + 1) : 16;
+                                carry = old >> (31 - (33 - 2 * nq_next));   // bit 31 (the word's top cell) -> the next word's first cell
+                            }
+                        }
+                        g_diag = g_in;                                      // G(i, j0), the first column's diagonal one row on
+                        o_g = (gw[NH - 1] & 0x80000000u) >> (31 - G_IN0);   // the lane's last column, where the neighbour's first cell takes it
+                    } else {
                     uint32_t *row_bt = bt + (size_t)t * NW * WAVE;
                     typedef uint32_t flag_vec __attribute__((ext_vector_type(NW)));
                     flag_vec fv;
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh) {
-                        if constexpr (LITE) {
-                            fv[hh] = acc_c[hh];  // (a last word of fewer than 16 cells has them in its top bits)
-                        } else if (LAST_PACKED && hh == NH - 1) {
+                        if (LAST_PACKED && hh == NH - 1) {
                             constexpr uint32_t LO = REM >= 16 ? ~0u : (1u << (2 * (REM & 15))) - 1u;
                             fv[2 * hh] = (acc_c[hh] & ~(~0u >> (2 * (REM & 15)))) | (acc_e[hh] & LO);
                         } else {
@@ -399,6 +455,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                         }
                     }
                     store_flags<NW>(row_bt, fv);
+                    }
                     diag = diag_next;
                     o_sw = left;
                     o_bgh = h_bg;
@@ -407,16 +464,29 @@ void phmm_sw_align_kernel(const SwParams p) {
                         e_bgh[i] = h_bg;
                     }
                     if constexpr (LEAN) {
+                        // (one v_and_or_b32 per column, written out: from `v |= up[k] & kmask[k]` the compiler builds a tree of bitop3 / or3
+                        // -- 30 instructions per step of 19 cells instead of 19 -- and from a select form two per column.  Measured and
+                        // dropped: `v = up[km]`, a compare-and-select chain on hoisted scalar masks: 2.80 -> 2.95 ms on the 8 x 19 instance.)
                         int32_t v = 0;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) v |= up[k] & (int32_t)kmask[k];
+                        // (four columns to a statement: the compiler keeps inline-assembly statements an s_nop apart)
+                        static_for_chunks4<K>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            if constexpr (k + 4 <= K)
+                                asm("v_and_or_b32 %0, %1, %2, %0\n\tv_and_or_b32 %0, %3, %4, %0\n\tv_and_or_b32 %0, %5, %6, %0\n\tv_and_or_b32 %0, %7, %8, %0"
+                                    : "+v"(v)
+                                    : "v"(up[k]), "v"(kmask[k]), "v"(up[k + 1]), "v"(kmask[k + 1]), "v"(up[k + 2]), "v"(kmask[k + 2]), "v"(up[k + 3]), "v"(kmask[k + 3]));
+                            else
+                                for (int q = k; q < K; ++q) v |= up[q] & (int32_t)kmask[q];
+                        });
                         const bool mine = live && l == lm;
+                        // (LITE: the cell's G rides in bit 0 of what the bottom row keeps -- scores are multiples of four there)
                         if constexpr (TR) {
-                            bottom[mine ? i : 0] = v;    // the last row, column by column (entry 0 is nobody's)
+                            bottom[mine ? i : 0] = LITE ? v | (int32_t)g_last() : v;    // the last row, column by column (entry 0 is nobody's)
                         } else {
                             const bool take = mine && v >= lc_score;
                             lc_score = take ? v : lc_score;
                             lc_row = take ? i : lc_row;
+                            if constexpr (LITE) lc_g = take ? g_last() : lc_g;
                         }
                     } else {
                         if (live && s == sm && l == lm) {
@@ -424,10 +494,11 @@ void phmm_sw_align_kernel(const SwParams p) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) v |= up[k] & (int32_t)kmask[k];
                             if constexpr (TR) {
-                                bottom[i] = v;               // the last row, column by column
+                                bottom[i] = LITE ? v | (int32_t)g_last() : v;               // the last row, column by column
                             } else if (v >= lc_score) {
                                 lc_score = v;
                                 lc_row = i;
+                                if constexpr (LITE) lc_g = g_last();
                             }
                         }
                     }
@@ -438,9 +509,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                                 if (j0 + k + 1 <= nl && up[k] >= lc_score) {
                                     lc_score = up[k];
                                     lc_row = j0 + k + 1;
+                                    if constexpr (LITE) lc_g = g_of(k);
                                 }
                             } else if (j0 + k + 1 <= nl) {
-                                bottom[j0 + k + 1] = up[k];
+                                bottom[j0 + k + 1] = LITE ? up[k] | (int32_t)g_of(k) : up[k];
                             }
                         }
                     }
@@ -481,22 +553,27 @@ void phmm_sw_align_kernel(const SwParams p) {
                 // the owner of the last column holds its best cell; everybody gets it
                 const int src = (lane & GMASK) | lm;
                 int32_t sc = __shfl(lc_score, src, WAVE), rw = __shfl(lc_row, src, WAVE);
+                uint32_t gg = LITE ? (uint32_t)__shfl((int)lc_g, src, WAVE) : 0u;
                 if constexpr (TR) {  // every lane holds the best of its rows: the highest, among equals the lowest row down
                     sc = lc_score;
                     rw = lc_row;
+                    gg = lc_g;
 #pragma unroll
                     for (int o = SW_L / 2; o >= 1; o >>= 1) {
                         const int32_t s2 = __shfl_xor(sc, o, WAVE), r2 = __shfl_xor(rw, o, WAVE);
+                        const uint32_t g2 = LITE ? (uint32_t)__shfl_xor((int)gg, o, WAVE) : 0u;
                         if (s2 > sc || (s2 == sc && r2 > rw)) {
                             sc = s2;
                             rw = r2;
+                            gg = g2;
                         }
                     }
                 }
-                best = Start{sc, abs(rw - m), 0, rw, m};
+                best = Start{sc, abs(rw - m), 0, rw, m, gg};
                 if (p.strategy != PHMM_SW_STRATEGY_LEADING_INDEL) {
                     for (int j = l + 1; j <= m; j += SW_L) {  // bottom row, every lane a share of the columns
-                        const Start c{bottom[j], abs(n - j), j, n, j};
+                        const int32_t bj = bottom[j];
+                        const Start c{LITE ? bj & ~3 : bj, abs(n - j), j, n, j, LITE ? (uint32_t)bj & 1u : 0u};
                         if (better(c, best)) best = c;
                     }
                 }
@@ -511,6 +588,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 c.order = __shfl_xor(best.order, o, WAVE);
                 c.p1 = __shfl_xor(best.p1, o, WAVE);
                 c.p2 = __shfl_xor(best.p2, o, WAVE);
+                if constexpr (LITE) c.g = (uint32_t)__shfl_xor((int)best.g, o, WAVE);
                 if (better(c, best)) best = c;
             }
         }
@@ -558,7 +636,20 @@ void phmm_sw_align_kernel(const SwParams p) {
                 }
                 int state = ST_MATCH;
                 constexpr int HB = TR ? 1 : 0, VB = TR ? 0 : 1;  // the sweep's gap is shifted in first, the lanes' second
-                for (;;) {
+                if constexpr (LITE) {
+                    // No flags were stored.  The start cell's G bit says whether the reference's walk from it (:372-417) takes the
+                    // diagonal all the way to row 0 / column 0 -- then it is `run` times the loop body with btrack == 0 -- or meets a
+                    // gap somewhere: then the full instance aligns this one again.
+                    if (best.g && my_strips == 1) {
+                        const int run = min(p1, p2);
+                        segment_length += run;
+                        p1 -= run;
+                        p2 -= run;
+                    } else {
+                        again = true;
+                    }
+                }
+                for (; !LITE;) {
                     // lane l looks at the cells (p1 - d, p2 - d), d = l, l + SW_L, ... (BQ of them, 32 cells per group and round trip:
                     // every fetch is a dependent read from HBM and the run of diagonal steps is usually the whole read);
                     // `run` = diagonal steps from (p1, p2) before anything else
@@ -593,10 +684,6 @@ void phmm_sw_align_kernel(const SwParams p) {
                         p2 -= run;
                         if (p1 <= 0 || p2 <= 0) break;
                         if (run == BQ * SW_L) continue;
-                    }
-                    if constexpr (LITE) {  // a gap: its length is not in the tags -- the full instance aligns this one again
-                        again = true;
-                        break;
                     }
                     // a gap ends at (p1, p2).  The reference's btrack entry (:257-266) is +k (k rows up) or -k (k columns
                     // left), k = the length the best gap ending here has: 1 where it opens, else one more than at the
