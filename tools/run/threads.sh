@@ -1,20 +1,25 @@
 #!/bin/bash
 # gpurun recipe 3: the reference's call pattern (one region per call from T host threads) through every entry point.
 # usage (on the GPU box): bash tools/run/threads.sh <round>   -> gpurun_out/<round>_threads_bench.txt (copy to profiles/)
-R=${1:-r03}
+R=${1:-r05}
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/${R}_threads_bench.txt
 {
 echo "# tools/threads_bench on MI355X: one region per call from T C++ host threads, host buffers (PCIe included)"
 echo "## PairHMM alone (phmm_compute / phmm_submit), private handles and one shared handle"
-TB_THREADS=1,2,4,8,16,32 tools/threads_bench 1
+TB_THREADS=1,2,4,8,10,16,32 tools/threads_bench 1
 echo "## likelihoods, then realignment, two calls per region (phmm_compute, then phmm_realign_reads with its likelihoods)"
 TB_MODE=pipeline TB_THREADS=1,2,4,8,16 tools/threads_bench 1
-echo "## the whole per-region path as ONE call (phmm_region_compute), private handles"
-TB_MODE=fused TB_THREADS=1,2,4,8,16 tools/threads_bench 1
+echo "## the whole per-region path as ONE call (phmm_region_compute), private handles (past four: routed through the device's shared lanes)"
+TB_MODE=fused TB_THREADS=1,2,4,5,8,10,16,32 tools/threads_bench 1
 echo "## ... through the shared handle (phmm_region_submit / phmm_wait)"
-TB_MODE=gshared TB_THREADS=1,2,4,8,16,32,64 tools/threads_bench 1
+TB_MODE=gshared TB_THREADS=1,2,4,8,10,16,32,64 tools/threads_bench 1
+echo "## ... two tickets in flight per worker (TB_DEPTH=2: region k+1 submitted before region k is waited for)"
+TB_DEPTH=2 TB_MODE=gshared TB_THREADS=4,8,10,16,32 tools/threads_bench 1
+echo "## ... private handles with the routing off (PHMM_ROUTE_SHARED=0: round 4's behaviour)"
+PHMM_ROUTE_SHARED=0 TB_MODE=fused TB_THREADS=8,16,32 tools/threads_bench 1
+PHMM_ROUTE_SHARED=0 TB_MODE=own TB_THREADS=8,16,32 tools/threads_bench 1
 echo "## ... without the gathering leader (PHMM_SUBMIT_GATHER_US=0)"
 PHMM_SUBMIT_GATHER_US=0 TB_MODE=gshared TB_THREADS=8,16,32 tools/threads_bench 1
 echo "## ... by regions per call (one and four caller threads)"
