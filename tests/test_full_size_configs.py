@@ -63,3 +63,34 @@ def test_ragged_mix_all_1536_regions(hip_engine):
     order = np.argsort(cells)
     sample = [int(order[0]), int(order[len(order) // 4]), int(order[len(order) // 2]), int(order[-40]), int(order[-1])]
     _check_full_set(hip_engine, b, sample)
+
+
+def test_one_region_at_the_reference_maximum_depth(hip_engine):
+    """SURVEY 8a trap 10: a region may hold up to --max-input-depth reads (200 000, cli.rs) against up to 128 haplotypes
+    (cli.rs:1588-1591).  One region of 70 000 short reads x 128 haplotypes (9 M pairs: past every 16-bit count) and one of 200 000 x 3,
+    alone in a call -- a single region cannot be cut into chunks -- through the host path, the resident path and, for the engine-
+    level call's pre- and post-step, phmm_engine_compute: the SIMD stand-in at 1e-5 on every pair, the scalar oracle at 1e-9 on
+    the first and last reads, every read's row a permutation-free copy of the same read in a small region."""
+    from lorikeet_amd.batch import RegionBatch
+    for nr, nh, H, R, seed in ((70000, 128, 64, [20, 30, 40], 31), (200000, 3, 120, [30, 50], 32)):
+        b = synthetic.make_regions(1, nr, nh, H, R, seed=seed)
+        assert b.n_regions == 1 and b.n_reads == nr and b.n_out == nr * nh
+        got = hip_engine.compute(b)
+        assert got.shape == (nr * nh,) and (got <= 0).all() and np.isfinite(got).all()
+        plan = hip_engine.plan(b)
+        plan.upload()
+        plan.launch()
+        assert np.max(np.abs(plan.download() - got)) <= 1e-12
+        plan.close()
+        simd, _ = oracle.compute_batch_simd(b.as_dict(), n_threads=16, native=False)
+        assert float(np.max(np.abs(got - simd))) <= 1e-5
+        # the first and the last 40 reads as a region of their own, scalar oracle
+        from lorikeet_amd.batch import Read
+        for r0 in (0, nr - 40):
+            reads = []
+            for r in range(r0, r0 + 40):
+                s0, s1 = int(b.read_off[r]), int(b.read_off[r + 1])
+                reads.append(Read(b.read_bases[s0:s1], b.base_q[s0:s1], b.ins_q[s0:s1], b.del_q[s0:s1], b.gcp[s0:s1]))
+            sub = RegionBatch.from_regions([(reads, [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(nh)])])
+            want = oracle.compute_batch(sub.as_dict(), n_threads=16)
+            assert float(np.max(np.abs(got[r0 * nh:(r0 + 40) * nh] - want))) <= 1e-9
