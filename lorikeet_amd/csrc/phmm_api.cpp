@@ -1473,7 +1473,9 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // (not while the chunks of a pipelined host call are in flight: those already overlap each other on the slot streams,
     // and forks of several chunks would queue behind one another on the side streams -- 1 536 mixed regions through host
     // buffers: 25 ms without, 32 ms with)
-    const bool fork = n_groups >= 2 && !h->sw.no_fork && !h->defer_d2h;  // (round 4, three large chunks: forking them changes nothing either)
+    // (round 4, three large chunks: forking them all changes nothing either.  Round 5: the LAST chunk of a mixed call alone -- the one
+    // whose launches have nothing of a later chunk beside them -- forks: `fork_chunk`, set by the chunk loop)
+    const bool fork = n_groups >= 2 && !h->sw.no_fork && (!h->defer_d2h || h->fork_chunk);
     if (fork) {
         for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
             if (!h->side_streams[i] && !hip_ok(h, hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking), "hipStreamCreate")) return PHMM_ERR_HIP;
@@ -2042,6 +2044,7 @@ int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32
                 }
             h->slot = 0;
             h->defer_d2h = false;
+            h->fork_chunk = false;
         }
     } drain{h, pend};
     int st = PHMM_OK;
@@ -2064,8 +2067,14 @@ int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32
         if (st != PHMM_OK) break;
         h->slot = slot;
         const size_t bo = c.read_byte0, co = c.hap_byte0;
+        // (A/B, off: the last chunk of a mixed call has no later chunk's kernels to fill the tails of its launches, one per range of
+        // K -- sending them out side by side like a resident batch's was measured at 19.8-20.0 ms against 18.7-18.8 one behind the
+        // other, three times on one box: beside the chunk before it the forked launches only take each other's vector units)
+        static const bool fork_last = getenv("PHMM_FORK_LAST_CHUNK") ? atoi(getenv("PHMM_FORK_LAST_CHUNK")) != 0 : false;
+        h->fork_chunk = fork_last && c.mixed && c.g1 == g_end && n_chunks > 0;
         st = enqueue_compute(h, c.g1 - c.g0, c.rro.data(), c.rho.data(), c.ro.data(), read_bases + bo, base_q + bo, ins_q + bo,
                              del_q + bo, gcp + bo, c.ho.data(), hap_bases + co, c.oo.data(), out + out_off[c.g0], &pend[slot]);
+        h->fork_chunk = false;
         ++n_chunks;
     }
     for (int i = 0; i < kSlots; ++i) {  // drain in submission order
@@ -2481,6 +2490,7 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
                 }
             h->slot = 0;
             h->defer_d2h = false;
+            h->fork_chunk = false;
         }
     } drain{h, pend};
     int st = PHMM_OK;

@@ -133,6 +133,7 @@ struct phmm_handle {
                                       // trading lanes for waves once the batch fills its share of the chip
     uint32_t busy_lanes = 1;          // a lane of a shared handle: lanes computing right now, this one included (phmm_wait)
     bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
+    bool fork_chunk = false;          // this chunk's chained launches go out side by side although chunks are in flight (the last one of a mixed call)
     std::once_flag comb_once;
 };
 

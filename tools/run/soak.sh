@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun recipe 4: random batches of every kind against the oracle (PairHMM through every kernel selection, the
 # engine-level call, Smith-Waterman, the projection).  usage (on the GPU box): bash tools/run/soak.sh <round> [seconds each]
-R=${1:-r03}; S=${2:-150}
+R=${1:-r05}; S=${2:-150}
 cd "$(dirname "$0")/../.."
 export PHMM_MIRROR_CANARY=1   # a device store that lands in the pinned mirror outside its call fails that call (phmm_api.cpp)
 {
