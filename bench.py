@@ -723,12 +723,15 @@ def main():
         r = Resident(eng, rb, dev)
         el, kms = timed_launches(Dist1(D), r, stream, 5, 1)
         got = r.out.cpu().numpy()
-        t = time.perf_counter()
+        # (the first call grows the arenas; of five more the best is quoted and the median kept beside it: the chunked path's
+        # time moves by +-0.5 ms from call to call with where the chunks' tails fall)
         host = eng.compute(rb)
-        t_host = time.perf_counter() - t
-        t = time.perf_counter()
-        host = eng.compute(rb)
-        t_host = min(t_host, time.perf_counter() - t)
+        t_calls = []
+        for _ in range(5):
+            t = time.perf_counter()
+            host = eng.compute(rb)
+            t_calls.append(time.perf_counter() - t)
+        t_host = min(t_calls)
         import numpy as np
         assert np.allclose(host, got, rtol=0, atol=1e-9)
         cells = sharding.region_cells(rb)
@@ -740,7 +743,8 @@ def main():
                "valu_f64": {"achieved": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9, 3), "peak": VALU_F64_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9 / VALU_F64_PEAK_TFLOPS, 4)},
                "host_buffers_incl_pcie": {"ms_per_call": round(t_host * 1e3, 3), "gcups": round(rb.cells() / t_host / 1e9, 1),
-                                          "regions_per_s": round(rb.n_regions / t_host, 1)},
+                                          "regions_per_s": round(rb.n_regions / t_host, 1),
+                                          "ms_median_of_5": round(sorted(t_calls)[2] * 1e3, 3)},
                "oracle_sample": oracle_sample_diff(rb, got, 64, int(1.5e9))}
         r.close()
         return row
