@@ -554,7 +554,7 @@ def main():
 
     # ---- rows every rank takes part in: the fixed sets of BASELINE.json configs[2..4], strong scaling -------------
     config3_row = config5_row = None
-    if extras and a.workload == "config2" and not strong:
+    if extras and a.workload == "config2" and not strong and (not os.environ.get("BENCH_ROWS") or "config35" in os.environ["BENCH_ROWS"].split(",")):
         try:
             config3_row = strong_row(D, eng, stream, "config3", 5, (2, int(2e8)))
         except Exception as exc:
@@ -1068,16 +1068,23 @@ def main():
             return float(x)
 
     single = f32_row = engine_row = calls_row = ragged_row = sw_row = None
+    # (BENCH_ROWS=ragged,sw ... : only these secondary rows -- developer runs; the driver's run has them all)
+    only_rows = set(filter(None, os.environ.get("BENCH_ROWS", "").split(",")))
+    want = lambda name: not only_rows or name in only_rows  # noqa: E731
     if rank == 0 and extras:
-        single = optional(single_region)
-        if not a.f32_first:
+        if want("single"):
+            single = optional(single_region)
+        if not a.f32_first and want("f32"):
             f32_row = optional(f32_first)
-        engine_row = optional(engine_call)
-        if world == 1:
+        if want("engine"):
+            engine_row = optional(engine_call)
+        if world == 1 and want("calls"):
             calls_row = optional(host_calls)
         if a.workload == "config2":
-            ragged_row = optional(ragged)
-            sw_row = optional(smith_waterman)
+            if want("ragged"):
+                ragged_row = optional(ragged)
+            if want("sw"):
+                sw_row = optional(smith_waterman)
 
     if rank == 0:
         got = out.cpu().numpy()
