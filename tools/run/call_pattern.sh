@@ -1,5 +1,6 @@
 #!/bin/bash
-# gpurun recipe: the call-pattern table, the soaks (canary on), the C++ verify matrix, the region timeline -- on the round's final code
+# gpurun recipe: the call-pattern table, the soaks (canary on), the C++ verify matrix, the region timeline -- one call on the round's
+# final code.  usage (on the GPU box): bash tools/run/call_pattern.sh   -> gpurun_out/r05_{threads_bench,soak_parity,verify_threads,region_timeline}.txt
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out

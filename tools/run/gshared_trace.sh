@@ -1,6 +1,7 @@
 #!/bin/bash
 # gpurun recipe: the shared handle's region call at 16 caller threads under rocprofv3 --kernel-trace: kernels in flight, per-kernel
 # durations under load; and the tags-only aligner on / off on the same box
+R=${1:-r05}
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -18,5 +19,5 @@ import csv, glob
 for r in list(csv.reader(open(glob.glob("/tmp/gs16/**/*kernel_stats.csv", recursive=True)[0])))[:14]:
     print("%-72s %s" % (r[0][:72], "  ".join("%12s" % x[:12] for x in r[1:6])))
 PY
-} > gpurun_out/r05_gshared_trace.txt 2>&1
-cat gpurun_out/r05_gshared_trace.txt
+} > gpurun_out/${R}_gshared_trace.txt 2>&1
+cat gpurun_out/${R}_gshared_trace.txt

@@ -2,7 +2,7 @@
 # gpurun recipe 2: kernel trace + PMC passes of every bench workload and of the engine / Smith-Waterman drivers.
 # usage (on the GPU box): bash tools/run/profiles.sh <round> [workloads...]   default: all
 # then, back in the build container: bash tools/run/profiles_post.sh <round>   (rocpd databases -> profiles/<round>_*)
-R=${1:-r03}; shift || true
+R=${1:-r05}; shift || true
 W=${*:-config2_f64 config2_f32 config3 config5 ragged engine_call sw_bench}
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp

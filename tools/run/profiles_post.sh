@@ -1,7 +1,7 @@
 #!/bin/bash
 # After tools/run/profiles.sh came back: rocpd databases -> profiles/<round>_*_summary.txt, *_pmc.json, pmc_traffic.json.
 # usage (build container): bash tools/run/profiles_post.sh <round>
-R=${1:-r03}
+R=${1:-r05}
 cd "$(dirname "$0")/../.."
 for T in config2_f64 config2_f32 config3 config5 ragged; do
   [ -d gpurun_out/${R}_$T ] || continue

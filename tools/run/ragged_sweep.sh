@@ -1,4 +1,6 @@
 #!/bin/bash
+# gpurun recipe: 1 536 mixed regions through host buffers by chunk schedule (tools/hostpath_ragged_sweep.py), every schedule twice
+# on one box -> gpurun_out/r05_ragged_sweep2.txt (profiles/r05_ragged_chunk_sweep.txt)
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
