@@ -88,6 +88,16 @@ int phmm_device_count(void);
  * owns a stream, pinned staging and device arenas that grow on demand.  While at most four engines are alive on a device,
  * each runs its one-enqueue calls on a hardware queue of its own (callers with an engine each then run side by side whatever
  * the runtime does with ordinary streams); env PHMM_REGION_OWN_QUEUE=0 at creation turns that off.
+ * While MORE than four of the caller's engines are alive on a device (an engine per worker thread at --threads 16 or 32), the
+ * one-shot calls of such a private engine -- phmm_compute, phmm_engine_compute, phmm_region_compute on up to eight regions or
+ * 512 KB per array -- are served by ONE shared engine of the same flags inside the library (the queue of phmm_submit: callers that
+ * are waiting anyway share a flush and sleep instead of spinning; 32 private engines ran at half the rate of 16 before).  Results
+ * and error reporting are the call's own; which regions share a launch depends on timing, so likelihoods are reproducible to
+ * ~1e-13 rather than bit for bit under that load.  An engine whose developer switches were set (phmm_set_switch) keeps to its
+ * own streams; env PHMM_ROUTE_SHARED=0 turns the routing off, =n moves the threshold.
+ * Debug environment: PHMM_MIRROR_CANARY=1 makes a device store that lands in the pinned hand-over buffer outside its call fail
+ * that call (PHMM_ERR_INTERNAL; =2: abort); PHMM_REGION_PICK_TIMEOUT_US (default 5 000) bounds the small region call's wait for
+ * its second hardware queue -- out of time, the call is redone the chained way (phmm_get_stat "region_pick_timeouts").
  * Replaces PairHMM::initialize's per-region table/matrix construction (pair_hmm.rs:63-165).
  * Returns NULL on failure (phmm_last_error(NULL) has the message). */
 phmm_handle *phmm_create(int device_id, unsigned flags);
