@@ -130,6 +130,7 @@ struct phmm_batch {
         int L = 0;
         bool f32 = false;  // the f32 sweep of a PHMM_FLAG_F32_FIRST handle (the f64 per-read redo follows per class)
         int single_k = 0;  // the K all items share (per-K kernel), 0 = mixed (any-K kernel)
+        uint64_t weight = 0;  // rows x instructions per row over its items: what phmm_batch_launch balances the streams by
         std::vector<ChainItem> items;
         ChainItem *d_items = nullptr;
     };
@@ -1133,7 +1134,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             for (const ChainItem &x : g.items) w += (uint64_t)(read_off[x.read_end] - read_off[x.read_begin]) * (uint64_t)(7 * x.k + 11);
             return w;
         };
-        std::stable_sort(split.begin(), split.end(), [&](const phmm_batch::ChainGroup &x, const phmm_batch::ChainGroup &y) { return weight(x) > weight(y); });
+        for (auto &g : split) g.weight = weight(g);
+        std::stable_sort(split.begin(), split.end(), [&](const phmm_batch::ChainGroup &x, const phmm_batch::ChainGroup &y) { return x.weight > y.weight; });
         b->chain_groups.swap(split);
     }
     // the dominant class under the name of the kernel that runs it (what rocprofv3 reports): the body alone for a launch
@@ -1484,11 +1486,73 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         if (!h->ev_fork && !hip_ok(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "hipEventCreate")) return PHMM_ERR_HIP;
         if (!hip_ok(h, hipEventRecord(h->ev_fork, stream), "hipEventRecord")) return PHMM_ERR_HIP;
     }
+    auto launch_class = [&](ShapeClass &c) -> int {
+        ForwardParams p = base_params(b);
+        p.class_reads = c.identity ? nullptr : c.d_reads;
+        p.n_items = (uint32_t)c.reads.size();
+        p.lds_rows = c.lds_rows;
+        p.cnd_select = c.cnd_select;
+        p.high_priority = (h->sw.region_prio & 2) ? 1u : 0u;
+        if (!p.n_items) return PHMM_OK;
+        hipError_t e;
+        if (c.chain && !c.f32_first) return PHMM_OK;  // done with its group
+        if (c.chain) {  // behind the f32 sweep: the f64 per-read kernel over exactly the reads it flagged
+            p.redo = b->d_redo;
+            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
+        } else if (c.L) {
+            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
+        } else {
+            GenericParams gp{};
+            gp.f = p;
+            gp.scratch = c.d_scratch;
+            gp.max_h = c.max_h;
+            gp.pair_first = c.d_pair_first;
+            gp.n_pairs = c.pair_first.back();
+            gp.n_blocks = c.generic_blocks;
+            e = gp.n_pairs ? launch_generic(gp, stream) : hipSuccess;
+        }
+        return hip_ok(h, e, c.name) ? PHMM_OK : PHMM_ERR_HIP;
+    };
+    // The per-read classes of a mixed batch (a few hundred microseconds of small kernels) depend on no chained launch: behind
+    // the join they ran alone at the end of the batch, one after the other.  With the launches forked they go out FIRST on the
+    // caller's stream -- the chained launches of the side streams start beside them, the caller's own behind them.
+    // (PHMM_CLASSES_LAST=1: the old order, A/B.)
+    static const bool classes_last = getenv("PHMM_CLASSES_LAST") != nullptr;
+    const bool early_classes = fork && !classes_last;
+    if (early_classes)
+        for (auto &c : b->classes)
+            if (!c.chain && launch_class(c) != PHMM_OK) return PHMM_ERR_HIP;
     bool side_used[phmm_handle::kSideStreams] = {};
-    for (size_t gi = 0, next_suffix = 0; gi < n_groups; ++gi) {
+    // Which stream a chained launch goes out on, and in which order.  Round 4: heaviest first, round robin -- with six launches on
+    // four streams the two LIGHTEST trailed the second and third heaviest and ran alone at the end of the batch (the mixed
+    // batch's timeline: 14.3 -> 15.9 ms of 15.9 with only small kernels on the chip).  Round 5: the launches are dealt to the
+    // streams heaviest first onto the least loaded one (so the streams' loads end up level), and every stream sends its own
+    // LIGHTEST first -- the small kernels run beside the other streams' big ones, and the big ones end together.
+    // (PHMM_LAUNCH_ORDER_R4=1: the old order, A/B; suffix launches of a sharing plan keep it: they follow their trunks.)
+    static const bool order_r4 = getenv("PHMM_LAUNCH_ORDER_R4") != nullptr;
+    constexpr int kStreams = 1 + phmm_handle::kSideStreams;
+    std::vector<size_t> launch_order(n_groups);
+    std::vector<int> stream_of(n_groups, 0);
+    for (size_t gi = 0; gi < n_groups; ++gi) launch_order[gi] = gi;
+    if (fork && !order_r4 && n_suffix == 0) {
+        uint64_t load[kStreams] = {};
+        for (size_t gi = 0; gi < n_groups; ++gi) {  // (chain_groups is sorted heaviest first)
+            int best = 0;
+            for (int q = 1; q < kStreams; ++q)
+                if (load[q] < load[best]) best = q;
+            stream_of[gi] = best;
+            load[best] += std::max<uint64_t>(b->chain_groups[gi].weight, 1);
+        }
+        std::reverse(launch_order.begin(), launch_order.end());  // lightest first: per stream that is its own ascending order
+    } else {
+        for (size_t gi = 1; gi < n_groups; ++gi) stream_of[gi] = fork ? 1 + (int)((gi - 1) % phmm_handle::kSideStreams) : 0;
+    }
+    size_t next_suffix = 0;
+    for (size_t oi = 0; oi < n_groups; ++oi) {
+        const size_t gi = launch_order[oi];
         hipStream_t s_x = stream;
-        if (fork && gi > 0) {
-            const int si = (int)((gi - 1) % phmm_handle::kSideStreams);
+        if (fork && stream_of[gi] > 0) {
+            const int si = stream_of[gi] - 1;
             s_x = h->side_streams[si];
             if (!side_used[si] && !hip_ok(h, hipStreamWaitEvent(s_x, h->ev_fork, 0), "hipStreamWaitEvent")) return PHMM_ERR_HIP;
             side_used[si] = true;
@@ -1516,33 +1580,9 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         if (side_used[i] && (!hip_ok(h, hipEventRecord(h->ev_join[i], h->side_streams[i]), "hipEventRecord") ||
                              !hip_ok(h, hipStreamWaitEvent(stream, h->ev_join[i], 0), "hipStreamWaitEvent")))
             return PHMM_ERR_HIP;
-    for (auto &c : b->classes) {
-        ForwardParams p = base_params(b);
-        p.class_reads = c.identity ? nullptr : c.d_reads;
-        p.n_items = (uint32_t)c.reads.size();
-        p.lds_rows = c.lds_rows;
-        p.cnd_select = c.cnd_select;
-        p.high_priority = (h->sw.region_prio & 2) ? 1u : 0u;
-        if (!p.n_items) continue;
-        hipError_t e;
-        if (c.chain && !c.f32_first) continue;  // done with its group above
-        if (c.chain) {  // behind the f32 sweep: the f64 per-read kernel over exactly the reads it flagged
-            p.redo = b->d_redo;
-            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
-        } else if (c.L) {
-            e = launch_forward(c.L, c.K, p, c.grid, c.waves_per_block, c.lds_bytes, stream);
-        } else {
-            GenericParams gp{};
-            gp.f = p;
-            gp.scratch = c.d_scratch;
-            gp.max_h = c.max_h;
-            gp.pair_first = c.d_pair_first;
-            gp.n_pairs = c.pair_first.back();
-            gp.n_blocks = c.generic_blocks;
-            e = gp.n_pairs ? launch_generic(gp, stream) : hipSuccess;
-        }
-        if (!hip_ok(h, e, c.name)) return PHMM_ERR_HIP;
-    }
+    // (the per-read classes that depend on no chained launch went out in front of the fork, above)
+    for (auto &c : b->classes)
+        if (!(early_classes && !c.chain) && launch_class(c) != PHMM_OK) return PHMM_ERR_HIP;
     // Results below kRescueBelow are redone in the reference's operation order.  Persistent batches and the
     // engine-level call carry the pass in-stream (it returns at once unless a forward kernel asked for it); the
     // host-buffer path looks at the status word in finish_compute instead and pays nothing in the common case.
