@@ -130,7 +130,6 @@ struct phmm_batch {
         int L = 0;
         bool f32 = false;  // the f32 sweep of a PHMM_FLAG_F32_FIRST handle (the f64 per-read redo follows per class)
         int single_k = 0;  // the K all items share (per-K kernel), 0 = mixed (any-K kernel)
-        uint64_t weight = 0;  // rows x instructions per row over its items: what phmm_batch_launch balances the streams by
         std::vector<ChainItem> items;
         ChainItem *d_items = nullptr;
     };
@@ -1134,8 +1133,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             for (const ChainItem &x : g.items) w += (uint64_t)(read_off[x.read_end] - read_off[x.read_begin]) * (uint64_t)(7 * x.k + 11);
             return w;
         };
-        for (auto &g : split) g.weight = weight(g);
-        std::stable_sort(split.begin(), split.end(), [&](const phmm_batch::ChainGroup &x, const phmm_batch::ChainGroup &y) { return x.weight > y.weight; });
+        std::stable_sort(split.begin(), split.end(), [&](const phmm_batch::ChainGroup &x, const phmm_batch::ChainGroup &y) { return weight(x) > weight(y); });
         b->chain_groups.swap(split);
     }
     // the dominant class under the name of the kernel that runs it (what rocprofv3 reports): the body alone for a launch
@@ -1516,43 +1514,19 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // The per-read classes of a mixed batch (a few hundred microseconds of small kernels) depend on no chained launch: behind
     // the join they ran alone at the end of the batch, one after the other.  With the launches forked they go out FIRST on the
     // caller's stream -- the chained launches of the side streams start beside them, the caller's own behind them.
-    // (PHMM_CLASSES_LAST=1: the old order, A/B.)
+    // (PHMM_CLASSES_LAST=1: the old order, A/B.  The mixed batch resident, three runs each on one box: 15.59-15.66 ms against 15.80-15.89.)
     static const bool classes_last = getenv("PHMM_CLASSES_LAST") != nullptr;
     const bool early_classes = fork && !classes_last;
     if (early_classes)
         for (auto &c : b->classes)
             if (!c.chain && launch_class(c) != PHMM_OK) return PHMM_ERR_HIP;
     bool side_used[phmm_handle::kSideStreams] = {};
-    // Which stream a chained launch goes out on, and in which order.  Round 4: heaviest first, round robin -- with six launches on
-    // four streams the two LIGHTEST trailed the second and third heaviest and ran alone at the end of the batch (the mixed
-    // batch's timeline: 14.3 -> 15.9 ms of 15.9 with only small kernels on the chip).  Round 5: the launches are dealt to the
-    // streams heaviest first onto the least loaded one (so the streams' loads end up level), and every stream sends its own
-    // LIGHTEST first -- the small kernels run beside the other streams' big ones, and the big ones end together.
-    // (PHMM_LAUNCH_ORDER_R4=1: the old order, A/B; suffix launches of a sharing plan keep it: they follow their trunks.)
-    static const bool order_r4 = getenv("PHMM_LAUNCH_ORDER_R4") != nullptr;
-    constexpr int kStreams = 1 + phmm_handle::kSideStreams;
-    std::vector<size_t> launch_order(n_groups);
-    std::vector<int> stream_of(n_groups, 0);
-    for (size_t gi = 0; gi < n_groups; ++gi) launch_order[gi] = gi;
-    if (fork && !order_r4 && n_suffix == 0) {
-        uint64_t load[kStreams] = {};
-        for (size_t gi = 0; gi < n_groups; ++gi) {  // (chain_groups is sorted heaviest first)
-            int best = 0;
-            for (int q = 1; q < kStreams; ++q)
-                if (load[q] < load[best]) best = q;
-            stream_of[gi] = best;
-            load[best] += std::max<uint64_t>(b->chain_groups[gi].weight, 1);
-        }
-        std::reverse(launch_order.begin(), launch_order.end());  // lightest first: per stream that is its own ascending order
-    } else {
-        for (size_t gi = 1; gi < n_groups; ++gi) stream_of[gi] = fork ? 1 + (int)((gi - 1) % phmm_handle::kSideStreams) : 0;
-    }
-    size_t next_suffix = 0;
-    for (size_t oi = 0; oi < n_groups; ++oi) {
-        const size_t gi = launch_order[oi];
+    // (Measured and dropped, round 5: dealing the launches to the streams by load, every stream sending its lightest first -- in the
+    // mixed batch's timeline the two lightest launches trail the second and third heaviest -- : 15.56-15.67 ms either way.)
+    for (size_t gi = 0, next_suffix = 0; gi < n_groups; ++gi) {
         hipStream_t s_x = stream;
-        if (fork && stream_of[gi] > 0) {
-            const int si = stream_of[gi] - 1;
+        if (fork && gi > 0) {
+            const int si = (int)((gi - 1) % phmm_handle::kSideStreams);
             s_x = h->side_streams[si];
             if (!side_used[si] && !hip_ok(h, hipStreamWaitEvent(s_x, h->ev_fork, 0), "hipStreamWaitEvent")) return PHMM_ERR_HIP;
             side_used[si] = true;

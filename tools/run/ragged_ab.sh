@@ -1,13 +1,12 @@
 #!/bin/bash
 # gpurun recipe (A/B): the mixed batch resident and through host buffers -- the per-read classes in front of the forked chained
-# launches (default) or behind the join (PHMM_CLASSES_LAST=1), the launches dealt to the streams by load, lightest first (default)
-# or heaviest first round robin (PHMM_LAUNCH_ORDER_R4=1) -- three times each on one box; then the mixed-batch parity tests
+# launches (default) or behind the join (PHMM_CLASSES_LAST=1), three times each on one box; then the mixed-batch parity tests
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 {
 for rep in 1 2 3; do
-for v in "" "PHMM_CLASSES_LAST=1" "PHMM_LAUNCH_ORDER_R4=1" "PHMM_CLASSES_LAST=1 PHMM_LAUNCH_ORDER_R4=1"; do
+for v in "" "PHMM_CLASSES_LAST=1"; do
   echo -n "[$v] "
   env $v BENCH_ROWS=ragged python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
