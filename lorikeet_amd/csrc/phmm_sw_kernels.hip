@@ -181,7 +181,11 @@ void phmm_sw_align_kernel(const SwParams p) {
     constexpr int NW = LITE ? sw_tag_words(K) : sw_flag_words(K);  // dwords stored per lane and step
     constexpr int REM = K % 16;
     constexpr bool LAST_PACKED = !LITE && REM != 0 && REM <= 8;  // the last pair shares a dword: tags in the top 2 REM bits, gap bits in the bottom 2 REM
-    // (LITE) a tag word holds its cells top-aligned: column q of a word of nq cells has its tag's high bit at 33 - 2 (nq - q)
+    // GBIT: the sweep carries "the walk from this cell is one diagonal" per column (see LITE above).  The tags-only sweep lives on
+    // it; the full instance uses it to skip the walk -- a dozen dependent round trips to the flags -- for the alignments that have
+    // no gap (SoftClip / Ignore, one strip), which is what a small region call's aligner spends its last ~15 us on.
+    constexpr bool GBIT = !WIDE && !EXT;
+    // a tag word holds its cells top-aligned: column q of a word of nq cells has its tag's high bit at 33 - 2 (nq - q)
     constexpr int NQ0 = K < 16 ? K : 16, G_IN0 = 33 - 2 * NQ0;   // ... so the first column of the lane sits at G_IN0
     uint32_t *slab = p.slab + (size_t)blockIdx.x * p.slab_stride;
     // scores times four; the low two bits name the candidate
@@ -306,8 +310,8 @@ void phmm_sw_align_kernel(const SwParams p) {
         // reaches it)
         const int lm = ((nl - 1) % strip_cols) / K, km = (nl - 1) % K, sm = (nl - 1) / strip_cols;
         int32_t lc_score = INT32_MIN, lc_row = 0;
-        uint32_t lc_g = 0u;  // (LITE) G of that cell
-        // (LITE) where the G bit of the lane's cell in the last column (row: TR) sits: word km / 16, bit 33 - 2 (nq - km % 16)
+        uint32_t lc_g = 0u;  // (GBIT) G of that cell
+        // (GBIT) where the G bit of the lane's cell in the last column (row: TR) sits: word km / 16, bit 33 - 2 (nq - km % 16)
         const int g_word = km >> 4, g_shift = 33 - 2 * (min(K - 16 * g_word, 16) - (km & 15));
         for (int s = 0; s < n_strips; ++s) {
             const bool strip_on = dp && s < my_strips;
@@ -332,7 +336,7 @@ void phmm_sw_align_kernel(const SwParams p) {
             int32_t diag = row0(j0);                     // sw[i-1][j0]
             int32_t o_sw = 0, o_bgh = 0;                 // what this lane hands to its right neighbour (row of the previous step)
             uint32_t acc_c[NH] = {}, acc_e[NH] = {};     // flag words: candidate tags (shifted in from the top), gap-open bits (from the bottom)
-            // LITE: "the walk from this cell is one diagonal", a bit per column in the position of its tag's high bit (odd bit
+            // GBIT: "the walk from this cell is one diagonal", a bit per column in the position of its tag's high bit (odd bit
             // positions; every shift below is even, so the even positions -- the tags' low bits, garbage here -- never mix in)
             uint32_t gw[NH];
 #pragma unroll
@@ -358,7 +362,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 kmask[k] = k == km ? ~0u : 0u;
                 asm volatile("" : "+v"(kmask[k]));       // (vector registers: as conditions they would be 2 K scalar registers, spilled)
             }
-            auto g_of = [&](int k) -> uint32_t {         // (LITE) G of the lane's column k, this row
+            auto g_of = [&](int k) -> uint32_t {         // (GBIT) G of the lane's column k, this row
                 const int hh = k >> 4, nq = min(K - 16 * hh, 16);
                 return (gw[hh] >> (33 - 2 * (nq - (k & 15)))) & 1u;
             };
@@ -373,7 +377,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 const int i = t - l + 1;                 // this lane's row at this step
                 int32_t left = row_shr1<SW_L>(o_sw), h_bg = row_shr1<SW_L>(o_bgh);
                 uint32_t g_in = 0u;
-                if constexpr (LITE) g_in = (uint32_t)row_shr1<SW_L>((int32_t)o_g) | (l == 0 ? 1u << G_IN0 : 0u);  // (column 0: 1)
+                if constexpr (GBIT) g_in = (uint32_t)row_shr1<SW_L>((int32_t)o_g) | (l == 0 ? 1u << G_IN0 : 0u);  // (column 0: 1)
                 const bool live = strip_on && i >= 1 && i <= ns;
                 const bool active = RAMP ? live : true;
                 const int32_t a_base = a_next;
@@ -422,7 +426,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                     // one store per lane and step: the lane's NW dwords lie next to each other ([strip][step][lane][dword]), a
                     // wave's store covers NW x 256 contiguous bytes.  (Three dword stores per step, 256 bytes apart, cost the
                     // kernel a fifth of its time: a vector-memory instruction holds up its wave's issue for ~100 clocks.)
-                    if constexpr (LITE) {
+                    if constexpr (GBIT) {
                         // G(i, k) = [tag(i, k) is DIAG] & G(i-1, k-1): the words move up one cell (two bits), the diagonal of the
                         // first column comes in at the bottom, a word's top cell goes on to the next word.  (A word of fewer than 16
                         // cells keeps older steps' tags below them: masked off before the shift.)
@@ -440,7 +444,8 @@ void phmm_sw_align_kernel(const SwParams p) {
                         }
                         g_diag = g_in;                                      // G(i, j0), the first column's diagonal one row on
                         o_g = (gw[NH - 1] & 0x80000000u) >> (31 - G_IN0);   // the lane's last column, where the neighbour's first cell takes it
-                    } else {
+                    }
+                    if constexpr (!LITE) {
                     uint32_t *row_bt = bt + (size_t)t * NW * WAVE;
                     typedef uint32_t flag_vec __attribute__((ext_vector_type(NW)));
                     flag_vec fv;
@@ -479,14 +484,14 @@ void phmm_sw_align_kernel(const SwParams p) {
                                 for (int q = k; q < K; ++q) v |= up[q] & (int32_t)kmask[q];
                         });
                         const bool mine = live && l == lm;
-                        // (LITE: the cell's G rides in bit 0 of what the bottom row keeps -- scores are multiples of four there)
+                        // (GBIT: the cell's G rides in bit 0 of what the bottom row keeps -- scores are multiples of four there)
                         if constexpr (TR) {
-                            bottom[mine ? i : 0] = LITE ? v | (int32_t)g_last() : v;    // the last row, column by column (entry 0 is nobody's)
+                            bottom[mine ? i : 0] = GBIT ? v | (int32_t)g_last() : v;    // the last row, column by column (entry 0 is nobody's)
                         } else {
                             const bool take = mine && v >= lc_score;
                             lc_score = take ? v : lc_score;
                             lc_row = take ? i : lc_row;
-                            if constexpr (LITE) lc_g = take ? g_last() : lc_g;
+                            if constexpr (GBIT) lc_g = take ? g_last() : lc_g;
                         }
                     } else {
                         if (live && s == sm && l == lm) {
@@ -494,11 +499,11 @@ void phmm_sw_align_kernel(const SwParams p) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) v |= up[k] & (int32_t)kmask[k];
                             if constexpr (TR) {
-                                bottom[i] = LITE ? v | (int32_t)g_last() : v;               // the last row, column by column
+                                bottom[i] = GBIT ? v | (int32_t)g_last() : v;               // the last row, column by column
                             } else if (v >= lc_score) {
                                 lc_score = v;
                                 lc_row = i;
-                                if constexpr (LITE) lc_g = g_last();
+                                if constexpr (GBIT) lc_g = g_last();
                             }
                         }
                     }
@@ -509,10 +514,10 @@ void phmm_sw_align_kernel(const SwParams p) {
                                 if (j0 + k + 1 <= nl && up[k] >= lc_score) {
                                     lc_score = up[k];
                                     lc_row = j0 + k + 1;
-                                    if constexpr (LITE) lc_g = g_of(k);
+                                    if constexpr (GBIT) lc_g = g_of(k);
                                 }
                             } else if (j0 + k + 1 <= nl) {
-                                bottom[j0 + k + 1] = LITE ? up[k] | (int32_t)g_of(k) : up[k];
+                                bottom[j0 + k + 1] = GBIT ? up[k] | (int32_t)g_of(k) : up[k];
                             }
                         }
                     }
@@ -553,7 +558,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 // the owner of the last column holds its best cell; everybody gets it
                 const int src = (lane & GMASK) | lm;
                 int32_t sc = __shfl(lc_score, src, WAVE), rw = __shfl(lc_row, src, WAVE);
-                uint32_t gg = LITE ? (uint32_t)__shfl((int)lc_g, src, WAVE) : 0u;
+                uint32_t gg = GBIT ? (uint32_t)__shfl((int)lc_g, src, WAVE) : 0u;
                 if constexpr (TR) {  // every lane holds the best of its rows: the highest, among equals the lowest row down
                     sc = lc_score;
                     rw = lc_row;
@@ -561,7 +566,7 @@ void phmm_sw_align_kernel(const SwParams p) {
 #pragma unroll
                     for (int o = SW_L / 2; o >= 1; o >>= 1) {
                         const int32_t s2 = __shfl_xor(sc, o, WAVE), r2 = __shfl_xor(rw, o, WAVE);
-                        const uint32_t g2 = LITE ? (uint32_t)__shfl_xor((int)gg, o, WAVE) : 0u;
+                        const uint32_t g2 = GBIT ? (uint32_t)__shfl_xor((int)gg, o, WAVE) : 0u;
                         if (s2 > sc || (s2 == sc && r2 > rw)) {
                             sc = s2;
                             rw = r2;
@@ -573,7 +578,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 if (p.strategy != PHMM_SW_STRATEGY_LEADING_INDEL) {
                     for (int j = l + 1; j <= m; j += SW_L) {  // bottom row, every lane a share of the columns
                         const int32_t bj = bottom[j];
-                        const Start c{LITE ? bj & ~3 : bj, abs(n - j), j, n, j, LITE ? (uint32_t)bj & 1u : 0u};
+                        const Start c{GBIT ? bj & ~3 : bj, abs(n - j), j, n, j, GBIT ? (uint32_t)bj & 1u : 0u};
                         if (better(c, best)) best = c;
                     }
                 }
@@ -588,7 +593,7 @@ void phmm_sw_align_kernel(const SwParams p) {
                 c.order = __shfl_xor(best.order, o, WAVE);
                 c.p1 = __shfl_xor(best.p1, o, WAVE);
                 c.p2 = __shfl_xor(best.p2, o, WAVE);
-                if constexpr (LITE) c.g = (uint32_t)__shfl_xor((int)best.g, o, WAVE);
+                if constexpr (GBIT) c.g = (uint32_t)__shfl_xor((int)best.g, o, WAVE);
                 if (better(c, best)) best = c;
             }
         }
@@ -636,20 +641,21 @@ void phmm_sw_align_kernel(const SwParams p) {
                 }
                 int state = ST_MATCH;
                 constexpr int HB = TR ? 1 : 0, VB = TR ? 0 : 1;  // the sweep's gap is shifted in first, the lanes' second
-                if constexpr (LITE) {
-                    // No flags were stored.  The start cell's G bit says whether the reference's walk from it (:372-417) takes the
-                    // diagonal all the way to row 0 / column 0 -- then it is `run` times the loop body with btrack == 0 -- or meets a
-                    // gap somewhere: then the full instance aligns this one again.
-                    if (best.g && my_strips == 1) {
-                        const int run = min(p1, p2);
-                        segment_length += run;
-                        p1 -= run;
-                        p2 -= run;
-                    } else {
-                        again = true;
-                    }
+                // The start cell's G bit says whether the reference's walk from it (:372-417) takes the diagonal all the way to row 0 /
+                // column 0 -- then it is `run` times the loop body with btrack == 0, and no flag is read -- or meets a gap somewhere:
+                // the tags-only sweep (which stored no flags) then hands the alignment to the full instance, the full instance walks.
+                bool diagonal = false;
+                if constexpr (GBIT)
+                    diagonal = best.g && my_strips == 1 && (p.strategy == PHMM_SW_STRATEGY_SOFTCLIP || p.strategy == PHMM_SW_STRATEGY_IGNORE);
+                if (diagonal) {
+                    const int run = min(p1, p2);
+                    segment_length += run;
+                    p1 -= run;
+                    p2 -= run;
+                } else if constexpr (LITE) {
+                    again = true;
                 }
-                for (; !LITE;) {
+                for (; !LITE && !diagonal;) {
                     // lane l looks at the cells (p1 - d, p2 - d), d = l, l + SW_L, ... (BQ of them, 32 cells per group and round trip:
                     // every fetch is a dependent read from HBM and the run of diagonal steps is usually the whole read);
                     // `run` = diagonal steps from (p1, p2) before anything else
