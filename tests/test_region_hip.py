@@ -507,3 +507,34 @@ def test_handles_come_and_go_with_their_hardware_queues(hip_engine):
             _equal_calls(region.region_compute(e, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars), want)
         finally:
             e.close()
+
+
+def test_a_region_of_forty_thousand_reads_equals_its_small_self_read_by_read(hip_engine):
+    """SURVEY 8a trap 10: a region may hold up to --max-input-depth reads.  Every read's result depends on nothing but the read and
+    its region's haplotypes, so a region made of enough copies of a small region's reads to hold 40 000 (one region: it cannot be chunked)
+    must give, read by read, the small region's likelihoods, keep flags, best alleles, positions and CIGARs."""
+    from lorikeet_amd.batch import RegionBatch
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = _scenario(2100, n_regions=1)
+    mapq = _noisy_quals(b, 21)
+    cfg = _cfg(pcr=3)
+    pri = _priorities(b, hap_cigars, ref_hap)
+    small = region.region_compute(hip_engine, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri)
+    nr, nh = b.n_reads, b.n_haps
+    copies = (40000 + nr - 1) // nr
+    reads = []
+    for r in range(nr):
+        s, e = int(b.read_off[r]), int(b.read_off[r + 1])
+        reads.append(Read(b.read_bases[s:e], b.base_q[s:e], b.ins_q[s:e], b.del_q[s:e], b.gcp[s:e]))
+    haps = [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(nh)]
+    deep = RegionBatch.from_regions([(reads * copies, haps)])
+    assert deep.n_regions == 1 and deep.n_reads == nr * copies >= 20000
+    got = region.region_compute(hip_engine, cfg, deep, np.tile(mapq, copies), hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars * copies,
+                                hap_priority=pri)
+    assert np.max(np.abs(got.likelihoods.reshape(copies, -1) - small.likelihoods.reshape(1, -1))) <= 1e-11   # (another lane geometry)
+    assert np.array_equal(got.keep.reshape(copies, nr), np.tile(small.keep, (copies, 1)))
+    assert np.array_equal(got.best.allele_index.reshape(copies, nr), np.tile(small.best.allele_index, (copies, 1)))
+    assert np.array_equal(got.reads.status.reshape(copies, nr), np.tile(small.reads.status, (copies, 1)))
+    assert np.array_equal(got.reads.new_pos.reshape(copies, nr), np.tile(small.reads.new_pos, (copies, 1)))
+    for k in (0, 1, copies // 2, copies - 1):
+        for r in range(nr):
+            assert np.array_equal(got.reads.cigars[k * nr + r], small.reads.cigars[r]), (k, r)
