@@ -292,6 +292,10 @@ static void read_env_switches(Switches &w) {
     env("PHMM_SW_LANES", w.sw_lanes);
     env("PHMM_SW_TRANSPOSE", w.sw_transpose);
     env("PHMM_REGION_SW_ALL", w.region_sw_all);
+    env("PHMM_REGION_SERVER", w.region_server);
+    env("PHMM_SERVER_IDLE_US", w.server_idle_us);
+    env("PHMM_SERVER_STALL_MS", w.server_stall_ms);
+    env("PHMM_SERVER_TRACE", w.server_trace);
     env("PHMM_REGION_PRIO", w.region_prio);
     env("PHMM_REGION_CU_HALVES", w.region_cu_halves);
     env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
@@ -446,6 +450,7 @@ void phmm_destroy(phmm_handle *h) {
                 }
         }
         for (phmm_handle *b : gone) phmm_destroy(b);
+        phmm_host::server_quiesce(device);  // (the region server leaves the chip by itself once idle: wait for that)
     }
 }
 
@@ -2561,6 +2566,10 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "sw_no_zero_copy") w.sw_no_zero_copy = value > 0;
     else if (n == "sw_clock") w.sw_clock = value != 0;
     else if (n == "region_sw_all") w.region_sw_all = value < 0 ? -1 : value;
+    else if (n == "region_server") w.region_server = value < 0 ? -1 : value > 0 ? 1 : 0;
+    else if (n == "server_idle_us") w.server_idle_us = value > 0 ? value : 1;
+    else if (n == "server_stall_ms") w.server_stall_ms = value > 0 ? value : 1;
+    else if (n == "server_trace") w.server_trace = value != 0;
     else if (n == "region_prio") w.region_prio = value > 0 ? value : 0;
     else if (n == "region_cu_halves") w.region_cu_halves = value != 0;
     else if (n == "region_flag_wait") w.region_flag_wait = value != 0;
@@ -2590,6 +2599,7 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name) {
     else if (n == "sw_clock_mhz") return h->swork.last_clock_mhz;
     else if (n == "region_sw_all") own = h->swork.region_sw_all_calls;
     else if (n == "region_pick_timeouts") own = h->swork.region_pick_timeouts;
+    else if (n.rfind("server_", 0) == 0) return phmm_host::server_stat(h->device, name);  // (the device's server: every handle's calls)
     else return 0;
     return own + (h->comb ? phmm_host::combiner_stat(h->comb, name) : 0);
 }

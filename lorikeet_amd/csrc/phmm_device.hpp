@@ -436,4 +436,80 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One read against the haplotype groups quad_begin, quad_begin + quad_step, ... of its region: the body of phmm_forward<L,K>
+// (phmm_kernels.hip) and of the resident region server's forward task (phmm_server_kernels.hip).  `smem_wave`: this wave's
+// own LDS, (R + 1) row records.  Wave-uniform control flow; every lane of the wave must arrive.
+template <int L, int K>
+__device__ __forceinline__ void forward_read(const ForwardParams &p, const uint32_t r, const int quad_begin, const int quad_step,
+                                             const bool cnd_select, unsigned char *smem_wave) {
+    constexpr int G = WAVE / L;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int grp = lane / L, l = lane % L;
+    const uint32_t reg = p.read_region[r];
+    const uint32_t ro = p.read_off[r];
+    const int R = (int)(p.read_off[r + 1] - ro);
+    const uint32_t h0 = p.region_hap_off[reg];
+    const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
+    double *out_row = p.out + p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh;
+
+    // ---- stage this read's per-row constants in wave-private LDS (72-byte records, conflict-free) ----------
+    RowConst *srow = reinterpret_cast<RowConst *>(smem_wave);
+    // gcp == 0 means im = 1 - eps(0) = 0 (and base quality 0 means pm = 0): such a read keeps plain rows
+    // (rare; production gcp is 10 and the engine caps base qualities at >= 6)
+    bool lane_zero_gcp = false;
+    for (int row = lane; row < R; row += WAVE) lane_zero_gcp |= row_blocks_prescale(p, ro + row);
+    const bool scaled = __ballot(lane_zero_gcp) == 0ull;
+    if (lane == 0) srow[0] = neutral_row();  // lanes that have not started yet run this row
+    for (int row = lane; row < R; row += WAVE) srow[row + 1] = make_row(p, ro, row, R, scaled);
+    // D(0,j) scale: pre-scaled rows carry im of the first read row
+    const double scale0 = (scaled && R > 0) ? 1.0 - p.eps[p.gcp[ro]] : 1.0;
+    const double fin = (scaled && R > 0) ? 1.0 - p.eps[p.base_q[ro + R - 1]] : 1.0;  // pm(R), see RowConst
+    lds_wave_sync();
+    const LdsView lds{srow};
+    const bool group_head = (L == 32) && (lane == 32);
+
+    const int nquads = (Nh + G - 1) / G;
+    for (int quad = quad_begin; quad < nquads; quad += quad_step) {
+        const int a = quad * G + grp;
+        const bool hv = a < Nh;
+        uint32_t ho = 0;
+        int H = 0;
+        if (hv) {
+            ho = p.hap_off[h0 + a];
+            H = (int)(p.hap_off[h0 + a + 1] - ho);
+        }
+        HapCols<K> hc;
+        bool lane_n = false;
+#pragma unroll
+        for (int w = 0; w < HapCols<K>::W; ++w) hc.y[w] = 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int col = l * K + k;
+            const uint32_t y = (col < H) ? (uint32_t)p.hap_bases[ho + col] : 0u;
+            const bool is_n = (y == 'N');
+            lane_n |= is_n;
+            hc.set(k, y);
+        }
+        const double c0 = p.initial_condition / (double)H * scale0;
+        double s;
+        if (scaled && __ballot(lane_n) == 0ull) {
+            if constexpr (K <= PHMM_CND_MAX_K) {
+                s = cnd_select ? sweep_fast<L, K, ROW_FAST_CND>(lds, R, l, group_head, hc, H, c0, fin)
+                               : sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
+            } else {
+                s = sweep_fast<L, K>(lds, R, l, group_head, hc, H, c0, fin);
+            }
+        } else {  // rare: haplotype 'N' is a wildcard too (pair_hmm.rs:643), or a read with gcp == 0 / base quality 0
+            s = sweep_general<L, K>(lds, R, l, group_head, hc, H, c0, scaled, fin);
+        }
+#pragma unroll
+        for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (l == 0 && hv) {
+            const double v = log10(s) - p.initial_condition_log10;
+            out_row[a] = v;
+            if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
+        }
+    }
+}
+
 }  // namespace phmm

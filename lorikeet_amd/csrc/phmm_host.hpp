@@ -63,6 +63,11 @@ struct Switches {
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
+    int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1 where its limits admit
+                                // them (a handle whose other switches were changed keeps the launched pipeline), 0 never, 1 also on such a handle
+    int server_idle_us = 200;   // PHMM_SERVER_IDLE_US: how long the server stays on the chip with nothing in flight and nothing arriving
+    int server_stall_ms = 500;  // PHMM_SERVER_STALL_MS: calls in flight and none finishing for this long: the server gives up (the calls fail)
+    int server_trace = 0;       // PHMM_SERVER_TRACE: every task leaves a record (tools/server_trace.py)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
 };
@@ -280,6 +285,15 @@ struct RegionArgs {
     int64_t *new_pos = nullptr;
     int32_t *status = nullptr;
 };
+// The resident region server (phmm_server.cpp): submit stages the call in a slot and hands it to the device's server, wait
+// polls for its finish word and hands the results over.
+struct ServerPending;
+constexpr int kServerNotTaken = -2000;  // server_region_submit: the call is outside the server's limits -- nothing was done
+constexpr int kServerRedo = -2001;      // server_region_wait: run the call again the launched way (an alignment outgrew its slot)
+int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out);
+int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);
+uint64_t server_stat(int device, const char *name);
+void server_quiesce(int device);
 // argument check of phmm_region_compute / phmm_region_submit: the message of the first violation, or empty
 std::string region_validate(const RegionArgs &a);
 // the call itself on validated arguments (phmm_region.cpp); one thread per handle

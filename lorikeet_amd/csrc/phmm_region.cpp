@@ -22,14 +22,13 @@
 
 #include "phmm_cigar_internal.hpp"
 #include "phmm_host.hpp"
+#include "phmm_region_internal.hpp"
 #include "phmm_sw_internal.hpp"
 
 using namespace phmm;
 using namespace phmm_host;
 
 namespace {
-
-size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct DevGuard {
     int prev = -1, dev;
@@ -48,67 +47,6 @@ bool ok(phmm_handle *h, hipError_t e, const char *what) {
     h->err_code = PHMM_ERR_HIP;
     return false;
 }
-
-// Where everything of one enqueue lies in the slot's arena (and, at the same offsets, in its pinned mirror), behind the
-// batch's own metadata: [inputs ... status_in] travel to the device, [q ... swo] exist on the device only, [res ... end)
-// come back.  Every piece starts on a 256-byte boundary.
-struct Layout {
-    size_t bases, q0, i0, d0, mapq, haps, refhap, pri, rstart, hco, hc, hs, oco, oc, outco, clip, status_in, in_end;
-    size_t q, i, d, g, thr, refidx, swc, nsw, swo, todo;
-    size_t res, keep, out, best, lk, conf, pst, pno, pos, pout, end;
-    Layout() { memset(this, 0, sizeof *this); }
-    // pair_stride > 0: the aligner's slots are one per (read, haplotype of its region), pair_stride of them per read
-    Layout(size_t base, const RegionArgs &a, uint32_t sw_capacity, uint32_t pair_stride) {
-        const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
-        const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;
-        const size_t rb = a.read_off[nr], hb = a.hap_off[nh];
-        size_t used = base;
-        auto take = [&](size_t bytes) {
-            const size_t off = up256(used);
-            used = off + bytes;
-            return off;
-        };
-        bases = take(rb);
-        q0 = take(rb);
-        i0 = take(a.ins_q ? rb : 0);
-        d0 = take(a.del_q ? rb : 0);
-        mapq = take(nr);
-        haps = take(hb);
-        refhap = take(4ull * ng);
-        pri = take(a.hap_priority ? 4ull * nh : 0);
-        rstart = take(8ull * ng);
-        hco = take(4ull * (nh + 1));
-        hc = take(4ull * a.hap_cigar_off[nh]);
-        hs = take(4ull * nh);
-        oco = take(4ull * (nr + 1));
-        oc = take(4ull * a.orig_cigar_off[nr]);
-        outco = take(8ull * (nr + 1));
-        clip = take(a.read_soft_clip ? 8ull * nr : 0);
-        status_in = take(256);
-        in_end = up256(used);
-        q = take(rb);
-        i = take(rb);
-        d = take(rb);
-        g = take(rb);
-        thr = take(8ull * nr);
-        refidx = take(4ull * nr);
-        swc = take(4ull * n_sw * sw_capacity);
-        nsw = take(4ull * n_sw);
-        swo = take(4ull * n_sw);
-        todo = take(4ull * nr);  // the list the aligner's tags-only pass leaves to its second pass (SW_LITE)
-        res = take(256);
-        keep = take(nr);
-        out = take(8ull * a.out_off[ng]);
-        best = take(4ull * nr);
-        lk = take(8ull * nr);
-        conf = take(8ull * nr);
-        pst = take(4ull * nr);
-        pno = take(4ull * nr);
-        pos = take(8ull * nr);
-        pout = take(4ull * a.out_cigar_off[nr]);
-        end = up256(used);
-    }
-};
 
 struct PendingRegion {
     phmm_batch *b = nullptr;
@@ -1179,6 +1117,20 @@ extern "C" int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg
                                        best_allele, likelihood, confidence, out_cigar, n_out_cigar, new_pos, status);
         const std::string bad = region_validate(a);
         if (!bad.empty()) return fail(h, bad);
+        // The device's resident server takes the call if it is within its limits: staged, one ring entry, a poll (phmm_server.cpp).
+        {
+            ServerPending *pending = nullptr;
+            int st = server_region_submit(h, a, &pending);
+            if (st == PHMM_OK) {
+                st = server_region_wait(h, pending, &h->err, nullptr);
+                if (st != kServerRedo) {
+                    if (st != PHMM_OK) h->err_code = st;
+                    return st;
+                }
+            } else if (st != kServerNotTaken) {
+                return h->err_code = st;
+            }
+        }
         // (one of many private handles on the device: a one-shot call goes through the device's shared handle -- route_shared)
         const uint32_t nr_all = region_read_off[n_regions];
         if (nr_all && (n_regions < 8 || (size_t)read_off[nr_all] <= one_shot_bytes()))

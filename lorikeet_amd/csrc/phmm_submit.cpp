@@ -21,6 +21,8 @@ using namespace phmm_host;
 // one set of launches, one D2H copy), then hands every region's results to its owner.  Nobody waits on a timer: batches
 // grow exactly as large as the number of threads that were waiting anyway.  Four lanes (private engine handles) let the
 // next flush stage and copy while the previous one computes.
+constexpr uint64_t kServerTicket = 1ull << 63;  // tickets of calls the region server has: the rest is the ServerPending's address
+
 struct Submission {
     uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
     const uint32_t *region_read_off = nullptr, *region_hap_off = nullptr, *read_off = nullptr, *hap_off = nullptr;
@@ -451,6 +453,17 @@ int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm
         a.status = status;
         const std::string bad = region_validate(a);
         if (!bad.empty()) return submit_fail(h, PHMM_ERR_INVALID_ARG, bad.c_str());
+        // The device's resident server takes the call if it is within its limits (phmm_server.cpp): staged by THIS thread, one
+        // ring entry, no flush to wait for; phmm_wait polls for its finish word.  The ticket's top bit tells the two kinds apart.
+        {
+            ServerPending *pending = nullptr;
+            const int st = server_region_submit(h, a, &pending);
+            if (st == PHMM_OK) {
+                *ticket = kServerTicket | (uint64_t)(uintptr_t)pending;
+                return PHMM_OK;
+            }
+            if (st != kServerNotTaken) return submit_fail(h, st, "phmm_region_submit: the region server refused the call");
+        }
         s.n_regions = n_regions;
         s.n_reads = region_read_off[n_regions];
         s.n_haps = region_hap_off[n_regions];
@@ -463,6 +476,33 @@ int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm
 
 int phmm_wait(phmm_handle *h, uint64_t ticket) {
     if (!h) return PHMM_ERR_INVALID_ARG;
+    if (ticket & kServerTicket) {  // a call the region server has (phmm_region_submit)
+        ServerPending *pending = (ServerPending *)(uintptr_t)(ticket & ~kServerTicket);
+        std::string err;
+        RegionArgs again;
+        int st = server_region_wait(h, pending, &err, &again);
+        if (st == kServerRedo) {  // (an alignment outgrew its slot: once more through the combiner, whose pipeline grows the slots)
+            try {
+                Submission s;
+                s.region = true;
+                s.ra = again;
+                s.n_regions = again.n_regions;
+                s.n_reads = again.region_read_off[again.n_regions];
+                s.n_haps = again.region_hap_off[again.n_regions];
+                s.read_bytes = again.read_off[s.n_reads];
+                uint64_t t2 = 0;
+                st = submit_impl(h, s, &t2);
+                return st == PHMM_OK ? phmm_wait(h, t2) : st;
+            } catch (const std::exception &e) {
+                return submit_fail(h, PHMM_ERR_NO_MEMORY, e.what());
+            }
+        }
+        if (st != PHMM_OK)
+            set_thread_error(h, err);
+        else
+            clear_thread_error(h);
+        return st;
+    }
     Combiner *c = h->comb;
     if (!c) return submit_fail(h, PHMM_ERR_INVALID_ARG, "phmm_wait: nothing was submitted on this handle");
     std::unique_lock<std::mutex> lk(c->mu);

@@ -1,0 +1,198 @@
+"""The resident region server (lorikeet_amd/csrc/phmm_server.cpp, phmm_server_kernels.hip): phmm_region_compute /
+phmm_region_submit as tasks of ONE kernel that stays on the chip -- the default way of a region call.  Held here to
+  * the launched pipeline (switch region_server = 0), field by field: everything discrete equal, likelihoods to 1e-11 (the two
+    sweep a pair with different lane geometries), and to the oracle pipeline at 1e-9;
+  * ITSELF, bit for bit: a region gives the same bits alone, beside other callers' regions, through the shared handle, aligned
+    to every haplotype or to the best one only, and from one launch of the server to the next.
+Reference: src/haplotype/haplotype_caller_engine.rs:1311-1357 (the sequence), src/assembly/assembly_region_walker.rs:210-273
+(the workers that call it, one region each)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from lorikeet_amd import region, synthetic
+from lorikeet_amd.engine import HipPairHMMEngine
+
+from project_scenarios import scenario as _scenario
+from test_region_hip import _cfg, _noisy_quals, _oracle_pipeline, _priorities, _uniform_extras
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    e = HipPairHMMEngine(0)  # (an engine of its own: no switch was ever set on it, so its region calls take the default way)
+    yield e
+    e.close()
+
+
+def _call(e, cfg, sc, mapq, pri, **kw):
+    b, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars = sc
+    return region.region_compute(e, cfg, b, mapq, hap_cigars, hap_starts, ref_hap, ref_start, orig_cigars, hap_priority=pri, **kw)
+
+
+def _equal(a, b, exact):
+    if exact:
+        assert np.array_equal(a.likelihoods, b.likelihoods)
+        assert np.array_equal(a.best.likelihood, b.best.likelihood) and np.array_equal(a.best.confidence, b.best.confidence, equal_nan=True)
+    else:
+        assert np.max(np.abs(a.likelihoods - b.likelihoods)) < 1e-11
+        assert np.allclose(a.best.likelihood, b.best.likelihood, rtol=0, atol=1e-11, equal_nan=True)
+    assert np.array_equal(a.keep, b.keep) and np.array_equal(a.best.allele_index, b.best.allele_index)
+    assert np.array_equal(a.reads.status, b.reads.status) and np.array_equal(a.reads.new_pos, b.reads.new_pos)
+    for r in range(len(a.reads.cigars)):
+        assert np.array_equal(a.reads.cigars[r], b.reads.cigars[r]), r
+
+
+@pytest.mark.parametrize("seed,pcr,symmetric,dynamic,low,n_regions", [(1, 3, True, False, False, 1), (2, 0, False, True, False, 3), (3, 1, True, True, True, 1),
+                                                                       (4, 2, False, False, True, 5), (5, 3, True, False, False, 7)])
+def test_the_server_gives_what_the_launched_pipeline_gives(eng, seed, pcr, symmetric, dynamic, low, n_regions):
+    sc = _scenario(seed, n_regions=n_regions, low_complexity=low)
+    b = sc[0]
+    mapq = _noisy_quals(b, seed)
+    cfg = _cfg(pcr=pcr, symmetric=symmetric, dynamic=dynamic)
+    pri = _priorities(b, sc[1], sc[3])
+    jobs = eng.stat("server_jobs")
+    got = _call(eng, cfg, sc, mapq, pri)
+    assert eng.stat("server_jobs") == jobs + 1, "the call did not go through the region server"
+    launched = HipPairHMMEngine(0)
+    try:
+        launched.set_switch("region_server", 0)
+        want = _call(launched, cfg, sc, mapq, pri)
+        assert launched.stat("server_jobs") == jobs + 1
+    finally:
+        launched.close()
+    _equal(got, want, exact=False)
+    assert (got.reads.status == 0).sum() > b.n_reads // 3
+    # ... and through the shared handle's submit / wait
+    got2 = _call(eng, cfg, sc, mapq, pri, shared=True)
+    assert eng.stat("server_jobs") == jobs + 2
+    _equal(got2, got, exact=True)
+
+
+@pytest.mark.parametrize("seed,low", [(21, False), (22, True)])
+def test_the_server_gives_what_the_oracle_pipeline_gives(eng, seed, low):
+    sc = _scenario(seed, n_regions=5, low_complexity=low)
+    b = sc[0]
+    mapq = _noisy_quals(b, seed)
+    cfg = _cfg(pcr=3, dynamic=True)
+    pri = _priorities(b, sc[1], sc[3])
+    jobs = eng.stat("server_jobs")
+    got = _call(eng, cfg, sc, mapq, pri)
+    assert eng.stat("server_jobs") == jobs + 1
+    out, keep, best = _oracle_pipeline(cfg, b, mapq, sc[3], pri)
+    assert np.max(np.abs(got.likelihoods - out)) < 1e-9
+    assert np.array_equal(got.keep, keep) and np.array_equal(got.best.allele_index, best)
+
+
+def _config2_regions(n, seed):
+    """n one-region calls of the bench's shape (128 reads x 8 haplotypes, 150 / 300 bases) with what the region call needs."""
+    calls = []
+    for i in range(n):
+        b = synthetic.make_regions(1, 128, 8, 300, 150, seed=seed + i)
+        extras = _uniform_extras(b, 300)
+        calls.append(((b,) + tuple(extras), np.full(b.n_reads, 60, np.uint8)))
+    return calls
+
+
+def test_a_region_gives_the_same_bits_alone_and_beside_other_callers(eng):
+    """Eight threads, an engine each, every one computing ITS region again and again while the others do the same: each call
+    equals, bit for bit, what the region gave alone on an idle chip -- the forward geometry is the region's own, nothing is
+    combined, nothing is planned for the load."""
+    calls = _config2_regions(8, 500)
+    cfg = _cfg(pcr=3)
+    alone = [_call(eng, cfg, sc, mapq, None) for sc, mapq in calls]
+    alone_again = [_call(eng, cfg, sc, mapq, None) for sc, mapq in calls]
+    for a, b in zip(alone, alone_again):
+        _equal(a, b, exact=True)
+    engines = [HipPairHMMEngine(0) for _ in calls]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(12):
+                _equal(_call(engines[i], cfg, calls[i][0], calls[i][1], None), alone[i], exact=True)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    jobs = eng.stat("server_jobs")
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(calls))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
+    assert eng.stat("server_jobs") == jobs + 12 * len(calls)
+
+
+def test_aligning_every_pair_or_only_the_best_gives_the_same(eng):
+    """A call alone on the chip aligns every read against every haplotype beside the PairHMM tasks and lets the best allele
+    pick; under load only the best haplotype is aligned.  Integer work: the two ways agree in every bit."""
+    sc = _scenario(7, n_regions=1)
+    b = sc[0]
+    mapq = _noisy_quals(b, 7)
+    cfg = _cfg(pcr=3)
+    pri = _priorities(b, sc[1], sc[3])
+    eng.set_switch("region_server", 1)
+    all_pairs = eng.stat("server_all_pairs")
+    eng.set_switch("region_sw_all", 4096)
+    a = _call(eng, cfg, sc, mapq, pri)
+    assert eng.stat("server_all_pairs") == all_pairs + 1
+    eng.set_switch("region_sw_all", 0)
+    c = _call(eng, cfg, sc, mapq, pri)
+    assert eng.stat("server_all_pairs") == all_pairs + 1
+    _equal(a, c, exact=True)
+
+
+def test_the_server_leaves_the_chip_when_idle_and_comes_back(eng):
+    sc, mapq = _config2_regions(1, 900)[0]
+    cfg = _cfg(pcr=3)
+    first = _call(eng, cfg, sc, mapq, None)
+    launches = eng.stat("server_launches")
+    time.sleep(0.05)  # (far beyond the idle time: the kernel has left)
+    again = _call(eng, cfg, sc, mapq, None)
+    assert eng.stat("server_launches") == launches + 1
+    _equal(first, again, exact=True)
+    assert eng.stat("server_broken") == 0
+
+
+def test_calls_outside_the_servers_limits_take_the_launched_pipeline(eng):
+    """Haplotypes beyond 400 bases (the forward instances the server carries end at 16 lanes x 25 columns): not taken, same API."""
+    b = synthetic.make_regions(1, 24, 3, 450, 120, seed=77)
+    extras = _uniform_extras(b, 450)
+    jobs = eng.stat("server_jobs")
+    got = region.region_compute(eng, _cfg(pcr=3), b, np.full(b.n_reads, 60, np.uint8), *extras)
+    assert eng.stat("server_jobs") == jobs
+    assert got.likelihoods.shape == (b.n_out,) and np.all(got.likelihoods <= 0)
+
+
+def test_two_tickets_per_thread_on_the_shared_handle(eng):
+    """phmm_region_submit twice, then phmm_wait twice (tools/threads_bench TB_DEPTH=2): both through the server, both right."""
+    import ctypes as C
+    from lorikeet_amd import _lib
+    calls = _config2_regions(2, 1200)
+    cfg = _cfg(pcr=3)
+    want = [_call(eng, cfg, sc, mapq, None) for sc, mapq in calls]
+    jobs = eng.stat("server_jobs")
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            results[i] = _call(eng, cfg, calls[i][0], calls[i][1], None, shared=True)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert eng.stat("server_jobs") == jobs + 2
+    for got, w in zip(results, want):
+        _equal(got, w, exact=True)
+    assert C.sizeof(_lib.EngineConfig) > 0
