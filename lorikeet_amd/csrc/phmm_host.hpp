@@ -93,6 +93,7 @@ struct phmm_handle {
     unsigned flags = 0;
     bool internal = false;     // a lane of a shared handle, or a device's backing handle (route_shared): not one of the caller's own
     bool sw_touched = false;   // phmm_set_switch was called on this handle: its calls stay on its own resources (A/B runs, tests)
+    void *server = nullptr;    // the device's resident region server (phmm_server.cpp), once this handle has asked for it
     phmm_handle *backing = nullptr;  // the shared handle of (device, flags) this handle's small calls go through while many are alive
     double *d_eps = nullptr, *d_eps_mis = nullptr, *d_mm = nullptr, *d_ratio_mis = nullptr, *d_inv_om = nullptr;
     uint8_t *d_pcr_cache = nullptr;  // [4][128]: PCR indel model caches, one row per model

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -49,13 +50,27 @@ struct Slot {
     char *dev = nullptr, *host = nullptr, *host_dev = nullptr;  // host_dev: the mirror as the device sees it
 };
 
+// The server's own lock: held for a handful of stores (a slot taken or given back, a ring entry written).  A spinning one: a
+// std::mutex parked and woke ten callers' threads for critical sections of 100 ns -- staging + publishing took 48 us a call
+// instead of 12, handing the results over 20 instead of 1 (tools/server_trace, NOTEBOOK 20.3).
+struct SpinLock {
+    std::atomic<bool> held{false};
+    void lock() {
+        for (;;) {
+            if (!held.exchange(true, std::memory_order_acquire)) return;
+            while (held.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+        }
+    }
+    void unlock() { held.store(false, std::memory_order_release); }
+};
+
 struct Server {
     int device = 0;
-    std::mutex mu;
+    SpinLock mu;
     bool ok = false, broken = false;
     std::string why_broken;
     hipStream_t stream = nullptr;
-    char *d_block = nullptr;  // [SrvCtl | SrvRec x SRV_RECS]: zeroed in front of every launch
+    char *d_block = nullptr;  // [SrvCtl | SrvMail x SRV_MAIL x 2]: zeroed in front of every launch
     size_t block_bytes = 0;
     SrvRegion *d_regions = nullptr;
     SrvEntry *ring = nullptr;
@@ -71,7 +86,9 @@ struct Server {
     int n_slots = 0;
     std::vector<int> free_slots;
     std::atomic<int> in_flight{0};
+    std::atomic<uint32_t> tasks_in_flight{0};  // of the calls in flight: kept below SRV_MAIL_TASKS (phmm_server.hpp)
     std::atomic<uint64_t> n_jobs{0}, n_launches{0}, n_all_pairs{0};
+    std::atomic<uint64_t> ns_stage{0}, ns_wait{0}, ns_out{0};  // host time of the calls so far: staging + publishing, polling, handing the results over
     SrvTrace *d_trace = nullptr;
     uint32_t trace_cap = 0;
 };
@@ -96,7 +113,7 @@ Server *server_create(int device) {
     S->n_blocks = (uint32_t)per_cu * (uint32_t)cus;
     // (the aligner's flags: one slab per worker wave, for the longest sweep the limits admit)
     S->slab_stride = (size_t)(std::max<uint32_t>(kMaxHap, SRV_MAX_ROWS) + 64) * (size_t)sw_flag_words(8) * 64;
-    S->block_bytes = sizeof(SrvCtl) + sizeof(SrvRec) * SRV_RECS;
+    S->block_bytes = sizeof(SrvCtl) + 2 * sizeof(SrvMail) * SRV_MAIL;
     void *ring_dev = nullptr, *exit_dev = nullptr;
     const bool good = hip_ok(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking)) && hip_ok(hipMalloc((void **)&S->d_block, S->block_bytes)) &&
                       hip_ok(hipMalloc((void **)&S->d_regions, sizeof(SrvRegion) * SRV_RING)) &&
@@ -141,7 +158,7 @@ bool launch_locked(Server &S, const Switches &sw) {
     }
     SrvParams P{};
     P.ctl = (SrvCtl *)S.d_block;
-    P.recs = (SrvRec *)(S.d_block + sizeof(SrvCtl));
+    P.mail = (SrvMail *)(S.d_block + sizeof(SrvCtl));
     P.regions = S.d_regions;
     P.ring = S.ring_dev;
     P.exit_word = S.exit_dev;
@@ -178,6 +195,7 @@ struct ServerPending {
     RegionArgs a;
     Layout L;
     uint64_t n_out = 0;
+    uint32_t n_tasks = 0;
     bool all_pairs = false;
     std::chrono::steady_clock::time_point t0;
 };
@@ -188,6 +206,7 @@ void server_pending_free(ServerPending *p) { delete p; }
 // the server is not to be used): nothing was done, the caller takes the launched pipeline.  `a` is validated.
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out) {
     *out = nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     if (h->sw.region_server == 0 || (h->sw_touched && h->sw.region_server < 0)) return kServerNotTaken;
     const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
     if (!ng || !nr || !nh) return kServerNotTaken;
@@ -224,7 +243,14 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
                                      std::max(std::llabs((long long)w.gap_open_penalty), std::llabs((long long)w.gap_extend_penalty)));
         if (big * ((int64_t)max_h + max_r + 2) >= 100000000) return kServerNotTaken;
     }
-    const uint32_t fwd_k = std::max<uint32_t>(2, (max_h + 15) / 16);
+    // The forward sweep's lane geometry: 32 lanes per pair (two haplotypes a wave) for a call of up to 2 048 pairs -- half the
+    // steps' work per wave, twice the waves: a region per call is a chain of dependent stages on a chip that is mostly idle, and
+    // a lone wave issues an f64 instruction every ~7 clocks whatever it has to do --, 16 lanes (four a wave, a third fewer
+    // instructions per cell) for larger calls.  A function of the call's own shape: the same bits under any load.
+    uint64_t n_pairs = 0;
+    for (uint32_t g = 0; g < ng; ++g) n_pairs += (uint64_t)(a.region_read_off[g + 1] - a.region_read_off[g]) * (a.region_hap_off[g + 1] - a.region_hap_off[g]);
+    const uint32_t fwd_l = n_pairs <= 2048 && h->sw.force_L != 16 ? 32u : 16u;
+    const uint32_t fwd_k = std::max<uint32_t>(2, (max_h + fwd_l - 1) / fwd_l);
     uint32_t sw_k = 0;
     for (int k : kSwKs)
         if (!sw_k && (uint32_t)k * 64 >= max_h) sw_k = (uint32_t)k;
@@ -234,7 +260,8 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     const uint32_t proj_per_task = (uint32_t)std::min<size_t>(64, SRV_LDS_BYTES / (16ull * pj_capacity));
     const uint32_t prep_rows = (max_r + 1 + 7) / 8 * 8;
     if (!sw_k || lds_group > SRV_LDS_BYTES || !proj_per_task || (size_t)prep_rows * 17 > SRV_LDS_BYTES) return kServerNotTaken;
-    Server *S = server_of(h->device);
+    if (!h->server) h->server = server_of(h->device);  // (the device's one server: looked up once per handle)
+    Server *S = (Server *)h->server;
     if (!S || !S->ok || S->broken) return kServerNotTaken;
     if ((size_t)(std::max(max_h, max_r) + 64) * (size_t)sw_flag_words((int)sw_k) * 64 > S->slab_stride) return kServerNotTaken;
     // A call alone on the chip aligns every read against EVERY haplotype beside the PairHMM tasks (phmm_region.cpp, NOTEBOOK 18.1):
@@ -255,10 +282,31 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
                  o_ho = take(4ull * (nh + 1)), o_oo = take(8ull * (ng + 1)), o_job = take(sizeof(SrvJob));
     const Layout L(up256(used), a, kSwCapacity, pair_stride);
     if (L.in_end > kStageMax || L.end > kSlotBytes) return kServerNotTaken;
+    // ---- the tasks ---------------------------------------------------------------------------------------------------------------------
+    const uint32_t haps_per_wave = 64 / fwd_l;
+    const uint32_t n16 = (uint32_t)((L.in_end + 15) / 16), quads = (max_nh + haps_per_wave - 1) / haps_per_wave;
+    const uint32_t prep_waves = std::max<uint32_t>(1, (max_r + 63) / 64);  // (a wave per 64 positions)
+    const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;
+    uint32_t n_tasks[SRV_KINDS];
+    n_tasks[SRV_STAGE] = (n16 + SRV_STAGE_UNITS - 1) / SRV_STAGE_UNITS;
+    n_tasks[SRV_PREP] = nr * prep_waves;
+    n_tasks[SRV_FWD] = nr * quads;
+    n_tasks[SRV_SWALL] = pair_stride ? (uint32_t)n_sw : 0u;
+    n_tasks[SRV_POST] = pair_stride ? (nr + proj_per_task - 1) / proj_per_task : (nr + 63) / 64;
+    n_tasks[SRV_SW] = pair_stride ? 0u : nr;
+    n_tasks[SRV_PROJ] = pair_stride ? 0u : (nr + proj_per_task - 1) / proj_per_task;
+    uint32_t total_tasks = 0;
+    for (uint32_t k = 0; k < SRV_KINDS; ++k) total_tasks += n_tasks[k];
+    // (every task posted waits in a mailbox of its own until a worker takes it: the calls in flight must not have more tasks than
+    // there are mailboxes to go round)
+    if (S->tasks_in_flight.fetch_add(total_tasks, std::memory_order_relaxed) + total_tasks > SRV_MAIL_TASKS) {
+        S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
+        return kServerNotTaken;
+    }
     // ---- a slot ----------------------------------------------------------------------------------------------------------------
     int slot = -1;
     {
-        std::lock_guard<std::mutex> lk(S->mu);
+        std::lock_guard<SpinLock> lk(S->mu);
         if (!S->free_slots.empty()) {
             slot = S->free_slots.back();
             S->free_slots.pop_back();
@@ -277,7 +325,10 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
             }
         }
     }
-    if (slot < 0) return kServerNotTaken;  // (every slot taken, or no memory for another: the launched pipeline)
+    if (slot < 0) {  // (every slot taken, or no memory for another: the launched pipeline)
+        S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
+        return kServerNotTaken;
+    }
     const Slot &T = S->slots[slot];
     char *const hs = T.host, *const dev = T.dev, *const mirror = T.host_dev;
     // ---- inputs into the mirror ------------------------------------------------------------------------------------------------------
@@ -335,7 +386,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         pp.out_gcp = (uint8_t *)(dev + L.g);
         pp.threshold = (double *)(dev + L.thr);
         pp.lds_rows = prep_rows;
-        pp.waves_per_read = std::max<uint32_t>(1, (max_r + 63) / 64);
+        pp.waves_per_read = prep_waves;
         pp.default_indel_qual = 45;  // ReadUtils::DEFAULT_INSERTION_DELETION_QUAL (read_utils.rs:23)
         pp.constant_gcp = a.cfg.constant_gcp;
         pp.base_quality_score_threshold = a.cfg.base_quality_score_threshold;
@@ -403,7 +454,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         job->pb.skip_single_allele = (a.rcfg.flags & PHMM_REGION_SKIP_SINGLE_ALLELE) ? 1u : 0u;
         job->pb.keep_final = (uint8_t *)(mirror + L.keep);
     }
-    const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;
     {
         SwParams &sp = job->sw;
         sp.a_begin = 0;
@@ -474,7 +524,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         pj.workspace = nullptr;  // (the lanes' builders live in the worker wave's LDS)
         pj.capacity = pj_capacity;
     }
-    const uint32_t quads = (max_nh + 3) / 4;
+    job->fwd_l = fwd_l;
     job->fwd_k = fwd_k;
     job->fwd_quads = quads;
     job->sw_k = sw_k;
@@ -489,15 +539,16 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     p->L = L;
     p->n_out = a.out_off[ng];
     p->all_pairs = pair_stride != 0;
+    p->n_tasks = total_tasks;
     p->t0 = std::chrono::steady_clock::now();
-    const uint32_t n16 = (uint32_t)((L.in_end + 15) / 16);
     S->in_flight.fetch_add(1, std::memory_order_relaxed);
     {
-        std::lock_guard<std::mutex> lk(S->mu);
+        std::lock_guard<SpinLock> lk(S->mu);
         observe_exit(*S);
         if (S->broken) {
             S->free_slots.push_back(slot);
             S->in_flight.fetch_sub(1, std::memory_order_relaxed);
+            S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
             delete p;
             return kServerNotTaken;
         }
@@ -505,13 +556,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         p->seq = seq;
         SrvEntry &e = S->ring[seq & (SRV_RING - 1)];
         e.slot = (uint32_t)slot;
-        e.n[SRV_STAGE] = (n16 + SRV_STAGE_UNITS - 1) / SRV_STAGE_UNITS;
-        e.n[SRV_PREP] = nr * job->prep.waves_per_read;
-        e.n[SRV_FWD] = nr * quads;
-        e.n[SRV_SWALL] = pair_stride ? (uint32_t)n_sw : 0u;
-        e.n[SRV_POST] = pair_stride ? (nr + proj_per_task - 1) / proj_per_task : (nr + 63) / 64;
-        e.n[SRV_SW] = pair_stride ? 0u : nr;
-        e.n[SRV_PROJ] = pair_stride ? 0u : (nr + proj_per_task - 1) / proj_per_task;
+        for (uint32_t k = 0; k < SRV_KINDS; ++k) e.n[k] = n_tasks[k];
         e.flags = h->sw.server_trace ? 1u : 0u;
         e.stage_n16 = n16;
         e.job_off = (uint32_t)o_job;
@@ -524,11 +569,13 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
             S->next_seq = seq;
             S->free_slots.push_back(slot);
             S->in_flight.fetch_sub(1, std::memory_order_relaxed);
+            S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
             delete p;
             return kServerNotTaken;
         }
     }
     S->n_jobs.fetch_add(1, std::memory_order_relaxed);
+    S->ns_stage.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count(), std::memory_order_relaxed);
     if (pair_stride) S->n_all_pairs.fetch_add(1, std::memory_order_relaxed);
     *out = p;
     return PHMM_OK;
@@ -547,6 +594,7 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
     const uint32_t *flag = (const uint32_t *)(hs + L.res + 224);
     int st = PHMM_OK;
     bool done = false;
+    const auto t_enter = std::chrono::steady_clock::now();
     const auto give_up = p->t0 + std::chrono::milliseconds(std::max(1, h->sw.server_stall_ms) * 4);
     for (uint32_t spins = 0; !done; ++spins) {
         done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
@@ -554,14 +602,14 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
         if ((spins & 63u) == 63u) {
             // (has the server left while this call was on its way?  then whoever notices first starts the next one)
             if (__atomic_load_n(&S.exit_word->epoch, __ATOMIC_ACQUIRE) == __atomic_load_n(&S.epoch, __ATOMIC_RELAXED)) {
-                std::lock_guard<std::mutex> lk(S.mu);
+                std::lock_guard<SpinLock> lk(S.mu);
                 observe_exit(S);
                 if (S.broken) break;
                 if (!S.running && (int32_t)(p->seq - S.consumed) >= 0 && !launch_locked(S, h->sw)) break;
             }
             if (spins > 4096u) {
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() >= give_up) {
-                    std::lock_guard<std::mutex> lk(S.mu);
+                    std::lock_guard<SpinLock> lk(S.mu);
                     S.broken = true;
                     S.why_broken = "a call did not come back from the region server";
                     break;
@@ -574,10 +622,13 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
     if (!done) {
         // (the slot is not given back: a kernel may still be writing into it)
         S.in_flight.fetch_sub(1, std::memory_order_relaxed);
+        S.tasks_in_flight.fetch_sub(p->n_tasks, std::memory_order_relaxed);
         const std::string why = S.why_broken;
         delete p;
         return fail(err, "phmm_region_compute: " + (why.empty() ? std::string("the region server failed") : why), PHMM_ERR_INTERNAL);
     }
+    const auto t_done = std::chrono::steady_clock::now();
+    S.ns_wait.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_done - t_enter).count(), std::memory_order_relaxed);
     const uint32_t *sw_st = (const uint32_t *)(hs + L.res + 64);
     bool redo = false;
     if (sw_st[SW_STATUS_CAPACITY]) {
@@ -602,10 +653,12 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
         }
     }
     {
-        std::lock_guard<std::mutex> lk(S.mu);
+        std::lock_guard<SpinLock> lk(S.mu);
         S.free_slots.push_back(p->slot);
     }
+    S.ns_out.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_done).count(), std::memory_order_relaxed);
     S.in_flight.fetch_sub(1, std::memory_order_relaxed);
+    S.tasks_in_flight.fetch_sub(p->n_tasks, std::memory_order_relaxed);
     delete p;
     return redo ? kServerRedo : st;
 }
@@ -619,6 +672,9 @@ uint64_t server_stat(int device, const char *name) {
     if (n == "server_launches") return S->n_launches.load();
     if (n == "server_all_pairs") return S->n_all_pairs.load();
     if (n == "server_broken") return S->broken ? 1 : 0;
+    if (n == "server_stage_ns") return S->ns_stage.load();
+    if (n == "server_wait_ns") return S->ns_wait.load();
+    if (n == "server_out_ns") return S->ns_out.load();
     return 0;
 }
 
@@ -633,12 +689,12 @@ void server_quiesce(int device) {
     if (!S || !S->ok || S->broken) return;
     DevGuard dg(device);
     (void)hipStreamSynchronize(S->stream);
-    std::lock_guard<std::mutex> lk(S->mu);
+    std::lock_guard<SpinLock> lk(S->mu);
     observe_exit(*S);
 }
 
 // The trace of the tasks run so far (developer runs, switch server_trace): up to `cap` records into `out`; returns how many exist.
-uint32_t server_trace_read(int device, SrvTrace *out, uint32_t cap) {
+uint32_t server_trace_read(int device, phmm::SrvTrace *out, uint32_t cap) {
     Server *S;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -656,3 +712,9 @@ uint32_t server_trace_read(int device, SrvTrace *out, uint32_t cap) {
 }
 
 }  // namespace phmm_host
+
+static_assert(sizeof(SrvTrace) == 40, "trace record as include/phmm.h describes it");
+extern "C" uint32_t phmm_server_trace(int device_id, void *out, uint32_t cap) {
+    if (device_id < 0 || device_id >= kMaxDevices) return 0;
+    return phmm_host::server_trace_read(device_id, (SrvTrace *)out, cap);
+}

@@ -30,51 +30,95 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_system(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// ---- the ready list ---------------------------------------------------------------------------------------------------
-// (one lane) `n` tasks of `kind` of region slot `region` may be claimed from now on
-__device__ void append_ready(const SrvParams &P, uint32_t region, uint32_t kind, uint32_t n) {
-    const uint32_t idx = __hip_atomic_fetch_add(&P.ctl->rec_reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    SrvRec *rec = &P.recs[idx & (SRV_RECS - 1)];
-    st_agent(&rec->n, n);
-    st_agent(&rec->next, 0u);
-    st_agent(&rec->region, region);
-    st_agent(&rec->kind, kind);
-    __hip_atomic_store(&rec->valid, idx + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// What the stages of a call hand each other (staged inputs, modified qualities, the likelihood matrix, best alleles, alignments)
+// lies in ordinary device memory, and the eight XCDs' L2s are not coherent with each other: a task begins with an agent-scope
+// acquire (its XCD's L2 and its CU's L1 forget what they hold) and ends with an agent-scope release (its stores are written back)
+// before it is counted.  Measured (NOTEBOOK 20.2): the pair costs ~20 % of the rate at ten callers; UNCACHED arenas with plain
+// waits instead lost tasks (a call in ~10 000 never came back); an ACQUIRE inside the polling loop -- one invalidate per poll and
+// idle wave -- kept every L2 of the chip empty and made a region call take 2 ms.
+__device__ __forceinline__ void task_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void task_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+// (every memory operation of this wave issued so far has completed)
+__device__ __forceinline__ void drain_memory_ops() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
-// (one lane) stage `kind` of the region has one predecessor fewer to wait for
-__device__ void arrive(const SrvParams &P, uint32_t region, SrvRegion *reg, uint32_t kind, uint32_t need) {
-    if (need > 1 && __hip_atomic_fetch_add(&reg->arrived[kind], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u != need) return;
-    append_ready(P, region, kind, reg->n[kind]);
+// ---- posting tasks -------------------------------------------------------------------------------------------------------
+// (the whole wave) tasks [idx0, idx0 + n) of `kind` of region slot `region` go to the next n tickets of class `cls`
+__device__ void post_to(const SrvParams &P, uint32_t cls, uint32_t region, uint32_t kind, uint32_t idx0, uint32_t n) {
+    if (!n) return;
+    const uint32_t lane = threadIdx.x;
+    SrvMail *ring = P.mail + (size_t)cls * SRV_MAIL;
+    uint32_t first = 0;
+    if (lane == 0) first = __hip_atomic_fetch_add(cls ? &P.ctl->posted1 : &P.ctl->posted0, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    first = __builtin_amdgcn_readfirstlane(first);
+    for (uint32_t i = lane; i < n; i += WAVE) {
+        SrvMail *m = &ring[(first + i) & (SRV_MAIL - 1)];
+        st_agent(&m->region, region);
+        st_agent(&m->kind, kind);
+        st_agent(&m->idx, idx0 + i);
+    }
+    task_release();  // (the words above are in place before the tags say so)
+    for (uint32_t i = lane; i < n; i += WAVE) st_agent(&ring[(first + i) & (SRV_MAIL - 1)].tag, first + i + 1u);
 }
 
-// (one lane, behind the wave's release) the last task of stage `kind` is through: what waited for it becomes ready.
+// (the whole wave) `n` tasks of `kind` become ready: to the primaries that are waiting for work, then to the secondaries that
+// are; what is left when nobody waits is split between the two lines (whoever comes free takes from its own).
+__device__ void post(const SrvParams &P, uint32_t region, uint32_t kind, uint32_t n) {
+    uint32_t n0 = 0, n1 = 0;
+    if (threadIdx.x == 0) {
+        const int32_t wait0 = (int32_t)(ld_agent(&P.ctl->next_ticket0) - ld_agent(&P.ctl->posted0));
+        const int32_t wait1 = (int32_t)(ld_agent(&P.ctl->next_ticket1) - ld_agent(&P.ctl->posted1));
+        n0 = (uint32_t)min(max(wait0, 0), (int32_t)n);
+        n1 = (uint32_t)min(max(wait1, 0), (int32_t)(n - n0));
+        const uint32_t rest = n - n0 - n1;
+        n0 += (rest + 1) / 2;
+        n1 += rest / 2;
+    }
+    n0 = __builtin_amdgcn_readfirstlane(n0);
+    n1 = __builtin_amdgcn_readfirstlane(n1);
+    post_to(P, 0, region, kind, 0, n0);
+    post_to(P, 1, region, kind, n0, n1);
+}
+
+// (the whole wave, behind its release) the last task of stage `kind` is through: what waited for it is posted.
 //   STAGE -> PREP (-> FWD) and, where the call aligns every pair, SWALL;  FWD (+ SWALL) -> POST;  POST -> SW -> PROJ.
 // The last stage stores the finish word for the caller.
 __device__ void stage_complete(const SrvParams &P, uint32_t region, SrvRegion *reg, uint32_t kind) {
-    const SrvJob *job = reg->job;
+    const uint32_t lane = threadIdx.x;
     const bool all_pairs = reg->n[SRV_SWALL] != 0;
     bool last = false;
     switch (kind) {
         case SRV_STAGE:
-            arrive(P, region, reg, SRV_PREP, 1);
-            if (all_pairs) arrive(P, region, reg, SRV_SWALL, 1);
+            post(P, region, SRV_PREP, reg->n[SRV_PREP]);
+            if (all_pairs) post(P, region, SRV_SWALL, reg->n[SRV_SWALL]);
             break;
-        case SRV_PREP: arrive(P, region, reg, SRV_FWD, 1); break;
-        case SRV_FWD: arrive(P, region, reg, SRV_POST, all_pairs ? 2 : 1); break;
-        case SRV_SWALL: arrive(P, region, reg, SRV_POST, 2); break;
+        case SRV_PREP: post(P, region, SRV_FWD, reg->n[SRV_FWD]); break;
+        case SRV_FWD:
+        case SRV_SWALL: {  // (a call that aligns every pair: its post-step waits for both)
+            uint32_t both = 1;
+            if (all_pairs) {
+                if (lane == 0) both = __hip_atomic_fetch_add(&reg->arrived[SRV_POST], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1u : 0u;
+                both = __builtin_amdgcn_readfirstlane(both);
+                if (both) task_acquire();
+            }
+            if (both) post(P, region, SRV_POST, reg->n[SRV_POST]);
+            break;
+        }
         case SRV_POST:
-            if (reg->n[SRV_SW]) arrive(P, region, reg, SRV_SW, 1);
+            if (reg->n[SRV_SW]) post(P, region, SRV_SW, reg->n[SRV_SW]);
             else last = true;
             break;
-        case SRV_SW: arrive(P, region, reg, SRV_PROJ, 1); break;
+        case SRV_SW: post(P, region, SRV_PROJ, reg->n[SRV_PROJ]); break;
         default: last = true; break;
     }
-    if (last) {
-        // (every task's stores are behind its own release and this lane's acquire of the count; now for the host)
+    if (last && lane == 0) {
+        // (every task's stores are behind its own release and this wave's acquire of the count; now for the host)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        __hip_atomic_store(job->finish_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_fetch_add(&P.ctl->finished, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reg->job->finish_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(&P.ctl->finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -133,7 +177,7 @@ __device__ __noinline__ void task_prep(const SrvJob *job_v, uint32_t idx_v) {
     if (r < p.n_reads) prepdev::prep_read_wave(p, r, c, smem);
 }
 
-template <int K>
+template <int L, int K>
 __device__ __noinline__ void task_fwd(const SrvJob *job_v, uint32_t idx_v) {
     const SrvJob *job = uniform(job_v);
     const uint32_t idx = uniform(idx_v);
@@ -141,7 +185,7 @@ __device__ __noinline__ void task_fwd(const SrvJob *job_v, uint32_t idx_v) {
     const ForwardParams p = fetch_uniform(&job->fwd);
     const uint32_t quads = fetch_uniform(&job->fwd_quads);
     const uint32_t r = idx / quads, quad = idx % quads;
-    forward_read<16, K>(p, r, (int)quad, (int)quads, false, smem);
+    forward_read<L, K>(p, r, (int)quad, (int)quads, false, smem);
 }
 
 template <int K>
@@ -195,6 +239,7 @@ __device__ __noinline__ void task_proj(const SrvJob *job_v, uint32_t idx_v) {
 
 #define PHMM_SRV_FWD_K(X) \
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25)
+#define PHMM_SRV_FWD_K32(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #define PHMM_SRV_SW_K(X) X(2) X(3) X(4) X(5) X(6) X(8)
 
 // ---- the dispatcher -------------------------------------------------------------------------------------------------------
@@ -236,10 +281,10 @@ __device__ void dispatcher(const SrvParams &P) {
                 reg->stage_src = reinterpret_cast<const void *>(src);
                 reg->stage_dst = reinterpret_cast<void *>(dst);
                 reg->job = reinterpret_cast<const SrvJob *>(dst + job_off);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                append_ready(P, slot_region, SRV_STAGE, reg->n[SRV_STAGE]);
             }
             (void)total;
+            task_release();
+            post(P, slot_region, SRV_STAGE, __builtin_amdgcn_readlane(w, 2 + SRV_STAGE));
             consumed += 1;
             last_activity = last_progress = wall_clock64();
             continue;
@@ -262,9 +307,21 @@ __device__ void dispatcher(const SrvParams &P) {
             break;
         }
     }
+    // Everybody out: a worker that takes a ticket from now on sees `closed`; those that are waiting on a ticket get a word each.
     if (lane == 0) {
         if (fault) st_agent(&P.ctl->fault, 1u);
-        __hip_atomic_store(&P.ctl->closed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (the store has to be out before the loads are issued: relaxed accesses with the wave's memory counter drained in between)
+        st_agent(&P.ctl->closed, 1u);
+    }
+    drain_memory_ops();
+    for (uint32_t cls = 0; cls < 2; ++cls) {
+        const uint32_t waiting_to = __builtin_amdgcn_readfirstlane(ld_agent(cls ? &P.ctl->next_ticket1 : &P.ctl->next_ticket0));
+        const uint32_t waiting_from = __builtin_amdgcn_readfirstlane(ld_agent(cls ? &P.ctl->posted1 : &P.ctl->posted0));
+        if ((int32_t)(waiting_to - waiting_from) > 0 && waiting_to - waiting_from < SRV_MAIL)
+            for (uint32_t t = waiting_from + lane; (int32_t)(waiting_to - t) > 0; t += WAVE)
+                st_agent(&P.mail[(size_t)cls * SRV_MAIL + (t & (SRV_MAIL - 1))].tag, SRV_MAIL_EXIT);
+    }
+    if (lane == 0) {
         // (the host starts the next launch from `consumed`; that launch runs behind this one on the server's stream)
         P.exit_word->consumed = consumed;
         P.exit_word->fault = fault;
@@ -281,68 +338,80 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_region_server(const SrvParams P)
         return;
     }
     const uint32_t lane = threadIdx.x;
-    uint32_t j = 0;  // the record this worker looks at
-    uint32_t naps = 0;
+    // The first of the server's waves on a SIMD is its primary worker, the second its secondary (SrvCtl): where this wave runs,
+    // from the hardware's own registers -- HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]; XCC_ID [3:0].
+    uint32_t cls = 0;
+    if (lane == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        const uint32_t where = (xcc & 15u) << 9 | ((hw >> 13) & 7u) << 7 | ((hw >> 12) & 1u) << 6 | ((hw >> 8) & 15u) << 2 | ((hw >> 4) & 3u);
+        cls = __hip_atomic_fetch_add(&P.ctl->simd_waves[where & 8191u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
+    cls = __builtin_amdgcn_readfirstlane(cls);
+    SrvMail *const ring = P.mail + (size_t)cls * SRV_MAIL;
+    uint32_t *const my_tickets = cls ? &P.ctl->next_ticket1 : &P.ctl->next_ticket0;
     for (;;) {
-        // ---- claim a task (lane 0) ------------------------------------------------------------------------------------------------
-        uint32_t got = 0, region = 0, kind = 0, idx = 0, n_kind = 0;
+        // ---- take a ticket and wait for its mailbox (lane 0) ------------------------------------------------------------------------
+        uint32_t got = 0, region = 0, kind = 0, idx = 0;
         uint64_t t_claim = 0;
         if (lane == 0) {
-            for (;;) {
-                SrvRec *rec = &P.recs[j & (SRV_RECS - 1)];
-                if (__hip_atomic_load(&rec->valid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == j + 1u) {
-                    n_kind = ld_agent(&rec->n);
-                    // (a look before the add: an exhausted record's counter is left alone)
-                    if (ld_agent(&rec->next) < n_kind) {
-                        idx = __hip_atomic_fetch_add(&rec->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (idx < n_kind) {
-                            region = ld_agent(&rec->region);
-                            kind = ld_agent(&rec->kind);
-                            got = 1;
-                            break;
-                        }
+            const uint32_t ticket = __hip_atomic_fetch_add(my_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            drain_memory_ops();  // (the ticket is taken before `closed` is looked at)
+            SrvMail *m = &ring[ticket & (SRV_MAIL - 1)];
+            // (the dispatcher sets `closed`, THEN reads next_ticket and tells every ticket below that to leave: a ticket taken
+            // later sees the flag here)
+            if (!ld_agent(&P.ctl->closed)) {
+                for (uint32_t naps = 0;; ++naps) {
+                    // (a RELAXED load: an acquire here is a cache invalidate per poll and wave -- two thousand pollers then keep every
+                    // L2 of the chip empty and each task's loads go to memory: 600 us for a PairHMM task of 50.  The one acquire
+                    // that is needed follows the claim, below.)
+                    const uint32_t tag = ld_agent(&m->tag);
+                    if (tag == ticket + 1u) {
+                        region = ld_agent(&m->region);
+                        kind = ld_agent(&m->kind);
+                        idx = ld_agent(&m->idx);
+                        got = 1;
+                        break;
                     }
-                    j += 1;  // every task of this record is taken
-                    __hip_atomic_fetch_max(&P.ctl->head_rec, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    continue;
+                    if (tag == SRV_MAIL_EXIT) break;
+                    if ((naps & 1023u) == 1023u && ld_agent(&P.ctl->closed)) break;  // (belt and braces: once in ~1 ms)
+                    // nobody else polls this word: ~0.25 us naps while a stage may be about to complete, then ~1 us
+                    if (naps < 32) __builtin_amdgcn_s_sleep(8);
+                    else __builtin_amdgcn_s_sleep(32);
                 }
-                const uint32_t head = ld_agent(&P.ctl->head_rec);
-                if ((int32_t)(head - j) > 0) {  // (others are further on)
-                    j = head;
-                    continue;
-                }
-                if (ld_agent(&P.ctl->closed)) break;
-                // nothing ready: poll (the first naps are short -- a stage that is about to complete -- then ~1 us, then ~4 us)
-                naps += 1;
-                if (naps < 16) __builtin_amdgcn_s_sleep(4);
-                else if (naps < 256) __builtin_amdgcn_s_sleep(32);
-                else __builtin_amdgcn_s_sleep(127);
             }
             if (got && P.trace) t_claim = wall_clock64();
         }
         got = __builtin_amdgcn_readfirstlane(got);
         if (!got) return;  // closed
-        naps = 0;
         region = __builtin_amdgcn_readfirstlane(region);
         kind = __builtin_amdgcn_readfirstlane(kind);
         idx = __builtin_amdgcn_readfirstlane(idx);
-        n_kind = __builtin_amdgcn_readfirstlane(n_kind);
-        j = __builtin_amdgcn_readfirstlane(j);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the stages before this one stored
+        task_acquire();  // what the stages before this one stored
         SrvRegion *reg = &P.regions[region];
         const SrvJob *job = reg->job;
+        const uint32_t n_kind = reg->n[kind];
         const uint64_t t_begin = P.trace ? wall_clock64() : 0;
         // ---- run it ---------------------------------------------------------------------------------------------------------------
         switch (kind) {
             case SRV_STAGE: task_stage(reg, idx); break;
             case SRV_PREP: task_prep(job, idx); break;
             case SRV_FWD:
-                switch (job->fwd_k) {
+                if (job->fwd_l == 32) {
+                    switch (job->fwd_k) {
 #define PHMM_CASE(KK) \
-    case KK: task_fwd<KK>(job, idx); break;
-                    PHMM_SRV_FWD_K(PHMM_CASE)
+    case KK: task_fwd<32, KK>(job, idx); break;
+                        PHMM_SRV_FWD_K32(PHMM_CASE)
 #undef PHMM_CASE
-                    default: break;
+                        default: break;
+                    }
+                } else {
+                    switch (job->fwd_k) {
+#define PHMM_CASE(KK) \
+    case KK: task_fwd<16, KK>(job, idx); break;
+                        PHMM_SRV_FWD_K(PHMM_CASE)
+#undef PHMM_CASE
+                        default: break;
+                    }
                 }
                 break;
             case SRV_SWALL:
@@ -363,7 +432,8 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_region_server(const SrvParams P)
             default: break;
         }
         // ---- count it in; the task that completes its stage makes the next ones ready --------------------------------------------
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        task_release();
+        uint32_t completes = 0;
         if (lane == 0) {
             if (P.trace && (reg->flags & 1u)) {
                 const uint32_t t = __hip_atomic_fetch_add(&P.ctl->trace_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -372,14 +442,17 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_region_server(const SrvParams P)
                     tr.seq = reg->seq;
                     tr.kind = kind;
                     tr.idx = idx;
-                    tr.worker = blockIdx.x;
+                    tr.worker = blockIdx.x | cls << 31;
                     tr.t_claim = t_claim;
                     tr.t_begin = t_begin;
                     tr.t_end = wall_clock64();
                 }
             }
-            const uint32_t before = __hip_atomic_fetch_add(&reg->done[kind], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1u == n_kind) stage_complete(P, region, reg, kind);
+            completes = __hip_atomic_fetch_add(&reg->done[kind], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_kind ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_readfirstlane(completes)) {
+            task_acquire();
+            stage_complete(P, region, reg, kind);
         }
     }
 }
