@@ -548,9 +548,9 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
 int phmm_set_switch(phmm_handle *h, const char *name, int value);
 uint64_t phmm_get_stat(phmm_handle *h, const char *name);
 /* Developer runs (switch "server_trace" / PHMM_SERVER_TRACE=1): the tasks the device's region server has run since its last
- * launch, one record each -- {u32 sequence number of the call, u32 kind (0 stage-in, 1 pre-step, 2 PairHMM, 3 aligner over
- * every pair, 4 post-step / pick, 5 aligner, 6 projection), u32 index, u32 worker, u64 claimed, u64 begun, u64 ended} in ticks
- * of the device's 100 MHz clock.  Copies up to `cap` records (40 bytes each) into `out`, returns how many exist; waits for
+ * launch, one record each -- {u32 sequence number of the call, u32 kind (0 stage-in, 1 a read's chain), u32 index, u32 worker,
+ * u64 claimed, u64 begun, u64 ended, u64[4] inside a chain: pre-step done, PairHMM done, post-step done, aligner done} in ticks
+ * of the device's 100 MHz clock.  Copies up to `cap` records (72 bytes each) into `out`, returns how many exist; waits for
  * the server to leave the chip first.  tools/server_trace.cpp prints a call's timeline from it. */
 uint32_t phmm_server_trace(int device_id, void *out, uint32_t cap);
 

@@ -491,9 +491,13 @@ phmm_handle *create_internal(int device, unsigned flags) {
     return phmm_create(device, flags);
 }
 
+int user_handles_on(int device) { return g_user_handles[device % kMaxDevices].load(std::memory_order_relaxed); }
+
 phmm_handle *route_shared(phmm_handle *h) {
-    if (h->internal || h->sw_touched || h->comb || h->sw.route_shared == 0) return nullptr;
-    const int above = h->sw.route_shared < 0 ? 4 : h->sw.route_shared;
+    // (opt-in since round 6: which regions share a flush depends on timing, so routed results are reproducible to ~1e-13, not bit
+    // for bit -- the default for many private handles is the region server, whose results never depend on the load)
+    if (h->internal || h->sw_touched || h->comb || h->sw.route_shared <= 0) return nullptr;
+    const int above = h->sw.route_shared;
     if (g_user_handles[h->device].load(std::memory_order_relaxed) <= above) return nullptr;
     if (h->backing) return h->backing;  // (lives as long as one of the caller's handles does on the device: at least as long as h)
     std::lock_guard<std::mutex> lk(g_backing_mu);

@@ -441,7 +441,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // own LDS, (R + 1) row records.  Wave-uniform control flow; every lane of the wave must arrive.
 template <int L, int K>
 __device__ __forceinline__ void forward_read(const ForwardParams &p, const uint32_t r, const int quad_begin, const int quad_step,
-                                             const bool cnd_select, unsigned char *smem_wave) {
+                                             const bool cnd_select, unsigned char *smem_wave, double *coherent_out = nullptr) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = lane / L, l = lane % L;
@@ -506,7 +506,10 @@ __device__ __forceinline__ void forward_read(const ForwardParams &p, const uint3
         for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (l == 0 && hv) {
             const double v = log10(s) - p.initial_condition_log10;
-            out_row[a] = v;
+            // (coherent_out: a helper wave of the region server, whose results a wave of another XCD reads -- agent-scope stores
+            // into words that only such accesses ever touch)
+            if (coherent_out) __hip_atomic_store(&coherent_out[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out_row[a] = v;
             if (const uint32_t sb = status_bits(v)) atomicOr(p.status, sb);  // reference asserts result <= 0 (pair_hmm.rs:478-481)
         }
     }

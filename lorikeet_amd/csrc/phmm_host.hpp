@@ -58,13 +58,14 @@ struct Switches {
     int region_debug_pick = 0;  // PHMM_REGION_DEBUG_PICK (tests): 1 = the all-pairs aligner is enqueued BEHIND phmm_pick_reads on the call's own
                                 // stream (both on one hardware queue, in order: the wait can only run out of time); 2 = the all-pairs aligner
                                 // stores two words into the call's status block ~300 us AFTER it has counted itself in (round 4's bug, on purpose)
-    int route_shared = -1;      // PHMM_ROUTE_SHARED: while MORE than this many of the caller's handles are alive on a device, the one-shot calls of
-                                // private handles go through the device's shared combiner (its lanes) instead of their own streams -- -1 = 4, 0 = never
+    int route_shared = 0;       // PHMM_ROUTE_SHARED (opt-in): while MORE than this many of the caller's handles are alive on a device, the one-shot calls
+                                // of private handles go through the device's shared combiner (its lanes) instead of their own streams -- 0 = never
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
-    int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1 where its limits admit
-                                // them (a handle whose other switches were changed keeps the launched pipeline), 0 never, 1 also on such a handle
+    int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1: the one-shot calls of
+                                // PRIVATE handles while more than four of the caller's handles are alive on the device (a handle whose other switches
+                                // were changed keeps the launched pipeline); 0 never; 1 every call the server's limits admit, a shared handle's too
     int server_idle_us = 200;   // PHMM_SERVER_IDLE_US: how long the server stays on the chip with nothing in flight and nothing arriving
     int server_stall_ms = 500;  // PHMM_SERVER_STALL_MS: calls in flight and none finishing for this long: the server gives up (the calls fail)
     int server_trace = 0;       // PHMM_SERVER_TRACE: every task leaves a record (tools/server_trace.py)
@@ -291,9 +292,12 @@ struct RegionArgs {
 struct ServerPending;
 constexpr int kServerNotTaken = -2000;  // server_region_submit: the call is outside the server's limits -- nothing was done
 constexpr int kServerRedo = -2001;      // server_region_wait: run the call again the launched way (an alignment outgrew its slot)
-int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out);
+int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit);
+int user_handles_on(int device);  // the caller's handles alive on the device (phmm_api.cpp)
 int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);
 uint64_t server_stat(int device, const char *name);
+void server_yield(int device);
+int region_calls_in_flight(int device);  // phmm_region_compute calls of the launched kind between enqueue and finish (phmm_region.cpp)
 void server_quiesce(int device);
 // argument check of phmm_region_compute / phmm_region_submit: the message of the first violation, or empty
 std::string region_validate(const RegionArgs &a);

@@ -70,7 +70,10 @@ constexpr size_t kHalvesUpToPairs = 512;  // (read, haplotype) pairs up to which
 std::atomic<int> g_region_calls[kMaxDevices];  // phmm_region_compute calls between enqueue and finish, per device (all handles of the process)
 struct InFlight {
     std::atomic<int> &n;
-    explicit InFlight(int device) : n(g_region_calls[device % kMaxDevices]) { n.fetch_add(1, std::memory_order_relaxed); }
+    explicit InFlight(int device) : n(g_region_calls[device % kMaxDevices]) {
+        n.fetch_add(1, std::memory_order_seq_cst);
+        phmm_host::server_yield(device);  // (the resident server, if it is on the chip, makes room: its waves fill every SIMD)
+    }
     ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
 };
 
@@ -82,6 +85,8 @@ constexpr uint32_t kFirstSwCapacity = 24;  // CIGAR elements reserved per read -
 }  // namespace
 
 namespace phmm_host {
+
+int region_calls_in_flight(int device) { return g_region_calls[device % kMaxDevices].load(std::memory_order_seq_cst); }
 
 std::string region_validate(const RegionArgs &a) {
     const std::string w = "phmm_region_compute: ";
@@ -1120,7 +1125,7 @@ extern "C" int phmm_region_compute(phmm_handle *h, const phmm_engine_config *cfg
         // The device's resident server takes the call if it is within its limits: staged, one ring entry, a poll (phmm_server.cpp).
         {
             ServerPending *pending = nullptr;
-            int st = server_region_submit(h, a, &pending);
+            int st = server_region_submit(h, a, &pending, false);
             if (st == PHMM_OK) {
                 st = server_region_wait(h, pending, &h->err, nullptr);
                 if (st != kServerRedo) {

@@ -32,7 +32,7 @@ constexpr size_t kSlotBytes = 4u << 20;   // one slot: staged inputs + device-on
 constexpr size_t kStageMax = 1u << 20;    // inputs of one job (the stage-in tasks copy them over the link)
 constexpr int kMaxSlots = 64;
 constexpr uint32_t kSwCapacity = 24;      // CIGAR elements per read -> haplotype alignment (a call that needs more takes the launched pipeline)
-constexpr uint32_t kMaxHap = 16 * SRV_MAX_K;  // 400
+constexpr uint32_t kMaxHap = 512;          // 16 lanes x 25 columns per pair up to 400 bases, 32 x 16 beyond
 const int kSwKs[] = {2, 3, 4, 5, 6, 8};
 
 struct DevGuard {
@@ -48,7 +48,11 @@ struct DevGuard {
 
 struct Slot {
     char *dev = nullptr, *host = nullptr, *host_dev = nullptr;  // host_dev: the mirror as the device sees it
+    char *sync = nullptr;  // device memory that only agent-scope atomics ever touch: [status | group_done x kSyncReads | helper_out]
 };
+constexpr size_t kSyncReads = 16384;                       // reads of one call at most
+constexpr size_t kSyncHelperBytes = 1u << 20;              // ... and reads x haplotypes (rounded up to eight) x 8 bytes of helpers' likelihoods
+constexpr size_t kSyncBytes = 256 + 4 * kSyncReads + kSyncHelperBytes;
 
 // The server's own lock: held for a handful of stores (a slot taken or given back, a ring entry written).  A spinning one: a
 // std::mutex parked and woke ten callers' threads for critical sections of 100 ns -- staging + publishing took 48 us a call
@@ -74,7 +78,7 @@ struct Server {
     size_t block_bytes = 0;
     SrvRegion *d_regions = nullptr;
     SrvEntry *ring = nullptr;
-    SrvExit *exit_word = nullptr;
+    SrvExit *exit_word = nullptr;   // [0]: what a launch says when it leaves; 128 bytes on: the yield word (host -> dispatcher)
     const SrvEntry *ring_dev = nullptr;
     SrvExit *exit_dev = nullptr;
     uint32_t *d_slab = nullptr;
@@ -87,7 +91,7 @@ struct Server {
     std::vector<int> free_slots;
     std::atomic<int> in_flight{0};
     std::atomic<uint32_t> tasks_in_flight{0};  // of the calls in flight: kept below SRV_MAIL_TASKS (phmm_server.hpp)
-    std::atomic<uint64_t> n_jobs{0}, n_launches{0}, n_all_pairs{0};
+    std::atomic<uint64_t> n_jobs{0}, n_launches{0};
     std::atomic<uint64_t> ns_stage{0}, ns_wait{0}, ns_out{0};  // host time of the calls so far: staging + publishing, polling, handing the results over
     SrvTrace *d_trace = nullptr;
     uint32_t trace_cap = 0;
@@ -149,8 +153,11 @@ void observe_exit(Server &S) {
     }
 }
 
-// (S.mu held) a launch that starts at ring entry S.consumed
+// (S.mu held) a launch that starts at ring entry S.consumed.  Not while region calls of the launched kind are in flight: the
+// server's waves fill every SIMD, and kernels launched beside them would wait for it to leave -- the calls that are waiting
+// for the server look again (server_region_wait) and launch it when those are through.
 bool launch_locked(Server &S, const Switches &sw) {
+    if (region_calls_in_flight(S.device) > 0) return true;
     DevGuard dg(S.device);
     if (sw.server_trace && !S.d_trace) {
         S.trace_cap = 1u << 20;
@@ -162,6 +169,7 @@ bool launch_locked(Server &S, const Switches &sw) {
     P.regions = S.d_regions;
     P.ring = S.ring_dev;
     P.exit_word = S.exit_dev;
+    P.yield_word = (const uint32_t *)((const char *)S.exit_dev + 128);
     P.start_seq = S.consumed;
     P.epoch = S.epoch + 1;
     P.idle_ticks = 100u * (uint32_t)std::max(1, sw.server_idle_us);
@@ -196,7 +204,6 @@ struct ServerPending {
     Layout L;
     uint64_t n_out = 0;
     uint32_t n_tasks = 0;
-    bool all_pairs = false;
     std::chrono::steady_clock::time_point t0;
 };
 
@@ -204,16 +211,21 @@ void server_pending_free(ServerPending *p) { delete p; }
 
 // Stage one call in a slot and hand it to the device's server.  kServerNotTaken: the call is outside the server's limits (or
 // the server is not to be used): nothing was done, the caller takes the launched pipeline.  `a` is validated.
-int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out) {
+int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit) {
     *out = nullptr;
     const auto t_enter = std::chrono::steady_clock::now();
-    if (h->sw.region_server == 0 || (h->sw_touched && h->sw.region_server < 0)) return kServerNotTaken;
+    // Which calls: with no switch set, the one-shot region calls of PRIVATE handles once more than four of the caller's handles are
+    // alive on the device -- a handle per worker thread at Lorikeet's --threads 10: past four, the handles' own hardware queues
+    // share the command processor's pipes and every caller sits in its own chain of launches (22 k regions/s at 16 callers, 12.5 k
+    // at 32); here nothing is launched and the results are the region's own bits whatever the load.  Up to four handles keep
+    // their queues (faster there), a shared handle's phmm_region_submit keeps its combiner (faster, and it says that it combines).
+    if (h->sw.region_server == 0) return kServerNotTaken;
+    if (h->sw.region_server < 0 && (via_submit || h->sw_touched || h->internal || h->comb || user_handles_on(h->device) <= 4)) return kServerNotTaken;
     const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
     if (!ng || !nr || !nh) return kServerNotTaken;
     if (ng >= 8 && (size_t)a.read_off[nr] > one_shot_bytes()) return kServerNotTaken;  // (large batches: the chunk pipeline)
     // ---- limits ------------------------------------------------------------------------------------------------------------
     uint32_t max_r = 0, max_h = 0, max_nh = 0, max_hap_cigar = 0;
-    bool plain = true;  // no empty read / haplotype, no read that is all soft clip, every region with reads and haplotypes
     for (uint32_t g = 0; g < ng; ++g) {
         const uint32_t nrg = a.region_read_off[g + 1] - a.region_read_off[g], nhg = a.region_hap_off[g + 1] - a.region_hap_off[g];
         if (!nrg || !nhg) return kServerNotTaken;
@@ -225,8 +237,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         const uint32_t len = a.read_off[r + 1] - a.read_off[r];
         if (!len) return kServerNotTaken;
         max_r = std::max(max_r, len);
-        const uint32_t clipped = a.read_soft_clip ? a.read_soft_clip[2 * r] + a.read_soft_clip[2 * r + 1] : 0u;
-        if (clipped >= len) plain = false;
     }
     for (uint32_t x = 0; x < nh; ++x) {
         const uint32_t len = a.hap_off[x + 1] - a.hap_off[x];
@@ -243,34 +253,21 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
                                      std::max(std::llabs((long long)w.gap_open_penalty), std::llabs((long long)w.gap_extend_penalty)));
         if (big * ((int64_t)max_h + max_r + 2) >= 100000000) return kServerNotTaken;
     }
-    // The forward sweep's lane geometry: 32 lanes per pair (two haplotypes a wave) for a call of up to 2 048 pairs -- half the
-    // steps' work per wave, twice the waves: a region per call is a chain of dependent stages on a chip that is mostly idle, and
-    // a lone wave issues an f64 instruction every ~7 clocks whatever it has to do --, 16 lanes (four a wave, a third fewer
-    // instructions per cell) for larger calls.  A function of the call's own shape: the same bits under any load.
-    uint64_t n_pairs = 0;
-    for (uint32_t g = 0; g < ng; ++g) n_pairs += (uint64_t)(a.region_read_off[g + 1] - a.region_read_off[g]) * (a.region_hap_off[g + 1] - a.region_hap_off[g]);
-    const uint32_t fwd_l = n_pairs <= 2048 && h->sw.force_L != 16 ? 32u : 16u;
-    const uint32_t fwd_k = std::max<uint32_t>(2, (max_h + fwd_l - 1) / fwd_l);
+    // (the sweep's lane geometry is a function of the call's own longest haplotype: the same bits under any load)
+    const uint32_t fwd_l = max_h <= 16u * SRV_MAX_K ? 16u : 32u, group_haps = 64 / fwd_l;
+    const uint32_t fwd_k = std::max<uint32_t>(fwd_l == 16 ? 2 : 13, (max_h + fwd_l - 1) / fwd_l);
     uint32_t sw_k = 0;
     for (int k : kSwKs)
         if (!sw_k && (uint32_t)k * 64 >= max_h) sw_k = (uint32_t)k;
     const size_t lds_ref = (max_h + 15) / 16 * 16, lds_alt = (max_r + 15) / 16 * 16;
     const size_t lds_group = (lds_ref + lds_alt + 4ull * (max_r + 1) + 15) / 16 * 16;
     const uint32_t pj_capacity = 4 * (kSwCapacity + max_hap_cigar + 2) + 8;
-    const uint32_t proj_per_task = (uint32_t)std::min<size_t>(64, SRV_LDS_BYTES / (16ull * pj_capacity));
     const uint32_t prep_rows = (max_r + 1 + 7) / 8 * 8;
-    if (!sw_k || lds_group > SRV_LDS_BYTES || !proj_per_task || (size_t)prep_rows * 17 > SRV_LDS_BYTES) return kServerNotTaken;
+    if (!sw_k || lds_group > SRV_LDS_BYTES || 16ull * pj_capacity > SRV_LDS_BYTES || (size_t)prep_rows * 17 > SRV_LDS_BYTES) return kServerNotTaken;
     if (!h->server) h->server = server_of(h->device);  // (the device's one server: looked up once per handle)
     Server *S = (Server *)h->server;
     if (!S || !S->ok || S->broken) return kServerNotTaken;
     if ((size_t)(std::max(max_h, max_r) + 64) * (size_t)sw_flag_words((int)sw_k) * 64 > S->slab_stride) return kServerNotTaken;
-    // A call alone on the chip aligns every read against EVERY haplotype beside the PairHMM tasks (phmm_region.cpp, NOTEBOOK 18.1):
-    // integer work either way, so the results do not depend on the choice.
-    uint32_t pair_stride = 0;
-    if (plain && max_nh >= 2 && h->sw.region_sw_all != 0) {
-        const uint64_t limit = h->sw.region_sw_all > 0 ? (uint64_t)h->sw.region_sw_all : S->in_flight.load(std::memory_order_relaxed) == 0 ? 2048u : 0u;
-        if ((uint64_t)nr * max_nh <= limit) pair_stride = max_nh;
-    }
     // ---- the job's layout in a slot: [offset arrays | job record | inputs ... status] staged, then device-only, then results ------
     size_t used = 0;
     auto take = [&](size_t bytes) {
@@ -280,21 +277,15 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     };
     const size_t o_read_region = take(4ull * nr), o_rro = take(4ull * (ng + 1)), o_rho = take(4ull * (ng + 1)), o_ro = take(4ull * (nr + 1)),
                  o_ho = take(4ull * (nh + 1)), o_oo = take(8ull * (ng + 1)), o_job = take(sizeof(SrvJob));
-    const Layout L(up256(used), a, kSwCapacity, pair_stride);
-    if (L.in_end > kStageMax || L.end > kSlotBytes) return kServerNotTaken;
+    const Layout L(up256(used), a, kSwCapacity, 0);
+    // (what waves of different XCDs hand each other lies in a buffer of the slot's own that only agent-scope atomics ever touch)
+    const size_t helper_stride = (max_nh + 7) / 8 * 8;
+    if (L.in_end > kStageMax || L.end > kSlotBytes || nr > kSyncReads || 8ull * nr * helper_stride > kSyncHelperBytes) return kServerNotTaken;
     // ---- the tasks ---------------------------------------------------------------------------------------------------------------------
-    const uint32_t haps_per_wave = 64 / fwd_l;
-    const uint32_t n16 = (uint32_t)((L.in_end + 15) / 16), quads = (max_nh + haps_per_wave - 1) / haps_per_wave;
-    const uint32_t prep_waves = std::max<uint32_t>(1, (max_r + 63) / 64);  // (a wave per 64 positions)
-    const size_t n_sw = pair_stride ? (size_t)nr * pair_stride : nr;
+    const uint32_t n16 = (uint32_t)((L.in_end + 15) / 16), groups = (max_nh + group_haps - 1) / group_haps;
     uint32_t n_tasks[SRV_KINDS];
     n_tasks[SRV_STAGE] = (n16 + SRV_STAGE_UNITS - 1) / SRV_STAGE_UNITS;
-    n_tasks[SRV_PREP] = nr * prep_waves;
-    n_tasks[SRV_FWD] = nr * quads;
-    n_tasks[SRV_SWALL] = pair_stride ? (uint32_t)n_sw : 0u;
-    n_tasks[SRV_POST] = pair_stride ? (nr + proj_per_task - 1) / proj_per_task : (nr + 63) / 64;
-    n_tasks[SRV_SW] = pair_stride ? 0u : nr;
-    n_tasks[SRV_PROJ] = pair_stride ? 0u : (nr + proj_per_task - 1) / proj_per_task;
+    n_tasks[SRV_CHAIN] = nr * groups;  // (a wave per read and group of four haplotypes; the group-0 wave goes on to the read's alignment)
     uint32_t total_tasks = 0;
     for (uint32_t k = 0; k < SRV_KINDS; ++k) total_tasks += n_tasks[k];
     // (every task posted waits in a mailbox of its own until a worker takes it: the calls in flight must not have more tasks than
@@ -314,12 +305,13 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
             DevGuard dg(S->device);
             Slot &T = S->slots[S->n_slots];
             void *dp = nullptr;
-            if (hip_ok(hipMalloc((void **)&T.dev, kSlotBytes)) && hip_ok(hipHostMalloc((void **)&T.host, kSlotBytes, hipHostMallocDefault)) &&
+            if (hip_ok(hipMalloc((void **)&T.dev, kSlotBytes)) && hip_ok(hipMalloc((void **)&T.sync, kSyncBytes)) && hip_ok(hipHostMalloc((void **)&T.host, kSlotBytes, hipHostMallocDefault)) &&
                 hip_ok(hipHostGetDevicePointer(&dp, T.host, 0)) && dp) {
                 T.host_dev = (char *)dp;
                 slot = S->n_slots++;
             } else {
                 if (T.dev) (void)hipFree(T.dev);
+                if (T.sync) (void)hipFree(T.sync);
                 if (T.host) (void)hipHostFree(T.host);
                 T = Slot();
             }
@@ -386,7 +378,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         pp.out_gcp = (uint8_t *)(dev + L.g);
         pp.threshold = (double *)(dev + L.thr);
         pp.lds_rows = prep_rows;
-        pp.waves_per_read = prep_waves;
+        pp.waves_per_read = 1;  // (the chain's wave takes the whole read)
         pp.default_indel_qual = 45;  // ReadUtils::DEFAULT_INSERTION_DELETION_QUAL (read_utils.rs:23)
         pp.constant_gcp = a.cfg.constant_gcp;
         pp.base_quality_score_threshold = a.cfg.base_quality_score_threshold;
@@ -418,7 +410,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         f.inv_om = h->d_inv_om;
         f.initial_condition = initial_condition();
         f.initial_condition_log10 = initial_condition_log10();
-        f.status = (uint32_t *)(dev + L.status_in);
+        f.status = (uint32_t *)T.sync;
     }
     {
         PostParams &po = job->pb.post;
@@ -432,8 +424,8 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         po.out_final = (double *)(mirror + L.out);
         po.threshold = (const double *)(dev + L.thr);
         po.keep = (uint8_t *)(dev + L.keep);
-        po.status_in = (const uint32_t *)(dev + L.status_in);
-        po.status_out = (uint32_t *)(mirror + L.res);
+        po.status_in = nullptr;
+        po.status_out = nullptr;  // (the call's last wave hands the status word on: SrvJob::status_out)
         po.max_likelihood_difference_cap = a.cfg.log10_global_read_mismapping_rate;
         po.symmetric = a.cfg.symmetrically_normalize_alleles_to_reference;
         BestParams &bp = job->pb.best;
@@ -457,10 +449,10 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     {
         SwParams &sp = job->sw;
         sp.a_begin = 0;
-        sp.n_alignments = (uint32_t)n_sw;
+        sp.n_alignments = nr;
         sp.ref_off = d_ho;
         sp.alt_off = d_ro;
-        sp.ref_index = pair_stride ? nullptr : (const uint32_t *)(dev + L.refidx);
+        sp.ref_index = (const uint32_t *)(dev + L.refidx);
         sp.ref_bases = (const uint8_t *)(dev + L.haps);
         sp.alt_bases = (const uint8_t *)(dev + L.bases);
         sp.w_match = a.rcfg.sw_parameters.match_value;
@@ -483,8 +475,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         sp.lds_alt_bytes = (uint32_t)lds_alt;
         sp.lds_group_bytes = (uint32_t)lds_group;
         sp.groups_per_block = 1;
-        sp.pair_stride = pair_stride;
-        sp.pair_single_nh = pair_stride && ng == 1 ? nh : 0u;
         sp.read_region = d_read_region;
         sp.region_hap_off = d_rho;
     }
@@ -508,7 +498,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         pj.ref_index = (const uint32_t *)(dev + L.refidx);
         pj.sw_cigar_off = nullptr;
         pj.sw_cigar_slot = kSwCapacity;
-        pj.sw_pair_stride = pair_stride;
+        pj.sw_pair_stride = 0;
         pj.sw_cigar = (const uint32_t *)(dev + L.swc);
         pj.n_sw_cigar = (const uint32_t *)(dev + L.nsw);
         pj.sw_offset = (const int32_t *)(dev + L.swo);
@@ -524,12 +514,17 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
         pj.workspace = nullptr;  // (the lanes' builders live in the worker wave's LDS)
         pj.capacity = pj_capacity;
     }
-    job->fwd_l = fwd_l;
     job->fwd_k = fwd_k;
-    job->fwd_quads = quads;
+    job->group_haps = group_haps;
+    job->groups = groups;
     job->sw_k = sw_k;
-    job->proj_per_task = proj_per_task;
-    job->all_pairs = pair_stride ? 1u : 0u;
+    job->n_reads = nr;
+    job->group_done = (uint32_t *)(T.sync + 256);
+    job->helper_out = (double *)(T.sync + 256 + 4 * kSyncReads);
+    job->helper_stride = (uint32_t)helper_stride;
+    job->status_in = (uint32_t *)T.sync;
+    job->status_out = (uint32_t *)(mirror + L.res);
+    job->wait_ticks = 100u * 1000u * (uint32_t)std::max(1, h->sw.server_stall_ms);
     job->finish_flag = (uint32_t *)(mirror + L.res + 224);
     // ---- the ring entry ----------------------------------------------------------------------------------------------------------------
     ServerPending *p = new ServerPending();
@@ -538,7 +533,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     p->a = a;
     p->L = L;
     p->n_out = a.out_off[ng];
-    p->all_pairs = pair_stride != 0;
     p->n_tasks = total_tasks;
     p->t0 = std::chrono::steady_clock::now();
     S->in_flight.fetch_add(1, std::memory_order_relaxed);
@@ -576,7 +570,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     }
     S->n_jobs.fetch_add(1, std::memory_order_relaxed);
     S->ns_stage.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count(), std::memory_order_relaxed);
-    if (pair_stride) S->n_all_pairs.fetch_add(1, std::memory_order_relaxed);
     *out = p;
     return PHMM_OK;
 }
@@ -595,26 +588,33 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
     int st = PHMM_OK;
     bool done = false;
     const auto t_enter = std::chrono::steady_clock::now();
+    // (measured, tools/threads_bench: spin / yield 33.4 / 42.5 / 22.9 k regions/s at 10 / 16 / 32 callers, short sleeps 32.7 / 42.1 / 45.6 k)
+    static const uint32_t wait_spins = getenv("PHMM_SERVER_WAIT_SPINS") ? (uint32_t)atoi(getenv("PHMM_SERVER_WAIT_SPINS")) : 64u;
+    static const int wait_mode = getenv("PHMM_SERVER_WAIT_MODE") ? atoi(getenv("PHMM_SERVER_WAIT_MODE")) : 1;
     const auto give_up = p->t0 + std::chrono::milliseconds(std::max(1, h->sw.server_stall_ms) * 4);
     for (uint32_t spins = 0; !done; ++spins) {
         done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
         if (done) break;
         if ((spins & 63u) == 63u) {
-            // (has the server left while this call was on its way?  then whoever notices first starts the next one)
-            if (__atomic_load_n(&S.exit_word->epoch, __ATOMIC_ACQUIRE) == __atomic_load_n(&S.epoch, __ATOMIC_RELAXED)) {
+            // (is no server on the chip -- it left while this call was on its way, or its launch was put off?  then whoever notices
+            // first starts one)
+            if (!__atomic_load_n(&S.running, __ATOMIC_RELAXED) || __atomic_load_n(&S.exit_word->epoch, __ATOMIC_ACQUIRE) == __atomic_load_n(&S.epoch, __ATOMIC_RELAXED)) {
                 std::lock_guard<SpinLock> lk(S.mu);
                 observe_exit(S);
                 if (S.broken) break;
                 if (!S.running && (int32_t)(p->seq - S.consumed) >= 0 && !launch_locked(S, h->sw)) break;
             }
-            if (spins > 4096u) {
+            // (a short spin, then short sleeps between looks -- no call comes back within 100 us anyway, and with more callers than
+            // cores a waiter that spins keeps a caller that has to stage off its core)
+            if (spins > wait_spins) {
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() >= give_up) {
                     std::lock_guard<SpinLock> lk(S.mu);
                     S.broken = true;
                     S.why_broken = "a call did not come back from the region server";
                     break;
                 }
-                std::this_thread::yield();  // (more callers than cores: let the others stage)
+                if (wait_mode == 1) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                else std::this_thread::yield();
             }
         }
         __builtin_ia32_pause();
@@ -648,6 +648,8 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
             st = fail(err, "PairHmm Log Probability cannot be greater than 0.0", PHMM_ERR_POSITIVE_RESULT);  // pair_hmm.rs:478-481
         } else if (sw_st[SW_STATUS_EMPTY]) {  // the reference asserts (smith_waterman_aligner.rs:65-68, :132-134)
             st = fail(err, "phmm_region_compute: non-empty sequences are required for the Smith-Waterman calculation", PHMM_ERR_INVALID_ARG);
+        } else if (((const uint32_t *)(hs + L.res + 128))[1]) {  // (a main wave gave up waiting for a helper)
+            st = fail(err, "phmm_region_compute: internal error, a wait inside the region server ran out of time", PHMM_ERR_INTERNAL);
         } else if (*(const uint32_t *)(hs + L.res + 128) & 1u) {
             st = fail(err, "phmm_region_compute: a CIGAR needs more elements than its slot holds (n_out_cigar has the sizes)", PHMM_ERR_CIGAR_CAPACITY);
         }
@@ -663,6 +665,18 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
     return redo ? kServerRedo : st;
 }
 
+// A region call of the launched kind is about to enqueue its kernels: if the server is on the chip it is asked to leave (it
+// finishes what it has and goes; its next launch waits until no such call is in flight, launch_locked).
+void server_yield(int device) {
+    Server *S;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        S = g_servers[device % kMaxDevices];
+    }
+    if (!S || !S->ok || !__atomic_load_n(&S->running, __ATOMIC_RELAXED)) return;
+    __atomic_fetch_add((uint32_t *)((char *)S->exit_word + 128), 1u, __ATOMIC_RELEASE);
+}
+
 uint64_t server_stat(int device, const char *name) {
     std::lock_guard<std::mutex> lk(g_mu);
     Server *S = g_servers[device % kMaxDevices];
@@ -670,7 +684,6 @@ uint64_t server_stat(int device, const char *name) {
     const std::string n(name);
     if (n == "server_jobs") return S->n_jobs.load();
     if (n == "server_launches") return S->n_launches.load();
-    if (n == "server_all_pairs") return S->n_all_pairs.load();
     if (n == "server_broken") return S->broken ? 1 : 0;
     if (n == "server_stage_ns") return S->ns_stage.load();
     if (n == "server_wait_ns") return S->ns_wait.load();
@@ -713,7 +726,7 @@ uint32_t server_trace_read(int device, phmm::SrvTrace *out, uint32_t cap) {
 
 }  // namespace phmm_host
 
-static_assert(sizeof(SrvTrace) == 40, "trace record as include/phmm.h describes it");
+static_assert(sizeof(SrvTrace) == 72, "trace record as include/phmm.h describes it");
 extern "C" uint32_t phmm_server_trace(int device_id, void *out, uint32_t cap) {
     if (device_id < 0 || device_id >= kMaxDevices) return 0;
     return phmm_host::server_trace_read(device_id, (SrvTrace *)out, cap);

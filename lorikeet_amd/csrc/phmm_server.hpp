@@ -1,10 +1,12 @@
 // The resident region server (phmm_server_kernels.hip, phmm_server.cpp): ONE kernel per device that stays on the chip while
-// region calls keep coming and runs every step of a call -- stage-in, pre-step, PairHMM, post-step / best allele, aligner,
-// projection -- as TASKS its waves take from a ready list in device memory.  What a call costs on the host is a memcpy into
-// its slot of pinned memory, one 64-byte ring entry and a poll of one word; nothing is launched, no stream is synchronised,
-// no caller waits for another caller's flush (NOTEBOOK section 20; SURVEY section 7 step 4, "persistent-kernel work queue
-// across regions").  The sequence it replaces is haplotype_caller_engine.rs:1311-1357 as one worker of
-// assembly_region_walker.rs:210-273 runs it per region.
+// region calls keep coming.  A call's inputs are copied from its slot of pinned host memory by a few STAGE tasks; then every
+// READ of the call is one CHAIN task -- a wave that runs the read's whole path by itself: pre-step, PairHMM against (a group
+// of) its region's haplotypes, post-step and best allele, the alignment to that haplotype, the projection onto the reference --
+// with helper waves for the further haplotype groups.  Nothing a read's steps hand each other ever leaves its wave (beyond four
+// likelihoods per helper), so there are no stages to wait for, no launches, no stream synchronisation, and no caller waits for
+// another caller's flush: what a call costs on the host is a memcpy into its slot, one 64-byte ring entry and a poll of one word
+// (NOTEBOOK section 20; SURVEY section 7 step 4, "persistent-kernel work queue across regions").  The sequence is
+// haplotype_caller_engine.rs:1311-1357 as one worker of assembly_region_walker.rs:210-273 runs it per region.
 //
 // Shared by the kernel file and the host side; plain data only.
 #pragma once
@@ -19,18 +21,12 @@ constexpr uint32_t SRV_MAIL = 1u << 17;   // mailboxes (a power of two): ticket 
 constexpr uint32_t SRV_MAIL_TASKS = SRV_MAIL / 2;  // the tasks of all calls in flight stay below this, so a mailbox is read before its turn comes again
 constexpr uint32_t SRV_LDS_BYTES = 19456;  // LDS of one worker wave: 8 waves per CU; 270 row records of the forward sweep
 constexpr uint32_t SRV_STAGE_UNITS = 1024;  // 16-byte units one stage-in task copies
-constexpr int SRV_MAX_K = 25;             // forward instances <16, 2..25> and <32, 2..13>: haplotypes up to 400 bases
+constexpr int SRV_MAX_K = 25;             // forward instances <16, 2..25> (haplotypes up to 400 bases) and <32, 13..16> (up to 512)
 constexpr uint32_t SRV_MAX_ROWS = SRV_LDS_BYTES / LDS_ROW_BYTES - 2;  // longest read
 
-// The kinds of task, in the order a region's stages can become ready.
 enum : uint32_t {
     SRV_STAGE = 0,  // 16 KB of the slot's pinned mirror -> its device arena (the job record travels with the inputs)
-    SRV_PREP,       // one read: PCR indel model, quality caps, disqualification threshold (phmm_prep_device.hpp)
-    SRV_FWD,        // one read x one group of four (two) haplotypes: forward_read<16 | 32, K>
-    SRV_SWALL,      // (a call alone on the chip) one read x one haplotype: the aligner beside the PairHMM tasks
-    SRV_POST,       // up to 64 reads: normalise, filter, best allele; with SRV_SWALL before it also the projection (pick_read)
-    SRV_SW,         // one read against its best haplotype
-    SRV_PROJ,       // some reads: the alignment onto the reference (project_read)
+    SRV_CHAIN,      // task i: read i / groups, one group of its region's haplotypes (four, or two long ones); the group-0 wave is the read's MAIN wave
     SRV_KINDS
 };
 
@@ -42,6 +38,7 @@ struct alignas(64) SrvEntry {
     uint32_t flags;            // bit 0: trace this job's tasks
     uint32_t stage_n16;        // 16-byte units to stage in
     uint32_t job_off;          // where the SrvJob lies inside the staged block
+    uint32_t pad[5];
     uint64_t stage_src;        // the mirror as the device sees it
     uint64_t stage_dst;        // the slot's device arena
 };
@@ -49,18 +46,27 @@ static_assert(sizeof(SrvEntry) == 64, "ring entry");
 
 // Everything the tasks of one submission need, made by the host inside the slot's mirror and staged with the inputs.
 struct SrvJob {
-    PrepParams prep;
+    PrepParams prep;          // (waves_per_read = 1: the chain's wave takes the whole read)
     ForwardParams fwd;
     PostBestParams pb;
     SwParams sw;
     ProjectParams pj;
-    uint32_t fwd_l, fwd_k;    // lanes per pair and columns per lane of the forward sweep: a function of the job's own shape (its pairs, its longest
-                              // haplotype), never of the load
-    uint32_t fwd_quads;       // groups of 64 / fwd_l haplotypes per read (tasks per read)
+    uint32_t fwd_k;           // columns per lane of the forward sweep: 16 lanes per pair up to 400 bases, 32 beyond -- a function of the job's
+                              // longest haplotype alone
+    uint32_t group_haps;      // haplotypes a wave sweeps side by side: 4 (16 lanes per pair) or 2
+    uint32_t groups;          // such groups per read = chain tasks per read
     uint32_t sw_k;            // rows per lane of the aligner's <64, k, transposed> instance
-    uint32_t proj_per_task;   // reads one SRV_PROJ / picking SRV_POST task takes (their builders share the wave's LDS)
-    uint32_t all_pairs;       // 1: SRV_SWALL beside SRV_FWD, SRV_POST picks
+    uint32_t n_reads;
+    // Words that waves of different XCDs hand each other are touched by agent-scope atomics ONLY, from the moment the stage-in's
+    // last wave has zeroed them (a plain store leaves a line in some L2 that a later agent-scope load of another call may still find):
+    uint32_t *group_done;     // [n_reads] helpers of the read that have stored their likelihoods
+    double *helper_out;       // [n_reads][helper_stride] the helpers' likelihoods, column = haplotype index inside the region
+    uint32_t helper_stride;
+    uint32_t pad0;
+    uint32_t *status_in;      // the forward sweeps' status word (device) ...
+    uint32_t *status_out;     // ... which the call's last wave hands on to the caller's mirror
     uint32_t *finish_flag;    // a word of the mirror: 1 when the last task is through (the caller polls it)
+    uint32_t wait_ticks;      // how long a main wave waits for its helpers at most (100 MHz ticks)
 };
 
 // Device side of a submission (device memory, written by the dispatcher).
@@ -69,20 +75,21 @@ struct alignas(128) SrvRegion {
     uint32_t flags;
     uint32_t n[SRV_KINDS];
     uint32_t stage_n16;
+    uint32_t pad0;
     const SrvJob *job;         // the staged copy
     const void *stage_src;
     void *stage_dst;
     // (a line of their own: the counters are what every finishing task touches)
     alignas(64) uint32_t done[SRV_KINDS];
-    uint32_t arrived[SRV_KINDS];  // predecessor stages that have completed (SRV_POST after SRV_SWALL waits for two)
+    uint32_t timed_out;        // a main wave gave up waiting for a helper: the call fails
 };
 
 // How a task reaches a worker.  A worker that wants work takes a TICKET (one atomic add on SrvCtl::next_ticket) and polls
-// mailbox ticket % SRV_MAIL -- a line nobody else polls.  Whoever makes a stage of n tasks ready reserves n tickets' worth of
-// mailboxes (one atomic add on SrvCtl::posted) and fills them in, a lane each.  Tickets are served in the order they were
-// taken, so the tasks of a stage go to the workers that have been idle longest, each told through its own word: no worker
-// ever polls a word another worker polls, and nobody claims a task somebody else gets (a first version with one shared
-// ready list had two thousand idle waves polling one address; a region call took 1 ms, NOTEBOOK 20.2).
+// mailbox ticket % SRV_MAIL -- a line nobody else polls.  Whoever makes n tasks ready reserves n tickets' worth of mailboxes
+// (one atomic add on SrvCtl::posted) and fills them in, a lane each.  Tickets are served in the order they were taken, so
+// tasks go to the workers that have been idle longest, each told through its own word: no worker ever polls a word another
+// worker polls, and nobody claims a task somebody else gets (a first version with one shared ready list had two thousand idle
+// waves polling one address; a region call took 1 ms, NOTEBOOK 20.2).
 struct alignas(16) SrvMail {
     uint32_t tag;     // ticket + 1 once the other words are in place; SRV_MAIL_EXIT: leave
     uint32_t region;  // index into the region ring
@@ -91,20 +98,13 @@ struct alignas(16) SrvMail {
 };
 constexpr uint32_t SRV_MAIL_EXIT = 0xffffffffu;
 
-// Two CLASSES of worker, a ticket line and a ring of mailboxes each: the first wave of the server on a SIMD is that SIMD's
-// PRIMARY worker, the second its SECONDARY.  Two waves that share a SIMD share its issue slots -- two PairHMM tasks side by side
-// take 85 us each, one alone 55 -- so tasks go to primaries while primaries are waiting, and to secondaries only when the chip
-// has more tasks than SIMDs (post(), phmm_server_kernels.hip).
 struct SrvCtl {
-    alignas(128) uint32_t next_ticket0;  // tickets taken by primary workers
-    alignas(128) uint32_t next_ticket1;  // ... by secondary workers
-    alignas(128) uint32_t posted0;       // tasks posted to the primaries' ring (mailboxes [0, posted) have been, or are being, filled in)
-    alignas(128) uint32_t posted1;
+    alignas(128) uint32_t next_ticket;   // tickets taken
+    alignas(128) uint32_t posted;        // tasks posted (mailboxes [0, posted) have been, or are being, filled in)
     alignas(128) uint32_t closed;        // the dispatcher is leaving: a worker that takes a ticket now leaves too
     uint32_t fault;
     alignas(128) uint32_t finished;      // submissions whose last task is through
     alignas(128) uint32_t trace_count;
-    alignas(128) uint32_t simd_waves[8192];  // by (XCC, SE, SH, CU, SIMD) of HW_ID: how many worker waves have reported from there
 };
 
 // What a server tells the host when it leaves (pinned host memory).
@@ -115,17 +115,20 @@ struct SrvExit {
     uint32_t pad;
 };
 
-struct SrvTrace {  // one task, where tracing is on (developer runs: tools/server_trace.py)
+struct SrvTrace {  // one task, where tracing is on (developer runs: tools/server_trace.cpp)
     uint32_t seq, kind, idx, worker;
     uint64_t t_claim, t_begin, t_end;  // 100 MHz ticks
+    uint64_t t_mid[4];                 // chain tasks: pre-step done, PairHMM done, helpers in + post-step done, aligner done
 };
 
 struct SrvParams {
     SrvCtl *ctl;
     SrvRegion *regions;        // [SRV_RING]
-    SrvMail *mail;             // [2][SRV_MAIL]: the primaries' ring, the secondaries'
+    SrvMail *mail;             // [SRV_MAIL]
     const SrvEntry *ring;      // [SRV_RING], pinned host memory by its device address
     SrvExit *exit_word;        // pinned host memory by its device address
+    const uint32_t *yield_word;  // pinned host memory: the host adds one when kernels of the launched kind need the chip -- the dispatcher
+                               // then takes no further call, lets those in flight finish and leaves (the next launch follows them)
     uint32_t start_seq;        // first ring entry this launch looks at
     uint32_t epoch;
     uint32_t idle_ticks;       // the dispatcher leaves when nothing is in flight and nothing has arrived for this long (100 MHz ticks)

@@ -457,7 +457,7 @@ int phmm_region_submit(phmm_handle *h, const phmm_engine_config *cfg, const phmm
         // ring entry, no flush to wait for; phmm_wait polls for its finish word.  The ticket's top bit tells the two kinds apart.
         {
             ServerPending *pending = nullptr;
-            const int st = server_region_submit(h, a, &pending);
+            const int st = server_region_submit(h, a, &pending, true);
             if (st == PHMM_OK) {
                 *ticket = kServerTicket | (uint64_t)(uintptr_t)pending;
                 return PHMM_OK;

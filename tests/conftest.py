@@ -9,14 +9,6 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Past four of the caller's handles alive on a device the library hands the one-shot calls of PRIVATE handles to the device's
-# shared lanes (phmm_host::route_shared).  Tests hold their handles to what THEY do (per-handle statistics, which stream a call
-# ran on, which way a region call went), and a session creates dozens of engines: routing is off for engines made under this
-# process's environment, and the tests of the routing itself (tests/test_submit_wait.py) and the C++ callers
-# (tools/threads_bench children) switch it back on for theirs.
-os.environ.setdefault("PHMM_ROUTE_SHARED", "0")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -1,9 +1,11 @@
 """The resident region server (lorikeet_amd/csrc/phmm_server.cpp, phmm_server_kernels.hip): phmm_region_compute /
-phmm_region_submit as tasks of ONE kernel that stays on the chip -- the default way of a region call.  Held here to
+phmm_region_submit as tasks of ONE kernel that stays on the chip -- every read of a call a wave that runs the read's whole path.
+The way a region call goes from the second concurrent caller on (a lone call on an idle chip takes the launched pipeline;
+switch region_server = 1: every call).  Held here to
   * the launched pipeline (switch region_server = 0), field by field: everything discrete equal, likelihoods to 1e-11 (the two
     sweep a pair with different lane geometries), and to the oracle pipeline at 1e-9;
-  * ITSELF, bit for bit: a region gives the same bits alone, beside other callers' regions, through the shared handle, aligned
-    to every haplotype or to the best one only, and from one launch of the server to the next.
+  * ITSELF, bit for bit: a region gives the same bits alone, beside other callers' regions, through the shared handle, and from
+    one launch of the server to the next.
 Reference: src/haplotype/haplotype_caller_engine.rs:1311-1357 (the sequence), src/assembly/assembly_region_walker.rs:210-273
 (the workers that call it, one region each)."""
 import threading
@@ -23,7 +25,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def eng():
-    e = HipPairHMMEngine(0)  # (an engine of its own: no switch was ever set on it, so its region calls take the default way)
+    e = HipPairHMMEngine(0)
+    e.set_switch("region_server", 1)  # (every call through the server, also the lone ones a test makes)
     yield e
     e.close()
 
@@ -108,6 +111,8 @@ def test_a_region_gives_the_same_bits_alone_and_beside_other_callers(eng):
     for a, b in zip(alone, alone_again):
         _equal(a, b, exact=True)
     engines = [HipPairHMMEngine(0) for _ in calls]
+    for e in engines:
+        e.set_switch("region_server", 1)
     errors = []
 
     def worker(i):
@@ -129,23 +134,41 @@ def test_a_region_gives_the_same_bits_alone_and_beside_other_callers(eng):
     assert eng.stat("server_jobs") == jobs + 12 * len(calls)
 
 
-def test_aligning_every_pair_or_only_the_best_gives_the_same(eng):
-    """A call alone on the chip aligns every read against every haplotype beside the PairHMM tasks and lets the best allele
-    pick; under load only the best haplotype is aligned.  Integer work: the two ways agree in every bit."""
-    sc = _scenario(7, n_regions=1)
-    b = sc[0]
-    mapq = _noisy_quals(b, 7)
+def test_private_handles_past_four_go_through_the_server_by_default():
+    """No switch set: up to four of the caller's handles on a device keep their own hardware queues (the launched pipeline); with
+    more alive -- a handle per worker thread at Lorikeet's --threads 10 -- their one-shot region calls go through the server, and
+    every call gives its region's own bits whatever the others are doing."""
+    calls = _config2_regions(6, 700)
     cfg = _cfg(pcr=3)
-    pri = _priorities(b, sc[1], sc[3])
-    eng.set_switch("region_server", 1)
-    all_pairs = eng.stat("server_all_pairs")
-    eng.set_switch("region_sw_all", 4096)
-    a = _call(eng, cfg, sc, mapq, pri)
-    assert eng.stat("server_all_pairs") == all_pairs + 1
-    eng.set_switch("region_sw_all", 0)
-    c = _call(eng, cfg, sc, mapq, pri)
-    assert eng.stat("server_all_pairs") == all_pairs + 1
-    _equal(a, c, exact=True)
+    few = [HipPairHMMEngine(0) for _ in range(2)]
+    try:
+        jobs = few[0].stat("server_jobs")
+        launched = [_call(few[0], cfg, sc, mapq, None) for sc, mapq in calls]
+        assert few[0].stat("server_jobs") == jobs, "a call of one of two handles went through the server"
+        engines = few + [HipPairHMMEngine(0) for _ in range(4)]
+        want = [_call(engines[5], cfg, sc, mapq, None) for sc, mapq in calls]   # (six alive: the server, one call at a time)
+        assert engines[0].stat("server_jobs") == jobs + 6
+        for a, b in zip(want, launched):
+            _equal(a, b, exact=False)
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(20):
+                    _equal(_call(engines[i], cfg, calls[i][0], calls[i][1], None), want[i], exact=True)
+            except BaseException as e:  # noqa: BLE001
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(calls))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert engines[0].stat("server_jobs") == jobs + 6 + 20 * 6 and engines[0].stat("server_broken") == 0
+    finally:
+        for e in engines if len(few) == 2 and 'engines' in dir() else few:
+            e.close()
 
 
 def test_the_server_leaves_the_chip_when_idle_and_comes_back(eng):
@@ -161,13 +184,31 @@ def test_the_server_leaves_the_chip_when_idle_and_comes_back(eng):
 
 
 def test_calls_outside_the_servers_limits_take_the_launched_pipeline(eng):
-    """Haplotypes beyond 400 bases (the forward instances the server carries end at 16 lanes x 25 columns): not taken, same API."""
-    b = synthetic.make_regions(1, 24, 3, 450, 120, seed=77)
-    extras = _uniform_extras(b, 450)
+    """Haplotypes beyond 512 bases (the forward instances the server carries end at 32 lanes x 16 columns): not taken, same API."""
+    b = synthetic.make_regions(1, 24, 3, 600, 120, seed=77)
+    extras = _uniform_extras(b, 600)
     jobs = eng.stat("server_jobs")
     got = region.region_compute(eng, _cfg(pcr=3), b, np.full(b.n_reads, 60, np.uint8), *extras)
     assert eng.stat("server_jobs") == jobs
     assert got.likelihoods.shape == (b.n_out,) and np.all(got.likelihoods <= 0)
+
+
+@pytest.mark.parametrize("hap_len,n_haps", [(450, 3), (512, 5), (401, 2), (16, 4), (33, 9)])
+def test_every_forward_geometry_of_the_server(eng, hap_len, n_haps):
+    """16 lanes per pair up to 400 bases, 32 beyond; one to three groups of haplotypes per read: equal to the launched pipeline."""
+    b = synthetic.make_regions(2, 20, n_haps, hap_len, min(120, hap_len), seed=hap_len)
+    extras = _uniform_extras(b, hap_len)
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    jobs = eng.stat("server_jobs")
+    got = region.region_compute(eng, _cfg(pcr=3), b, mapq, *extras)
+    assert eng.stat("server_jobs") == jobs + 1
+    launched = HipPairHMMEngine(0)
+    try:
+        launched.set_switch("region_server", 0)
+        want = region.region_compute(launched, _cfg(pcr=3), b, mapq, *extras)
+    finally:
+        launched.close()
+    _equal(got, want, exact=False)
 
 
 def test_two_tickets_per_thread_on_the_shared_handle(eng):

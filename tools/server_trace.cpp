@@ -18,6 +18,7 @@
 struct Rec {
     uint32_t seq, kind, idx, worker;
     uint64_t t_claim, t_begin, t_end;
+    uint64_t t_mid[4];  // chain tasks: pre-step done, PairHMM done, helpers in + post-step done, aligner done
 };
 struct Region {
     std::vector<uint32_t> rro, rho, ro, ho, hco, hc, hs, oco, oc, cig, ncig;
@@ -103,6 +104,7 @@ int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 1, calls = argc > 2 ? atoi(argv[2]) : 50;
     const uint32_t nr = argc > 6 ? atoi(argv[3]) : 128, nh = argc > 6 ? atoi(argv[4]) : 8, R = argc > 6 ? atoi(argv[5]) : 150, H = argc > 6 ? atoi(argv[6]) : 300;
     setenv("PHMM_SERVER_TRACE", "1", 1);
+    setenv("PHMM_REGION_SERVER", "1", 1);  // (every call through the server, a lone thread's too)
     if (!getenv("PHMM_SERVER_IDLE_US")) setenv("PHMM_SERVER_IDLE_US", "20000", 1);  // (one launch for the whole run: the trace starts over with every launch)
     std::vector<phmm_handle *> hs(T);
     std::vector<Region> gs;
@@ -126,16 +128,16 @@ int main(int argc, char **argv) {
     std::vector<Rec> recs(1u << 20);
     const uint32_t n = std::min<uint32_t>(phmm_server_trace(0, recs.data(), (uint32_t)recs.size()), (uint32_t)recs.size());
     recs.resize(n);
-    printf("%d thread(s) x %d calls of %u x %u (R %u, H %u): %.0f regions/s, %.1f us per call per thread; %u task records, server launches %llu, jobs %llu, all-pairs %llu\n",
+    printf("%d thread(s) x %d calls of %u x %u (R %u, H %u): %.0f regions/s, %.1f us per call per thread; %u task records, server launches %llu, jobs %llu\n",
            T, calls, nr, nh, R, H, T * calls / secs, secs / calls * 1e6, n, (unsigned long long)phmm_get_stat(hs[0], "server_launches"),
-           (unsigned long long)phmm_get_stat(hs[0], "server_jobs"), (unsigned long long)phmm_get_stat(hs[0], "server_all_pairs"));
+           (unsigned long long)phmm_get_stat(hs[0], "server_jobs"));
     {
         const double jobs = (double)phmm_get_stat(hs[0], "server_jobs");
         printf("host side, mean per call: staging + publishing %.1f us, polling %.1f us, results out %.1f us\n", phmm_get_stat(hs[0], "server_stage_ns") / jobs / 1e3,
                phmm_get_stat(hs[0], "server_wait_ns") / jobs / 1e3, phmm_get_stat(hs[0], "server_out_ns") / jobs / 1e3);
     }
     if (!n) return 0;
-    const char *names[] = {"stage-in", "pre-step", "PairHMM", "aligner (all pairs)", "post-step / pick", "aligner", "projection"};
+    const char *names[] = {"stage-in", "chain"};
     // per call and kind: first claim, first begin, last end
     struct Span {
         uint64_t first_claim = ~0ull, first_begin = ~0ull, last_end = 0, busy = 0;
@@ -143,10 +145,11 @@ int main(int argc, char **argv) {
     };
     std::map<uint32_t, std::vector<Span>> by_call;
     uint64_t t_min = ~0ull, t_max = 0;
+    double main_n = 0, helper_n = 0, ph[6] = {0, 0, 0, 0, 0, 0}, helper_us = 0;
     for (const Rec &r : recs) {
         auto &v = by_call[r.seq];
-        v.resize(7);
-        Span &s = v[r.kind % 7];
+        v.resize(2);
+        Span &s = v[r.kind % 2];
         s.first_claim = std::min(s.first_claim, r.t_claim);
         s.first_begin = std::min(s.first_begin, r.t_begin);
         s.last_end = std::max(s.last_end, r.t_end);
@@ -154,9 +157,21 @@ int main(int argc, char **argv) {
         s.n += 1;
         t_min = std::min(t_min, r.t_begin);
         t_max = std::max(t_max, r.t_end);
+        if (r.kind == 1 && r.t_mid[3]) {  // a main wave
+            main_n += 1;
+            ph[0] += r.t_mid[0] - r.t_begin;
+            ph[1] += r.t_mid[1] - r.t_mid[0];
+            ph[2] += r.t_mid[2] - r.t_mid[1];
+            ph[3] += r.t_mid[3] - r.t_mid[2];
+            ph[4] += r.t_end - r.t_mid[3];
+            ph[5] += r.t_end - r.t_begin;
+        } else if (r.kind == 1) {
+            helper_n += 1;
+            helper_us += r.t_end - r.t_begin;
+        }
     }
-    printf("%-22s %8s %12s %14s %16s %14s\n", "kind", "tasks", "mean task us", "stage span us", "start after prev", "claim -> begin");
-    for (int k = 0; k < 7; ++k) {
+    printf("%-10s %8s %12s %14s %16s %14s\n", "kind", "tasks", "mean task us", "span us", "start after prev", "claim -> begin");
+    for (int k = 0; k < 2; ++k) {
         double tasks = 0, dur = 0, span = 0, gap = 0, cb = 0;
         int calls_with = 0;
         for (auto &c : by_call) {
@@ -166,18 +181,17 @@ int main(int argc, char **argv) {
             tasks += s.n;
             dur += (double)s.busy / s.n;
             span += (double)(s.last_end - s.first_begin);
-            uint64_t prev_end = 0;
-            for (int p = 0; p < k; ++p)
-                if (c.second[p].n && !(k == 4 && false)) prev_end = std::max(prev_end, c.second[p].last_end);
-            if (k == 3) prev_end = c.second[0].last_end;                   // (beside pre-step and PairHMM: behind stage-in)
-            if (k == 1) prev_end = c.second[0].last_end;
-            gap += prev_end ? (double)((int64_t)s.first_begin - (int64_t)prev_end) : 0;
+            gap += k ? (double)((int64_t)s.first_begin - (int64_t)c.second[0].last_end) : 0;
             cb += (double)(s.first_begin - s.first_claim);
         }
         if (!calls_with) continue;
-        printf("%-22s %8.0f %12.2f %14.2f %16.2f %14.2f\n", names[k], tasks / calls_with, dur / calls_with / 100, span / calls_with / 100, gap / calls_with / 100,
+        printf("%-10s %8.0f %12.2f %14.2f %16.2f %14.2f\n", names[k], tasks / calls_with, dur / calls_with / 100, span / calls_with / 100, gap / calls_with / 100,
                cb / calls_with / 100);
     }
+    if (main_n)
+        printf("a read's main wave, mean us: inputs + pre-step %.1f, PairHMM %.1f, helpers in + post-step %.1f, aligner %.1f, projection + out %.1f = %.1f; a helper wave %.1f\n",
+               ph[0] / main_n / 100, ph[1] / main_n / 100, ph[2] / main_n / 100, ph[3] / main_n / 100, ph[4] / main_n / 100, ph[5] / main_n / 100,
+               helper_n ? helper_us / helper_n / 100 : 0.0);
     double in_server = 0;
     for (auto &c : by_call) {
         uint64_t b = ~0ull, e = 0;
