@@ -164,24 +164,8 @@ def cpu_baselines(batch, budget_s=12.0):
     return scalar, simd
 
 
-KERNEL_SOURCES = {  # what each kernel family is compiled from (lorikeet_amd/csrc)
-    "pairhmm": ("phmm_device.hpp", "phmm_internal.hpp", "phmm_kernels.hip", "phmm_chain_kernels.hip", "phmm_chain32_kernels.hip",
-                "phmm_exact_kernels.hip", "phmm_engine_kernels.hip"),
-    "sw": ("phmm_sw_internal.hpp", "phmm_sw_kernels.hip"),
-    "cigar": ("phmm_cigar_internal.hpp", "phmm_cigar_kernels.hip"),
-}
-
-
-def source_hash(family="pairhmm"):
-    """Hash of the kernel sources the library in this tree was built from (what a committed PMC entry must match): the
-    files the family's kernels are compiled from -- the PairHMM and engine kernels, or the Smith-Waterman kernel with the
-    shared parameter header."""
-    h = hashlib.sha256()
-    for name in sorted(KERNEL_SOURCES[family]):
-        f = os.path.join(ROOT, "lorikeet_amd", "csrc", name)
-        h.update(name.encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from source_hash import KERNEL_SOURCES, source_hash  # noqa: E402  (shared with the Makefile: phmm_build_info() carries the same hashes)
 
 
 def pmc_entry(workload, regions, kernel, precision="f64"):

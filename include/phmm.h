@@ -554,6 +554,10 @@ uint64_t phmm_get_stat(phmm_handle *h, const char *name);
  * the server to leave the chip first.  tools/server_trace.cpp prints a call's timeline from it. */
 uint32_t phmm_server_trace(int device_id, void *out, uint32_t cap);
 
+/* What the library was built from: "cigar=<hash> pairhmm=<hash> server=<hash> sw=<hash>", the hashes of the kernel sources of each
+ * family (tools/source_hash.py) at compile time.  smoke() and bench.py compare it with the tree they run in. */
+const char *phmm_build_info(void);
+
 /* Host copies of the device tables, for parity tests against the oracle:
  * eps[q] = 10^(-q/10) for q in 0..=255, mm = triangular match->match table incl. row 255. */
 size_t phmm_table_eps(const double **eps);

@@ -554,6 +554,10 @@ extern "C" {
 
     pub fn phmm_set_switch(h: *mut phmm_handle, name: *const c_char, value: c_int) -> c_int;
     pub fn phmm_get_stat(h: *mut phmm_handle, name: *const c_char) -> u64;
+    /// (developer runs: the task records of the device's region server, 72 bytes each)
+    pub fn phmm_server_trace(device_id: c_int, out: *mut c_void, cap: u32) -> u32;
+    /// "cigar=<hash> pairhmm=<hash> server=<hash> sw=<hash>": the kernel sources the library was built from
+    pub fn phmm_build_info() -> *const c_char;
 
     pub fn phmm_table_eps(eps: *mut *const f64) -> usize;
     pub fn phmm_table_match_to_match(mm: *mut *const f64) -> usize;

@@ -120,6 +120,8 @@ SYMBOLS = [
     ("phmm_calculate_cigar", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u32p, u8p, C.c_void_p, C.c_int, u64p, u32p, u32p, C.POINTER(C.c_int32)]),
     ("phmm_set_switch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("phmm_get_stat", C.c_uint64, [C.c_void_p, C.c_char_p]),
+    ("phmm_build_info", C.c_char_p, []),
+    ("phmm_server_trace", C.c_uint32, [C.c_int, C.c_void_p, C.c_uint32]),
     ("phmm_table_eps", C.c_size_t, [C.POINTER(f64p)]),
     ("phmm_table_match_to_match", C.c_size_t, [C.POINTER(f64p)]),
 ]

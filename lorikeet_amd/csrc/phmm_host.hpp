@@ -295,6 +295,9 @@ constexpr int kServerRedo = -2001;      // server_region_wait: run the call agai
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit);
 int user_handles_on(int device);  // the caller's handles alive on the device (phmm_api.cpp)
 int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);
+int server_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
+                   const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
+                   const uint8_t *hap_bases, const uint64_t *out_off, double *out, std::string *err);
 uint64_t server_stat(int device, const char *name);
 void server_yield(int device);
 int region_calls_in_flight(int device);  // phmm_region_compute calls of the launched kind between enqueue and finish (phmm_region.cpp)

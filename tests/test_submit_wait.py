@@ -227,18 +227,23 @@ def test_shared_handle_in_f32_first_mode():
 def test_many_private_handles_are_served_by_the_devices_shared_lanes():
     """INTEGRATION.md section 4 gives every rayon worker a handle of its own (thread_local!).  Past four of the caller's handles
     alive on a device their one-shot calls go through ONE shared handle inside the library (phmm_host::route_shared: phmm_submit /
-    phmm_wait, the callers that are waiting anyway merge into one flush) -- 32 private handles used to run at HALF the rate of
-    16.  Same results, per handle, as a lone handle's; a handle whose switches were touched stays on its own streams."""
+    phmm_wait, the callers that are waiting anyway merge into one flush) when PHMM_ROUTE_SHARED asks for it -- 32 private handles
+    used to run at HALF the rate of 16.  Same results, per handle, as a lone handle's (to 1e-11: a combined flush may sweep a
+    region with another lane geometry, which is why the routing is opt-in); a handle whose switches were touched stays on its own
+    streams."""
     lone = HipPairHMMEngine(0)
     work = _regions(10, 91)
     want = [lone.compute(b) for b, _ in work]
     import os
-    keep_env = os.environ.pop("PHMM_ROUTE_SHARED", None)     # (conftest.py switches the routing off for every other test's engines)
+    keep_env = os.environ.get("PHMM_ROUTE_SHARED")
+    os.environ["PHMM_ROUTE_SHARED"] = "4"                    # (opt-in since round 6: which regions share a flush depends on timing)
     try:
         engines = [HipPairHMMEngine(0) for _ in range(12)]   # the switch is read at phmm_create
     finally:
         if keep_env is not None:
             os.environ["PHMM_ROUTE_SHARED"] = keep_env
+        else:
+            del os.environ["PHMM_ROUTE_SHARED"]
     errors = []
 
     def worker(e):
@@ -287,8 +292,9 @@ def test_thirty_two_private_handles_are_not_slower_than_sixteen():
     from conftest import ROOT
     exe = os.path.join(ROOT, "tools", "threads_bench")
     for mode in ("own", "fused"):
+        # (the library's defaults: past four private handles their small calls go through the device's region server)
         env = dict(os.environ, TB_MODE=mode, TB_THREADS="16,32", TMPDIR="/tmp")
-        env.pop("PHMM_ROUTE_SHARED", None)                   # the library's default
+        env.pop("PHMM_ROUTE_SHARED", None)
         r = subprocess.run([exe, "1.5"], capture_output=True, text=True, timeout=300, env=env)
         print(r.stdout, r.stderr[-1000:])
         assert r.returncode == 0, r.stdout + r.stderr
