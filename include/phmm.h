@@ -219,17 +219,11 @@ int phmm_batch_status(phmm_batch *b);
 uint64_t phmm_batch_cells(const phmm_batch *b);           /* sum over regions of (sum R)*(sum H)      */
 uint64_t phmm_batch_algorithmic_bytes(const phmm_batch *b); /* sum 5R + sum H + 8*Nr*Nh    */
 uint32_t phmm_batch_num_launches(const phmm_batch *b);    /* kernel launches one phmm_batch_launch does */
-/*
- * Shared haplotype prefixes -- what the reference's scalar arm gets from find_first_position_where_haplotypes_differ
- * (pair_hmm.rs:452-464, 706-717): columns left of the first base where a haplotype differs from its region's first one
- * hold the same numbers for every read.  phmm_batch_share_prefixes re-plans the regions of a batch of phmm_batch_create
- * where that pays (16 lanes per pair, five haplotypes or more, no 'N'): the first haplotype's wave parks one column per
- * group of sharers, the sharers' waves sweep their suffixes from there.  Results are bit-identical to the unshared plan.
- * `hap_bases`: the haplotype bytes on the HOST under the batch's hap_off (a plan is made from offsets; this is the one
- * step that looks at payload).  Call once, before phmm_batch_launch; no effect on PHMM_FLAG_F32_FIRST handles.
- * phmm_batch_cells stays the metric's count (sum R x sum H); phmm_batch_executed_cells is what the kernels sweep.
- */
-int phmm_batch_share_prefixes(phmm_batch *b, const uint8_t *hap_bases);
+/* What the planned launches sweep, in lane-cells: every row of every wave x 64 lanes x its columns per lane -- the columns beyond a
+ * haplotype's end, the haplotype slots a wave leaves empty.  executed / phmm_batch_cells is what a batch's shapes cost in padding
+ * (1.01 for the uniform 150 / 300 batch).  (The reference's scalar arm skips the columns a haplotype shares with the one before it,
+ * find_first_position_where_haplotypes_differ, pair_hmm.rs:452-464, 706-717; here every pair is swept in full: a device form of the
+ * sharing was built in round 4, measured at x 0.96-1.10 and removed in round 6, NOTEBOOK.md 18.4.) */
 uint64_t phmm_batch_executed_cells(const phmm_batch *b);
 /* Name of the kernel doing most cells of this batch as rocprofv3 reports it, e.g. "phmm_forward_chain_k<16,19>". */
 const char *phmm_batch_dominant_kernel(const phmm_batch *b);
@@ -533,17 +527,28 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
                          const uint64_t *cigar_off, uint32_t *cigar, uint32_t *n_cigar, int32_t *status);
 
 /*
- * Developer switches and counters (tests, A/B measurements; never needed in production, NOTEBOOK.md §11).
- * The PHMM_* environment variables are read once, by phmm_create; phmm_set_switch changes one switch of one handle
- * afterwards ("force_L", "force_quad_split", "force_chain", "force_streams", "waves_per_block", "force_cnd_select",
- * "no_pipeline", "no_rescue", "no_xcd_interleave", "trace", "sw_waves_per_cu", "sw_chunks", "sw_lanes", "sw_transpose", "sw_no_zero_copy", "sw_lite", "submit_gather_us", "no_fork", "region_sw_all" (pairs up to which a small phmm_region_compute call aligns every read against every haplotype beside the PairHMM kernels: -1 by load, 0 never), "region_prio", "region_cu_halves", "region_flag_wait" (0: a small region call waits in hipStreamSynchronize instead of polling the word its last kernel stores into the pinned mirror); value -1 / 0 = back to the
- * planner's choice as documented there).  Not to be called while another thread computes on the handle.  Returns PHMM_ERR_INVALID_ARG for an unknown name.
+ * Developer switches and counters (tests, A/B measurements; never needed in production, NOTEBOOK.md section 11).
+ * The PHMM_* environment variables of the same names (upper case) are read once, by phmm_create; phmm_set_switch changes one
+ * switch of one handle afterwards.  What is left of them after round 6 (every switch whose A/B was closed went with its code):
+ *   planner        "force_L" (16 / 32 / 64 lanes per pair), "force_chain" (reads per run of the chained kernel; 0 = per-read kernel
+ *                  only), "force_streams", "no_pipeline" (a host-buffer call in one shot whatever its size), "no_rescue", "trace"
+ *   aligner        "sw_lite" (the tags-only first pass: -1 where it pays, 0 never, 1 always), "sw_chunks", "sw_lanes",
+ *                  "sw_transpose", "sw_no_zero_copy", "sw_clock"
+ *   region call    "region_server" (the resident region server: -1 the one-shot calls of private handles past four alive on the
+ *                  device, 0 never, 1 every call its limits admit), "server_idle_us", "server_stall_ms", "server_trace";
+ *                  "region_sw_all" (pairs up to which a lone launched call aligns every read against every haplotype beside the
+ *                  PairHMM kernels: -1 by load, 0 never), "region_flag_wait", "region_pick_timeout_us", "region_debug_pick" (tests),
+ *                  "mirror_canary", "region_own_queue" (environment only)
+ *   many callers   "submit_gather_us", "route_shared" (opt-in: private handles' small calls through the shared combiner)
+ * Value -1 / 0 = back to the planner's choice as documented there.  Not to be called while another thread computes on the handle.
+ * Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned
  * staging so far), "rescue_passes" (batches that needed the exact pass below -600), "sw_kernel_us" / "sw_backtrack_bytes" /
  * "sw_clock_mhz" (device time of the last phmm_sw_align's kernels by HIP events, the backtrack bytes they stored, the shader
  * clock one of their blocks saw), "sw_second_pass" (alignments of the last aligner call whose walk met a gap behind the
  * tags-only sweep and which the full instance aligned again; 0 when the call took one pass), "region_sw_all" (region calls that
- * aligned every pair beside the PairHMM kernels so far); unknown names give 0.
+ * aligned every pair beside the PairHMM kernels so far), "server_jobs" / "server_launches" / "server_broken" (the device's region
+ * server: calls it has taken, times it was launched, whether it gave up); unknown names give 0.
  */
 int phmm_set_switch(phmm_handle *h, const char *name, int value);
 uint64_t phmm_get_stat(phmm_handle *h, const char *name);

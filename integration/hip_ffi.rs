@@ -216,7 +216,6 @@ extern "C" {
     pub fn phmm_batch_cells(b: *const phmm_batch) -> u64;
     pub fn phmm_batch_algorithmic_bytes(b: *const phmm_batch) -> u64;
     pub fn phmm_batch_num_launches(b: *const phmm_batch) -> u32;
-    pub fn phmm_batch_share_prefixes(b: *mut phmm_batch, hap_bases: *const u8) -> c_int;
     pub fn phmm_batch_executed_cells(b: *const phmm_batch) -> u64;
     pub fn phmm_batch_dominant_kernel(b: *const phmm_batch) -> *const c_char;
     pub fn phmm_plan_describe(

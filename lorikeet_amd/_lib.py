@@ -89,7 +89,6 @@ SYMBOLS = [
     ("phmm_batch_cells", C.c_uint64, [C.c_void_p]),
     ("phmm_batch_algorithmic_bytes", C.c_uint64, [C.c_void_p]),
     ("phmm_batch_num_launches", C.c_uint32, [C.c_void_p]),
-    ("phmm_batch_share_prefixes", C.c_int, [C.c_void_p, u8p]),
     ("phmm_batch_executed_cells", C.c_uint64, [C.c_void_p]),
     ("phmm_batch_dominant_kernel", C.c_char_p, [C.c_void_p]),
     ("phmm_plan_describe", C.c_int, [C.c_uint, C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, C.POINTER(PlanInfo)]),

@@ -62,14 +62,13 @@ constexpr uint64_t kGenericScratchBytes = 1ull << 30;
 // from kFirstChunkBytes (the GPU starts early) to kChunkBytes (large launches are the efficient ones).  Measured on
 // config-2 batches, one shot vs chunked: 32 regions 548 -> 479 us, 256 regions 4.36 -> 3.13 ms, 4096 regions 43.2 ms with
 // 4 MB chunks vs 45.5 ms with 512 KB chunks throughout.  (PHMM_CHUNK_KB, PHMM_FIRST_CHUNK_KB, PHMM_ONESHOT_KB: tuning.)
-static const size_t kChunkBytes = getenv("PHMM_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_CHUNK_KB")) << 10 : (4u << 20);
-static const size_t kFirstChunkBytes = getenv("PHMM_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_FIRST_CHUNK_KB")) << 10 : (512u << 10);
-static const size_t kMixedFirstChunkBytes = getenv("PHMM_MIXED_FIRST_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_FIRST_CHUNK_KB")) << 10 : (4u << 20);
-static const size_t kMixedChunkBytes = getenv("PHMM_MIXED_CHUNK_KB") ? (size_t)atoi(getenv("PHMM_MIXED_CHUNK_KB")) << 10 : (8u << 20);
-static const bool kNoStageThreads = getenv("PHMM_NO_STAGE_THREADS") != nullptr;  // (A/B only) large chunks staged by the calling thread alone
-static const size_t kOneShotBytes = getenv("PHMM_ONESHOT_KB") ? (size_t)atoi(getenv("PHMM_ONESHOT_KB")) << 10 : (512u << 10);
-static const size_t kStageInBytes = getenv("PHMM_STAGE_IN_KB") ? (size_t)atoi(getenv("PHMM_STAGE_IN_KB")) << 10 : (640u << 10);
-static const size_t kZeroCopyOutBytes = getenv("PHMM_ZERO_COPY_OUT_KB") ? (size_t)atoi(getenv("PHMM_ZERO_COPY_OUT_KB")) << 10 : (160u << 10);
+static const size_t kChunkBytes = 4u << 20;
+static const size_t kFirstChunkBytes = 512u << 10;
+static const size_t kMixedFirstChunkBytes = 4u << 20;  // (swept in round 5, tools/hostpath_ragged_sweep.py: 4 / 8 / 8 / 7 MB was the best schedule)
+static const size_t kMixedChunkBytes = 8u << 20;
+static const size_t kOneShotBytes = 512u << 10;
+static const size_t kStageInBytes = 640u << 10;
+static const size_t kZeroCopyOutBytes = 160u << 10;
 static const int kForcedEagerD2H = getenv("PHMM_EAGER_D2H") ? atoi(getenv("PHMM_EAGER_D2H")) : -1;
 // (these six are tuning knobs of the host path, latched when the library is loaded; everything else is in Switches)
 
@@ -156,22 +155,8 @@ struct phmm_batch {
     uint32_t rescue_blocks = 0;
     bool bound = false;
     std::string dominant;
-    // ---- shared haplotype prefixes (phmm_batch_share_prefixes; phmm_internal.hpp) ------------------------------------------
-    struct RegionPlan {  // what the planner decided for a region's chained class (persistent batches keep it for the sharing pass)
-        int8_t L = 0;
-        uint8_t K = 0, streams = 0;
-        uint32_t run = 0;  // reads per work item
-    };
-    std::vector<RegionPlan> rplan;
-    std::vector<uint32_t> h_rro, h_rho, h_ro, h_ho;  // host copies of the offset arrays (persistent batches)
-    struct Share {
-        std::vector<ChainItemX> park[kChainRanges], suffix[kChainRanges];
-        ChainItemX *d_park[kChainRanges] = {}, *d_suffix[kChainRanges] = {};
-        double *d_area = nullptr;      // the parking area
-        uint64_t rows = 0;             // its 16-byte rows
-        uint64_t skipped_cells = 0;    // cells of the metric's definition that are not executed
-        uint32_t regions = 0;
-    } share;
+    uint64_t swept_cells = 0;  // lane-cells the planned launches sweep: every row of every wave x 64 lanes x its K columns, padding
+                               // columns, empty haplotype slots and all (phmm_batch_executed_cells)
 };
 
 namespace {
@@ -279,14 +264,9 @@ static void read_env_switches(Switches &w) {
         if (const char *e = getenv(name)) dst = atoi(e);
     };
     env("PHMM_FORCE_L", w.force_L);
-    env("PHMM_FORCE_QUAD_SPLIT", w.force_split);
     env("PHMM_FORCE_CHAIN", w.force_chain);
     env("PHMM_FORCE_STREAMS", w.force_streams);
-    env("PHMM_WAVES_PER_BLOCK", w.waves_per_block);
-    env("PHMM_FORCE_CND_SELECT", w.force_cnd_select);
-    env("PHMM_SUBMIT_LANES", w.submit_lanes);
     env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
-    env("PHMM_SW_WAVES_PER_CU", w.sw_waves_per_cu);
     env("PHMM_SW_LITE", w.sw_lite);
     env("PHMM_SW_CHUNKS", w.sw_chunks);
     env("PHMM_SW_LANES", w.sw_lanes);
@@ -296,8 +276,6 @@ static void read_env_switches(Switches &w) {
     env("PHMM_SERVER_IDLE_US", w.server_idle_us);
     env("PHMM_SERVER_STALL_MS", w.server_stall_ms);
     env("PHMM_SERVER_TRACE", w.server_trace);
-    env("PHMM_REGION_PRIO", w.region_prio);
-    env("PHMM_REGION_CU_HALVES", w.region_cu_halves);
     env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
     env("PHMM_REGION_OWN_QUEUE", w.region_own_queue);
     env("PHMM_REGION_PICK_TIMEOUT_US", w.region_pick_timeout_us);
@@ -308,8 +286,6 @@ static void read_env_switches(Switches &w) {
     w.sw_clock = getenv("PHMM_SW_CLOCK") != nullptr;
     w.no_pipeline = getenv("PHMM_NO_PIPELINE") != nullptr;
     w.no_rescue = getenv("PHMM_NO_RESCUE") != nullptr;
-    w.no_xcd_interleave = getenv("PHMM_NO_XCD_INTERLEAVE") != nullptr;
-    w.no_fork = getenv("PHMM_NO_FORK") != nullptr;
     w.trace = getenv("PHMM_TRACE") != nullptr;
 }
 
@@ -803,21 +779,6 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     reg_run[g] = std::min<uint32_t>(CHAIN_MAX_READS, (uint32_t)r * (uint32_t)kv.second.streams);
                 }
     }
-    if (!use_arena && !dry) {  // (persistent batches: what phmm_batch_share_prefixes needs later)
-        b->rplan.assign(n_regions, phmm_batch::RegionPlan{});
-        for (const auto &kv : by_shape)
-            if (kv.second.chain)
-                for (uint32_t g : kv.second.regions) {
-                    b->rplan[g].L = (int8_t)kv.second.L;
-                    b->rplan[g].K = (uint8_t)kv.second.K;
-                    b->rplan[g].streams = (uint8_t)kv.second.streams;
-                    b->rplan[g].run = reg_run[g];
-                }
-        b->h_rro.assign(region_read_off, region_read_off + n_regions + 1);
-        b->h_rho.assign(region_hap_off, region_hap_off + n_regions + 1);
-        b->h_ro.assign(read_off, read_off + n_reads + 1);
-        b->h_ho.assign(hap_off, hap_off + n_haps + 1);
-    }
     // bytes of per-class work lists the plan will place in device memory
     size_t class_meta = 0;
     for (const auto &kv : by_shape) {
@@ -996,20 +957,15 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             // One wave per workgroup: waves are independent (no barrier, private LDS), and a multi-wave block
             // would hold its LDS until its longest read finishes -- with mixed read lengths that idles SIMDs.
             c.waves_per_block = 1;
-            if (sw.waves_per_block > 0)
-                c.waves_per_block = (int)std::min<size_t>((size_t)sw.waves_per_block,
-                                                          std::min<size_t>(MAX_WAVES_PER_BLOCK, kLdsBytesPerCU / per_wave));
             c.lds_bytes = per_wave * c.waves_per_block;
             // Enough reads to fill the chip -> one wave walks all haplotype groups of its read (row
             // constants staged once); otherwise spread the groups over gridDim.y.
             bool split = (uint64_t)n_items < 4ull * kNumSimd;
-            if (h->sw.force_split >= 0) split = h->sw.force_split != 0;
             c.grid = dim3((n_items + c.waves_per_block - 1) / c.waves_per_block, split ? c.max_quads : 1, 1);
             // a wave alone on its SIMD is latency-bound: the v_cndmask select (one more VALU op, no EXEC round
             // trip) is ~8 % faster there; with two resident waves the EXEC-masked select wins
             const uint64_t waves = (uint64_t)n_items * (split ? c.max_quads : 1);
             c.cnd_select = waves < 2ull * kNumSimd ? 1u : 0u;
-            if (sw.force_cnd_select >= 0) c.cnd_select = sw.force_cnd_select ? 1u : 0u;
             snprintf(c.name, sizeof c.name, "phmm_forward<%d,%d>", c.L, c.K);
         } else {
             // generic: exclusive prefix of pairs per read, scratch for a bounded grid
@@ -1042,6 +998,26 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         b->classes.push_back(std::move(c));
     }
     mark();  // 5: work items per class
+    {   // what these launches sweep, padding and all (phmm_batch_executed_cells)
+        uint64_t swept = 0;
+        for (const auto &grp : b->chain_groups)
+            for (const ChainItem &x : grp.items)  // (a multi-stream item sweeps its sub-runs of reads side by side)
+                swept += (uint64_t)(read_off[x.read_end] - read_off[x.read_begin]) / std::max<uint32_t>(1, x.streams) * 64ull * x.k;
+        for (const auto &c : b->classes) {
+            if (c.chain) continue;  // (counted above; the f64 redo behind an f32 sweep touches the reads it flags only)
+            if (!c.L) {
+                swept += c.cells;
+                continue;
+            }
+            const size_t n = c.identity ? n_reads : c.reads.size();
+            for (size_t i = 0; i < n; ++i) {
+                const uint32_t r = c.identity ? (uint32_t)i : c.reads[i], g = read_region[r];
+                const uint32_t per_wave = 64u / (uint32_t)c.L, quads = (shape[g].nh + per_wave - 1) / per_wave;
+                swept += (uint64_t)(read_off[r + 1] - read_off[r]) * quads * 64ull * (uint64_t)c.K;
+            }
+        }
+        b->swept_cells = swept;
+    }
     for (auto &grp : b->chain_groups) {
         // longest item first across all classes of the launch: (rows of the run + its SUM / RESET rows) x the cost of a
         // step at the item's K (7 VALU per column + ~11 per step)
@@ -1077,7 +1053,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         // each XCD with an L2 of its own, so neighbours in the launch never share one: take eight runs at a time and
         // emit their first groups, then their second groups, ... -- the groups of a run are then 8 blocks apart, on
         // the same XCD, started together.
-        if (!sw.no_xcd_interleave) {
+        {
             std::vector<ChainItem> out;
             out.reserve(grp.items.size());
             auto same_run = [](const ChainItem &x, const ChainItem &y) {
@@ -1196,160 +1172,10 @@ phmm_batch *phmm_batch_create(phmm_handle *h, uint32_t n_regions, const uint32_t
     PHMM_GUARD_END(h, "phmm_batch_create", PHMM_FAIL_NULL)
 }
 
-// Shared haplotype prefixes (phmm_internal.hpp): regions of a persistent batch whose haplotypes share enough of their front with
-// the region's first haplotype are re-planned -- the trunk's wave parks a column, the sharers' waves sweep their suffixes only.
-// `hap_bases`: the haplotype bytes on the HOST, laid out by the batch's hap_off (the plan itself never sees payload).
-int phmm_batch_share_prefixes(phmm_batch *b, const uint8_t *hap_bases) {
-    if (!b) return PHMM_ERR_INVALID_ARG;
-    phmm_handle *h = b->h;
-    if (!hap_bases || b->rplan.empty() || b->arena) {
-        h->err = "phmm_batch_share_prefixes: a batch of phmm_batch_create and the haplotype bases on the host are required";
-        return h->err_code = PHMM_ERR_INVALID_ARG;
-    }
-    if (b->share.regions) return PHMM_OK;  // (done already)
-    PHMM_GUARD_BEGIN
-    if (h->flags & PHMM_FLAG_F32_FIRST) return PHMM_OK;  // (the f32 sweep has no such kernels)
-    // (suffix items leave NaN + STATUS_RESCUE for reads the scaled sweep cannot hold and rely on the exact pass behind them: with
-    // PHMM_NO_RESCUE that pass never runs and the NaNs would reach the caller under PHMM_OK -- such a handle keeps the plain plan)
-    if (h->sw.no_rescue) return PHMM_OK;
-    DeviceGuard dg(h->device);
-    const uint32_t *rro = b->h_rro.data(), *rho = b->h_rho.data(), *ro = b->h_ro.data(), *ho = b->h_ho.data();
-    auto cost_of = [](int K) { return 7.0 * K + 11.0; };
-    std::vector<uint8_t> shared(b->n_regions, 0);
-    phmm_batch::Share &sh = b->share;
-    uint64_t rows_total = 0;
-    constexpr uint64_t kMaxParkBytes = 24ull << 30;
-    for (uint32_t g = 0; g < b->n_regions; ++g) {
-        const phmm_batch::RegionPlan &rp = b->rplan[g];
-        const uint32_t h0 = rho[g], nh = rho[g + 1] - h0, r0 = rro[g], r1 = rro[g + 1];
-        if (rp.L != 16 || rp.streams != 1 || !rp.run || nh < 5 || nh > 0xfffeu || r1 == r0) continue;
-        const int K = rp.K;
-        const uint8_t *root = hap_bases + ho[h0];
-        const uint32_t Hroot = ho[h0 + 1] - ho[h0];
-        bool has_n = false;
-        for (uint32_t i = ho[h0]; i < ho[h0 + nh] && !has_n; ++i) has_n = hap_bases[i] == 'N';
-        if (has_n) continue;  // (the wildcard path is the general sweep: whole pairs only)
-        // lanes of the trunk in front of a haplotype's first difference
-        std::vector<uint32_t> lanes(nh, 0), order;
-        for (uint32_t k = 1; k < nh; ++k) {
-            const uint8_t *y = hap_bases + ho[h0 + k];
-            const uint32_t Hk = ho[h0 + k + 1] - ho[h0 + k], n = std::min(Hroot, Hk);
-            uint32_t p = 0;
-            while (p < n && y[p] == root[p]) ++p;
-            lanes[k] = std::min<uint32_t>(std::min<uint32_t>(p / (uint32_t)K, (Hk - 1) / (uint32_t)K), 15u);
-            order.push_back(k);
-        }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return lanes[x] > lanes[y]; });
-        // the trunk's wave: the first haplotype and the three that share least; the others four to a wave, most sharing first
-        const uint32_t n_rest = nh - 1 - 3;
-        struct Group { uint32_t first, n, lanes; int K2; bool suffix; };
-        std::vector<Group> groups;
-        double cost_new = cost_of(K) + 6.0, cost_now = (double)((nh + 3) / 4) * cost_of(K);
-        bool any = false;
-        uint32_t mask = 0;
-        for (uint32_t i = 0; i < n_rest; i += 4) {
-            Group gr{i, std::min<uint32_t>(4, n_rest - i), 16, K, false};
-            uint32_t hmax = 0;
-            for (uint32_t j = 0; j < gr.n; ++j) {
-                gr.lanes = std::min(gr.lanes, lanes[order[i + j]]);
-                hmax = std::max(hmax, ho[h0 + order[i + j] + 1] - ho[h0 + order[i + j]]);
-            }
-            if (gr.lanes >= 1) {
-                const int k2 = std::max(2, round_up_k((int)((hmax - gr.lanes * (uint32_t)K + 15) / 16)));
-                if (k2 >= 2 && k2 <= chain_max_k() && cost_of(k2) + 6.0 < 0.97 * cost_of(K)) {
-                    gr.K2 = k2;
-                    gr.suffix = true;
-                    any = true;
-                    mask |= 1u << (gr.lanes - 1);
-                }
-            }
-            cost_new += gr.suffix ? cost_of(gr.K2) + 6.0 : cost_of(K);
-            groups.push_back(gr);
-        }
-        if (!any || cost_new > 0.95 * cost_now) continue;
-        // ---- the region's work items, run by run --------------------------------------------------------------------------
-        const uint32_t nb = (uint32_t)__builtin_popcount(mask);
-        bool fits = true;
-        std::vector<ChainItemX> park_items, suffix_items;
-        uint64_t skipped = 0;
-        for (uint32_t r = r0; r < r1 && fits; r += rp.run) {
-            const uint32_t re = std::min(r1, r + rp.run);
-            const uint64_t rows = (uint64_t)(ro[re] - ro[r]) + 2ull * (re - r);          // the stream: every read + SUM + RESET
-            const uint64_t T = (rows + 16) & ~1ull, park_rows = (T + 16 + 15) / 16 * 16;  // (the kernel's step count + the lanes' lead)
-            if (park_rows / 16 > 0xffffu || (rows_total + (uint64_t)nb * park_rows) * 16 > kMaxParkBytes ||
-                rows_total + (uint64_t)nb * park_rows > 0xffffffffull) {
-                fits = false;
-                break;
-            }
-            ChainItemX t{};
-            t.it = ChainItem{g, 0, (uint8_t)K, 1, r, re};
-            t.hap[0] = 0;
-            for (int j = 0; j < 3; ++j) t.hap[1 + j] = (uint16_t)order[n_rest + j];
-            t.park_row0 = (uint32_t)rows_total;
-            t.park_rows16 = (uint16_t)(park_rows / 16);
-            t.mask_or_col0 = (uint16_t)mask;
-            park_items.push_back(t);
-            for (const Group &gr : groups) {
-                ChainItemX x{};
-                x.it = ChainItem{g, 0, (uint8_t)gr.K2, 1, r, re};
-                for (uint32_t j = 0; j < 4; ++j) x.hap[j] = j < gr.n ? (uint16_t)order[gr.first + j] : (uint16_t)0xffffu;
-                x.park_rows16 = (uint16_t)(park_rows / 16);
-                if (gr.suffix) {
-                    const uint32_t bidx = (uint32_t)__builtin_popcount(mask & ((1u << (gr.lanes - 1)) - 1u));
-                    x.park_row0 = (uint32_t)(rows_total + (uint64_t)bidx * park_rows);
-                    x.mask_or_col0 = (uint16_t)(gr.lanes * (uint32_t)K);
-                    suffix_items.push_back(x);
-                    skipped += (uint64_t)(ro[re] - ro[r]) * gr.n * (uint64_t)(gr.lanes * (uint32_t)K);
-                } else {  // whole pairs under named haplotypes: the parking kernel with nothing to park
-                    x.mask_or_col0 = 0;
-                    park_items.push_back(x);
-                }
-            }
-            rows_total += (uint64_t)nb * park_rows;
-        }
-        if (!fits) break;  // (the parking area is full: the remaining regions stay as they are)
-        shared[g] = 1;
-        sh.regions += 1;
-        sh.skipped_cells += skipped;
-        for (const ChainItemX &x : park_items) sh.park[chain_range_of(x.it.k)].push_back(x);
-        for (const ChainItemX &x : suffix_items) sh.suffix[chain_range_of(x.it.k)].push_back(x);
-    }
-    if (!sh.regions) return PHMM_OK;
-    sh.rows = rows_total;
-    // ---- the re-planned regions leave the plain launches; longest item first in the new ones -------------------------------
-    for (auto &grp : b->chain_groups) {
-        if (grp.f32 || grp.L != 16) continue;
-        std::vector<ChainItem> kept;
-        kept.reserve(grp.items.size());
-        for (const ChainItem &it : grp.items)
-            if (!shared[it.region]) kept.push_back(it);
-        if (kept.size() == grp.items.size()) continue;
-        grp.items.swap(kept);
-        if (!grp.items.empty())
-            HIP_TRY(h, hipMemcpy(grp.d_items, grp.items.data(), grp.items.size() * sizeof(ChainItem), hipMemcpyHostToDevice), PHMM_ERR_HIP);
-    }
-    auto cost = [&](const ChainItemX &x) {
-        return (uint64_t)(ro[x.it.read_end] - ro[x.it.read_begin] + 2 * (x.it.read_end - x.it.read_begin) + 16) * (uint64_t)(7 * x.it.k + 11);
-    };
-    auto upload = [&](std::vector<ChainItemX> &v, ChainItemX **d) {
-        if (v.empty()) return true;
-        std::stable_sort(v.begin(), v.end(), [&](const ChainItemX &x, const ChainItemX &y) { return cost(x) > cost(y); });
-        if (!hip_ok(h, hipMalloc((void **)d, v.size() * sizeof(ChainItemX)), "hipMalloc(share items)")) return false;
-        b->mallocs.push_back(*d);
-        return hip_ok(h, hipMemcpy(*d, v.data(), v.size() * sizeof(ChainItemX), hipMemcpyHostToDevice), "H2D share items");
-    };
-    for (int r = 0; r < kChainRanges; ++r)
-        if (!upload(sh.park[r], &sh.d_park[r]) || !upload(sh.suffix[r], &sh.d_suffix[r])) return PHMM_ERR_HIP;
-    HIP_TRY(h, hipMalloc((void **)&sh.d_area, std::max<uint64_t>(rows_total, 1) * 16), PHMM_ERR_HIP);
-    b->mallocs.push_back(sh.d_area);
-    if (h->sw.trace)
-        fprintf(stderr, "phmm share: %u of %u regions re-planned, %.3f of the cells not executed, parking area %.1f MB\n", sh.regions, b->n_regions,
-                (double)sh.skipped_cells / (double)std::max<uint64_t>(b->cells, 1), (double)rows_total * 16 / 1e6);
-    return PHMM_OK;
-    PHMM_GUARD_END(h, "phmm_batch_share_prefixes", PHMM_FAIL_CODE)
-}
-
-uint64_t phmm_batch_executed_cells(const phmm_batch *b) { return b ? b->cells - b->share.skipped_cells : 0; }
+// What the planned launches sweep, in lane-cells: every row of every wave x 64 lanes x its K columns -- the columns beyond a
+// haplotype's end inside its 16 x K lanes, haplotype slots a wave leaves empty, the rows of a multi-stream item's shorter
+// streams.  executed / cells is the padding a batch's shapes cost (1.01 for the uniform config-2 batch: 304 columns for 300).
+uint64_t phmm_batch_executed_cells(const phmm_batch *b) { return b ? b->swept_cells : 0; }
 
 int phmm_batch_bind_device(phmm_batch *b, const uint8_t *d_read_bases, const uint8_t *d_base_q, const uint8_t *d_ins_q,
                            const uint8_t *d_del_q, const uint8_t *d_gcp, const uint8_t *d_hap_bases, double *d_out) {
@@ -1465,26 +1291,13 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // The chained sweeps: one launch per lanes-per-pair value, precision and (mixed batches) range of K.  Several launches
     // run side by side: the first on the caller's stream, the others on the handle's side streams between a fork and a
     // join event -- each alone would leave the chip to its own tail before the next could start.
-    // shared haplotype prefixes: the trunks first (they park the columns the suffix launches below start from)
-    ChainShareParams shp{};
-    if (b->share.regions) {
-        shp.f = base_params(b);
-        shp.park = b->share.d_area;
-        for (int r = 0; r < kChainRanges; ++r) {
-            shp.items = b->share.d_park[r];
-            shp.n_items = (uint32_t)b->share.park[r].size();
-            if (shp.n_items && !hip_ok(h, launch_chain_share(CHAIN_PARK, r, shp, stream), "phmm_forward_chain_share (trunks)")) return PHMM_ERR_HIP;
-        }
-    }
-    int n_suffix = 0;
-    for (int r = 0; r < kChainRanges; ++r) n_suffix += b->share.suffix[r].empty() ? 0 : 1;
-    const size_t n_groups = b->chain_groups.size() + (size_t)n_suffix;
+    const size_t n_groups = b->chain_groups.size();
     // (not while the chunks of a pipelined host call are in flight: those already overlap each other on the slot streams,
     // and forks of several chunks would queue behind one another on the side streams -- 1 536 mixed regions through host
     // buffers: 25 ms without, 32 ms with)
-    // (round 4, three large chunks: forking them all changes nothing either.  Round 5: the LAST chunk of a mixed call alone -- the one
-    // whose launches have nothing of a later chunk beside them -- forks: `fork_chunk`, set by the chunk loop)
-    const bool fork = n_groups >= 2 && !h->sw.no_fork && (!h->defer_d2h || h->fork_chunk);
+    // (round 4, three large chunks: forking them all changes nothing either; round 5, the LAST chunk of a mixed call alone: 19.8-20.0
+    // ms against 18.7-18.8 -- both measured and dropped)
+    const bool fork = n_groups >= 2 && !h->defer_d2h;
     if (fork) {
         for (int i = 0; i < phmm_handle::kSideStreams; ++i) {
             if (!h->side_streams[i] && !hip_ok(h, hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking), "hipStreamCreate")) return PHMM_ERR_HIP;
@@ -1499,7 +1312,6 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
         p.n_items = (uint32_t)c.reads.size();
         p.lds_rows = c.lds_rows;
         p.cnd_select = c.cnd_select;
-        p.high_priority = (h->sw.region_prio & 2) ? 1u : 0u;
         if (!p.n_items) return PHMM_OK;
         hipError_t e;
         if (c.chain && !c.f32_first) return PHMM_OK;  // done with its group
@@ -1523,30 +1335,21 @@ int phmm_batch_launch(phmm_batch *b, void *stream_v) {
     // The per-read classes of a mixed batch (a few hundred microseconds of small kernels) depend on no chained launch: behind
     // the join they ran alone at the end of the batch, one after the other.  With the launches forked they go out FIRST on the
     // caller's stream -- the chained launches of the side streams start beside them, the caller's own behind them.
-    // (PHMM_CLASSES_LAST=1: the old order, A/B.  The mixed batch resident, three runs each on one box: 15.59-15.66 ms against 15.80-15.89.)
-    static const bool classes_last = getenv("PHMM_CLASSES_LAST") != nullptr;
-    const bool early_classes = fork && !classes_last;
+    // (The mixed batch resident, three runs each on one box: 15.59-15.66 ms against 15.80-15.89 the other way round.)
+    const bool early_classes = fork;
     if (early_classes)
         for (auto &c : b->classes)
             if (!c.chain && launch_class(c) != PHMM_OK) return PHMM_ERR_HIP;
     bool side_used[phmm_handle::kSideStreams] = {};
     // (Measured and dropped, round 5: dealing the launches to the streams by load, every stream sending its lightest first -- in the
     // mixed batch's timeline the two lightest launches trail the second and third heaviest -- : 15.56-15.67 ms either way.)
-    for (size_t gi = 0, next_suffix = 0; gi < n_groups; ++gi) {
+    for (size_t gi = 0; gi < n_groups; ++gi) {
         hipStream_t s_x = stream;
         if (fork && gi > 0) {
             const int si = (int)((gi - 1) % phmm_handle::kSideStreams);
             s_x = h->side_streams[si];
             if (!side_used[si] && !hip_ok(h, hipStreamWaitEvent(s_x, h->ev_fork, 0), "hipStreamWaitEvent")) return PHMM_ERR_HIP;
             side_used[si] = true;
-        }
-        if (gi >= b->chain_groups.size()) {  // a suffix launch of the sharing plan
-            while (b->share.suffix[next_suffix].empty()) ++next_suffix;
-            shp.items = b->share.d_suffix[next_suffix];
-            shp.n_items = (uint32_t)b->share.suffix[next_suffix].size();
-            if (!hip_ok(h, launch_chain_share(CHAIN_SUFFIX, (int)next_suffix, shp, s_x), "phmm_forward_chain_share (suffixes)")) return PHMM_ERR_HIP;
-            ++next_suffix;
-            continue;
         }
         auto &grp = b->chain_groups[gi];
         if (grp.items.empty()) continue;
@@ -1726,7 +1529,7 @@ int enqueue_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_r
             // A chunk of a large call is five arrays of megabytes: the quality tracks go through helper threads while this one
             // copies the bases and the haplotypes (1 536 mixed regions: 0.7-1.1 ms of staging per chunk on the calling thread,
             // a quarter of the call).  Small calls stay on the calling thread -- a thread costs more than their copies.
-            if (b->read_bytes >= (1u << 20) && !kNoStageThreads) {
+            if (b->read_bytes >= (1u << 20)) {
                 std::thread helpers[4];
                 int started = 0;
                 try {
@@ -1831,8 +1634,7 @@ bool next_chunk(ChunkView &c, uint32_t n_regions, const uint32_t *region_read_of
     // Round 5, the cap swept on one box (tools/hostpath_ragged_sweep.py, best of six calls, twice): 4 / 8 / 16: 18.75-18.85 ms;
     // 4 / 8 / 8 / 7: 18.1-18.3; cap 6: 19.3-19.4; cap 12: 18.7-18.8; first chunk 3 / 6 MB: 18.5 / 20.1; a first chunk of 1 or 2 MB and
     // 8 MB ones behind it (the device starts 0.5 ms earlier, one more set of launches): 18.1-18.3 -- so the cap is 8 MB.
-    static const bool mixed_flat = getenv("PHMM_MIXED_FLAT") != nullptr;  // (A/B: the first mixed chunk, then chunks of the cap at once)
-    const uint32_t step = c.f32_first ? c.index + 1 : c.mixed ? (mixed_flat && c.index ? 16u : c.index) : (c.index < 4 ? 0 : (c.index - 2) / 2);
+    const uint32_t step = c.f32_first ? c.index + 1 : c.mixed ? c.index : (c.index < 4 ? 0 : (c.index - 2) / 2);
     const size_t max_bytes = c.mixed && !c.f32_first ? kMixedChunkBytes : kChunkBytes;
     const size_t limit = std::min(max_bytes, (c.f32_first ? (1u << 20) / 2 : c.mixed ? kMixedFirstChunkBytes : kFirstChunkBytes) << std::min<uint32_t>(step, 16));
     if (whole) {
@@ -2067,7 +1869,6 @@ int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32
                 }
             h->slot = 0;
             h->defer_d2h = false;
-            h->fork_chunk = false;
         }
     } drain{h, pend};
     int st = PHMM_OK;
@@ -2090,14 +1891,8 @@ int compute_range(phmm_handle *h, uint32_t g_begin, uint32_t g_end, const uint32
         if (st != PHMM_OK) break;
         h->slot = slot;
         const size_t bo = c.read_byte0, co = c.hap_byte0;
-        // (A/B, off: the last chunk of a mixed call has no later chunk's kernels to fill the tails of its launches, one per range of
-        // K -- sending them out side by side like a resident batch's was measured at 19.8-20.0 ms against 18.7-18.8 one behind the
-        // other, three times on one box: beside the chunk before it the forked launches only take each other's vector units)
-        static const bool fork_last = getenv("PHMM_FORK_LAST_CHUNK") ? atoi(getenv("PHMM_FORK_LAST_CHUNK")) != 0 : false;
-        h->fork_chunk = fork_last && c.mixed && c.g1 == g_end && n_chunks > 0;
         st = enqueue_compute(h, c.g1 - c.g0, c.rro.data(), c.rho.data(), c.ro.data(), read_bases + bo, base_q + bo, ins_q + bo,
                              del_q + bo, gcp + bo, c.ho.data(), hap_bases + co, c.oo.data(), out + out_off[c.g0], &pend[slot]);
-        h->fork_chunk = false;
         ++n_chunks;
     }
     for (int i = 0; i < kSlots; ++i) {  // drain in submission order
@@ -2523,7 +2318,6 @@ int phmm_engine_compute(phmm_handle *h, const phmm_engine_config *cfg, uint32_t 
                 }
             h->slot = 0;
             h->defer_d2h = false;
-            h->fork_chunk = false;
         }
     } drain{h, pend};
     int st = PHMM_OK;
@@ -2559,18 +2353,12 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     Switches &w = h->sw;
     const std::string n(name);
     if (n == "force_L") w.force_L = value > 0 ? value : 0;
-    else if (n == "force_quad_split") w.force_split = value;
     else if (n == "force_chain") w.force_chain = value;
     else if (n == "force_streams") w.force_streams = value > 0 ? value : 0;
-    else if (n == "waves_per_block") w.waves_per_block = value > 0 ? value : 0;
-    else if (n == "force_cnd_select") w.force_cnd_select = value;
     else if (n == "no_pipeline") w.no_pipeline = value != 0;
     else if (n == "no_rescue") w.no_rescue = value != 0;
-    else if (n == "no_xcd_interleave") w.no_xcd_interleave = value != 0;
-    else if (n == "no_fork") w.no_fork = value != 0;
     else if (n == "trace") w.trace = value != 0;
     else if (n == "submit_gather_us") w.submit_gather_us = value > 0 ? value : 0;
-    else if (n == "sw_waves_per_cu") w.sw_waves_per_cu = value > 0 ? value : 0;
     else if (n == "sw_lite") {
         w.sw_lite = value;
         h->swork.lite_skip = 0;  // (what earlier calls have taught the handle starts over)
@@ -2584,8 +2372,6 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "server_idle_us") w.server_idle_us = value > 0 ? value : 1;
     else if (n == "server_stall_ms") w.server_stall_ms = value > 0 ? value : 1;
     else if (n == "server_trace") w.server_trace = value != 0;
-    else if (n == "region_prio") w.region_prio = value > 0 ? value : 0;
-    else if (n == "region_cu_halves") w.region_cu_halves = value != 0;
     else if (n == "region_flag_wait") w.region_flag_wait = value != 0;
     else if (n == "region_pick_timeout_us") w.region_pick_timeout_us = value > 0 ? value : 1;
     else if (n == "region_debug_pick") w.region_debug_pick = value > 0 ? value : 0;
@@ -2661,7 +2447,6 @@ uint32_t phmm_batch_num_launches(const phmm_batch *b) {
     if (!b) return 0;
     uint32_t n = 0;
     for (const auto &g : b->chain_groups) n += g.items.empty() ? 0u : 1u;
-    for (int r = 0; r < kChainRanges; ++r) n += (b->share.park[r].empty() ? 0u : 1u) + (b->share.suffix[r].empty() ? 0u : 1u);
     for (const auto &c : b->classes)
         if (!c.chain || c.f32_first) n += 1u;  // per-read classes, and the f64 redo behind an f32 sweep
     return n;

@@ -427,46 +427,6 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
     }
 }
 
-#ifdef PHMM_CHAIN_SHARE
-// ---- shared haplotype prefixes: the two item kinds as kernels of their own, one per range of K (this file compiled once
-// more with -DPHMM_CHAIN_SHARE -DPHMM_CHAIN_L=16; the plain kernels below stay exactly what they are) ---------------------
-#define PHMM_CHAIN_K_LIST_X(X) \
-    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
-    X(23) X(24) X(25)
-template <int CLT, int KLO, int KHI, int MODE>
-__global__ __launch_bounds__(WAVE, 2) void phmm_forward_chain_share(const ChainShareParams sp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ChainItemX *x = sp.items + blockIdx.x;
-    const ChainItem it = x->it;
-    switch (__builtin_amdgcn_readfirstlane((int)it.k)) {
-#define PHMM_CASE(KK)                                                                                   \
-    case KK:                                                                                            \
-        if constexpr (KK >= KLO && KK <= KHI) chain_body<CLT, KK, MODE>(sp.f, it, smem, x, sp.park);    \
-        break;
-        PHMM_CHAIN_K_LIST_X(PHMM_CASE)
-#undef PHMM_CASE
-        default:
-            break;
-    }
-}
-
-hipError_t launch_chain_share(int mode, int range, const ChainShareParams &sp, hipStream_t stream) {
-    if (!sp.n_items) return hipSuccess;
-    const size_t lds = (size_t)RING_SLOTS * sizeof(RowConst) + (CHAIN_META + 4) * sizeof(uint32_t);
-#define PHMM_RANGE(R, LO, HI)                                                                                                    \
-    if (range == R && mode == CHAIN_PARK) {                                                                                      \
-        hipLaunchKernelGGL((phmm_forward_chain_share<CL, LO, HI, CHAIN_PARK>), dim3(sp.n_items), dim3(WAVE), lds, stream, sp);   \
-        return hipGetLastError();                                                                                                \
-    }                                                                                                                            \
-    if (range == R && mode == CHAIN_SUFFIX) {                                                                                    \
-        hipLaunchKernelGGL((phmm_forward_chain_share<CL, LO, HI, CHAIN_SUFFIX>), dim3(sp.n_items), dim3(WAVE), lds, stream, sp); \
-        return hipGetLastError();                                                                                                \
-    }
-    PHMM_CHAIN_RANGES(PHMM_RANGE)
-#undef PHMM_RANGE
-    return hipErrorInvalidValue;
-}
-#else  // PHMM_CHAIN_SHARE
 
 // ---- the kernel: every item carries its own K (and stream count), so ONE launch per lanes-per-pair value covers
 // every shape class of a batch.  A long-tailed mix of regions (3 x 2 ... 5 000 x 128, haplotypes of 60 ... 500 bases)
@@ -542,6 +502,5 @@ hipError_t launch_chain(int L, int single_k, const ChainParams &cp, hipStream_t 
          : L == 64 ? launch_chain_L64(single_k, cp, stream) : hipErrorInvalidValue;
 }
 #endif
-#endif  // PHMM_CHAIN_SHARE
 
 }  // namespace phmm

@@ -31,26 +31,18 @@ struct Arena {
 // changed afterwards only through phmm_set_switch -- nothing on the host path calls getenv.
 struct Switches {
     int force_L = 0;            // PHMM_FORCE_L: 16 / 32 / 64 lanes per pair, 0 = planner's choice
-    int force_split = -1;       // PHMM_FORCE_QUAD_SPLIT: 1 = one wave per (read, hap group), 0 = loop in wave
     int force_chain = -1;       // PHMM_FORCE_CHAIN: reads per run of the chained kernel, 0 = per-read kernel only, -1 = planner
     int force_streams = 0;      // PHMM_FORCE_STREAMS: 1 / 2 / 4 streams of the chained kernel
-    int waves_per_block = 0;    // PHMM_WAVES_PER_BLOCK
-    int force_cnd_select = -1;  // PHMM_FORCE_CND_SELECT
     int no_pipeline = 0;        // PHMM_NO_PIPELINE: host path in one shot whatever the size
-    int no_xcd_interleave = 0;  // PHMM_NO_XCD_INTERLEAVE: haplotype groups of a run adjacent in the launch instead of 8 blocks apart
-    int no_fork = 0;            // PHMM_NO_FORK: the chained launches of a batch one after the other on the caller's stream (A/B only)
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
-    int submit_lanes = 4;       // PHMM_SUBMIT_LANES: lanes of a shared handle (1-8)
     int submit_gather_us = 40;  // PHMM_SUBMIT_GATHER_US: how long the leader of a flush lets submissions that are on their way arrive (0 = never)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
     int sw_lite = -1;           // PHMM_SW_LITE: the tags-only first pass of the aligner -- -1 where it pays (adaptive), 0 never, 1 always
-    int sw_waves_per_cu = 0;    // PHMM_SW_WAVES_PER_CU: cap on the Smith-Waterman kernel's waves per CU (0 = 32)
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
     int sw_chunks = 0;          // PHMM_SW_CHUNKS: pieces a phmm_sw_align call is pipelined in (0 = by size, at most 4)
     int sw_transpose = -1;      // PHMM_SW_TRANSPOSE: 0 = small calls never sweep along the alternate sequence, 1 = whenever possible, -1 = by cost
     int sw_clock = 0;           // PHMM_SW_CLOCK: the aligner's block 0 reports the shader clock it ran at (phmm_get_stat "sw_clock_mhz"; also with PHMM_TRACE)
     int sw_no_zero_copy = 0;    // PHMM_SW_NO_ZERO_COPY: small one-piece calls fetch their results by copies like large ones (A/B only)
-    int region_prio = 0;        // PHMM_REGION_PRIO (A/B): bit 0 = the all-pairs aligner's waves, bit 1 = the PairHMM waves of a small launch at raised issue priority
     int region_flag_wait = 1;   // PHMM_REGION_FLAG_WAIT: 0 = a small region call's thread waits in hipStreamSynchronize instead of polling the
                                 // word its last kernel stores into the pinned mirror (A/B)
     int region_pick_timeout_us = 5000;  // PHMM_REGION_PICK_TIMEOUT_US: how long phmm_pick_reads waits for the all-pairs aligner on the other
@@ -62,7 +54,6 @@ struct Switches {
                                 // of private handles go through the device's shared combiner (its lanes) instead of their own streams -- 0 = never
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
-    int region_cu_halves = 1;   // PHMM_REGION_CU_HALVES: 0 = such a call's two streams both see every CU whatever its size (A/B)
     int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1: the one-shot calls of
                                 // PRIVATE handles while more than four of the caller's handles are alive on the device (a handle whose other switches
                                 // were changed keeps the launched pipeline); 0 never; 1 every call the server's limits admit, a shared handle's too
@@ -140,7 +131,6 @@ struct phmm_handle {
                                       // trading lanes for waves once the batch fills its share of the chip
     uint32_t busy_lanes = 1;          // a lane of a shared handle: lanes computing right now, this one included (phmm_wait)
     bool defer_d2h = false;           // see eager_d2h(): set around pipelined chunks and combined flushes
-    bool fork_chunk = false;          // this chunk's chained launches go out side by side although chunks are in flight (the last one of a mixed call)
     std::once_flag comb_once;
 };
 

@@ -36,7 +36,7 @@ struct ForwardParams {
     double initial_condition_log10;  // log10(2^1020), host libm
     uint32_t lds_rows;               // rows of LDS staging reserved per wave (>= longest read of the class)
     const uint8_t *redo;             // not null: only reads with redo[r] != 0 are computed (f64 pass of the f32-first mode)
-    uint32_t high_priority;          // 1: the per-read kernel's waves raise their issue priority (s_setprio; A/B switch region_prio)
+    uint32_t pad_was_priority;       // (a wave-priority A/B of round 4 lived here: the time only moved to the other kernel)
     uint32_t cnd_select;             // 1: v_cndmask prior select (launches with < 2 waves per SIMD, K <= PHMM_CND_MAX_K)
     uint32_t *status;                // device status word (STATUS_POSITIVE | STATUS_RESCUE)
 };
@@ -110,7 +110,8 @@ struct ChainParams {
     uint32_t n_items;
     uint8_t *redo;     // f32-first kernel only: [n_reads] flags, set where the f64 per-read kernel has to redo a read
 };
-// ---- shared haplotype prefixes (phmm_batch_share_prefixes) -------------------------------------------------------------
+// ---- shared haplotype prefixes (the chained body's PARK / SUFFIX modes: built and measured in round 4 -- x 0.96-1.10 effective,
+// NOTEBOOK 18.4 -- and no longer instantiated: the host side, the API call and the kernels went in round 6) ---------------------
 // Columns left of the first base where a haplotype differs from its region's first haplotype (the "trunk") hold the same
 // M / I / D for every read -- what the reference's scalar arm skips through find_first_position_where_haplotypes_differ
 // (pair_hmm.rs:452-464, 706-717).  Here: the trunk's item PARKS, for every stream row, M~ and D' of the last column of
@@ -130,15 +131,6 @@ struct ChainItemX {
                             // set); SUFFIX: first haplotype column of the item
 };
 static_assert(sizeof(ChainItemX) == 32, "work item record");
-struct ChainShareParams {
-    ForwardParams f;
-    const ChainItemX *items;
-    uint32_t n_items;
-    double *park;        // the parking area: (M~, D') per row
-};
-// one launch per kind (CHAIN_PARK | CHAIN_SUFFIX) and range of K (chain_range_of); L = 16
-hipError_t launch_chain_share(int mode, int range, const ChainShareParams &p, hipStream_t stream);
-
 // The K ranges a mixed launch is cut into: one kernel per range holds only that range's bodies (phmm_chain_kernels.hip).
 #define PHMM_CHAIN_RANGES(X) X(0, 2, 9) X(1, 10, 15) X(2, 16, 19) X(3, 20, 25)
 constexpr int kChainRanges = 4;

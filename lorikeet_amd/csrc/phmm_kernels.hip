@@ -27,7 +27,6 @@ __global__ __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (K <= PHMM_TWO_WAVE_MAX_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= p.n_items) return;  // wave-uniform
-    if (p.high_priority) __builtin_amdgcn_s_setprio(3);
     const uint32_t r = p.class_reads ? p.class_reads[item] : item;
     if (p.redo && p.redo[r] == 0) return;  // f32-first mode: this launch only redoes the flagged reads (wave-uniform)
     forward_read<L, K>(p, r, (int)blockIdx.y, (int)gridDim.y, p.cnd_select != 0, smem + (size_t)wave * p.lds_rows * sizeof(RowConst));

@@ -332,7 +332,7 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
     }
     int pair_set = 0;  // 0 WHOLE: the handle's pair of the device's pool; 1 HALVES (see where the streams are used, below)
     if (pair_stride) {
-        pair_set = (size_t)nr * pair_stride <= kHalvesUpToPairs && h->sw.region_cu_halves ? 1 : 0;
+        pair_set = (size_t)nr * pair_stride <= kHalvesUpToPairs ? 1 : 0;
         if (pair_set == 0 && !queues_acquire(h)) pair_set = 1;  // (the halves suit any small call)
         if (pair_set == 1 && !halves_acquire(h)) pair_stride = 0;  // (no queues to be had: the chain)
     }
@@ -499,7 +499,6 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         sp.ref_index = nullptr;
         sp.pair_stride = pair_stride;
         sp.pair_single_nh = ng == 1 ? nh : 0u;
-        sp.high_priority = (h->sw.region_prio & 1) ? 1u : 0u;
         sp.report_clock = (h->sw.region_debug_pick & 2) ? 2u : 0u;  // (never the clock words here; 2 = the canary's negative control)
         sp.read_region = (const uint32_t *)(mirror + ((const char *)V.d_read_region - A.dev));
         sp.region_hap_off = (const uint32_t *)(mirror + ((const char *)V.d_region_hap_off - A.dev));
@@ -513,11 +512,10 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
             W.region_sw_all_calls += 1;
         }
     };
-    const bool all_pairs_behind_prep = (h->sw.region_prio & 4) != 0;  // (A/B)
     // (tests: the aligner BEHIND phmm_pick_reads on the call's own stream -- in order on one queue the wait cannot be met)
     const bool all_pairs_behind_pick = pair_stride && (h->sw.region_debug_pick & 1) != 0;
     if (all_pairs_behind_pick) T_all = S;
-    if (good && pair_stride && !all_pairs_behind_prep && !all_pairs_behind_pick) launch_all_pairs();
+    if (good && pair_stride && !all_pairs_behind_pick) launch_all_pairs();
     // ---- pre-step ----------------------------------------------------------------------------------------------------------
     if (good && nr) {
         PrepParams pp{};
@@ -554,7 +552,6 @@ int region_enqueue(phmm_handle *h, const RegionArgs &a, const std::vector<Region
         }
         good = ok(h, launch_prep(pp, S), "phmm_prep_reads");
     }
-    if (good && pair_stride && all_pairs_behind_prep && !all_pairs_behind_pick) launch_all_pairs();
     // ---- PairHMM ---------------------------------------------------------------------------------------------------------
     // The exact pass below -600 rides in-stream -- unless no pair of this batch can get there: every likelihood is at least
     // the path "first base matched anywhere, everything else inserted", 10^-(q/10)/3 x (1 - 10^-(gcp/10)) x 10^-(ins/10) x

@@ -596,8 +596,7 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
     Server &S = *p->S;
     bool done = false;
     // (measured, tools/threads_bench: spin / yield 33.4 / 42.5 / 22.9 k regions/s at 10 / 16 / 32 callers, short sleeps 32.7 / 42.1 / 45.6 k)
-    static const uint32_t wait_spins = getenv("PHMM_SERVER_WAIT_SPINS") ? (uint32_t)atoi(getenv("PHMM_SERVER_WAIT_SPINS")) : 64u;
-    static const int wait_mode = getenv("PHMM_SERVER_WAIT_MODE") ? atoi(getenv("PHMM_SERVER_WAIT_MODE")) : 1;
+    constexpr uint32_t wait_spins = 64;
     const auto give_up = p->t0 + std::chrono::milliseconds(std::max(1, h->sw.server_stall_ms) * 4);
     for (uint32_t spins = 0; !done; ++spins) {
         done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
@@ -620,8 +619,7 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
                     S.why_broken = "a call did not come back from the region server";
                     break;
                 }
-                if (wait_mode == 1) std::this_thread::sleep_for(std::chrono::microseconds(20));
-                else std::this_thread::yield();
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
         }
         __builtin_ia32_pause();

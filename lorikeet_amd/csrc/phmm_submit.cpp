@@ -315,7 +315,7 @@ namespace {
 int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
     std::call_once(h->comb_once, [h] {
         Combiner *c = new Combiner();
-        c->n_lanes = std::min(std::max(h->sw.submit_lanes, 1), (int)Combiner::kMaxLanes);
+        c->n_lanes = 4;  // (2 / 3 / 6 / 8 lanes measured in round 5: none better at 8 or 16 callers, NOTEBOOK 19.2)
         c->trace = h->sw.trace != 0;
         c->gather_us = h->sw.submit_gather_us;
         h->comb = c;

@@ -282,7 +282,6 @@ int sw_plan(phmm_handle *h, const std::string &who, uint32_t n_alignments, uint3
         h->err = who + ": the kernel does not fit a compute unit";
         return h->err_code = PHMM_ERR_INTERNAL;
     }
-    if (h->sw.sw_waves_per_cu > 0) per_cu = h->sw.sw_waves_per_cu;  // (developer switch: more than the chip holds simply queue)
     // backtrack flags per block: strips x (rows + L - 1) steps x sw_flag_words(K) ~ K / 8 dwords x 64 lanes (four bits per cell)
     const size_t flag_words = (size_t)sw_flag_words(K);
     const size_t slab_stride = strips * (size_t)((transposed ? std::max(max_ref, max_alt) : max_ref) + L) * flag_words * 64;

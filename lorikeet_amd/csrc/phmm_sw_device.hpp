@@ -173,7 +173,6 @@ __device__ __forceinline__ void sw_align_body(const SwParams &p, unsigned char *
     const size_t strip_stride = (size_t)(p.max_ref + SW_L) * NW * WAVE;  // flag dwords of one strip
     auto row0 = [&](int jj) { return (edge_gaps && jj > 0) ? x_open + (jj - 1) * x_extend : 0; };  // :150-158
 
-    if (p.high_priority) __builtin_amdgcn_s_setprio(3);
     // (block 0 reports the shader clock it ran at -- phmm_get_stat "sw_clock_mhz" -- only where the launch asks for it:
     // SwParams::report_clock, measurement runs of the aligner's own entry points; never inside a region call)
     const long long clk0 = p.report_clock ? clock64() : 0, wall0 = p.report_clock ? wall_clock64() : 0;

@@ -54,7 +54,7 @@ struct SwParams {
     uint32_t report_clock;                 // 1: block 0 stores shader clocks / 100 MHz ticks into status[2..3] (measurement: PHMM_TRACE or the
                                            // switch "sw_clock"; phmm_sw.cpp only, whose status block is the call's own until it returns);
                                            // 2 (tests, switch region_debug_pick bit 1): two words stored LATE, behind the count -- the canary's negative control
-    uint32_t high_priority;                // 1: the waves raise their issue priority (s_setprio) over other kernels' waves on their SIMDs
+    uint32_t pad_was_priority;             // (a wave-priority A/B of round 4 lived here)
     const uint32_t *read_region, *region_hap_off;
     unsigned char *ext;                    // sequences too long for everything to fit LDS: the bottom row and the strip edges of
     size_t ext_stride;                     // block b live at ext + b * ext_stride (device memory), LDS holds the two sequences only

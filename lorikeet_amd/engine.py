@@ -60,12 +60,6 @@ class DevicePlan:
     def status(self):
         self.engine._check(self.engine.lib.phmm_batch_status(self._b))
 
-    def share_prefixes(self):
-        """phmm_batch_share_prefixes: re-plan the regions whose haplotypes share the front of their first one (bit-identical
-        results, fewer cells swept).  Before the first launch."""
-        self.engine._check(self.engine.lib.phmm_batch_share_prefixes(self._b, _p(self.batch.hap_bases, _lib.u8p)))
-        return self.executed_cells
-
     @property
     def cells(self):
         return int(self.engine.lib.phmm_batch_cells(self._b))
@@ -172,8 +166,7 @@ class HipPairHMMEngine:
         """Context manager: set developer switches for the duration of a `with` block, then back to the planner's
         choice (force_L=0, force_chain=-1, force_streams=0, no_pipeline=0, ...)."""
         import contextlib
-        defaults = {"force_L": 0, "force_quad_split": -1, "force_chain": -1, "force_streams": 0, "waves_per_block": 0,
-                    "force_cnd_select": -1, "no_pipeline": 0, "no_rescue": 0, "trace": 0}
+        defaults = {"force_L": 0, "force_chain": -1, "force_streams": 0, "no_pipeline": 0, "no_rescue": 0, "trace": 0}
 
         @contextlib.contextmanager
         def cm():
