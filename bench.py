@@ -418,13 +418,21 @@ def compact_line(line, full_path):
     c["config"] = {"workload": cfg["workload"].split(":")[0] if line["scaling"] == "strong" else cfg["workload"].split(" (")[0],
                    "regions_per_gpu": cfg["regions_per_gpu"], "cells_per_gpu_per_step": cfg["cells_per_gpu_per_step"], "seed": cfg["seed"],
                    "per_rank_cells": prc if len(prc) <= 8 else None,
-                   "imbalance": round(max(prc) * len(prc) / max(sum(prc), 1), 4) if prc else None, "sharding": "regions; no collective"}
+                   "imbalance": round(max(prc) * len(prc) / max(sum(prc), 1), 4) if prc else None, "sharding": "regions; no collective",
+                   "env": cfg.get("env")}
     c["regions_per_s"] = line["regions_per_s"]
     c["roofline"] = pick(line["roofline"], bound="bound", achieved="achieved", peak="peak", unit="unit", frac="frac", traffic="traffic",
                          l2_hit_rate="l2_hit_rate", kernel="kernel", kernel_ms="kernel_ms",
                          algorithmic_bytes_per_launch="algorithmic_bytes_per_launch", src_hash="src_hash")
     if isinstance(line["roofline"].get("hbm"), dict):   # (the HBM figure the metric's wording asks for, beside the bound that binds)
         c["roofline"]["hbm"] = pick(line["roofline"]["hbm"], achieved="achieved", peak="peak", unit="unit", frac="frac")
+    c["roofline"]["definition"] = "r5+: the bound that binds (valu_f64); the HBM figure of r1-r4 lines is roofline.hbm"
+    f32 = line.get("f32_first")
+    if isinstance(f32, dict) and "error" not in f32:  # (the arithmetic the reference ships -- gkl, f32 first -- priced like the headline)
+        c["roofline_f32"] = {"bound": "valu_f32", "achieved": g(f32, "valu_f32", "achieved"), "peak": g(f32, "valu_f32", "peak"), "unit": "TFLOP/s",
+                             "frac": g(f32, "valu_f32", "frac"), "kernel": g(f32, "kernel"), "kernel_ms": g(f32, "ms_per_step"),
+                             "issue_frac": g(f32, "valu_issue", "frac"), "valu_per_cell": g(f32, "valu_issue", "valu_per_cell"),
+                             "traffic": g(f32, "valu_issue", "hbm_bytes_per_launch"), "l2_hit_rate": g(f32, "valu_issue", "l2_hit_rate")}
     c["valu_f64"] = pick(line["valu_f64"], achieved="achieved", peak="peak", unit="unit", frac="frac")
     c["valu_issue"] = pick(line["valu_issue"], achieved="achieved", peak="peak", frac="frac", valu_per_cell="valu_per_cell")
     for k in ("cpu_baseline", "cpu_baseline_simd"):
@@ -441,15 +449,14 @@ def compact_line(line, full_path):
     rows = {
         "config3_10k": strong(line.get("config3_10k")), "config5_256": strong(line.get("config5_256")),
         "ragged": pick(line.get("ragged"), gcups="gcups", ms="ms_per_step", regions_per_s="regions_per_s", launches="launches_per_step",
+                       executed_per_cell="executed_per_cell",
                        host_gcups=("host_buffers_incl_pcie", "gcups"), host_ms=("host_buffers_incl_pcie", "ms_per_call"),
                        valu_f64_frac=("valu_f64", "frac"), max_abs_diff=("oracle_sample", "max_abs_diff")),
-        "f32_first": pick(line.get("f32_first"), gcups="value", ms="ms_per_step", valu_f32_frac=("valu_f32", "frac"),
-                          issue_frac=("valu_issue", "frac"), valu_per_cell=("valu_issue", "valu_per_cell"), max_abs_diff="max_abs_diff_vs_f64"),
+        "f32_first": pick(line.get("f32_first"), gcups="value", ms="ms_per_step", max_abs_diff="max_abs_diff_vs_f64"),
         "single_region_us": g(line, "single_region", "us_per_region"),
         "engine_call": pick(line.get("engine_call"), gcups_incl_pcie="gcups_incl_pcie", ms="ms_per_call", regions="regions"),
         # regions/s through host buffers, one region per call unless the name says otherwise (tools/threads_bench)
         "host_calls": None if not hc else ({"error": str(hc["error"])[:80]} if "error" in hc else {
-            "pairhmm_4t_own": rps("one_region_per_call_4_threads_own_handles"),
             "pairhmm_8t_own": rps("one_region_per_call_8_threads_own_handles"), "pairhmm_32t_shared": rps("one_region_per_call_32_threads_shared_handle_submit_wait"),
             "region_1t": rps("region_call_one_region_per_call_1_thread"), "region_1t_us": g(hc, "region_call_one_region_per_call_1_thread", "us_per_call"),
             "region_4t_own": rps("region_call_one_region_per_call_4_threads_own_handles"),
@@ -461,6 +468,7 @@ def compact_line(line, full_path):
             "region_8t_shared_2tk": rps("region_call_one_region_per_call_8_threads_shared_handle_2_tickets"),
             "region_10t_shared_2tk": rps("region_call_one_region_per_call_10_threads_shared_handle_2_tickets"),
             "region_16t_shared_2tk": rps("region_call_one_region_per_call_16_threads_shared_handle_2_tickets"),
+            "region_10t_own": rps("region_call_one_region_per_call_10_threads_own_handles"),
             "region_16t_own": rps("region_call_one_region_per_call_16_threads_own_handles"),
             "region_32t_own": rps("region_call_one_region_per_call_32_threads_own_handles"),
             "pairhmm_16t_own": rps("one_region_per_call_16_threads_own_handles"),
@@ -469,7 +477,6 @@ def compact_line(line, full_path):
             "small_1t": rps("region_call_small_30x3_1_thread"), "small_1t_us": g(hc, "region_call_small_30x3_1_thread", "us_per_call"),
             "small_8t_shared": rps("region_call_small_30x3_8_threads_shared_handle"), "small_32t_shared": rps("region_call_small_30x3_32_threads_shared_handle"),
             "ragged_1t": rps("region_call_ragged_1_thread"), "ragged_8t_shared": rps("region_call_ragged_8_threads_shared_handle"),
-            "ragged_32t_shared": rps("region_call_ragged_32_threads_shared_handle"),
             "two_calls_1t": rps("likelihoods_then_realignment_one_region_per_call_1_thread")}),
         "smith_waterman": pick(sw, gcups_i32="gcups_i32", ms="ms_per_call", kernel_gcups_i32=("kernel", "gcups_i32"), kernel_ms=("kernel", "ms"),
                                one_piece_gcups_i32=("kernel_one_piece", "gcups_i32"), full_instance_gcups_i32=("full_instance_only", "kernel_gcups_i32"),
@@ -686,8 +693,10 @@ def main():
                 "region_call_one_region_per_call_8_threads_shared_handle_2_tickets": point("gshared", 8, 1, depth=2),
                 "region_call_one_region_per_call_10_threads_shared_handle_2_tickets": point("gshared", 10, 1, depth=2),
                 "region_call_one_region_per_call_16_threads_shared_handle_2_tickets": point("gshared", 16, 1, depth=2),
-                # ... and a private handle per worker past four (INTEGRATION.md section 4's thread_local!): the library routes their
-                # one-shot calls through the device's shared lanes (round 5; round 4: 22 k at 16 threads, 12.5 k at 32)
+                # ... and a private handle per worker past four (INTEGRATION.md section 4's thread_local!): their one-shot calls go through
+                # the device's resident region server (round 6: nothing launched, results bit-reproducible; round 5 routed them through
+                # the shared combiner, round 4: 22 k at 16 threads, 12.5 k at 32)
+                "region_call_one_region_per_call_10_threads_own_handles": point("fused", 10, 1),
                 "region_call_one_region_per_call_16_threads_own_handles": point("fused", 16, 1),
                 "region_call_one_region_per_call_32_threads_own_handles": point("fused", 32, 1),
                 "one_region_per_call_16_threads_own_handles": point("own", 16, 1),
@@ -726,6 +735,8 @@ def main():
                "gcups": round(r.plan.cells * 5 / el / 1e9, 1), "regions_per_s": round(rb.n_regions * 5 / el, 1),
                "ms_per_step": round(el / 5 * 1e3, 4), "launches_per_step": r.plan.num_launches,
                "dominant_kernel": r.plan.dominant_kernel,
+               # what the launches sweep over what the metric counts: padding columns inside a lane group, empty haplotype slots
+               "executed_per_cell": round(r.plan.executed_cells / max(r.plan.cells, 1), 4),
                "valu_f64": {"achieved": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9, 3), "peak": VALU_F64_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * r.plan.cells / (sum(kms) / len(kms)) / 1e9 / VALU_F64_PEAK_TFLOPS, 4)},
                "host_buffers_incl_pcie": {"ms_per_call": round(t_host * 1e3, 3), "gcups": round(rb.cells() / t_host / 1e9, 1),
@@ -1100,7 +1111,9 @@ def main():
                        "per_rank_cells": per_rank_cells,
                        "regions_per_gpu": regions, "pairs_per_gpu": int(batch.n_out),
                        "cells_per_gpu_per_step": int(plan.cells), "seed": a.seed,
-                       "sharding": "regions, one process per GPU, no collective"},
+                       "sharding": "regions, one process per GPU, no collective",
+                       # (what this process changed in its own environment; the threads_bench children run with the library's defaults)
+                       "env": None if own_queue_given else "PHMM_REGION_OWN_QUEUE=0 in this process only"},
             "regions_per_s": round(regions_total * a.steps / elapsed, 1),
             # The bound that BINDS leads: FP64 vector flops of the reference recurrence against the chip's FP64
             # VALU peak.  The HBM figure the metric's wording asks for stays beside it under "hbm" -- 2.3e-3 compulsory bytes per

@@ -69,7 +69,7 @@ def test_the_compact_line_holds_the_contract_and_every_row_in_four_kilobytes():
     assert rows["config3_10k"]["gcups"] > 0 and rows["config5_256"]["gcups"] > 0 and rows["ragged"]["host_gcups"] > 0
     assert rows["f32_first"]["gcups"] > 0 and rows["single_region_us"] > 0
     hc = rows["host_calls"]
-    assert hc["region_1t"] > 0 and hc["region_8t_shared"] > 0 and hc["small_1t"] == 12345 and hc["ragged_32t_shared"] == 12345
+    assert hc["region_1t"] > 0 and hc["region_8t_shared"] > 0 and hc["small_1t"] == 12345 and hc["ragged_8t_shared"] == 12345
     assert rows["smith_waterman"]["issue_peak"] == 1.2 and rows["smith_waterman"]["mix_ceiling"] == 0.7
     # numbers only: no string in `rows` but kernel-free booleans / error texts
     def strings(x):

@@ -94,3 +94,22 @@ def test_one_region_at_the_reference_maximum_depth(hip_engine):
             sub = RegionBatch.from_regions([(reads, [b.hap_bases[int(b.hap_off[a]):int(b.hap_off[a + 1])] for a in range(nh)])])
             want = oracle.compute_batch(sub.as_dict(), n_threads=16)
             assert float(np.max(np.abs(got[r0 * nh:(r0 + 40) * nh] - want))) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["config3", "config5", "ragged"])
+def test_f32_first_on_the_full_sets(name):
+    """The arithmetic the reference ships (pair_hmm.rs:348-366 -> gkl: f32 first, f64 where f32 cannot be trusted) on EVERY pair of
+    the full-size sets, as the f64 default above: against the SIMD stand-in at the reference's own gate for that arm, 1e-5, and
+    against this library's f64 results at the same gate (the f32 tests stopped at 400 / 8 regions)."""
+    from lorikeet_amd import HipPairHMMEngine
+    b = {"config3": synthetic.config3, "config5": synthetic.config5, "ragged": synthetic.ragged}[name]()
+    e32, e64 = HipPairHMMEngine(0, f32_first=True), HipPairHMMEngine(0)
+    try:
+        r32 = e32.compute(b)
+        assert r32.shape == (b.n_out,) and (r32 <= 0).all() and np.isfinite(r32).all()
+        simd, _ = oracle.compute_batch_simd(b.as_dict(), n_threads=16, native=False)
+        assert float(np.max(np.abs(r32 - simd))) <= 1e-5, "f32-first, full set vs the vector-arm stand-in"
+        assert float(np.max(np.abs(r32 - e64.compute(b)))) <= 1e-5, "f32-first vs the f64 default"
+    finally:
+        e32.close()
+        e64.close()
