@@ -2015,17 +2015,9 @@ int phmm_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read
         h->err = "phmm_compute: null pointer";
         return h->err_code = PHMM_ERR_INVALID_ARG;
     }
-    // (one of many private handles on the device: the device's region server takes the call if it is within its limits -- nothing
-    // is launched, and the results are the regions' own bits whatever the other callers do: phmm_server.cpp)
-    {
-        const int st = server_compute(h, n_regions, region_read_off, region_hap_off, read_off, read_bases, base_q, ins_q, del_q, gcp, hap_off, hap_bases,
-                                      out_off, out, &h->err);
-        if (st != kServerNotTaken && st != kServerRedo) {
-            if (st != PHMM_OK) h->err_code = st;
-            return st;
-        }
-    }
-    // (... or, opt-in, through the device's shared handle -- route_shared)
+    // (one of many private handles on the device: opt-in, PHMM_ROUTE_SHARED, a one-shot call goes through the device's shared handle.
+    // The PairHMM alone through the region server -- built in round 6 -- gave a wrong likelihood once in 150 000 calls of the ragged
+    // mix under TB_VERIFY and was taken out again; the whole region call, whose waves go on to the alignment, soaks clean.)
     if (n_regions < 8 || (size_t)read_off[n_reads] <= kOneShotBytes)
         if (phmm_handle *via = route_shared(h)) {
             uint64_t ticket = 0;

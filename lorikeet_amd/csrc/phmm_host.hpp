@@ -58,7 +58,8 @@ struct Switches {
                                 // PRIVATE handles while more than four of the caller's handles are alive on the device (a handle whose other switches
                                 // were changed keeps the launched pipeline); 0 never; 1 every call the server's limits admit, a shared handle's too
     int server_idle_us = 200;   // PHMM_SERVER_IDLE_US: how long the server stays on the chip with nothing in flight and nothing arriving
-    int server_stall_ms = 500;  // PHMM_SERVER_STALL_MS: calls in flight and none finishing for this long: the server gives up (the calls fail)
+    int server_stall_ms = 5000; // PHMM_SERVER_STALL_MS: calls in flight and none finishing for this long: the server gives up and is not used again by the
+                                // process (its calls are run again by the launched pipeline)
     int server_trace = 0;       // PHMM_SERVER_TRACE: every task leaves a record (tools/server_trace.py)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs
@@ -285,9 +286,6 @@ constexpr int kServerRedo = -2001;      // server_region_wait: run the call agai
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit);
 int user_handles_on(int device);  // the caller's handles alive on the device (phmm_api.cpp)
 int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);
-int server_compute(phmm_handle *h, uint32_t n_regions, const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
-                   const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
-                   const uint8_t *hap_bases, const uint64_t *out_off, double *out, std::string *err);
 uint64_t server_stat(int device, const char *name);
 void server_yield(int device);
 int region_calls_in_flight(int device);  // phmm_region_compute calls of the launched kind between enqueue and finish (phmm_region.cpp)

@@ -228,8 +228,6 @@ struct ServerPending {
     Layout L;
     uint64_t n_out = 0;
     uint32_t n_tasks = 0;
-    double *compute_out = nullptr;   // phmm_compute jobs: where the likelihoods go, and where they lie in the slot
-    size_t o_out = 0, o_res = 0;
     std::chrono::steady_clock::time_point t0;
 };
 
@@ -571,7 +569,6 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     job->status_out = (uint32_t *)(mirror + L.res);
     job->wait_ticks = 100u * 1000u * (uint32_t)std::max(1, h->sw.server_stall_ms);
     job->finish_flag = (uint32_t *)(mirror + L.res + 224);
-    job->full = 1;
     // ---- the ring entry ----------------------------------------------------------------------------------------------------------------
     ServerPending *p = new ServerPending();
     p->S = S;
@@ -642,12 +639,14 @@ int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, Regio
     const auto t_enter = std::chrono::steady_clock::now();
     const bool done = poll_finish(h, p, flag);
     if (!done) {
-        // (the slot is not given back: a kernel may still be writing into it)
+        // The server gave up (nothing finished within its time limit: its waves starved behind long launched kernels, or worse) or
+        // never answered.  It is not used again by this process (phmm_get_stat "server_broken"); the slot is not given back -- a
+        // kernel may still be writing into it -- and the call is run again by the launched pipeline.
         S.in_flight.fetch_sub(1, std::memory_order_relaxed);
         S.tasks_in_flight.fetch_sub(p->n_tasks, std::memory_order_relaxed);
-        const std::string why = S.why_broken;
+        if (redo_args) *redo_args = a;
         delete p;
-        return fail(err, "phmm_region_compute: " + (why.empty() ? std::string("the region server failed") : why), PHMM_ERR_INTERNAL);
+        return kServerRedo;
     }
     const auto t_done = std::chrono::steady_clock::now();
     S.ns_wait.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_done - t_enter).count(), std::memory_order_relaxed);
@@ -697,162 +696,6 @@ void server_yield(int device) {
     }
     if (!S || !S->ok || !__atomic_load_n(&S->running, __ATOMIC_RELAXED)) return;
     __atomic_fetch_add((uint32_t *)((char *)S->exit_word + 128), 1u, __ATOMIC_RELEASE);
-}
-
-// phmm_compute through the server: the PairHMM alone -- every (read, group of haplotypes) a wave that sweeps and stores its
-// likelihoods into the caller's mirror.  For the one-shot calls of private handles once more than four of them are alive (the
-// region calls' rule, server_region_submit).  kServerNotTaken: outside the limits, nothing was done; kServerRedo: a result came
-// out below -600, where only the launched path's exact pass agrees with the reference -- the caller runs the call that way.
-int server_compute(phmm_handle *h, uint32_t ng, const uint32_t *region_read_off, const uint32_t *region_hap_off, const uint32_t *read_off,
-                   const uint8_t *read_bases, const uint8_t *base_q, const uint8_t *ins_q, const uint8_t *del_q, const uint8_t *gcp, const uint32_t *hap_off,
-                   const uint8_t *hap_bases, const uint64_t *out_off, double *out, std::string *err) {
-    if (h->sw.region_server == 0) return kServerNotTaken;
-    if (h->sw.region_server < 0 && (h->sw_touched || h->internal || h->comb || h->sw.route_shared > 0 || user_handles_on(h->device) <= 4)) return kServerNotTaken;
-    if (h->flags & PHMM_FLAG_F32_FIRST) return kServerNotTaken;  // (that arithmetic has kernels of its own)
-    const uint32_t nr = region_read_off[ng], nh = region_hap_off[ng];
-    if (!ng || !nr || !nh || out_off[0] != 0) return kServerNotTaken;
-    if (ng >= 8 && (size_t)read_off[nr] > one_shot_bytes()) return kServerNotTaken;
-    uint32_t max_r = 0, max_h = 0, max_nh = 0, max_gcp = 0;
-    for (uint32_t g = 0; g < ng; ++g) {
-        const uint32_t nrg = region_read_off[g + 1] - region_read_off[g], nhg = region_hap_off[g + 1] - region_hap_off[g];
-        if (!nrg || !nhg || out_off[g + 1] - out_off[g] != (uint64_t)nrg * nhg) return kServerNotTaken;
-        max_nh = std::max(max_nh, nhg);
-    }
-    for (uint32_t r = 0; r < nr; ++r) {
-        const uint32_t len = read_off[r + 1] - read_off[r];
-        if (!len) return kServerNotTaken;
-        max_r = std::max(max_r, len);
-    }
-    for (uint32_t x = 0; x < nh; ++x) max_h = std::max(max_h, hap_off[x + 1] - hap_off[x]);
-    if (max_r > SRV_MAX_ROWS || max_h > kMaxHap || !max_h || nr > kSyncReads) return kServerNotTaken;
-    const size_t rb = read_off[nr], hb = hap_off[nh];
-    for (size_t i = 0; i < rb; ++i) max_gcp = std::max<uint32_t>(max_gcp, gcp[i]);
-    // (can a result get below -600?  then the launched path, whose exact pass rides behind its kernels: phmm_region.cpp has the bound)
-    if (53.0 + (double)max_r * max_gcp / 10.0 >= 590.0 || h->sw.no_rescue) return kServerNotTaken;
-    if (!h->server) h->server = server_of(h->device);
-    Server *S = (Server *)h->server;
-    if (!S || !S->ok || S->broken) return kServerNotTaken;
-    const uint32_t fwd_l = max_h <= 16u * SRV_MAX_K ? 16u : 32u, group_haps = 64 / fwd_l;
-    const uint32_t fwd_k = std::max<uint32_t>(fwd_l == 16 ? 2 : 13, (max_h + fwd_l - 1) / fwd_l);
-    const uint32_t groups = (max_nh + group_haps - 1) / group_haps;
-    // ---- layout: [offset arrays | job record | the five per-base arrays | haplotypes] staged; [status | likelihoods] come back -----------
-    size_t used = 0;
-    auto take = [&](size_t bytes) {
-        const size_t off = up256(used);
-        used = off + bytes;
-        return off;
-    };
-    const size_t o_read_region = take(4ull * nr), o_rro = take(4ull * (ng + 1)), o_rho = take(4ull * (ng + 1)), o_ro = take(4ull * (nr + 1)),
-                 o_ho = take(4ull * (nh + 1)), o_oo = take(8ull * (ng + 1)), o_job = take(sizeof(SrvJob)), o_bases = take(rb), o_q = take(rb), o_i = take(rb),
-                 o_d = take(rb), o_g = take(rb), o_haps = take(hb);
-    const size_t in_end = up256(used), o_res = take(256), o_out = take(8ull * out_off[ng]), end = up256(used);
-    if (in_end > kStageMax || end > kSlotBytes) return kServerNotTaken;
-    const uint32_t n16 = (uint32_t)((in_end + 15) / 16);
-    uint32_t n_tasks[SRV_KINDS] = {(n16 + SRV_STAGE_UNITS - 1) / SRV_STAGE_UNITS, nr * groups};
-    const uint32_t total_tasks = n_tasks[0] + n_tasks[1];
-    if (S->tasks_in_flight.fetch_add(total_tasks, std::memory_order_relaxed) + total_tasks > SRV_MAIL_TASKS) {
-        S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
-        return kServerNotTaken;
-    }
-    const int slot = take_slot(*S);
-    if (slot < 0) {
-        S->tasks_in_flight.fetch_sub(total_tasks, std::memory_order_relaxed);
-        return kServerNotTaken;
-    }
-    const Slot &T = S->slots[slot];
-    char *const hs = T.host, *const dev = T.dev, *const mirror = T.host_dev;
-    {
-        uint32_t *rr = (uint32_t *)(hs + o_read_region);
-        for (uint32_t g = 0; g < ng; ++g)
-            for (uint32_t r = region_read_off[g]; r < region_read_off[g + 1]; ++r) rr[r] = g;
-    }
-    memcpy(hs + o_rro, region_read_off, 4ull * (ng + 1));
-    memcpy(hs + o_rho, region_hap_off, 4ull * (ng + 1));
-    memcpy(hs + o_ro, read_off, 4ull * (nr + 1));
-    memcpy(hs + o_ho, hap_off, 4ull * (nh + 1));
-    memcpy(hs + o_oo, out_off, 8ull * (ng + 1));
-    memcpy(hs + o_bases, read_bases, rb);
-    memcpy(hs + o_q, base_q, rb);
-    memcpy(hs + o_i, ins_q, rb);
-    memcpy(hs + o_d, del_q, rb);
-    memcpy(hs + o_g, gcp, rb);
-    memcpy(hs + o_haps, hap_bases, hb);
-    memset(hs + o_res, 0, 256);
-    __atomic_fetch_add(&h->stat_staged_bytes, (uint64_t)(5 * rb + hb), __ATOMIC_RELAXED);
-    SrvJob *job = new (hs + o_job) SrvJob();
-    {
-        ForwardParams &f = job->fwd;
-        f.n_items = nr;
-        f.read_region = (const uint32_t *)(dev + o_read_region);
-        f.region_read_off = (const uint32_t *)(dev + o_rro);
-        f.region_hap_off = (const uint32_t *)(dev + o_rho);
-        f.read_off = (const uint32_t *)(dev + o_ro);
-        f.hap_off = (const uint32_t *)(dev + o_ho);
-        f.out_off = (const uint64_t *)(dev + o_oo);
-        f.read_bases = (const uint8_t *)(dev + o_bases);
-        f.base_q = (const uint8_t *)(dev + o_q);
-        f.ins_q = (const uint8_t *)(dev + o_i);
-        f.del_q = (const uint8_t *)(dev + o_d);
-        f.gcp = (const uint8_t *)(dev + o_g);
-        f.hap_bases = (const uint8_t *)(dev + o_haps);
-        f.out = (double *)(mirror + o_out);  // (straight into the caller's mirror)
-        f.eps = h->d_eps;
-        f.eps_mis = h->d_eps_mis;
-        f.mm = h->d_mm;
-        f.ratio_mis = h->d_ratio_mis;
-        f.inv_om = h->d_inv_om;
-        f.initial_condition = initial_condition();
-        f.initial_condition_log10 = initial_condition_log10();
-        f.status = (uint32_t *)T.sync;
-    }
-    job->fwd_k = fwd_k;
-    job->group_haps = group_haps;
-    job->groups = groups;
-    job->n_reads = nr;
-    job->group_done = (uint32_t *)(T.sync + 256);
-    job->status_in = (uint32_t *)T.sync;
-    job->status_out = (uint32_t *)(mirror + o_res);
-    job->finish_flag = (uint32_t *)(mirror + o_res + 224);
-    job->full = 0;
-    ServerPending *p = new ServerPending();
-    p->S = S;
-    p->slot = slot;
-    p->n_out = out_off[ng];
-    p->n_tasks = total_tasks;
-    p->compute_out = out;
-    p->o_out = o_out;
-    p->o_res = o_res;
-    p->t0 = std::chrono::steady_clock::now();
-    if (!publish(*S, h->sw, p, n_tasks, n16, (uint32_t)o_job)) {
-        delete p;
-        return kServerNotTaken;
-    }
-    S->n_jobs.fetch_add(1, std::memory_order_relaxed);
-    // ---- wait, hand over ----------------------------------------------------------------------------------------------------------------
-    const bool done = poll_finish(h, p, (const uint32_t *)(hs + o_res + 224));
-    if (!done) {
-        S->in_flight.fetch_sub(1, std::memory_order_relaxed);
-        S->tasks_in_flight.fetch_sub(p->n_tasks, std::memory_order_relaxed);
-        const std::string why = S->why_broken;
-        delete p;
-        return fail(err, "phmm_compute: " + (why.empty() ? std::string("the region server failed") : why), PHMM_ERR_INTERNAL);
-    }
-    const uint32_t bits = *(const uint32_t *)(hs + o_res);
-    int st = PHMM_OK;
-    if (bits & STATUS_RESCUE) {
-        st = kServerRedo;  // (never with the bound above; the launched path's exact pass decides such a pair)
-    } else {
-        if (p->n_out) memcpy(out, hs + o_out, 8ull * p->n_out);
-        if (bits & STATUS_POSITIVE) st = fail(err, "PairHmm Log Probability cannot be greater than 0.0", PHMM_ERR_POSITIVE_RESULT);  // pair_hmm.rs:478-481
-    }
-    {
-        std::lock_guard<SpinLock> lk(S->mu);
-        S->free_slots.push_back(p->slot);
-    }
-    S->in_flight.fetch_sub(1, std::memory_order_relaxed);
-    S->tasks_in_flight.fetch_sub(p->n_tasks, std::memory_order_relaxed);
-    delete p;
-    return st;
 }
 
 uint64_t server_stat(int device, const char *name) {

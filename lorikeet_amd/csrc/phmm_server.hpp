@@ -67,8 +67,6 @@ struct SrvJob {
     uint32_t *status_out;     // ... which the call's last wave hands on to the caller's mirror
     uint32_t *finish_flag;    // a word of the mirror: 1 when the last task is through (the caller polls it)
     uint32_t wait_ticks;      // how long a main wave waits for its helpers at most (100 MHz ticks)
-    uint32_t full;            // 1: phmm_region_compute (the whole chain); 0: phmm_compute -- every wave sweeps its group of haplotypes and
-                              // stores the likelihoods straight into the caller's mirror, nothing else
     uint32_t pad1;
 };
 

@@ -136,7 +136,7 @@ __device__ __noinline__ void chain_fwd(const SrvJob *job_v, uint32_t r_v, uint32
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ForwardParams p = fetch_uniform(&job->fwd);
     const uint32_t groups = fetch_uniform(&job->groups);
-    double *const helper_row = group && fetch_uniform(&job->full) ? fetch_uniform(&job->helper_out) + (size_t)r * fetch_uniform(&job->helper_stride) : nullptr;
+    double *const helper_row = group ? fetch_uniform(&job->helper_out) + (size_t)r * fetch_uniform(&job->helper_stride) : nullptr;
     forward_read<L, K>(p, r, (int)group, (int)groups, false, smem, helper_row);
 }
 
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_region_server(const SrvParams P)
         } else {
             acquire_inputs();
             const uint32_t groups = uniform(job->groups), r = idx / groups, group = groups - 1u - idx % groups;  // (helpers first, the main wave last)
-            const uint32_t full = uniform(job->full);
-            if (full) chain_prep(job, r);
+            chain_prep(job, r);
             drain_memory_ops();  // (what the pre-step stored is what the sweep's row staging loads)
             if (P.trace) t_mid[0] = wall_clock64();
             if (uniform(job->group_haps) == 2u) {  // (haplotypes beyond 400 bases: 32 lanes per pair, two a wave)
@@ -346,9 +345,7 @@ __global__ __launch_bounds__(WAVE, 2) void phmm_region_server(const SrvParams P)
             }
             if (P.trace) t_mid[1] = wall_clock64();
             uint32_t *group_done = uniform(job->group_done) + r;
-            if (!full) {
-                // (phmm_compute: the likelihoods are in the caller's mirror, that is all)
-            } else if (group != 0) {  // a helper: its likelihoods are out (agent-scope stores), the main wave may count on them
+            if (group != 0) {  // a helper: its likelihoods are out (agent-scope stores), the main wave may count on them
                 drain_memory_ops();
                 if (lane == 0) __hip_atomic_fetch_add(group_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {

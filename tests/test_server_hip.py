@@ -238,36 +238,3 @@ def test_two_tickets_per_thread_on_the_shared_handle(eng):
         _equal(got, w, exact=True)
     assert C.sizeof(_lib.EngineConfig) > 0
 
-
-def test_phmm_compute_of_many_private_handles_goes_through_the_server():
-    """The PairHMM alone (phmm_compute, what PairHMM::compute_likelihoods binds to): past four private handles on a device a
-    small call is a set of server tasks -- a wave per read and group of haplotypes -- instead of a launch of the handle's own.
-    Equal to the oracle at 1e-9, and bit for bit the same from whichever handle, alone or beside the others."""
-    from oracle import oracle
-    batches = [synthetic.make_regions(1 + i % 3, 40, 3 + i, 90 + 60 * i, [40, 80, 120], seed=300 + i) for i in range(6)]
-    engines = [HipPairHMMEngine(0) for _ in range(6)]
-    try:
-        jobs = engines[0].stat("server_jobs")
-        want = [engines[0].compute(b) for b in batches]
-        assert engines[0].stat("server_jobs") == jobs + 6, "phmm_compute of one of six private handles did not go through the server"
-        for w, b in zip(want, batches):
-            assert np.max(np.abs(w - oracle.compute_batch(b.as_dict(), n_threads=4))) < 1e-9
-        errors = []
-
-        def worker(i):
-            try:
-                for _ in range(25):
-                    assert np.array_equal(engines[i].compute(batches[i]), want[i])
-            except BaseException as e:  # noqa: BLE001
-                errors.append((i, repr(e)))
-
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        assert not errors, errors
-        assert engines[0].stat("server_jobs") == jobs + 6 + 150 and engines[0].stat("server_broken") == 0
-    finally:
-        for e in engines:
-            e.close()

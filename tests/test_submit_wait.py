@@ -292,9 +292,12 @@ def test_thirty_two_private_handles_are_not_slower_than_sixteen():
     from conftest import ROOT
     exe = os.path.join(ROOT, "tools", "threads_bench")
     for mode in ("own", "fused"):
-        # (the library's defaults: past four private handles their small calls go through the device's region server)
+        # (the region call: the library's default, past four private handles through the device's region server; the PairHMM alone:
+        # the opt-in routing through the shared combiner)
         env = dict(os.environ, TB_MODE=mode, TB_THREADS="16,32", TMPDIR="/tmp")
         env.pop("PHMM_ROUTE_SHARED", None)
+        if mode == "own":
+            env["PHMM_ROUTE_SHARED"] = "4"
         r = subprocess.run([exe, "1.5"], capture_output=True, text=True, timeout=300, env=env)
         print(r.stdout, r.stderr[-1000:])
         assert r.returncode == 0, r.stdout + r.stderr
