@@ -88,13 +88,18 @@ int phmm_device_count(void);
  * owns a stream, pinned staging and device arenas that grow on demand.  While at most four engines are alive on a device,
  * each runs its one-enqueue calls on a hardware queue of its own (callers with an engine each then run side by side whatever
  * the runtime does with ordinary streams); env PHMM_REGION_OWN_QUEUE=0 at creation turns that off.
- * While MORE than four of the caller's engines are alive on a device (an engine per worker thread at --threads 16 or 32), the
- * one-shot calls of such a private engine -- phmm_compute, phmm_engine_compute, phmm_region_compute on up to eight regions or
- * 512 KB per array -- are served by ONE shared engine of the same flags inside the library (the queue of phmm_submit: callers that
- * are waiting anyway share a flush and sleep instead of spinning; 32 private engines ran at half the rate of 16 before).  Results
- * and error reporting are the call's own; which regions share a launch depends on timing, so likelihoods are reproducible to
- * ~1e-13 rather than bit for bit under that load.  An engine whose developer switches were set (phmm_set_switch) keeps to its
- * own streams; env PHMM_ROUTE_SHARED=0 turns the routing off, =n moves the threshold.
+ * While MORE than four of the caller's engines are alive on a device (an engine per worker thread at Lorikeet's --threads 10),
+ * the one-shot phmm_region_compute calls of such a private engine are served by the device's resident REGION SERVER (a kernel
+ * that stays on the chip while calls keep coming: the region is staged into a slot of pinned memory, every read runs as one wave
+ * from pre-step to projection, nothing is launched; phmm_server.cpp).  Results and error reporting are the call's own, and the
+ * likelihoods are the region's own bits whatever else is in flight (16 lanes x ceil(H / 16) columns per pair: a function of the
+ * region's longest haplotype).  Calls outside the server's limits (reads beyond 268 bases, haplotypes beyond 512, more than 1 MB of
+ * inputs) take the engine's own streams.  env PHMM_REGION_SERVER=0 turns the server off, =1 sends every region call through it.
+ * Opt-in, env PHMM_ROUTE_SHARED=n: while more than n engines are alive, the one-shot calls of private engines -- phmm_compute,
+ * phmm_engine_compute, phmm_region_compute on up to eight regions or 512 KB per array -- go through ONE shared engine of the same
+ * flags inside the library instead (the queue of phmm_submit: callers that are waiting anyway share a flush); which regions share a
+ * launch depends on timing, so likelihoods are then reproducible to ~1e-13 rather than bit for bit.  An engine whose developer
+ * switches were set (phmm_set_switch) keeps to its own streams.
  * Debug environment: PHMM_MIRROR_CANARY=1 makes a device store that lands in the pinned hand-over buffer outside its call fail
  * that call (PHMM_ERR_INTERNAL; =2: abort); PHMM_REGION_PICK_TIMEOUT_US (default 5 000) bounds the small region call's wait for
  * its second hardware queue -- out of time, the call is redone the chained way (phmm_get_stat "region_pick_timeouts").

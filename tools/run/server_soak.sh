@@ -5,9 +5,9 @@ R=${1:-r06}; S=${2:-30}
 cd "$(dirname "$0")/../.."
 O=gpurun_out/${R}_server_soak.txt
 {
-echo "# tools/threads_bench TB_VERIFY=1 PHMM_MIRROR_CANARY=1, $S s per point: private handles past four go through the region server"
+echo "# tools/threads_bench TB_VERIFY=1 PHMM_MIRROR_CANARY=1, $S s per point: the region calls of private handles past four go through the region server"
 for shape in ragged config2; do
-  for mode in own fused; do
+  for mode in fused; do
     echo "## $mode, $shape"
     if [ $shape = ragged ]; then export TB_SHAPE=ragged; else unset TB_SHAPE; fi
     PHMM_MIRROR_CANARY=1 TB_VERIFY=1 TB_MODE=$mode TB_THREADS=8,16,32 timeout $((S * 4 + 60)) tools/threads_bench $S 2>&1 | tail -5
