@@ -410,13 +410,19 @@ void phmm_destroy(phmm_handle *h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    const bool last_of_the_callers = !h->internal && g_user_handles[h->device].fetch_sub(1, std::memory_order_acq_rel) == 1;
+    const bool internal = h->internal;
     const int device = h->device;
     delete h;
-    if (last_of_the_callers) {  // nobody is left to route: the device's backing handles go too
-        std::vector<phmm_handle *> gone;
-        {
-            std::lock_guard<std::mutex> lk(g_backing_mu);
+    if (internal) return;
+    // The count reaching zero and the backing handles leaving the map are ONE step under the map's lock (route_shared looks
+    // them up under the same lock): a handle created after this step finds no entry and makes its own backing handle; one
+    // created before it keeps the count above zero.
+    std::vector<phmm_handle *> gone;
+    bool last_of_the_callers = false;
+    {
+        std::lock_guard<std::mutex> lk(g_backing_mu);
+        last_of_the_callers = g_user_handles[device].fetch_sub(1, std::memory_order_acq_rel) == 1;
+        if (last_of_the_callers)
             for (auto it = g_backing.begin(); it != g_backing.end();)
                 if (it->first.first == device) {
                     gone.push_back(it->second);
@@ -424,7 +430,8 @@ void phmm_destroy(phmm_handle *h) {
                 } else {
                     ++it;
                 }
-        }
+    }
+    if (last_of_the_callers) {  // nobody is left to route: the device's backing handles go too
         for (phmm_handle *b : gone) phmm_destroy(b);
         phmm_host::server_quiesce(device);  // (the region server leaves the chip by itself once idle: wait for that)
     }

@@ -271,12 +271,16 @@ def test_many_private_handles_are_served_by_the_devices_shared_lanes():
         b, _ = work[0]
         assert np.array_equal(engines[0].compute(b), want[0])
         assert engines[0].stat("staged_bytes") > staged0[0]
-        # errors of a routed call come back on the caller's own handle
-        bad = synthetic.make_regions(1, 2, 1, 50, 20, seed=3)
-        bad.hap_off[-1] = 0                                     # an empty haplotype: refused by every entry point
-        with pytest.raises(PhmmError):
-            engines[1].compute(bad)
-        assert "phmm" in engines[1].last_error()
+        # errors of a routed call come back on the caller's own handle: one that only the FLUSH can raise (the reference's `<= 0`
+        # assert, pair_hmm.rs:478-481 -- the arguments are valid, the entry point's own checks pass, the backing handle's lane fails)
+        hap = np.full(40, ord("A"), np.uint8)
+        weird = RegionBatch.from_regions([([Read(hap[:8].copy(), np.full(8, 93), np.zeros(8, int), np.zeros(8, int), np.full(8, 10))], [hap])])
+        staged1 = engines[1].stat("staged_bytes")
+        with pytest.raises(PhmmError) as e:
+            engines[1].compute(weird)
+        assert e.value.code == _lib.PHMM_ERR_POSITIVE_RESULT and "greater than 0.0" in engines[1].last_error()
+        assert engines[1].stat("staged_bytes") == staged1       # (it was the backing handle that ran it)
+        assert np.max(np.abs(engines[1].compute(work[1][0]) - want[1])) <= 1e-11   # ... and the handle goes on
     finally:
         for e in engines:
             e.close()
