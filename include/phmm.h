@@ -248,6 +248,11 @@ typedef struct phmm_plan_info {
     uint32_t min_reads_per_run;  /* shortest run of reads a chained work item holds (0: nothing chains)     */
     uint32_t reserved;
     char dominant_kernel[64];
+    /* What the launches sweep (phmm_batch_executed_cells), in lane-cells = steps x 64 lanes x K columns of every wave ...          */
+    uint64_t swept_cells;
+    uint64_t pad_column_cells;   /* ... of which columns beyond a haplotype's end (lanes x K - H per pair)                      */
+    uint64_t pad_slot_cells;     /* ... haplotype slots a wave leaves empty; the rest above `cells` is steps without a read row */
+                                 /*     (SUM / RESET rows between the reads of a run, the fill of the lane pipeline)            */
 } phmm_plan_info;
 int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_regions, const uint32_t *region_read_off,
                        const uint32_t *region_hap_off, const uint32_t *read_off, const uint32_t *hap_off, phmm_plan_info *info);

@@ -57,7 +57,8 @@ class PlanInfo(C.Structure):
     """phmm_plan_info (include/phmm.h)."""
     _fields_ = [("cells", C.c_uint64), ("chain_cells", C.c_uint64), ("chain_items", C.c_uint64), ("n_launches", C.c_uint32),
                 ("n_chain_launches", C.c_uint32), ("min_reads_per_run", C.c_uint32), ("reserved", C.c_uint32),
-                ("dominant_kernel", C.c_char * 64)]
+                ("dominant_kernel", C.c_char * 64), ("swept_cells", C.c_uint64), ("pad_column_cells", C.c_uint64),
+                ("pad_slot_cells", C.c_uint64)]
 
 
 _REGION_ARGS = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p,

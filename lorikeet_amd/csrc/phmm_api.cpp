@@ -155,6 +155,7 @@ struct phmm_batch {
     uint32_t rescue_blocks = 0;
     bool bound = false;
     std::string dominant;
+    uint64_t pad_column_cells = 0, pad_slot_cells = 0;  // ... of which columns beyond a haplotype's end / haplotype slots left empty
     uint64_t swept_cells = 0;  // lane-cells the planned launches sweep: every row of every wave x 64 lanes x its K columns, padding
                                // columns, empty haplotype slots and all (phmm_batch_executed_cells)
 };
@@ -422,14 +423,16 @@ void phmm_destroy(phmm_handle *h) {
     {
         std::lock_guard<std::mutex> lk(g_backing_mu);
         last_of_the_callers = g_user_handles[device].fetch_sub(1, std::memory_order_acq_rel) == 1;
-        if (last_of_the_callers)
-            for (auto it = g_backing.begin(); it != g_backing.end();)
+        if (last_of_the_callers) {
+            for (auto it = g_backing.begin(); it != g_backing.end();) {
                 if (it->first.first == device) {
                     gone.push_back(it->second);
                     it = g_backing.erase(it);
                 } else {
                     ++it;
                 }
+            }
+        }
     }
     if (last_of_the_callers) {  // nobody is left to route: the device's backing handles go too
         for (phmm_handle *b : gone) phmm_destroy(b);
@@ -1005,11 +1008,42 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         b->classes.push_back(std::move(c));
     }
     mark();  // 5: work items per class
-    {   // what these launches sweep, padding and all (phmm_batch_executed_cells)
-        uint64_t swept = 0;
+    {   // What these launches sweep, padding and all (phmm_batch_executed_cells), in lane-cells = steps x 64 lanes x K columns per
+        // wave, and where the padding comes from: columns beyond a haplotype's end (16 K - H), haplotype slots a wave leaves
+        // empty, and steps that carry no read row (the SUM / RESET rows between the reads of a run, the L - 1 steps a run needs to
+        // reach its last lane, the rows the longest of a wave's streams has more than the others).
+        uint64_t swept = 0, pad_cols = 0, pad_slots = 0, t_marks = 0, t_fill = 0, t_uneven = 0;  // (t_*: PHMM_TRACE only)
+        auto haps_of = [&](uint32_t g, uint32_t first, uint32_t slots, uint32_t lanes_cols, uint64_t &sum_h, uint32_t &valid) {
+            const uint32_t h0 = region_hap_off[g], nh = region_hap_off[g + 1] - h0;
+            sum_h = 0;
+            valid = 0;
+            for (uint32_t a = first; a < first + slots && a < nh; ++a) {
+                sum_h += std::min<uint32_t>(hap_off[h0 + a + 1] - hap_off[h0 + a], lanes_cols);
+                ++valid;
+            }
+        };
         for (const auto &grp : b->chain_groups)
-            for (const ChainItem &x : grp.items)  // (a multi-stream item sweeps its sub-runs of reads side by side)
-                swept += (uint64_t)(read_off[x.read_end] - read_off[x.read_begin]) / std::max<uint32_t>(1, x.streams) * 64ull * x.k;
+            for (const ChainItem &x : grp.items) {
+                const uint32_t S = std::max<uint32_t>(1, x.streams), L = (uint32_t)grp.L, GS = (64u / L) / S, LK = L * x.k;
+                const uint32_t n = x.read_end - x.read_begin, n_sub = (n + S - 1) / S;
+                uint64_t longest = 0, read_rows = 0;
+                for (uint32_t st = 0; st < S; ++st) {  // (stream st sweeps reads [st n_sub, (st + 1) n_sub) of the run)
+                    const uint32_t lo = std::min(n, st * n_sub), hi = std::min(n, lo + n_sub);
+                    const uint64_t rows = read_off[x.read_begin + hi] - read_off[x.read_begin + lo];
+                    read_rows += rows;
+                    longest = std::max<uint64_t>(longest, rows + 2ull * (hi - lo));
+                }
+                const uint64_t steps = (longest + L) & ~1ull;
+                swept += steps * 64ull * x.k;
+                t_marks += 2ull * n * GS * LK;                                          // the SUM / RESET rows of its reads
+                t_fill += (steps - longest) * 64ull * x.k;                              // reaching the last lane
+                t_uneven += (longest * S - read_rows - 2ull * n) * (uint64_t)GS * LK;   // streams shorter than the longest
+                uint64_t sum_h;
+                uint32_t valid;
+                haps_of(x.region, (uint32_t)x.quad * GS, GS, LK, sum_h, valid);
+                pad_cols += read_rows * ((uint64_t)valid * LK - sum_h);
+                pad_slots += read_rows * (uint64_t)(GS - valid) * LK;
+            }
         for (const auto &c : b->classes) {
             if (c.chain) continue;  // (counted above; the f64 redo behind an f32 sweep touches the reads it flags only)
             if (!c.L) {
@@ -1017,13 +1051,27 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 continue;
             }
             const size_t n = c.identity ? n_reads : c.reads.size();
+            const uint32_t per_wave = 64u / (uint32_t)c.L, LK = (uint32_t)(c.L * c.K);
             for (size_t i = 0; i < n; ++i) {
                 const uint32_t r = c.identity ? (uint32_t)i : c.reads[i], g = read_region[r];
-                const uint32_t per_wave = 64u / (uint32_t)c.L, quads = (shape[g].nh + per_wave - 1) / per_wave;
-                swept += (uint64_t)(read_off[r + 1] - read_off[r]) * quads * 64ull * (uint64_t)c.K;
+                const uint32_t quads = (shape[g].nh + per_wave - 1) / per_wave;
+                const uint64_t rows = read_off[r + 1] - read_off[r];
+                swept += (rows + (uint64_t)c.L - 1) * quads * 64ull * (uint64_t)c.K;
+                for (uint32_t qd = 0; qd < quads; ++qd) {
+                    uint64_t sum_h;
+                    uint32_t valid;
+                    haps_of(g, qd * per_wave, per_wave, LK, sum_h, valid);
+                    pad_cols += rows * ((uint64_t)valid * LK - sum_h);
+                    pad_slots += rows * (uint64_t)(per_wave - valid) * LK;
+                }
             }
         }
+        if (sw.trace)
+            fprintf(stderr, "phmm plan: swept %.4e lane-cells for %.4e cells: columns %.4e, slots %.4e; chained items' SUM / RESET rows %.4e, fill %.4e, uneven streams %.4e\n",
+                    (double)swept, (double)b->cells, (double)pad_cols, (double)pad_slots, (double)t_marks, (double)t_fill, (double)t_uneven);
         b->swept_cells = swept;
+        b->pad_column_cells = pad_cols;
+        b->pad_slot_cells = pad_slots;
     }
     for (auto &grp : b->chain_groups) {
         // longest item first across all classes of the launch: (rows of the run + its SUM / RESET rows) x the cost of a
@@ -2431,6 +2479,9 @@ int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_r
         }
         for (const auto &c : b->classes)
             if (c.chain) info->chain_cells += c.cells;
+        info->swept_cells = b->swept_cells;
+        info->pad_column_cells = b->pad_column_cells;
+        info->pad_slot_cells = b->pad_slot_cells;
         snprintf(info->dominant_kernel, sizeof info->dominant_kernel, "%s", b->dominant.c_str());
         return PHMM_OK;
     } catch (const std::bad_alloc &) {

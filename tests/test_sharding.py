@@ -162,3 +162,21 @@ def test_every_rank_of_an_8_gpu_node_still_fills_its_chip():
     # the whole set on one GPU is the N = 1 row of the same experiment
     one = plan_describe(synthetic.config("config5"))
     assert one.chain_cells == one.cells == int(synthetic.config_cells("config5").sum())
+
+
+def test_the_plan_says_what_it_sweeps_and_where_the_padding_is():
+    """phmm_plan_info.swept_cells (= phmm_batch_executed_cells, the bench's rows.*.executed_per_cell): steps x 64 lanes x K columns
+    of every wave, with the columns beyond a haplotype's end and the empty haplotype slots counted apart.  The uniform 128 x 8 batch
+    (H = 300 in 16 lanes x 19 columns = 304): 4 / 300 of the useful cells in column padding exactly, no empty slot (eight haplotypes,
+    four per wave), a few per cent of steps without a read row; the ragged mix pays for its shapes (tools/ragged_padding.py,
+    NOTEBOOK.md 20.6)."""
+    from lorikeet_amd.engine import plan_describe
+    u = plan_describe(synthetic.config2(1024))
+    assert u.pad_column_cells * 300 == u.cells * 4 and u.pad_slot_cells == 0
+    steps = u.swept_cells - u.cells - u.pad_column_cells - u.pad_slot_cells
+    assert 0.01 * u.cells < steps < 0.04 * u.cells            # SUM / RESET rows (2 per 150) + the fill of each run
+    r = plan_describe(synthetic.ragged())
+    assert r.swept_cells >= r.cells + r.pad_column_cells + r.pad_slot_cells
+    assert 1.08 < r.swept_cells / r.cells < 1.20 and r.pad_column_cells > 0 and r.pad_slot_cells > 0
+    one = plan_describe(synthetic.config2(1))                  # a lone region: 64 lanes x 5 columns per pair, one read per wave
+    assert one.pad_column_cells * 300 == one.cells * 20 and one.swept_cells > one.cells

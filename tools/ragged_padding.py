@@ -1,10 +1,13 @@
-"""Developer tool: what the shapes of the bench's ragged mix cost the chained PairHMM kernels in padding, by range of K
-(VERDICT r5 item 3).  Per region the planner sweeps 16 lanes x K = ceil(H / 16) columns per haplotype and four haplotype slots per
-wave: columns beyond a haplotype's end and slots a wave leaves empty are swept like real cells.  Counted here from the shapes alone
-(no GPU): useful cells = sum R x H over the pairs; column padding = R x (16 K - H); slot padding = the empty slots of a region's last
-wave where the remainder is not re-packed into multi-stream items (1 or 2 of 4 slots filled twice or four times over); per-read
-rows = the SUM / RESET rows and the 15 fill steps a run of reads pays once (CHAIN_MAX_READS = 64 reads per run at most).
-usage: python tools/ragged_padding.py  ->  the table of NOTEBOOK.md 20.6"""
+"""Developer tool: what the shapes of a bench workload cost the PairHMM kernels in padding, from the LIBRARY'S
+OWN PLAN of the batch -- phmm_plan_describe, host only, no GPU: swept lane-cells = steps x 64 lanes x K columns of every wave
+(= phmm_batch_executed_cells, rows.<workload>.executed_per_cell of the bench line), split into
+  columns     lanes x K - H per pair: the columns beyond a haplotype's end
+  slots       haplotype slots a wave leaves empty (a region's haplotype count against 4 / 2 / 1 slots per wave or stream)
+  steps       steps that carry no read row: the SUM / RESET rows between the reads of a run, the L - 1 steps a run needs to reach its
+              last lane, what the longest stream of a wave has more than the others.
+The whole batch first (the plan the bench runs), then the regions by K = ceil(longest haplotype / 16) -- each range planned as a
+batch of its own, so the ranges' plans need not add up to the whole batch's exactly.
+usage: python tools/ragged_padding.py [ragged|config2|config3|config5]  ->  the table of NOTEBOOK.md 20.6"""
 import os
 import sys
 
@@ -12,50 +15,54 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lorikeet_amd import synthetic  # noqa: E402
+from lorikeet_amd.engine import plan_describe  # noqa: E402
 
 RANGES = [(2, 9), (10, 15), (16, 19), (20, 25), (26, 99)]
 
 
-def main():
-    b = synthetic.ragged()
+def subset(b, regions):
+    """The regions `regions` of b as a batch of their own (offsets only: the planner reads nothing else)."""
     rro, rho, ro, ho = (x.astype(np.int64) for x in (b.region_read_off, b.region_hap_off, b.read_off, b.hap_off))
-    rows = {r: dict(regions=0, useful=0, cols=0, slots=0, steps=0, swept=0) for r in RANGES}
+    rl, hl, nr, nh = [], [], [0], [0]
+    for g in regions:
+        rl.append(np.diff(ro[rro[g]:rro[g + 1] + 1]))
+        hl.append(np.diff(ho[rho[g]:rho[g + 1] + 1]))
+        nr.append(nr[-1] + len(rl[-1]))
+        nh.append(nh[-1] + len(hl[-1]))
+    class Offsets:  # (what plan_describe reads of a RegionBatch)
+        pass
+    s = Offsets()
+    s.region_read_off = np.asarray(nr, np.uint32)
+    s.region_hap_off = np.asarray(nh, np.uint32)
+    s.read_off = np.concatenate([[0], np.cumsum(np.concatenate(rl))]).astype(np.uint32)
+    s.hap_off = np.concatenate([[0], np.cumsum(np.concatenate(hl))]).astype(np.uint32)
+    s.n_regions = len(regions)
+    return s
+
+
+def line(name, n, info):
+    u = info.cells
+    steps = info.swept_cells - u - info.pad_column_cells - info.pad_slot_cells
+    print("%-10s %8d %14.3e %9.1f%% %9.1f%% %9.1f%% %12.3f   %s" % (name, n, u, 100 * info.pad_column_cells / u, 100 * info.pad_slot_cells / u,
+                                                                 100 * steps / u, info.swept_cells / u, info.dominant_kernel.decode()))
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "ragged"
+    b = {"ragged": synthetic.ragged, "config2": lambda: synthetic.config2(1024), "config3": synthetic.config3, "config5": synthetic.config5}[what]()
+    ho, rho = b.hap_off.astype(np.int64), b.region_hap_off.astype(np.int64)
+    print("%s: %d regions; padding in %% of the useful cells, from phmm_plan_describe" % (what, b.n_regions))
+    print("%-10s %8s %14s %10s %10s %10s %12s   %s" % ("K range", "regions", "useful cells", "columns", "slots", "steps", "swept/useful", "dominant kernel"))
+    line("all", b.n_regions, plan_describe(b))
+    by_range = {r: [] for r in RANGES}
     for g in range(b.n_regions):
-        R = np.diff(ro[rro[g]:rro[g + 1] + 1])
         H = np.diff(ho[rho[g]:rho[g + 1] + 1])
-        if not len(R) or not len(H):
-            continue
-        L = 16 if H.max() <= 400 else 32 if H.max() <= 800 else 64
-        K = max(2, int(-(-H.max() // L)))
-        per_wave = 64 // L
-        rng = next(r for r in RANGES if r[0] <= K <= r[1])
-        sum_r, nh = int(R.sum()), len(H)
-        useful = sum_r * int(H.sum())
-        cols = sum_r * int((L * K - H).sum())                      # columns beyond each haplotype's end
-        rem = nh % per_wave
-        # (a remainder of 1 or 2 haplotypes at 16 lanes -- a whole region of 1 or 2 as well -- is swept as 4 or 2 streams of reads
-        # side by side: no empty slot; a remainder of 3 leaves one slot of its wave empty)
-        empty = 0 if rem == 0 or (L == 16 and rem in (1, 2)) else per_wave - rem
-        slots = sum_r * empty * L * K
-        waves = -(-nh // per_wave)
-        runs = -(-len(R) // 64)
-        steps = waves * (2 * len(R) + (L - 1) * runs) * 64 * K    # SUM / RESET rows per read, fill steps per run of reads
-        d = rows[rng]
-        d["regions"] += 1
-        d["useful"] += useful
-        d["cols"] += cols
-        d["slots"] += slots
-        d["steps"] += steps
-        d["swept"] += useful + cols + slots + steps
-    tot = {k: sum(d[k] for d in rows.values()) for k in ("regions", "useful", "cols", "slots", "steps", "swept")}
-    print("ragged mix: %d regions, %.3e useful cells" % (b.n_regions, tot["useful"]))
-    print("%-10s %8s %14s %10s %10s %12s %12s" % ("K range", "regions", "useful cells", "columns", "slots", "extra rows", "swept/useful"))
-    for r, d in list(rows.items()) + [("all", tot)]:
-        if not d["useful"]:
-            continue
-        u = d["useful"]
-        print("%-10s %8d %14.3e %9.1f%% %9.1f%% %11.1f%% %12.3f" % ("%d-%d" % r if r != "all" else "all", d["regions"], u, 100 * d["cols"] / u,
-                                                                100 * d["slots"] / u, 100 * d["steps"] / u, d["swept"] / u))
+        if len(H) and b.region_read_off[g + 1] > b.region_read_off[g]:
+            K = max(2, int(-(-H.max() // 16)))
+            by_range[next(r for r in RANGES if r[0] <= K <= r[1])].append(g)
+    for r, regions in by_range.items():
+        if regions:
+            line("%d-%d" % r, len(regions), plan_describe(subset(b, regions)))
 
 
 if __name__ == "__main__":
