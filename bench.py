@@ -426,7 +426,7 @@ def compact_line(line, full_path):
                          algorithmic_bytes_per_launch="algorithmic_bytes_per_launch", src_hash="src_hash")
     if isinstance(line["roofline"].get("hbm"), dict):   # (the HBM figure the metric's wording asks for, beside the bound that binds)
         c["roofline"]["hbm"] = pick(line["roofline"]["hbm"], achieved="achieved", peak="peak", unit="unit", frac="frac")
-    c["roofline"]["definition"] = "r5+: the bound that binds (valu_f64); the HBM figure of r1-r4 lines is roofline.hbm"
+    c["roofline"]["definition"] = "r5+: the bound that binds (%s); the HBM figure of r1-r4 lines is roofline.hbm" % line["roofline"]["bound"]
     f32 = line.get("f32_first")
     if isinstance(f32, dict) and "error" not in f32:  # (the arithmetic the reference ships -- gkl, f32 first -- priced like the headline)
         c["roofline_f32"] = {"bound": "valu_f32", "achieved": g(f32, "valu_f32", "achieved"), "peak": g(f32, "valu_f32", "peak"), "unit": "TFLOP/s",
@@ -1118,9 +1118,10 @@ def main():
             # The bound that BINDS leads: FP64 vector flops of the reference recurrence against the chip's FP64
             # VALU peak.  The HBM figure the metric's wording asks for stays beside it under "hbm" -- 2.3e-3 compulsory bytes per
             # cell make it a fraction of a per cent whatever the kernel does; `traffic` is the PMC byte count against it.
-            "roofline": {"bound": "valu_f64", "achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
-                         "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
+            # (--f32-first, the PMC passes of the opt-in mode: its sweep computes in f32, so its bound is the FP32 vector peak)
+            "roofline": {"bound": "valu_f32" if a.f32_first else "valu_f64", "achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
+                         "peak": VALU_F32_PEAK_TFLOPS if a.f32_first else VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / (VALU_F32_PEAK_TFLOPS if a.f32_first else VALU_F64_PEAK_TFLOPS), 4),
                          "traffic": e["hbm_bytes_per_launch"] if e else None, "l2_hit_rate": e.get("l2_hit_rate") if e else None,
                          "hbm": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(alg_bytes)},
@@ -1133,7 +1134,7 @@ def main():
                                  "the same duration; traffic, l2_hit_rate and valu_issue come from the committed rocprofv3 --pmc passes of "
                                  "the same command (profiles/pmc_traffic.json), used only when they were taken on this kernel built from "
                                  "these sources (src_hash)" + ("" if e else "; traffic: " + why)},
-            "valu_f64": {"achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
+            "valu_f64": None if a.f32_first else {"achieved": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12, 3),
                          "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(FLOP_PER_CELL * plan.cells / mean_kernel_s / 1e12 / VALU_F64_PEAK_TFLOPS, 4),
                          "flop_per_cell": FLOP_PER_CELL,
