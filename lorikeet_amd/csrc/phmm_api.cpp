@@ -1012,7 +1012,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         // wave, and where the padding comes from: columns beyond a haplotype's end (16 K - H), haplotype slots a wave leaves
         // empty, and steps that carry no read row (the SUM / RESET rows between the reads of a run, the L - 1 steps a run needs to
         // reach its last lane, the rows the longest of a wave's streams has more than the others).
-        uint64_t swept = 0, pad_cols = 0, pad_slots = 0, t_marks = 0, t_fill = 0, t_uneven = 0;  // (t_*: PHMM_TRACE only)
+        uint64_t swept = 0, pad_cols = 0, pad_slots = 0, t_marks = 0, t_fill = 0, t_uneven = 0, t_uneven_best = 0;  // (t_*: PHMM_TRACE only)
         auto haps_of = [&](uint32_t g, uint32_t first, uint32_t slots, uint32_t lanes_cols, uint64_t &sum_h, uint32_t &valid) {
             const uint32_t h0 = region_hap_off[g], nh = region_hap_off[g + 1] - h0;
             sum_h = 0;
@@ -1038,6 +1038,25 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 t_marks += 2ull * n * GS * LK;                                          // the SUM / RESET rows of its reads
                 t_fill += (steps - longest) * 64ull * x.k;                              // reaching the last lane
                 t_uneven += (longest * S - read_rows - 2ull * n) * (uint64_t)GS * LK;   // streams shorter than the longest
+                if (sw.trace && S > 1) {  // ... and what the best cut of the run into S contiguous parts would leave of that
+                    uint64_t lo_b = 0, hi_b = read_rows + 2ull * n;
+                    for (uint32_t i = 0; i < n; ++i) lo_b = std::max<uint64_t>(lo_b, read_off[x.read_begin + i + 1] - read_off[x.read_begin + i] + 2);
+                    while (lo_b < hi_b) {
+                        const uint64_t mid = (lo_b + hi_b) / 2;
+                        uint32_t parts = 1;
+                        uint64_t acc = 0;
+                        for (uint32_t i = 0; i < n; ++i) {
+                            const uint64_t len = read_off[x.read_begin + i + 1] - read_off[x.read_begin + i] + 2;
+                            if (acc + len > mid) {
+                                ++parts;
+                                acc = 0;
+                            }
+                            acc += len;
+                        }
+                        if (parts <= S) hi_b = mid; else lo_b = mid + 1;
+                    }
+                    t_uneven_best += (lo_b * S - read_rows - 2ull * n) * (uint64_t)GS * LK;
+                }
                 uint64_t sum_h;
                 uint32_t valid;
                 haps_of(x.region, (uint32_t)x.quad * GS, GS, LK, sum_h, valid);
@@ -1067,8 +1086,8 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             }
         }
         if (sw.trace)
-            fprintf(stderr, "phmm plan: swept %.4e lane-cells for %.4e cells: columns %.4e, slots %.4e; chained items' SUM / RESET rows %.4e, fill %.4e, uneven streams %.4e\n",
-                    (double)swept, (double)b->cells, (double)pad_cols, (double)pad_slots, (double)t_marks, (double)t_fill, (double)t_uneven);
+            fprintf(stderr, "phmm plan: swept %.4e lane-cells for %.4e cells: columns %.4e, slots %.4e; chained items' SUM / RESET rows %.4e, fill %.4e, uneven streams %.4e (cut by rows: %.4e)\n",
+                    (double)swept, (double)b->cells, (double)pad_cols, (double)pad_slots, (double)t_marks, (double)t_fill, (double)t_uneven, (double)t_uneven_best);
         b->swept_cells = swept;
         b->pad_column_cells = pad_cols;
         b->pad_slot_cells = pad_slots;

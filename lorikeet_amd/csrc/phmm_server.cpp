@@ -275,16 +275,20 @@ namespace phmm_host {
 
 // Stage one call in a slot and hand it to the device's server.  kServerNotTaken: the call is outside the server's limits (or
 // the server is not to be used): nothing was done, the caller takes the launched pipeline.  `a` is validated.
+constexpr int kServerFromHandles = 6;
+
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit) {
     *out = nullptr;
     const auto t_enter = std::chrono::steady_clock::now();
-    // Which calls: with no switch set, the one-shot region calls of PRIVATE handles once more than four of the caller's handles are
-    // alive on the device -- a handle per worker thread at Lorikeet's --threads 10: past four, the handles' own hardware queues
-    // share the command processor's pipes and every caller sits in its own chain of launches (22 k regions/s at 16 callers, 12.5 k
-    // at 32); here nothing is launched and the results are the region's own bits whatever the load.  Up to four handles keep
+    // Which calls: with no switch set, the one-shot region calls of PRIVATE handles once more than kServerFromHandles of the
+    // caller's handles are alive on the device -- a handle per worker thread at Lorikeet's --threads 10.  The launched pipelines of
+    // many handles share the command processor's pipes and every caller sits in its own chain of launches: 22 k regions/s
+    // (128 x 8) from five callers on, 12.5 k at 32; a call through the server is ~295 us whatever the count, so N callers get
+    // N / 295 us: the server overtakes at seven callers (23.6 against 22.2 k; 30 x 3 regions at six, the ragged mix at seven --
+    // profiles/r06_server_threshold.txt), and its results are the region's own bits whatever the load.  Up to six handles keep
     // their queues (faster there), a shared handle's phmm_region_submit keeps its combiner (faster, and it says that it combines).
     if (h->sw.region_server == 0) return kServerNotTaken;
-    if (h->sw.region_server < 0 && (via_submit || h->sw_touched || h->internal || h->comb || h->sw.route_shared > 0 || user_handles_on(h->device) <= 4))
+    if (h->sw.region_server < 0 && (via_submit || h->sw_touched || h->internal || h->comb || h->sw.route_shared > 0 || user_handles_on(h->device) <= kServerFromHandles))
         return kServerNotTaken;  // (route_shared > 0: the caller asked for the combiner instead)
     const uint32_t ng = a.n_regions, nr = a.region_read_off[ng], nh = a.region_hap_off[ng];
     if (!ng || !nr || !nh) return kServerNotTaken;

@@ -1,7 +1,7 @@
 """The resident region server (lorikeet_amd/csrc/phmm_server.cpp, phmm_server_kernels.hip): phmm_region_compute /
 phmm_region_submit as tasks of ONE kernel that stays on the chip -- every read of a call a wave that runs the read's whole path.
-The way a region call goes from the second concurrent caller on (a lone call on an idle chip takes the launched pipeline;
-switch region_server = 1: every call).  Held here to
+The way a private handle's region call goes once more than six handles are alive on the device (up to six keep the launched
+pipeline; switch region_server = 1: every call).  Held here to
   * the launched pipeline (switch region_server = 0), field by field: everything discrete equal, likelihoods to 1e-11 (the two
     sweep a pair with different lane geometries), and to the oracle pipeline at 1e-9;
   * ITSELF, bit for bit: a region gives the same bits alone, beside other callers' regions, through the shared handle, and from
@@ -134,17 +134,17 @@ def test_a_region_gives_the_same_bits_alone_and_beside_other_callers(eng):
     assert eng.stat("server_jobs") == jobs + 12 * len(calls)
 
 
-def test_private_handles_past_four_go_through_the_server_by_default():
-    """No switch set: up to four of the caller's handles on a device keep their own hardware queues (the launched pipeline); with
-    more alive -- a handle per worker thread at Lorikeet's --threads 10 -- their one-shot region calls go through the server, and
-    every call gives its region's own bits whatever the others are doing."""
-    calls = _config2_regions(6, 700)
+def test_private_handles_past_six_go_through_the_server_by_default():
+    """No switch set: up to six of the caller's handles on a device keep their own launched pipelines (faster there,
+    profiles/r06_server_threshold.txt); with more alive -- a handle per worker thread at Lorikeet's --threads 10 -- their one-shot
+    region calls go through the server, and every call gives its region's own bits whatever the others are doing."""
+    calls = _config2_regions(8, 700)
     cfg = _cfg(pcr=3)
-    engines = [HipPairHMMEngine(0) for _ in range(6)]
+    engines = [HipPairHMMEngine(0) for _ in range(8)]
     try:
         jobs = engines[0].stat("server_jobs")
-        want = [_call(engines[5], cfg, sc, mapq, None) for sc, mapq in calls]   # (six alive: the server, one call at a time)
-        assert engines[0].stat("server_jobs") == jobs + 6, "a call of one of six private handles did not go through the server"
+        want = [_call(engines[7], cfg, sc, mapq, None) for sc, mapq in calls]   # (eight alive: the server, one call at a time)
+        assert engines[0].stat("server_jobs") == jobs + 8, "a call of one of eight private handles did not go through the server"
         launched = HipPairHMMEngine(0)
         launched.set_switch("region_server", 0)
         engines.append(launched)
@@ -165,7 +165,7 @@ def test_private_handles_past_four_go_through_the_server_by_default():
         for t in threads:
             t.join()
         assert not errors, errors
-        assert engines[0].stat("server_jobs") == jobs + 6 + 20 * 6 and engines[0].stat("server_broken") == 0
+        assert engines[0].stat("server_jobs") == jobs + 8 + 20 * 8 and engines[0].stat("server_broken") == 0
     finally:
         for e in engines:
             e.close()

@@ -296,7 +296,7 @@ def test_thirty_two_private_handles_are_not_slower_than_sixteen():
     from conftest import ROOT
     exe = os.path.join(ROOT, "tools", "threads_bench")
     for mode in ("own", "fused"):
-        # (the region call: the library's default, past four private handles through the device's region server; the PairHMM alone:
+        # (the region call: the library's default, past six private handles through the device's region server; the PairHMM alone:
         # the opt-in routing through the shared combiner)
         env = dict(os.environ, TB_MODE=mode, TB_THREADS="16,32", TMPDIR="/tmp")
         env.pop("PHMM_ROUTE_SHARED", None)
