@@ -545,11 +545,11 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
  *   aligner        "sw_lite" (the tags-only first pass: -1 where it pays, 0 never, 1 always), "sw_chunks", "sw_lanes",
  *                  "sw_transpose", "sw_no_zero_copy", "sw_clock"
  *   region call    "region_server" (the resident region server: -1 the one-shot calls of private handles past six alive on the
- *                  device, 0 never, 1 every call its limits admit), "server_idle_us", "server_stall_ms", "server_trace";
+ *                  device, 0 never, 1 every call its limits admit), "server_idle_us", "server_trace";
  *                  "region_sw_all" (pairs up to which a lone launched call aligns every read against every haplotype beside the
  *                  PairHMM kernels: -1 by load, 0 never), "region_flag_wait", "region_pick_timeout_us", "region_debug_pick" (tests),
  *                  "mirror_canary", "region_own_queue" (environment only)
- *   many callers   "submit_gather_us", "route_shared" (opt-in: private handles' small calls through the shared combiner)
+ *   many callers   "route_shared" (opt-in: private handles' small calls through the shared combiner)
  * Value -1 / 0 = back to the planner's choice as documented there.  Not to be called while another thread computes on the handle.
  * Returns PHMM_ERR_INVALID_ARG for an unknown name.
  * phmm_get_stat: "staged_bytes" (payload bytes this handle -- for a shared handle, its lanes -- copied into pinned

@@ -267,7 +267,6 @@ static void read_env_switches(Switches &w) {
     env("PHMM_FORCE_L", w.force_L);
     env("PHMM_FORCE_CHAIN", w.force_chain);
     env("PHMM_FORCE_STREAMS", w.force_streams);
-    env("PHMM_SUBMIT_GATHER_US", w.submit_gather_us);
     env("PHMM_SW_LITE", w.sw_lite);
     env("PHMM_SW_CHUNKS", w.sw_chunks);
     env("PHMM_SW_LANES", w.sw_lanes);
@@ -275,7 +274,6 @@ static void read_env_switches(Switches &w) {
     env("PHMM_REGION_SW_ALL", w.region_sw_all);
     env("PHMM_REGION_SERVER", w.region_server);
     env("PHMM_SERVER_IDLE_US", w.server_idle_us);
-    env("PHMM_SERVER_STALL_MS", w.server_stall_ms);
     env("PHMM_SERVER_TRACE", w.server_trace);
     env("PHMM_REGION_FLAG_WAIT", w.region_flag_wait);
     env("PHMM_REGION_OWN_QUEUE", w.region_own_queue);
@@ -2424,7 +2422,6 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "no_pipeline") w.no_pipeline = value != 0;
     else if (n == "no_rescue") w.no_rescue = value != 0;
     else if (n == "trace") w.trace = value != 0;
-    else if (n == "submit_gather_us") w.submit_gather_us = value > 0 ? value : 0;
     else if (n == "sw_lite") {
         w.sw_lite = value;
         h->swork.lite_skip = 0;  // (what earlier calls have taught the handle starts over)
@@ -2436,7 +2433,6 @@ int phmm_set_switch(phmm_handle *h, const char *name, int value) {
     else if (n == "region_sw_all") w.region_sw_all = value < 0 ? -1 : value;
     else if (n == "region_server") w.region_server = value < 0 ? -1 : value > 0 ? 1 : 0;
     else if (n == "server_idle_us") w.server_idle_us = value > 0 ? value : 1;
-    else if (n == "server_stall_ms") w.server_stall_ms = value > 0 ? value : 1;
     else if (n == "server_trace") w.server_trace = value != 0;
     else if (n == "region_flag_wait") w.region_flag_wait = value != 0;
     else if (n == "region_pick_timeout_us") w.region_pick_timeout_us = value > 0 ? value : 1;

@@ -35,7 +35,6 @@ struct Switches {
     int force_streams = 0;      // PHMM_FORCE_STREAMS: 1 / 2 / 4 streams of the chained kernel
     int no_pipeline = 0;        // PHMM_NO_PIPELINE: host path in one shot whatever the size
     int no_rescue = 0;          // PHMM_NO_RESCUE: leave results below kRescueBelow as the fast kernels made them (A/B only)
-    int submit_gather_us = 40;  // PHMM_SUBMIT_GATHER_US: how long the leader of a flush lets submissions that are on their way arrive (0 = never)
     int trace = 0;              // PHMM_TRACE: plan and host-path timing on stderr
     int sw_lite = -1;           // PHMM_SW_LITE: the tags-only first pass of the aligner -- -1 where it pays (adaptive), 0 never, 1 always
     int sw_lanes = 0;           // PHMM_SW_LANES: 8 / 16 / 32 / 64 lanes per Smith-Waterman alignment (0 = by the batch)
@@ -55,11 +54,9 @@ struct Switches {
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1: the one-shot calls of
-                                // PRIVATE handles while more than four of the caller's handles are alive on the device (a handle whose other switches
+                                // PRIVATE handles while more than six of the caller's handles are alive on the device (a handle whose other switches
                                 // were changed keeps the launched pipeline); 0 never; 1 every call the server's limits admit, a shared handle's too
     int server_idle_us = 200;   // PHMM_SERVER_IDLE_US: how long the server stays on the chip with nothing in flight and nothing arriving
-    int server_stall_ms = 5000; // PHMM_SERVER_STALL_MS: calls in flight and none finishing for this long: the server gives up and is not used again by the
-                                // process (its calls are run again by the launched pipeline)
     int server_trace = 0;       // PHMM_SERVER_TRACE: every task leaves a record (tools/server_trace.py)
     int region_sw_all = -1;     // PHMM_REGION_SW_ALL: a small phmm_region_compute call aligns every read against EVERY haplotype beside the
                                 // PairHMM kernels (the best allele picks afterwards) -- -1 up to 2 048 pairs, 0 never, n > 0 up to n pairs

@@ -31,6 +31,8 @@ namespace {
 constexpr size_t kSlotBytes = 4u << 20;   // one slot: staged inputs + device-only pieces + results
 constexpr size_t kStageMax = 1u << 20;    // inputs of one job (the stage-in tasks copy them over the link)
 constexpr int kMaxSlots = 64;
+constexpr int kServerStallMs = 5000;     // calls in flight and none finishing for this long: the server gives up, is not used again by the process,
+                                          // and its calls are run again by the launched pipeline
 constexpr uint32_t kSwCapacity = 24;      // CIGAR elements per read -> haplotype alignment (a call that needs more takes the launched pipeline)
 constexpr uint32_t kMaxHap = 512;          // 16 lanes x 25 columns per pair up to 400 bases, 32 x 16 beyond
 const int kSwKs[] = {2, 3, 4, 5, 6, 8};
@@ -173,7 +175,7 @@ bool launch_locked(Server &S, const Switches &sw) {
     P.start_seq = S.consumed;
     P.epoch = S.epoch + 1;
     P.idle_ticks = 100u * (uint32_t)std::max(1, sw.server_idle_us);
-    P.stall_ticks = 100u * 1000u * (uint32_t)std::max(1, sw.server_stall_ms);
+    P.stall_ticks = 100u * 1000u * (uint32_t)kServerStallMs;
     P.trace = sw.server_trace ? S.d_trace : nullptr;
     P.trace_cap = S.trace_cap;
     if (!hip_ok(hipMemsetAsync(S.d_block, 0, S.block_bytes, S.stream)) || !hip_ok(launch_server(P, S.n_blocks, S.stream))) {
@@ -571,7 +573,7 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     job->helper_stride = (uint32_t)helper_stride;
     job->status_in = (uint32_t *)T.sync;
     job->status_out = (uint32_t *)(mirror + L.res);
-    job->wait_ticks = 100u * 1000u * (uint32_t)std::max(1, h->sw.server_stall_ms);
+    job->wait_ticks = 100u * 1000u * (uint32_t)kServerStallMs;
     job->finish_flag = (uint32_t *)(mirror + L.res + 224);
     // ---- the ring entry ----------------------------------------------------------------------------------------------------------------
     ServerPending *p = new ServerPending();
@@ -598,7 +600,7 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
     bool done = false;
     // (measured, tools/threads_bench: spin / yield 33.4 / 42.5 / 22.9 k regions/s at 10 / 16 / 32 callers, short sleeps 32.7 / 42.1 / 45.6 k)
     constexpr uint32_t wait_spins = 64;
-    const auto give_up = p->t0 + std::chrono::milliseconds(std::max(1, h->sw.server_stall_ms) * 4);
+    const auto give_up = p->t0 + std::chrono::milliseconds(kServerStallMs * 4);
     for (uint32_t spins = 0; !done; ++spins) {
         done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
         if (done) break;

@@ -69,7 +69,7 @@ struct Combiner {
     std::mutex mu;
     std::condition_variable gather_cv;  // the one leader that is letting submissions arrive (below) sleeps here; phmm_submit wakes it
     bool gathering = false;
-    int gather_us = 40;
+    int gather_us = 40;  // (0 / 40 / 100 measured in round 5, tools/run/threads.sh: 40)
     std::deque<uint64_t> queue;  // tickets nobody has picked up yet, in submission order
     std::unordered_map<uint64_t, Submission> live;  // until phmm_wait returns them (element addresses are stable)
     uint64_t next_ticket = 1;
@@ -118,7 +118,6 @@ void combiner_destroy(Combiner *c) {
 
 void combiner_set_switches(Combiner *c, const Switches &sw) {
     std::lock_guard<std::mutex> lk(c->mu);
-    c->gather_us = sw.submit_gather_us;
     for (int l = 0; l < Combiner::kMaxLanes; ++l)
         if (c->lane[l]) c->lane[l]->sw = sw;
 }
@@ -317,7 +316,6 @@ int submit_impl(phmm_handle *h, Submission &s, uint64_t *ticket) {
         Combiner *c = new Combiner();
         c->n_lanes = 4;  // (2 / 3 / 6 / 8 lanes measured in round 5: none better at 8 or 16 callers, NOTEBOOK 19.2)
         c->trace = h->sw.trace != 0;
-        c->gather_us = h->sw.submit_gather_us;
         h->comb = c;
     });
     Combiner *c = h->comb;

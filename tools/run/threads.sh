@@ -20,8 +20,6 @@ TB_DEPTH=2 TB_MODE=gshared TB_THREADS=4,8,10,16,32 tools/threads_bench 1
 echo "## ... private handles with the routing off (PHMM_ROUTE_SHARED=0: round 4's behaviour)"
 PHMM_ROUTE_SHARED=0 TB_MODE=fused TB_THREADS=8,16,32 tools/threads_bench 1
 PHMM_ROUTE_SHARED=0 TB_MODE=own TB_THREADS=8,16,32 tools/threads_bench 1
-echo "## ... without the gathering leader (PHMM_SUBMIT_GATHER_US=0)"
-PHMM_SUBMIT_GATHER_US=0 TB_MODE=gshared TB_THREADS=8,16,32 tools/threads_bench 1
 echo "## ... by regions per call (one and four caller threads)"
 for pc in 2 4 8 16 64 256; do TB_MODE=fused TB_THREADS=1,4 tools/threads_bench 0.7 128 8 150 300 $pc | grep fused | sed "s/^/$pc regions per call: /"; done
 echo "## kernels of one region call (rocprofv3 --kernel-trace --stats, one caller thread)"
