@@ -48,7 +48,8 @@ struct Switches {
                                 // stream before it gives up (the host then runs the call again the chained way)
     int region_debug_pick = 0;  // PHMM_REGION_DEBUG_PICK (tests): 1 = the all-pairs aligner is enqueued BEHIND phmm_pick_reads on the call's own
                                 // stream (both on one hardware queue, in order: the wait can only run out of time); 2 = the all-pairs aligner
-                                // stores two words into the call's status block ~300 us AFTER it has counted itself in (round 4's bug, on purpose)
+                                // stores two words into the call's status block ~300 us AFTER it has counted itself in (round 4's bug, on purpose);
+                                // 4 = a call's answer from the region server counts as lost (what a stalled server looks like to its caller)
     int route_shared = 0;       // PHMM_ROUTE_SHARED (opt-in): while MORE than this many of the caller's handles are alive on a device, the one-shot calls
                                 // of private handles go through the device's shared combiner (its lanes) instead of their own streams -- 0 = never
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()

@@ -101,9 +101,52 @@ struct ChainItem {
     uint32_t region;                // region index
     uint16_t quad;                  // haplotype group ((64/L)/streams haplotypes) inside the region
     uint8_t k, streams;             // columns per lane of this item's body; 1 | 2 | 4 sub-runs swept side by side (L = 16)
-    uint32_t read_begin, read_end;  // global read indices [begin, end), all of that region
+    uint32_t read_begin;            // global index of the run's first read; the run is n_reads reads of that region
+    // n_reads (1 .. CHAIN_MAX_READS) in the low byte, then where streams 1, 2, 3 begin inside the run (stream 0 begins at 0; a
+    // stream that does not exist begins at n_reads).  The planner cuts a run so that its longest stream has as few ROWS as
+    // contiguous cuts allow (chain_cut_run): reads of 30-250 bases cut by count left the longest of four streams ~25 % above
+    // their mean (NOTEBOOK 20.6).
+    uint32_t cuts;
+    __host__ __device__ uint32_t n_reads() const { return cuts & 0xffu; }
+    __host__ __device__ uint32_t read_end() const { return read_begin + (cuts & 0xffu); }
+    __host__ __device__ uint32_t stream_begin(int s) const { return s <= 0 ? 0u : s >= 4 ? (cuts & 0xffu) : (cuts >> (8 * s)) & 0xffu; }
 };
 static_assert(sizeof(ChainItem) == 16, "work item record");
+// The cuts of a run of n reads (lengths in rows: len(i), SUM / RESET rows included) into `streams` contiguous parts whose
+// longest has the fewest rows: binary search on that length, parts filled greedily.  Host only (the planner).
+template <class Len>
+inline uint32_t chain_cut_run(uint32_t n, uint32_t streams, Len len, uint64_t *longest_out = nullptr) {
+    uint64_t lo = 0, hi = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        lo = lo > len(i) ? lo : len(i);
+        hi += len(i);
+    }
+    uint32_t begin[5] = {0, n, n, n, n};
+    auto fill = [&](uint64_t limit, bool keep) {
+        uint32_t parts = 1;
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (acc + len(i) > limit && acc) {
+                if (keep && parts < 4) begin[parts] = i;
+                ++parts;
+                acc = 0;
+            }
+            acc += len(i);
+        }
+        return parts;
+    };
+    if (streams > 1) {
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (fill(mid, false) <= streams) hi = mid; else lo = mid + 1;
+        }
+        fill(lo, true);
+    } else {
+        lo = hi;
+    }
+    if (longest_out) *longest_out = lo;
+    return n | begin[1] << 8 | begin[2] << 16 | begin[3] << 24;
+}
 struct ChainParams {
     ForwardParams f;
     const ChainItem *items;

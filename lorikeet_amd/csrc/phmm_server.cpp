@@ -601,6 +601,12 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
     // (measured, tools/threads_bench: spin / yield 33.4 / 42.5 / 22.9 k regions/s at 10 / 16 / 32 callers, short sleeps 32.7 / 42.1 / 45.6 k)
     constexpr uint32_t wait_spins = 64;
     const auto give_up = p->t0 + std::chrono::milliseconds(kServerStallMs * 4);
+    if (h->sw.region_debug_pick & 4) {  // (tests: this call's answer counts as lost -- what a stalled server looks like from here)
+        std::lock_guard<SpinLock> lk(S.mu);
+        S.broken = true;
+        S.why_broken = "tests: region_debug_pick & 4";
+        return false;
+    }
     for (uint32_t spins = 0; !done; ++spins) {
         done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
         if (done) break;

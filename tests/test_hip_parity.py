@@ -501,6 +501,34 @@ def test_chained_kernel_streams(engines, force_chain, streams, kat_rows):
         hip_engine.set_switch("force_streams", 0)
 
 
+@pytest.mark.parametrize("nh", [1, 2])
+def test_streams_cut_by_rows(engines, nh):
+    """Round 6: a run's streams are cut where the longest has the fewest rows, not into equal counts of reads (chain_cut_run;
+    tests/test_sharding.py holds the cuts themselves).  Runs of twelve reads whose lengths make the two cuts differ -- one long
+    read first, last, in the middle; a run shorter than its streams; equal reads -- against the oracle, read by read."""
+    eng = engines[16]
+    eng.set_switch("force_chain", 12)
+    try:
+        rng = np.random.default_rng(600 + nh)
+        alpha = np.frombuffer(b"ACGT", np.uint8)
+
+        def region(lens):
+            haps = [alpha[rng.integers(0, 4, int(rng.integers(100, 300)))] for _ in range(nh)]
+            return [Read(alpha[rng.integers(0, 4, n)], rng.integers(2, 60, n), rng.integers(6, 60, n), rng.integers(6, 60, n), rng.integers(2, 60, n))
+                    for n in lens], haps
+
+        shapes = [[250] + [30] * 11, [30] * 11 + [250], [30] * 5 + [250] + [30] * 6, [250, 250, 30, 30, 30], [100] * 12, [77], [200, 10],
+                  [1, 1, 1, 300, 1, 1, 1], list(range(10, 130, 10)), [300] * 12]
+        regions = [region(lens) for lens in shapes for _ in range(3)]
+        b = RegionBatch.from_regions(regions)
+        plan = eng.plan(b)
+        assert plan.dominant_kernel.endswith("x%d streams" % (4 if nh == 1 else 2)), plan.dominant_kernel
+        plan.close()
+        _close(eng.compute(b), oracle.compute_batch(b.as_dict(), n_threads=8))
+    finally:
+        eng.set_switch("force_chain", -1)
+
+
 def test_planner_fills_the_wave_for_any_haplotype_count(hip_engine):
     """Large batches of regions with 1, 2, 3, 5 and 6 haplotypes: chained with 4, 2, 4, 4 and 2 streams."""
     for nh, streams in ((1, 4), (2, 2), (3, 4), (5, 4), (6, 2), (8, 1)):

@@ -238,3 +238,46 @@ def test_two_tickets_per_thread_on_the_shared_handle(eng):
         _equal(got, w, exact=True)
     assert C.sizeof(_lib.EngineConfig) > 0
 
+
+_LOST_ANSWER = r"""
+import numpy as np
+from lorikeet_amd import region
+from lorikeet_amd.engine import HipPairHMMEngine
+from test_server_hip import _call, _config2_regions, _equal
+from test_region_hip import _cfg
+(sc, mapq), (sc2, mapq2) = _config2_regions(2, 4100)
+cfg = _cfg(pcr=3)
+launched = HipPairHMMEngine(0)
+launched.set_switch("region_server", 0)
+want, want2 = _call(launched, cfg, sc, mapq, None), _call(launched, cfg, sc2, mapq2, None)
+e = HipPairHMMEngine(0)
+e.set_switch("region_server", 1)
+ok = _call(e, cfg, sc, mapq, None)
+assert e.stat("server_jobs") == 1 and e.stat("server_broken") == 0
+_equal(ok, want, exact=False)
+e.set_switch("region_debug_pick", 4)          # the next answer counts as lost: the call is run again by the launched pipeline
+got = _call(e, cfg, sc2, mapq2, None)
+assert e.stat("server_jobs") == 2 and e.stat("server_broken") == 1
+_equal(got, want2, exact=True)                # (the launched pipeline's own bits)
+e.set_switch("region_debug_pick", 0)
+again = _call(e, cfg, sc, mapq, None)         # ... and so is every later call of the process: the server is not used again
+assert e.stat("server_jobs") == 2
+_equal(again, want, exact=True)
+others = [HipPairHMMEngine(0) for _ in range(8)]
+_equal(_call(others[7], cfg, sc2, mapq2, None), want2, exact=True)
+assert e.stat("server_jobs") == 2
+print("fallback ok")
+"""
+
+
+def test_a_lost_answer_sends_the_call_and_all_later_ones_to_the_launched_pipeline():
+    """The server's own failure never fails a call: a stall (nothing finishing for 5 s) or a call that does not come back marks the
+    device's server broken -- phmm_stat "server_broken" --, the call is run again by the launched pipeline and so is every later
+    one.  In a process of its own (the mark stays for the process' life); the lost answer is the test hook region_debug_pick & 4."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]), TMPDIR="/tmp")
+    r = subprocess.run([sys.executable, "-c", _LOST_ANSWER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
