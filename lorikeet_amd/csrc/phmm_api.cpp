@@ -917,7 +917,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 }
                 // (a run's streams: cut where the longest of them has the fewest rows, phmm_internal.hpp)
                 auto item = [&](uint32_t q, uint32_t streams, uint32_t r, uint32_t r_end) {
-                    const uint32_t cuts = chain_cut_run(r_end - r, streams, [&](uint32_t i) { return (uint64_t)(read_off[r + i + 1] - read_off[r + i]) + 2; });
+                    const uint32_t cuts = chain_cut_run(r_end - r, streams, [&](uint32_t i) { return (uint64_t)(read_off[r + i] - read_off[r]) + 2ull * i; });
                     return ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)streams, r, cuts};
                 };
                 for (uint32_t r = r0; r < r1; r += run) {
