@@ -915,28 +915,15 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                     if (rest_streams > 1) nq_main = shape[g].nh / 4;
                     else rest = 0;
                 }
-                // (a run's streams: cut where the longest of them has the fewest rows, phmm_internal.hpp)
-                auto item = [&](uint32_t q, uint32_t streams, uint32_t r, uint32_t r_end) {
-                    const uint32_t cuts = chain_cut_run(r_end - r, streams, [&](uint32_t i) { return (uint64_t)(read_off[r + i] - read_off[r]) + 2ull * i; });
-                    return ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)streams, r, cuts};
-                };
-                for (uint32_t r = r0; r < r1; r += run) {
-                    const ChainItem first = item(0, (uint32_t)c.streams, r, std::min(r1, r + run));
-                    for (uint32_t q = 0; q < nq_main; ++q) {  // (the haplotype groups of a run share its cuts)
-                        c.chain_items.push_back(first);
-                        c.chain_items.back().quad = (uint16_t)q;
-                    }
-                }
+                for (uint32_t r = r0; r < r1; r += run)
+                    for (uint32_t q = 0; q < nq_main; ++q)
+                        c.chain_items.push_back(ChainItem{g, (uint16_t)q, (uint8_t)c.K, (uint8_t)c.streams, r, std::min(r1, r + run)});
                 if (rest) {
                     const uint32_t gs2 = 4 / rest_streams, q0 = nq_main * 4 / gs2, nq2 = (rest + gs2 - 1) / gs2;
                     const uint32_t run2 = std::min<uint32_t>(CHAIN_MAX_READS, run * rest_streams);
-                    for (uint32_t r = r0; r < r1; r += run2) {
-                        const ChainItem first = item(q0, rest_streams, r, std::min(r1, r + run2));
-                        for (uint32_t q = 0; q < nq2; ++q) {
-                            c.chain_items.push_back(first);
-                            c.chain_items.back().quad = (uint16_t)(q0 + q);
-                        }
-                    }
+                    for (uint32_t r = r0; r < r1; r += run2)
+                        for (uint32_t q = 0; q < nq2; ++q)
+                            c.chain_items.push_back(ChainItem{g, (uint16_t)(q0 + q), (uint8_t)c.K, (uint8_t)rest_streams, r, std::min(r1, r + run2)});
                 }
             }
             // (the launch is ordered longest item first below, across all classes: one sort there instead of one per class and
@@ -1036,10 +1023,10 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         for (const auto &grp : b->chain_groups)
             for (const ChainItem &x : grp.items) {
                 const uint32_t S = std::max<uint32_t>(1, x.streams), L = (uint32_t)grp.L, GS = (64u / L) / S, LK = L * x.k;
-                const uint32_t n = x.n_reads();
+                const uint32_t n = x.read_end - x.read_begin, n_sub = (n + S - 1) / S;
                 uint64_t longest = 0, read_rows = 0;
-                for (uint32_t st = 0; st < S; ++st) {  // (stream st sweeps reads [stream_begin(st), stream_begin(st + 1)) of the run)
-                    const uint32_t lo = x.stream_begin((int)st), hi = st + 1 < S ? x.stream_begin((int)st + 1) : n;
+                for (uint32_t st = 0; st < S; ++st) {  // (stream st sweeps reads [st n_sub, (st + 1) n_sub) of the run)
+                    const uint32_t lo = std::min(n, st * n_sub), hi = std::min(n, lo + n_sub);
                     const uint64_t rows = read_off[x.read_begin + hi] - read_off[x.read_begin + lo];
                     read_rows += rows;
                     longest = std::max<uint64_t>(longest, rows + 2ull * (hi - lo));
@@ -1049,14 +1036,24 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
                 t_marks += 2ull * n * GS * LK;                                          // the SUM / RESET rows of its reads
                 t_fill += (steps - longest) * 64ull * x.k;                              // reaching the last lane
                 t_uneven += (longest * S - read_rows - 2ull * n) * (uint64_t)GS * LK;   // streams shorter than the longest
-                if (sw.trace && S > 1) {  // ... and what a cut into equal COUNTS of reads (rounds 2-5) would leave of that
-                    const uint32_t n_sub = (n + S - 1) / S;
-                    uint64_t by_count = 0;
-                    for (uint32_t st = 0; st < S; ++st) {
-                        const uint32_t lo = std::min(n, st * n_sub), hi = std::min(n, lo + n_sub);
-                        by_count = std::max<uint64_t>(by_count, read_off[x.read_begin + hi] - read_off[x.read_begin + lo] + 2ull * (hi - lo));
+                if (sw.trace && S > 1) {  // ... and what the best cut of the run into S contiguous parts would leave of that
+                    uint64_t lo_b = 0, hi_b = read_rows + 2ull * n;
+                    for (uint32_t i = 0; i < n; ++i) lo_b = std::max<uint64_t>(lo_b, read_off[x.read_begin + i + 1] - read_off[x.read_begin + i] + 2);
+                    while (lo_b < hi_b) {
+                        const uint64_t mid = (lo_b + hi_b) / 2;
+                        uint32_t parts = 1;
+                        uint64_t acc = 0;
+                        for (uint32_t i = 0; i < n; ++i) {
+                            const uint64_t len = read_off[x.read_begin + i + 1] - read_off[x.read_begin + i] + 2;
+                            if (acc + len > mid) {
+                                ++parts;
+                                acc = 0;
+                            }
+                            acc += len;
+                        }
+                        if (parts <= S) hi_b = mid; else lo_b = mid + 1;
                     }
-                    t_uneven_best += (by_count * S - read_rows - 2ull * n) * (uint64_t)GS * LK;
+                    t_uneven_best += (lo_b * S - read_rows - 2ull * n) * (uint64_t)GS * LK;
                 }
                 uint64_t sum_h;
                 uint32_t valid;
@@ -1087,7 +1084,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             }
         }
         if (sw.trace)
-            fprintf(stderr, "phmm plan: swept %.4e lane-cells for %.4e cells: columns %.4e, slots %.4e; chained items' SUM / RESET rows %.4e, fill %.4e, uneven streams %.4e (cut by count: %.4e)\n",
+            fprintf(stderr, "phmm plan: swept %.4e lane-cells for %.4e cells: columns %.4e, slots %.4e; chained items' SUM / RESET rows %.4e, fill %.4e, uneven streams %.4e (cut by rows: %.4e)\n",
                     (double)swept, (double)b->cells, (double)pad_cols, (double)pad_slots, (double)t_marks, (double)t_fill, (double)t_uneven, (double)t_uneven_best);
         b->swept_cells = swept;
         b->pad_column_cells = pad_cols;
@@ -1096,14 +1093,9 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
     for (auto &grp : b->chain_groups) {
         // longest item first across all classes of the launch: (rows of the run + its SUM / RESET rows) x the cost of a
         // step at the item's K (7 VALU per column + ~11 per step)
-        auto cost = [&](const ChainItem &x) {  // (the steps of the item's longest stream)
-            const uint32_t S = std::max<uint32_t>(1, x.streams), n = x.n_reads();
-            uint64_t longest = 0;
-            for (uint32_t st = 0; st < S; ++st) {
-                const uint32_t lo = x.stream_begin((int)st), hi = st + 1 < S ? x.stream_begin((int)st + 1) : n;
-                longest = std::max<uint64_t>(longest, read_off[x.read_begin + hi] - read_off[x.read_begin + lo] + 2ull * (hi - lo));
-            }
-            return (longest + (uint64_t)grp.L) * (uint64_t)(7 * x.k + 11);
+        auto cost = [&](const ChainItem &x) {
+            return (uint64_t)(read_off[x.read_end] - read_off[x.read_begin] + 2 * (x.read_end - x.read_begin) + grp.L) *
+                   (uint64_t)(7 * x.k + 11);
         };
         {   // (keys made once -- the comparator used to fetch four offsets per comparison -- and unique, so a plain sort keeps
             // items of equal cost in the order they were made: the groups of a run stay next to each other)
@@ -1137,7 +1129,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
             std::vector<ChainItem> out;
             out.reserve(grp.items.size());
             auto same_run = [](const ChainItem &x, const ChainItem &y) {
-                return x.region == y.region && x.read_begin == y.read_begin && x.cuts == y.cuts;
+                return x.region == y.region && x.read_begin == y.read_begin && x.read_end == y.read_end;
             };
             size_t i = 0;
             const size_t n = grp.items.size();
@@ -1195,7 +1187,7 @@ static phmm_batch *batch_create_impl(phmm_handle *h, uint32_t n_regions, const u
         // the heaviest launch first (it starts on the caller's stream, the others join it from the side streams)
         auto weight = [&](const phmm_batch::ChainGroup &g) {
             uint64_t w = 0;
-            for (const ChainItem &x : g.items) w += (uint64_t)(read_off[x.read_end()] - read_off[x.read_begin]) * (uint64_t)(7 * x.k + 11);
+            for (const ChainItem &x : g.items) w += (uint64_t)(read_off[x.read_end] - read_off[x.read_begin]) * (uint64_t)(7 * x.k + 11);
             return w;
         };
         std::stable_sort(split.begin(), split.end(), [&](const phmm_batch::ChainGroup &x, const phmm_batch::ChainGroup &y) { return weight(x) > weight(y); });
@@ -2497,7 +2489,7 @@ int phmm_plan_describe(unsigned flags, uint32_t concurrent_callers, uint32_t n_r
             info->n_chain_launches += 1;
             info->chain_items += g.items.size();
             uint32_t fewest = 0xffffffffu;
-            for (const ChainItem &it : g.items) fewest = std::min(fewest, it.n_reads());
+            for (const ChainItem &it : g.items) fewest = std::min(fewest, it.read_end - it.read_begin);
             info->min_reads_per_run = info->min_reads_per_run ? std::min(info->min_reads_per_run, fewest) : fewest;
         }
         for (const auto &c : b->classes)

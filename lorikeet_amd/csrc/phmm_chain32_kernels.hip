@@ -146,7 +146,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     const int grp = lane / CL, l = lane % CL;
     const bool group_head = (CL == 32) && (lane == 32);
     const uint32_t reg = it.region;
-    const int n_chain = (int)it.n_reads();
+    const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
     const int S = (CL == 16) ? (int)it.streams : 1;
@@ -154,11 +154,10 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     const int sid = grp / GS;
     const int a = (int)it.quad * GS + grp % GS;
     const bool hv = a < Nh;
-    const uint32_t cuts = it.cuts;  // (where the run's streams begin: phmm_chain_kernels.hip)
-    auto s_begin = [&](int s) { return s <= 0 ? 0 : s >= S ? n_chain : (int)((cuts >> (8 * s)) & 0xffu); };
+    const int n_sub = (n_chain + S - 1) / S;
     const int TPS = WAVE / S;
     const int NM = RING / S - 1;
-    auto n_of = [&](int s) { return s_begin(s + 1) - s_begin(s); };
+    auto n_of = [&](int s) { return max(0, min(n_sub, n_chain - s * n_sub)); };
     const int n_mine = n_of(sid);
     uint32_t ho = 0;
     int H = 0;
@@ -167,7 +166,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
     Row32 *ring = reinterpret_cast<Row32 *>(smem);                     // RING_SLOTS records
-    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s_begin(s) + s: byte offset of each of its reads, and the end
+    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s*(n_sub+1): byte offset of each read
     uint32_t *stot = roff + CHAIN_META;                                // [4] rows of each stream
 
     HapCols<K> hc;
@@ -184,7 +183,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
 
     const uint32_t rb = it.read_begin;
     const uint32_t byte0 = p.read_off[rb];
-    const uint32_t bytes = p.read_off[it.read_end()] - byte0;
+    const uint32_t bytes = p.read_off[it.read_end] - byte0;
     bool z = false;
     for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // general path needed: leave the whole run to the f64 kernel
@@ -192,7 +191,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
         return;
     }
     {
-        const int sj = (lane >= s_begin(1)) + (lane >= s_begin(2)) + (lane >= s_begin(3)), ij = lane - s_begin(sj);
+        const int sj = lane / n_sub, ij = lane % n_sub;
         uint32_t len = lane < n_chain ? p.read_off[rb + lane + 1] - p.read_off[rb + lane] + 2u : 0u;  // + SUM + RESET
         uint32_t incl = len;
 #pragma unroll
@@ -200,14 +199,14 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
             const uint32_t v = __shfl_up(incl, off, WAVE);
             if (lane >= off) incl += v;
         }
-        const uint32_t before = __shfl(incl, max(s_begin(sj) - 1, 0), WAVE);
-        const int cb = s_begin(sj) + sj;
+        const uint32_t before = __shfl(incl, max(sj * n_sub - 1, 0), WAVE);
+        const int cb = sj * (n_sub + 1);
         if (lane < 4) stot[lane] = 0u;
         if (lane < n_chain) {
             roff[cb + ij] = p.read_off[rb + lane];
             if (ij + 1 == n_of(sj)) {
                 roff[cb + ij + 1] = p.read_off[rb + lane + 1];
-                stot[sj] = incl - (s_begin(sj) > 0 ? before : 0u);
+                stot[sj] = incl - (sj > 0 ? before : 0u);
             }
         }
         if (lane == 0) ring[RING_SLOTS - 1] = neutral_row32();
@@ -219,7 +218,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     // ---- row producer (see phmm_chain_kernels.hip): constants in f64 from the f64 tables, rounded once -------
     uint32_t pb_x = 0, pb_q = 0, pb_qp = 0, pb_i = 0, pb_d = 0, pb_dp = 0, pb_g = 0, pb_gn = 0;
     const int ps = lane / TPS, pj = lane % TPS;
-    const int pcb = s_begin(ps) + ps, pn = n_of(ps);
+    const int pcb = ps * (n_sub + 1), pn = n_of(ps);
     int p_lo = 0, p_row = pj - LEAD - TPS;
     uint32_t p_ro = pn > 0 ? roff[pcb] : 0u;
     int p_R = pn > 0 ? (int)(roff[pcb + 1] - p_ro) : 0;
@@ -285,7 +284,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     issue();
 
     // ---- state ---------------------------------------------------------------------------------------
-    const float c0 = c_unit * (float)(n_mine > 0 ? 1.0 - p.eps[p.gcp[roff[s_begin(sid) + sid]]] : 1.0);
+    const float c0 = c_unit * (float)(n_mine > 0 ? 1.0 - p.eps[p.gcp[roff[sid * (n_sub + 1)]]] : 1.0);
     float Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -300,7 +299,7 @@ __device__ __forceinline__ void chain_body_f32(const ChainParams &cp, const Chai
     const double log10_scale = 100.0 * 0.30102999566398119521 + log10((double)H);  // log10(2^100 * H)
     auto emit = [&](const Row32 &c) {
         if (last_lane && c.x == X_PAD && hv) {
-            const uint32_t r = rb + (uint32_t)s_begin(sid) + c.pad0;
+            const uint32_t r = rb + (uint32_t)(sid * n_sub) + c.pad0;
             int ek = edge_k;
             asm volatile("" : "+v"(ek));
             float sum = 0.f;

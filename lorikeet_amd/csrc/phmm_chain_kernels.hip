@@ -72,7 +72,7 @@ __device__ __forceinline__ void chain_fallback(const ForwardParams &p, const Cha
                                                int grp, int l, const HapCols<K> &hc, int H, bool hv, int a, int Nh) {
     // Per read: stage plain or pre-scaled rows linearly (slot 0 neutral, row r at r+1), general sweep, reduce.
     const uint32_t reg = it.region;
-    for (uint32_t r = it.read_begin; r < it.read_end(); ++r) {
+    for (uint32_t r = it.read_begin; r < it.read_end; ++r) {
         const uint32_t ro = p.read_off[r];
         const int R = (int)(p.read_off[r + 1] - ro);
         bool z = false;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
     const int grp = lane / CL, l = lane % CL;
     const bool group_head = (CL == 32) && (lane == 32);
     const uint32_t reg = it.region;
-    const int n_chain = (int)it.n_reads();
+    const int n_chain = (int)(it.read_end - it.read_begin);
     const uint32_t h0 = p.region_hap_off[reg];
     const int Nh = (int)(p.region_hap_off[reg + 1] - h0);
     // streams (see the header): S sub-runs of reads side by side, each on G/S haplotype slots
@@ -157,13 +157,10 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
     const int sid = grp / GS;                   // stream of this lane's group
     const int a = MODE == CHAIN_PLAIN ? (int)it.quad * GS + grp % GS : (int)x->hap[grp & 3];  // (the sharing kernels name their haplotypes)
     const bool hv = a < Nh;
-    // stream s sweeps reads [s_begin(s), s_begin(s + 1)) of the run: the planner's cuts (the longest stream as short as
-    // contiguous cuts allow, chain_cut_run); a stream may be empty
-    const uint32_t cuts = it.cuts;
-    auto s_begin = [&](int s) { return s <= 0 ? 0 : s >= S ? n_chain : (int)((cuts >> (8 * s)) & 0xffu); };
+    const int n_sub = (n_chain + S - 1) / S;    // reads per stream (the last streams may get fewer, or none)
     const int TPS = (RING / 4) / S;             // rows produced per stream and tick == steps per tick (a quarter of the stream's ring)
     const int NM = RING / S - 1;                // ring rows per stream - 1 (mask)
-    auto n_of = [&](int s) { return s_begin(s + 1) - s_begin(s); };
+    auto n_of = [&](int s) { return max(0, min(n_sub, n_chain - s * n_sub)); };
     const int n_mine = n_of(sid);
     uint32_t ho = 0;
     int H = 0;
@@ -172,7 +169,7 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
         H = (int)(p.hap_off[h0 + a + 1] - ho);
     }
     RowConst *ring = reinterpret_cast<RowConst *>(smem);          // RING_SLOTS records
-    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s_begin(s) + s: byte offset of each of its reads, and the end
+    uint32_t *roff = reinterpret_cast<uint32_t *>(ring + RING_SLOTS);  // per stream s at s*(n_sub+1): byte offset of each read
     uint32_t *stot = roff + CHAIN_META;                              // [4] rows of each stream
 
     // ---- haplotype columns: real bases, one EDGE column, then padding -------------------------------
@@ -192,13 +189,13 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
     // ---- the chain: stream offsets, and whether every read can be pre-scaled ------------------------
     const uint32_t rb = it.read_begin;
     const uint32_t byte0 = p.read_off[rb];
-    const uint32_t bytes = p.read_off[it.read_end()] - byte0;
+    const uint32_t bytes = p.read_off[it.read_end] - byte0;
     bool z = false;
     for (uint32_t i = lane; i < bytes; i += WAVE) z |= row_blocks_prescale(p, byte0 + i);
     if ((__ballot(z) | __ballot(lane_n)) != 0ull) {  // rare: exact but unchained
         if constexpr (MODE == CHAIN_SUFFIX) {
             // (a suffix cannot be swept alone the general way: its pairs are left to the exact pass -- NaN asks for it)
-            for (uint32_t r = rb + (uint32_t)l; r < it.read_end() && hv; r += CL)
+            for (uint32_t r = rb + (uint32_t)l; r < it.read_end && hv; r += CL)
                 p.out[p.out_off[reg] + (uint64_t)(r - p.region_read_off[reg]) * (uint64_t)Nh + a] = __longlong_as_double(0x7ff8000000000000ll);
             if (lane == 0) atomicOr(p.status, STATUS_RESCUE);
             return;
@@ -206,11 +203,11 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
         if (S == 1)
             chain_fallback<K>(p, it, ring, lane, grp, l, hc, H, hv, a, Nh);
         else if constexpr (CL == 16)
-            chain_fallback_streams<K>(p, reg, rb + (uint32_t)s_begin(sid), n_mine, max(max(n_of(0), n_of(1)), max(n_of(2), n_of(3))), lane, l, hc, H, hv, a, Nh);
+            chain_fallback_streams<K>(p, reg, rb + (uint32_t)(sid * n_sub), n_mine, n_sub, lane, l, hc, H, hv, a, Nh);
         return;
     }
     {   // lane j describes read j of the run: its stream sj and index ij there; offsets by a wave scan
-        const int sj = (lane >= s_begin(1)) + (lane >= s_begin(2)) + (lane >= s_begin(3)), ij = lane - s_begin(sj);
+        const int sj = lane / n_sub, ij = lane % n_sub;
         uint32_t len = lane < n_chain ? p.read_off[rb + lane + 1] - p.read_off[rb + lane] + 2u : 0u;  // + SUM + RESET
         uint32_t incl = len;
 #pragma unroll
@@ -218,14 +215,14 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
             const uint32_t v = __shfl_up(incl, off, WAVE);
             if (lane >= off) incl += v;
         }
-        const uint32_t before = __shfl(incl, max(s_begin(sj) - 1, 0), WAVE);  // scan value just before my stream starts
-        const int cb = s_begin(sj) + sj;
+        const uint32_t before = __shfl(incl, max(sj * n_sub - 1, 0), WAVE);  // scan value just before my stream starts
+        const int cb = sj * (n_sub + 1);
         if (lane < 4) stot[lane] = 0u;  // rows of each stream (streams without reads stay 0)
         if (lane < n_chain) {
             roff[cb + ij] = p.read_off[rb + lane];
             if (ij + 1 == n_of(sj)) {
                 roff[cb + ij + 1] = p.read_off[rb + lane + 1];
-                stot[sj] = incl - (s_begin(sj) > 0 ? before : 0u);
+                stot[sj] = incl - (sj > 0 ? before : 0u);
             }
         }
         if (lane == 0) ring[RING_SLOTS - 1] = neutral_row();
@@ -245,7 +242,7 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
     // (p_lo = read of the stream, p_row = row of that read, counting SUM and RESET), moves on by TPS rows per tick.
     const bool producer = lane < S * TPS;       // RING / 4 lanes build a row per tick (all 64 with the 256-row ring)
     const int ps = producer ? lane / TPS : 0, pj = lane % TPS;
-    const int pcb = s_begin(ps) + ps, pn = n_of(ps);
+    const int pcb = ps * (n_sub + 1), pn = n_of(ps);
     int p_lo = 0, p_row = pj - LEAD - TPS;  // before the first advance(); rows < 0 are the neutral lead-in
     p_Q = pj - TPS;                         // ring position of that row
     uint32_t p_ro = pn > 0 ? roff[pcb] : 0u;
@@ -325,7 +322,7 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
 
     // ---- state ---------------------------------------------------------------------------------------
     // planner guarantees every read has >= 1 base; a stream without reads only ever sees neutral rows
-    const double c0 = c_unit * (n_mine > 0 ? 1.0 - p.eps[p.gcp[roff[s_begin(sid) + sid]]] : 1.0);
+    const double c0 = c_unit * (n_mine > 0 ? 1.0 - p.eps[p.gcp[roff[sid * (n_sub + 1)]]] : 1.0);
     double Mp[K], Ip[K], Dp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -344,7 +341,7 @@ __device__ __forceinline__ void chain_body(const ForwardParams &p, const ChainIt
         // after the owning lane's SUM step, see above
         {
             if (last_lane && c.x == X_PAD && hv) {
-                const uint32_t r = rb + (uint32_t)s_begin(sid) + c.pad0;
+                const uint32_t r = rb + (uint32_t)(sid * n_sub) + c.pad0;
                 // the column is a per-lane value: a K-way select.  `ek` is made opaque so that the K compare masks are
                 // built here, once per read, instead of living in 2*K SGPRs across the sweep loop
                 int ek = edge_k;

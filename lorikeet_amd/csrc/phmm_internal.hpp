@@ -101,59 +101,9 @@ struct ChainItem {
     uint32_t region;                // region index
     uint16_t quad;                  // haplotype group ((64/L)/streams haplotypes) inside the region
     uint8_t k, streams;             // columns per lane of this item's body; 1 | 2 | 4 sub-runs swept side by side (L = 16)
-    uint32_t read_begin;            // global index of the run's first read; the run is n_reads reads of that region
-    // n_reads (1 .. CHAIN_MAX_READS) in the low byte, then where streams 1, 2, 3 begin inside the run (stream 0 begins at 0; a
-    // stream that does not exist begins at n_reads).  The planner cuts a run so that its longest stream has as few ROWS as
-    // contiguous cuts allow (chain_cut_run): reads of 30-250 bases cut by count left the longest of four streams ~25 % above
-    // their mean (NOTEBOOK 20.6).
-    uint32_t cuts;
-    __host__ __device__ uint32_t n_reads() const { return cuts & 0xffu; }
-    __host__ __device__ uint32_t read_end() const { return read_begin + (cuts & 0xffu); }
-    __host__ __device__ uint32_t stream_begin(int s) const { return s <= 0 ? 0u : s >= 4 ? (cuts & 0xffu) : (cuts >> (8 * s)) & 0xffu; }
+    uint32_t read_begin, read_end;  // global read indices [begin, end), all of that region
 };
 static_assert(sizeof(ChainItem) == 16, "work item record");
-// The cuts of a run of n reads into `streams` contiguous parts whose longest has the fewest rows.  rows(i) = the rows of the run's
-// first i reads, their SUM / RESET rows included (strictly increasing, rows(0) == 0).  Binary search on the longest part's
-// length between max(longest read, total / streams) and that + the longest read; a part's end by binary search on rows():
-// ~200 steps a run (a linear version cost the planner of the 1 536-region mix 5.8 of its 11 ms).  Host only (the planner).
-template <class Rows>
-inline uint32_t chain_cut_run(uint32_t n, uint32_t streams, Rows rows, uint64_t *longest_out = nullptr) {
-    const uint64_t total = rows(n);
-    uint32_t begin[5] = {0, n, n, n, n};
-    if (streams <= 1 || n <= 1) {
-        if (longest_out) *longest_out = total;
-        return n | n << 8 | n << 16 | n << 24;
-    }
-    uint64_t longest_read = 0;
-    for (uint32_t i = 0; i < n; ++i) longest_read = longest_read > rows(i + 1) - rows(i) ? longest_read : rows(i + 1) - rows(i);
-    // the parts under a limit, filled greedily: part p ends at the last read that still fits
-    auto fill = [&](uint64_t limit, bool keep) {
-        uint32_t pos = 0, parts = 0;
-        while (pos < n) {
-            const uint64_t upto = rows(pos) + limit;
-            uint32_t lo_i = pos + 1, hi_i = n;  // (a read never exceeds the limit: the part holds at least one)
-            while (lo_i < hi_i) {
-                const uint32_t mid = (lo_i + hi_i + 1) / 2;
-                if (rows(mid) <= upto) lo_i = mid; else hi_i = mid - 1;
-            }
-            pos = lo_i;
-            ++parts;
-            if (keep && parts < 4 && pos < n) begin[parts] = pos;
-            if (parts > streams) break;
-        }
-        return parts;
-    };
-    uint64_t lo = (total + streams - 1) / streams, hi;
-    lo = lo > longest_read ? lo : longest_read;
-    hi = lo + longest_read < total ? lo + longest_read : total;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) / 2;
-        if (fill(mid, false) <= streams) hi = mid; else lo = mid + 1;
-    }
-    fill(lo, true);
-    if (longest_out) *longest_out = lo;
-    return n | begin[1] << 8 | begin[2] << 16 | begin[3] << 24;
-}
 struct ChainParams {
     ForwardParams f;
     const ChainItem *items;

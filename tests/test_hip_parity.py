@@ -502,10 +502,11 @@ def test_chained_kernel_streams(engines, force_chain, streams, kat_rows):
 
 
 @pytest.mark.parametrize("nh", [1, 2])
-def test_streams_cut_by_rows(engines, nh):
-    """Round 6: a run's streams are cut where the longest has the fewest rows, not into equal counts of reads (chain_cut_run;
-    tests/test_sharding.py holds the cuts themselves).  Runs of twelve reads whose lengths make the two cuts differ -- one long
-    read first, last, in the middle; a run shorter than its streams; equal reads -- against the oracle, read by read."""
+def test_streams_of_uneven_runs(engines, nh):
+    """Runs of up to twelve reads of very different lengths swept as four / two streams side by side (one / two haplotypes): one
+    long read first, last, in the middle; a run shorter than its streams; equal reads -- against the oracle, read by read.  (Round
+    6 built cuts of a run by ROWS instead of by count of reads with these cases and took them out again: fewer swept cells, slower
+    small launches and host-buffer calls -- NOTEBOOK.md 20.6.)"""
     eng = engines[16]
     eng.set_switch("force_chain", 12)
     try:

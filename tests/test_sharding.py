@@ -181,35 +181,3 @@ def test_the_plan_says_what_it_sweeps_and_where_the_padding_is():
     one = plan_describe(synthetic.config2(1))                  # a lone region: 64 lanes x 5 columns per pair, one read per wave
     assert one.pad_column_cells * 300 == one.cells * 20 and one.swept_cells > one.cells
 
-
-def test_a_runs_streams_are_cut_by_rows(monkeypatch):
-    """A region with one or two haplotypes is swept as four or two sub-runs of its reads side by side in one wave (16 lanes per
-    pair).  The planner cuts the run where the LONGEST stream has the fewest rows (chain_cut_run, phmm_internal.hpp; rounds 2-5
-    cut into equal counts of reads and left the longest of four streams of 30-250-base reads ~25 % above their mean): the steps a
-    wave sweeps are its longest stream's rows (+ 2 per read: SUM / RESET) + the 16 steps to its last lane, rounded to even --
-    read off phmm_plan_info.swept_cells = steps x 64 lanes x K for every item."""
-    from lorikeet_amd.engine import plan_describe
-    monkeypatch.setenv("PHMM_FORCE_L", "16")
-    monkeypatch.setenv("PHMM_FORCE_CHAIN", "12")
-
-    class Offsets:
-        pass
-
-    def steps(lens, nh, n_regions=64, H=160):
-        b = Offsets()
-        b.n_regions = n_regions
-        b.region_read_off = (np.arange(n_regions + 1) * len(lens)).astype(np.uint32)
-        b.region_hap_off = (np.arange(n_regions + 1) * nh).astype(np.uint32)
-        b.read_off = np.concatenate([[0], np.cumsum(np.tile(lens, n_regions))]).astype(np.uint32)
-        b.hap_off = (np.arange(n_regions * nh + 1) * H).astype(np.uint32)
-        info = plan_describe(b)
-        assert info.chain_items == n_regions and info.swept_cells % (n_regions * 64 * 10) == 0, info.dominant_kernel
-        return info.swept_cells // (n_regions * 64 * 10)
-
-    even = lambda rows: (rows + 16) & ~1  # noqa: E731
-    assert steps([250] + [30] * 11, 1) == even(252)           # [250] | 4 x 30 | 4 x 30 | 3 x 30   (by count: 250 + 30 + 30 + 6 = 316)
-    assert steps([30] * 11 + [250], 1) == even(252)
-    assert steps([250, 250, 30, 30, 30], 1) == even(252)      # [250] | [250] | 3 x 30 | nothing
-    assert steps([100] * 12, 1) == even(3 * 102)              # equal reads: equal counts
-    assert steps([250] + [30] * 11, 2) == even(252 + 2 * 32)  # two streams: [250, 30, 30] | 9 x 30 (288 rows)
-    assert steps([77], 1) == even(79)                         # one read: three empty streams

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Developer tool: tools/ab/ragged_ab.py over prebuilt tools/ab/libphmm_<variant>.so files, twice each, on ONE box.
+# usage (through gpurun): bash tools/ab/ragged_ab.sh "prev new"
+cd "$(dirname "$0")/../.."
+cp lorikeet_amd/libphmm.so /tmp/libphmm_cur.so
+for rep in 1 2; do
+for v in ${1:-prev new}; do
+  cp tools/ab/libphmm_$v.so lorikeet_amd/libphmm.so
+  echo "== $v"; python tools/ab/ragged_ab.py 2>&1 | grep -v "amdgpu.ids"
+done
+done
+cp /tmp/libphmm_cur.so lorikeet_amd/libphmm.so
