@@ -738,7 +738,7 @@ __device__ __forceinline__ void sw_align_body(const SwParams &p, unsigned char *
         if (lane == 0) __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (tests only, report_clock == 2: round 4's bug on purpose -- two words stored BEHIND the count, ~300 us late, i.e. when the
-    // caller may already have staged its next call where this call's status block was.  tests/test_mirror_canary.py shows
+    // caller may already have staged its next call where this call's status block was.  tests/test_region_handoffs.py shows
     // that PHMM_MIRROR_CANARY turns such a store into a failed call.)
     // (EVERY block: the one that completes the count is then ~300 us late for sure)
     if (p.report_clock == 2u && lane == 0) {
