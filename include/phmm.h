@@ -64,7 +64,8 @@ extern "C" {
                                   * trust in f32 (< ~1e-59 / haplotype length), or that needs the general path, is
                                   * recomputed in f64.  Results of the f32 pairs differ from the f64 path by f32
                                   * rounding (<= 2e-6 in log10 measured, the reference's gate is 1e-5); default OFF:
-                                  * everything in f64. */
+                                  * everything in f64.  Small calls, and region calls that go through the resident region
+                                  * server, are computed in f64 under this flag too (NOTEBOOK.md 20.7). */
 
 /* status codes (0 == success) */
 #define PHMM_OK 0

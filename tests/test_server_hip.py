@@ -281,3 +281,55 @@ def test_a_lost_answer_sends_the_call_and_all_later_ones_to_the_launched_pipelin
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]), TMPDIR="/tmp")
     r = subprocess.run([sys.executable, "-c", _LOST_ANSWER], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_output_slots_too_small_are_reported_by_the_server_like_by_the_launched_pipeline(eng):
+    """capacity = 1: the projected CIGARs do not fit the caller's slots -- PHMM_ERR_CIGAR_CAPACITY with the sizes in n_out_cigar,
+    the mirror retries with those; both attempts go through the server and the result is the launched pipeline's."""
+    sc = _scenario(31, n_regions=3, low_complexity=False)
+    b = sc[0]
+    mapq = _noisy_quals(b, 31)
+    cfg = _cfg(pcr=3)
+    pri = _priorities(b, sc[1], sc[3])
+    jobs = eng.stat("server_jobs")
+    got = _call(eng, cfg, sc, mapq, pri, capacity=1)
+    assert eng.stat("server_jobs") == jobs + 2, "capacity 1 must fail once (sizes reported) and pass on the retry, both through the server"
+    launched = HipPairHMMEngine(0)
+    try:
+        launched.set_switch("region_server", 0)
+        _equal(got, _call(launched, cfg, sc, mapq, pri), exact=False)
+    finally:
+        launched.close()
+    assert max(len(c) for c in got.reads.cigars) > 1
+
+
+def test_a_handles_flags_hold_inside_the_server():
+    """PHMM_FLAG_NO_TRISTATE: the server sweeps with the HANDLE'S tables (mismatch prior eps instead of eps / 3), so its results are
+    that handle's launched results -- and differ from a default handle's.  PHMM_FLAG_F32_FIRST: the server has one arithmetic, f64
+    (what the f32-first mode falls back to): such a handle's calls through the server give the f64 results."""
+    sc = _scenario(41, n_regions=2, low_complexity=False)
+    b = sc[0]
+    mapq = _noisy_quals(b, 41)
+    cfg = _cfg(pcr=3)
+    pri = _priorities(b, sc[1], sc[3])
+    plain = HipPairHMMEngine(0)
+    plain.set_switch("region_server", 0)
+    want_f64 = _call(plain, cfg, sc, mapq, pri)
+    for kw, same_as_plain in (({"do_not_use_tristate_correction": True}, False), ({"f32_first": True}, True)):
+        served, launched = HipPairHMMEngine(0, **kw), HipPairHMMEngine(0, **kw)
+        try:
+            served.set_switch("region_server", 1)
+            launched.set_switch("region_server", 0)
+            jobs = served.stat("server_jobs")
+            got = _call(served, cfg, sc, mapq, pri)
+            assert served.stat("server_jobs") == jobs + 1
+            if same_as_plain:
+                _equal(got, want_f64, exact=False)            # f64, whatever the launched f32-first sweep rounds to
+                assert np.max(np.abs(_call(launched, cfg, sc, mapq, pri).likelihoods - got.likelihoods)) < 1e-5
+            else:
+                _equal(got, _call(launched, cfg, sc, mapq, pri), exact=False)
+                assert np.max(np.abs(got.likelihoods - want_f64.likelihoods)) > 1e-3
+        finally:
+            served.close()
+            launched.close()
+    plain.close()
