@@ -25,11 +25,13 @@
 #include <mutex>
 #include <string>
 #include <system_error>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
 #include "phmm_cigar_internal.hpp"
 #include "phmm_host.hpp"
+#include <sched.h>
 #include "phmm_internal.hpp"
 #include "phmm_tables.hpp"
 
@@ -476,6 +478,35 @@ phmm_handle *create_internal(int device, unsigned flags) {
 }
 
 int user_handles_on(int device) { return g_user_handles[device % kMaxDevices].load(std::memory_order_relaxed); }
+
+// The wait of a one-shot call.  hipStreamSynchronize spins; with more caller threads than the process has cores -- its affinity
+// mask or its container's CPU quota: 16 of 256 on the GPU box -- the spinning waiters are throttled together with the callers
+// that have something to stage, and 32 private handles ran at HALF the rate of 16 (phmm_compute 46 -> 22 k regions/s, VERDICT r4;
+// round 5 hid it by routing such handles through the shared combiner; the region server's waiters showed the same: 22.9 k
+// spinning, 45.6 k with short sleeps, NOTEBOOK 20.2).  So: when the caller holds more handles on the device than it has cores,
+// look at the stream, sleep 20 us, look again: 24 / 32 handles 31 / 22 -> 46 / 45 k, nothing routed, nothing combined.
+bool more_callers_than_cores(const phmm_handle *h) {
+    static const int cores = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // (a container's CPU quota: spinning beyond it is throttled)
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<int>(n, (int)((quota + period - 1) / period));
+            fclose(f);
+        }
+        return n > 0 ? n : 1;
+    }();
+    return !h->internal && user_handles_on(h->device) > cores;
+}
+hipError_t wait_stream(const phmm_handle *h, hipStream_t s) {
+    if (!more_callers_than_cores(h)) return hipStreamSynchronize(s);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
 
 phmm_handle *route_shared(phmm_handle *h) {
     // (opt-in since round 6: which regions share a flush depends on timing, so routed results are reproducible to ~1e-13, not bit
@@ -1769,9 +1800,9 @@ int finish_compute(phmm_handle *h, PendingCompute *p) {
     auto fetch = [&]() {  // [status | out] -> pinned mirror
         return hip_ok(h, hipMemcpyAsync(A.host + b->out_arena_off, A.dev + b->out_arena_off, res_bytes, hipMemcpyDeviceToHost, S),
                       "D2H results") &&
-               hip_ok(h, hipStreamSynchronize(S), "sync(D2H)");
+               hip_ok(h, wait_stream(h, S), "sync(D2H)");
     };
-    if (!hip_ok(h, hipStreamSynchronize(S), "sync") || (p->d2h_pending && !fetch())) {  // kernels are done: fetch now
+    if (!hip_ok(h, wait_stream(h, S), "sync") || (p->d2h_pending && !fetch())) {  // kernels are done: fetch now
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + b->out_arena_off;
@@ -2290,11 +2321,11 @@ int engine_finish(phmm_handle *h, PendingEngine *p) {
     phmm_batch *b = p->b;
     Arena &A = h->arenas[p->slot];
     hipStream_t S = p->stream ? p->stream : h->streams[p->slot];
-    if (!hip_ok(h, hipStreamSynchronize(S), "sync") ||
+    if (!hip_ok(h, wait_stream(h, S), "sync") ||
         (p->d2h_pending &&
          (!hip_ok(h, hipMemcpyAsync(A.host + p->res_off, A.dev + p->res_off, p->res_bytes, hipMemcpyDeviceToHost, S),
                   "D2H results") ||
-          !hip_ok(h, hipStreamSynchronize(S), "sync(D2H)")))) {
+          !hip_ok(h, wait_stream(h, S), "sync(D2H)")))) {
         st = PHMM_ERR_HIP;
     } else {
         const char *hs = A.host + p->res_off;

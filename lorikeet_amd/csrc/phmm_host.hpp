@@ -283,6 +283,9 @@ constexpr int kServerNotTaken = -2000;  // server_region_submit: the call is out
 constexpr int kServerRedo = -2001;      // server_region_wait: run the call again the launched way (an alignment outgrew its slot)
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit);
 int user_handles_on(int device);  // the caller's handles alive on the device (phmm_api.cpp)
+// the wait of a one-shot call: hipStreamSynchronize, or -- more caller handles than cores -- looks at the stream between 20 us sleeps
+bool more_callers_than_cores(const phmm_handle *h);
+hipError_t wait_stream(const phmm_handle *h, hipStream_t s);
 int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);
 uint64_t server_stat(int device, const char *name);
 void server_yield(int device);

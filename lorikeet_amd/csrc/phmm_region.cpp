@@ -18,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "phmm_cigar_internal.hpp"
@@ -752,15 +753,17 @@ int region_finish(phmm_handle *h, PendingRegion *p, uint32_t *sw_needed) {
     bool told = false;
     if (p->finish_flag) {
         const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        const bool naps = more_callers_than_cores(h);  // (spinning waiters beyond the process' cores starve the callers that stage)
         for (uint32_t spins = 0; !told; ++spins) {
             told = __atomic_load_n(p->finish_flag, __ATOMIC_ACQUIRE) != 0;
             if (!told && (spins & 255u) == 255u && std::chrono::steady_clock::now() >= give_up) break;
+            if (!told && naps && (spins & 63u) == 63u) std::this_thread::sleep_for(std::chrono::microseconds(20));
             if (!told) __builtin_ia32_pause();
         }
     }
-    if ((!told && !ok(h, hipStreamSynchronize(S), "sync")) ||
+    if ((!told && !ok(h, wait_stream(h, S), "sync")) ||
         (p->d2h_pending && (!ok(h, hipMemcpyAsync(A.host + L.res, A.dev + L.res, L.end - L.res, hipMemcpyDeviceToHost, S), "D2H results") ||
-                            !ok(h, hipStreamSynchronize(S), "sync(D2H)"))))
+                            !ok(h, wait_stream(h, S), "sync(D2H)"))))
         return done(PHMM_ERR_HIP);
     const char *hs = A.host;
     const uint32_t *sw_st = (const uint32_t *)(hs + L.res + 64);
