@@ -89,13 +89,16 @@ int phmm_device_count(void);
  * owns a stream, pinned staging and device arenas that grow on demand.  While at most four engines are alive on a device,
  * each runs its one-enqueue calls on a hardware queue of its own (callers with an engine each then run side by side whatever
  * the runtime does with ordinary streams); env PHMM_REGION_OWN_QUEUE=0 at creation turns that off.
- * While MORE than four of the caller's engines are alive on a device (an engine per worker thread at Lorikeet's --threads 10),
+ * While MORE than six of the caller's engines are alive on a device (an engine per worker thread at Lorikeet's --threads 10),
  * the one-shot phmm_region_compute calls of such a private engine are served by the device's resident REGION SERVER (a kernel
  * that stays on the chip while calls keep coming: the region is staged into a slot of pinned memory, every read runs as one wave
  * from pre-step to projection, nothing is launched; phmm_server.cpp).  Results and error reporting are the call's own, and the
  * likelihoods are the region's own bits whatever else is in flight (16 lanes x ceil(H / 16) columns per pair: a function of the
  * region's longest haplotype).  Calls outside the server's limits (reads beyond 268 bases, haplotypes beyond 512, more than 1 MB of
  * inputs) take the engine's own streams.  env PHMM_REGION_SERVER=0 turns the server off, =1 sends every region call through it.
+ * While the caller holds more engines on a device than the process has cores (its affinity mask, its container's CPU quota), a
+ * one-shot call waits for its kernels in 20 us naps instead of spinning: spinning waiters beyond the cores are throttled together
+ * with the callers that stage (32 engines on 16 cores ran at half the rate of 16; NOTEBOOK.md 20.5).
  * Opt-in, env PHMM_ROUTE_SHARED=n: while more than n engines are alive, the one-shot calls of private engines -- phmm_compute,
  * phmm_engine_compute, phmm_region_compute on up to eight regions or 512 KB per array -- go through ONE shared engine of the same
  * flags inside the library instead (the queue of phmm_submit: callers that are waiting anyway share a flush); which regions share a
