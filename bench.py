@@ -693,7 +693,7 @@ def main():
                 "region_call_one_region_per_call_8_threads_shared_handle_2_tickets": point("gshared", 8, 1, depth=2),
                 "region_call_one_region_per_call_10_threads_shared_handle_2_tickets": point("gshared", 10, 1, depth=2),
                 "region_call_one_region_per_call_16_threads_shared_handle_2_tickets": point("gshared", 16, 1, depth=2),
-                # ... and a private handle per worker past six (INTEGRATION.md section 4's thread_local!): their one-shot calls go through
+                # ... and a private handle per worker past five (INTEGRATION.md section 4's thread_local!): their one-shot calls go through
                 # the device's resident region server (round 6: nothing launched, results bit-reproducible; round 5 routed them through
                 # the shared combiner, round 4: 22 k at 16 threads, 12.5 k at 32)
                 "region_call_one_region_per_call_10_threads_own_handles": point("fused", 10, 1),

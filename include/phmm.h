@@ -89,7 +89,7 @@ int phmm_device_count(void);
  * owns a stream, pinned staging and device arenas that grow on demand.  While at most four engines are alive on a device,
  * each runs its one-enqueue calls on a hardware queue of its own (callers with an engine each then run side by side whatever
  * the runtime does with ordinary streams); env PHMM_REGION_OWN_QUEUE=0 at creation turns that off.
- * While MORE than six of the caller's engines are alive on a device (an engine per worker thread at Lorikeet's --threads 10),
+ * While MORE than five of the caller's engines are alive on a device (an engine per worker thread at Lorikeet's --threads 10),
  * the one-shot phmm_region_compute calls of such a private engine are served by the device's resident REGION SERVER (a kernel
  * that stays on the chip while calls keep coming: the region is staged into a slot of pinned memory, every read runs as one wave
  * from pre-step to projection, nothing is launched; phmm_server.cpp).  Results and error reporting are the call's own, and the
@@ -548,7 +548,7 @@ int phmm_calculate_cigar(phmm_handle *h, uint32_t n, const uint32_t *ref_off, co
  *                  only), "force_streams", "no_pipeline" (a host-buffer call in one shot whatever its size), "no_rescue", "trace"
  *   aligner        "sw_lite" (the tags-only first pass: -1 where it pays, 0 never, 1 always), "sw_chunks", "sw_lanes",
  *                  "sw_transpose", "sw_no_zero_copy", "sw_clock"
- *   region call    "region_server" (the resident region server: -1 the one-shot calls of private handles past six alive on the
+ *   region call    "region_server" (the resident region server: -1 the one-shot calls of private handles past five alive on the
  *                  device, 0 never, 1 every call its limits admit), "server_idle_us", "server_trace";
  *                  "region_sw_all" (pairs up to which a lone launched call aligns every read against every haplotype beside the
  *                  PairHMM kernels: -1 by load, 0 never), "region_flag_wait", "region_pick_timeout_us", "region_debug_pick" (tests),

@@ -485,7 +485,7 @@ int user_handles_on(int device) { return g_user_handles[device % kMaxDevices].lo
 // round 5 hid it by routing such handles through the shared combiner; the region server's waiters showed the same: 22.9 k
 // spinning, 45.6 k with short sleeps, NOTEBOOK 20.2).  So: when the caller holds more handles on the device than it has cores,
 // look at the stream, sleep 20 us, look again: 24 / 32 handles 31 / 22 -> 46 / 45 k, nothing routed, nothing combined.
-bool more_callers_than_cores(const phmm_handle *h) {
+int process_cores() {
     static const int cores = [] {
         cpu_set_t set;
         CPU_ZERO(&set);
@@ -497,8 +497,9 @@ bool more_callers_than_cores(const phmm_handle *h) {
         }
         return n > 0 ? n : 1;
     }();
-    return !h->internal && user_handles_on(h->device) > cores;
+    return cores;
 }
+bool more_callers_than_cores(const phmm_handle *h) { return !h->internal && user_handles_on(h->device) > process_cores(); }
 hipError_t wait_stream(const phmm_handle *h, hipStream_t s) {
     if (!more_callers_than_cores(h)) return hipStreamSynchronize(s);
     for (;;) {

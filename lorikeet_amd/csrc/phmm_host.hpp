@@ -55,7 +55,7 @@ struct Switches {
     int mirror_canary = 0;      // PHMM_MIRROR_CANARY: 1 = late / stray device stores into the pinned mirror fail the call (Arena::canary_*), 2 = abort()
     int region_own_queue = 1;   // PHMM_REGION_OWN_QUEUE: 0 = one-enqueue calls stay on the handle's ordinary slot-0 stream (A/B)
     int region_server = -1;     // PHMM_REGION_SERVER: region calls go through the device's resident server (phmm_server.cpp) -- -1: the one-shot calls of
-                                // PRIVATE handles while more than six of the caller's handles are alive on the device (a handle whose other switches
+                                // PRIVATE handles while more than five of the caller's handles are alive on the device (a handle whose other switches
                                 // were changed keeps the launched pipeline); 0 never; 1 every call the server's limits admit, a shared handle's too
     int server_idle_us = 200;   // PHMM_SERVER_IDLE_US: how long the server stays on the chip with nothing in flight and nothing arriving
     int server_trace = 0;       // PHMM_SERVER_TRACE: every task leaves a record (tools/server_trace.py)
@@ -284,6 +284,7 @@ constexpr int kServerRedo = -2001;      // server_region_wait: run the call agai
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit);
 int user_handles_on(int device);  // the caller's handles alive on the device (phmm_api.cpp)
 // the wait of a one-shot call: hipStreamSynchronize, or -- more caller handles than cores -- looks at the stream between 20 us sleeps
+int process_cores();  // what the process may run on: its affinity mask, its container's CPU quota
 bool more_callers_than_cores(const phmm_handle *h);
 hipError_t wait_stream(const phmm_handle *h, hipStream_t s);
 int server_region_wait(phmm_handle *h, ServerPending *p, std::string *err, RegionArgs *redo_args);

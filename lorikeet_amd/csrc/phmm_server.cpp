@@ -277,7 +277,7 @@ namespace phmm_host {
 
 // Stage one call in a slot and hand it to the device's server.  kServerNotTaken: the call is outside the server's limits (or
 // the server is not to be used): nothing was done, the caller takes the launched pipeline.  `a` is validated.
-constexpr int kServerFromHandles = 6;
+constexpr int kServerFromHandles = 5;
 
 int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **out, bool via_submit) {
     *out = nullptr;
@@ -285,10 +285,11 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
     // Which calls: with no switch set, the one-shot region calls of PRIVATE handles once more than kServerFromHandles of the
     // caller's handles are alive on the device -- a handle per worker thread at Lorikeet's --threads 10.  The launched pipelines of
     // many handles share the command processor's pipes and every caller sits in its own chain of launches: 22 k regions/s
-    // (128 x 8) from five callers on, 12.5 k at 32; a call through the server is ~295 us whatever the count, so N callers get
-    // N / 295 us: the server overtakes at seven callers (23.6 against 22.2 k; 30 x 3 regions at six, the ragged mix at seven --
-    // profiles/r06_server_threshold.txt), and its results are the region's own bits whatever the load.  Up to six handles keep
-    // their queues (faster there), a shared handle's phmm_region_submit keeps its combiner (faster, and it says that it combines).
+    // (128 x 8) from four callers on, whatever their number; a call through the server is ~260 us with few callers (its waiters
+    // spin while cores are free), so N callers get N / 260 us: the server overtakes at six callers (23.3 against 22.1 k; 30 x 3
+    // regions at five, the ragged mix at six to seven -- profiles/r06_server_threshold.txt), and its results are the region's own
+    // bits whatever the load.  Up to five handles keep their queues (faster there), a shared handle's phmm_region_submit keeps its
+    // combiner (faster, and it says that it combines).
     if (h->sw.region_server == 0) return kServerNotTaken;
     if (h->sw.region_server < 0 && (via_submit || h->sw_touched || h->internal || h->comb || h->sw.route_shared > 0 || user_handles_on(h->device) <= kServerFromHandles))
         return kServerNotTaken;  // (route_shared > 0: the caller asked for the combiner instead)
@@ -598,8 +599,13 @@ int server_region_submit(phmm_handle *h, const RegionArgs &a, ServerPending **ou
 bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
     Server &S = *p->S;
     bool done = false;
-    // (measured, tools/threads_bench: spin / yield 33.4 / 42.5 / 22.9 k regions/s at 10 / 16 / 32 callers, short sleeps 32.7 / 42.1 / 45.6 k)
+    // How to wait (tools/ab/waiters.sh, one box): while the calls in flight leave two of the process' cores free the waiter SPINS --
+    // a nap of 20 us is 70 with the timer's slack, a tenth of a call: 8 callers 26.9 -> 30.0 k regions/s, 10 callers 32.8 -> 33.4 k,
+    // 30 x 3 regions from 10 callers 64 -> 78 k, the ragged mix 26.3 -> 28.5 k; with more calls in flight than that a short spin
+    // and then naps between looks (spinning waiters beyond the cores are throttled together with the callers that stage: 32
+    // callers 22.9 k spinning, 45.6 k napping; 16: the same either way).
     constexpr uint32_t wait_spins = 64;
+    const bool naps = S.in_flight.load(std::memory_order_relaxed) > process_cores() - 2;
     const auto give_up = p->t0 + std::chrono::milliseconds(kServerStallMs * 4);
     if (h->sw.region_debug_pick & 4) {  // (tests: this call's answer counts as lost -- what a stalled server looks like from here)
         std::lock_guard<SpinLock> lk(S.mu);
@@ -619,8 +625,6 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
                 if (S.broken) break;
                 if (!S.running && (int32_t)(p->seq - S.consumed) >= 0 && !launch_locked(S, h->sw)) break;
             }
-            // (a short spin, then short sleeps between looks -- no call comes back within 100 us anyway, and with more callers than
-            // cores a waiter that spins keeps a caller that has to stage off its core)
             if (spins > wait_spins) {
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() >= give_up) {
                     std::lock_guard<SpinLock> lk(S.mu);
@@ -628,7 +632,7 @@ bool poll_finish(phmm_handle *h, ServerPending *p, const uint32_t *flag) {
                     S.why_broken = "a call did not come back from the region server";
                     break;
                 }
-                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (naps) std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
         }
         __builtin_ia32_pause();

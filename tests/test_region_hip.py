@@ -397,7 +397,7 @@ def test_two_callers_with_private_handles_align_every_pair_at_the_same_time(hip_
         hip_engine.set_switch("region_sw_all", -1)
     engines = [HipPairHMMEngine(0), HipPairHMMEngine(0)]
     for e in engines:
-        e.set_switch("region_server", 0)   # (this test is about the launched pipeline's two queues; a session may hold more than six engines)
+        e.set_switch("region_server", 0)   # (this test is about the launched pipeline's two queues; a session may hold more than five engines)
     got, errs = [None] * len(jobs), []
 
     def worker(t):

@@ -1,6 +1,6 @@
 """The resident region server (lorikeet_amd/csrc/phmm_server.cpp, phmm_server_kernels.hip): phmm_region_compute /
 phmm_region_submit as tasks of ONE kernel that stays on the chip -- every read of a call a wave that runs the read's whole path.
-The way a private handle's region call goes once more than six handles are alive on the device (up to six keep the launched
+The way a private handle's region call goes once more than five handles are alive on the device (up to five keep the launched
 pipeline; switch region_server = 1: every call).  Held here to
   * the launched pipeline (switch region_server = 0), field by field: everything discrete equal, likelihoods to 1e-11 (the two
     sweep a pair with different lane geometries), and to the oracle pipeline at 1e-9;
@@ -134,8 +134,8 @@ def test_a_region_gives_the_same_bits_alone_and_beside_other_callers(eng):
     assert eng.stat("server_jobs") == jobs + 12 * len(calls)
 
 
-def test_private_handles_past_six_go_through_the_server_by_default():
-    """No switch set: up to six of the caller's handles on a device keep their own launched pipelines (faster there,
+def test_private_handles_past_five_go_through_the_server_by_default():
+    """No switch set: up to five of the caller's handles on a device keep their own launched pipelines (faster there,
     profiles/r06_server_threshold.txt); with more alive -- a handle per worker thread at Lorikeet's --threads 10 -- their one-shot
     region calls go through the server, and every call gives its region's own bits whatever the others are doing."""
     calls = _config2_regions(8, 700)

@@ -6,8 +6,8 @@ cd "$(dirname "$0")/../.."
 O=gpurun_out/${R}_server_rates.txt
 {
 echo "# tools/threads_bench: phmm_region_compute / phmm_region_submit, one region (128 x 8, 150 / 300) per call, regions/s"
-echo "## private handles, defaults (up to six: their own launched pipelines; past six: the region server)"
-TB_MODE=fused TB_THREADS=1,2,4,6,7,8,10,16,32 tools/threads_bench 1
+echo "## private handles, defaults (up to five: their own launched pipelines; past five: the region server)"
+TB_MODE=fused TB_THREADS=1,2,4,5,6,8,10,16,32 tools/threads_bench 1
 echo "## private handles, every call through the region server (PHMM_REGION_SERVER=1)"
 PHMM_REGION_SERVER=1 TB_MODE=fused TB_THREADS=1,4 tools/threads_bench 1
 echo "## private handles, launched pipeline only (PHMM_REGION_SERVER=0)"

@@ -5,7 +5,7 @@ R=${1:-r06}; S=${2:-30}
 cd "$(dirname "$0")/../.."
 O=gpurun_out/${R}_server_soak.txt
 {
-echo "# tools/threads_bench TB_VERIFY=1 PHMM_MIRROR_CANARY=1, $S s per point: the region calls of private handles past six go through the region server"
+echo "# tools/threads_bench TB_VERIFY=1 PHMM_MIRROR_CANARY=1, $S s per point: the region calls of private handles past five go through the region server"
 for shape in ragged config2; do
   for mode in fused; do
     echo "## $mode, $shape"

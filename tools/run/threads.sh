@@ -11,7 +11,7 @@ echo "## PairHMM alone (phmm_compute / phmm_submit), private handles and one sha
 TB_THREADS=1,2,4,8,10,16,32 tools/threads_bench 1
 echo "## likelihoods, then realignment, two calls per region (phmm_compute, then phmm_realign_reads with its likelihoods)"
 TB_MODE=pipeline TB_THREADS=1,2,4,8,16 tools/threads_bench 1
-echo "## the whole per-region path as ONE call (phmm_region_compute), private handles (past six: through the resident region server)"
+echo "## the whole per-region path as ONE call (phmm_region_compute), private handles (past five: through the resident region server)"
 TB_MODE=fused TB_THREADS=1,2,4,5,8,10,16,32 tools/threads_bench 1
 echo "## ... through the shared handle (phmm_region_submit / phmm_wait)"
 TB_MODE=gshared TB_THREADS=1,2,4,8,10,16,32,64 tools/threads_bench 1
